@@ -1,0 +1,133 @@
+"""The CPU oracle against the reference's own outputs (tests/golden/*.npz from tools/gen_golden.py).
+
+Integer / index results must be bit-exact; floating-point results within the tolerance written here.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, unpack
+from oracle import features as OF
+from oracle import geometry as OG
+from oracle import semantic as OS
+
+
+@pytest.mark.parametrize("t", [1, 2])
+def test_geometry_bit_exact(t):
+    d = golden(f"geometry_t{t}")
+    assert np.array_equal(OG.frustum_corners(d["depth"], d["c2w"], d["K"]), d["corners"])
+    ids = OG.frustum_point_ids(d["pts"], d["corners"])
+    assert np.array_equal(ids, d["frustum_ids"])
+    fp = d["pts"][ids]
+    hom = np.hstack([fp, np.ones((len(fp), 1), np.float32)])
+    assert np.array_equal(OG.project(hom, d["K"], d["w2c"]), d["project_uv"])
+    mi, muv = OG.match(d["depth"], d["w2c"], fp, d["K"], float(d["th"]))
+    assert np.array_equal(mi, d["match_idx"]) and np.array_equal(muv, d["match_uv"])
+
+
+def test_vanilla_mapper_bit_exact():
+    d = golden("vanilla_mapper")
+    pm = OS.PointMap(d["K"])
+    for i in range(3):
+        pm.integrate(d[f"rgb{i}"], d[f"depth{i}"], d[f"c2w{i}"])
+        assert pm.xyz.shape[0] == int(d[f"n{i}"])
+    assert np.array_equal(pm.xyz, d["pcd"])            # fp32 coordinates, bit-exact (FMA chain)
+    assert np.array_equal(pm.ids, d["pcd_ids"])
+    assert np.array_equal(pm.rgb, d["pcd_colors"])
+    assert (d["pcd_obj_ids"] == -1).all()
+
+
+@pytest.mark.parametrize("tag,filt", [("nofilter", False), ("filter", True)])
+def test_tracking_bit_exact(tag, filt):
+    d = golden(f"tracking_{tag}")
+    w = int(d["mask_w"])
+    pm = OS.PointMap(d["K"])
+    tr = OS.SemanticTracker(d["K"], 0.05, int(d["track_th"]), filt, int(d["n_top_views"]))
+    for i in range(4):
+        pm.integrate(d[f"rgb{i}"], d[f"depth{i}"], d[f"c2w{i}"])
+        assert pm.xyz.shape[0] == int(d[f"pcd_n{i}"])
+        assert np.array_equal(pm.ins, d[f"ins_before{i}"])
+        masks = unpack(d[f"masks{i}"], w)
+        matched, fused, n_matched, updated = tr.step(d[f"depth{i}"], (), pm.xyz, pm.ids, pm.ins,
+                                                     d[f"c2w{i}"], d[f"seg{i}"], masks)
+        pm.ins = updated
+        assert n_matched == int(d[f"n_matched{i}"])
+        assert matched == d[f"matched_ins_ids{i}"].tolist()
+        assert np.array_equal(updated, d[f"updated{i}"])
+        assert np.array_equal(fused, unpack(d[f"bmaps{i}"], w))
+        assert tr.next_ins == int(d[f"next_ins_id{i}"])
+    assert sorted(tr.objects) == d["obj_ids"].tolist()
+    for j in tr.objects:
+        o = tr.objects[j]
+        assert o.kfs == d[f"obj{j}_kfs"].tolist()
+        assert o.points == d[f"obj{j}_points"].reshape(-1).tolist()
+        assert sorted(o.heap) == [tuple(r) for r in d[f"obj{j}_topkf"].tolist()]
+
+
+def test_fusion():
+    d = golden("fusion")
+    rows = d["clips"][0]
+    a, ka = OS.fuse_views(rows, "l1_medoid")
+    b, kb = OS.fuse_views(rows, "cossim_medoid")
+    c, _ = OS.fuse_views(rows, "avg_pooling")
+    assert np.array_equal(a, d["l1"]) and np.array_equal(b, d["cos"]) and kb == int(d["cos_kf"])
+    assert np.array_equal(c, d["avg"])
+    rec = OS.InstanceRecord(5, 3)
+    feats = {}
+    for kf, area in enumerate(d["areas"].tolist()):
+        rec.observe([kf * 10], kf, area)
+        feats[kf] = {5: d["feats"][kf]}
+        rec.refresh_feature(feats, "avg_pooling")
+        np.testing.assert_allclose(rec.feature.reshape(-1), d["trace"][kf], rtol=0, atol=1e-7)
+    assert sorted(rec.heap) == [tuple(r) for r in d["top_kf"].tolist()]
+
+
+def test_similarity_and_crop_fusion():
+    d = golden("similarity")
+    np.testing.assert_allclose(OF.similarity(d["F"], d["T"]), d["clip"], atol=2e-6, rtol=0)
+    s = OF.similarity(d["F"], d["T"], True, float(d["logit_scale"][0]), float(d["logit_bias"]))
+    np.testing.assert_allclose(s, d["siglip"], atol=2e-6, rtol=0)
+    for mode in ("fixed_weights", "hovsg", "adaptive_weights", "concept_fusion", "vanilla"):
+        out = OF.fuse_crop_descriptors(d["cg"], d["cs"], d["cb"], mode, 0.4418, 0.1)
+        np.testing.assert_allclose(out, d["fuse_" + mode], atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_textregion_pooling(tag):
+    d = golden("textregion")
+    gh, gw, nh, nw = d[f"{tag}_grid"].tolist()
+    P = int(d["crop"]) // int(d["patch"])
+    masks = unpack(d[f"{tag}_masks"], int(d[f"{tag}_mask_w"]))
+    fm = OF.feature_masks(masks, gh, gw)
+    np.testing.assert_allclose(fm, d[f"{tag}_feature_masks"], atol=1e-6, rtol=0)
+    x = OF.stitch_tokens(d[f"{tag}_tokens"][:, 1:], P, gh, gw, nh, nw)
+    np.testing.assert_allclose(x, d[f"{tag}_x_input"][0], atol=1e-6, rtol=0)
+    D = x.shape[1]
+    w, b = d["in_proj_weight"], d["in_proj_bias"]
+    out = OF.region_pool(x, fm, w[2 * D:], b[2 * D:], d["out_proj_weight"], d["out_proj_bias"], d["proj"])
+    np.testing.assert_allclose(out, d[f"{tag}_out"], atol=2e-6, rtol=0)   # masked-mean identity
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_mask_nms_and_segmap(tag):
+    d = golden(f"segment_{tag}")
+    masks = unpack(d["masks"], int(d["mask_w"]))
+    keep = OF.mask_nms(masks, d["stability"] * d["pred_iou"])
+    assert keep.tolist() == d["keep"].tolist()
+    kept = sorted(keep.tolist())                                  # filter(): original order
+    seg, bm = OF.paint_segmap(masks[kept], d["stability"][kept])
+    assert np.array_equal(seg, d["seg_map"])
+    assert np.array_equal(bm, unpack(d["bmaps"], int(d["mask_w"])))
+    assert np.array_equal(OF.masks_to_boxes(masks), d["boxes"])
+
+
+def test_query_and_classify():
+    d = golden("query")
+    rows = d["table"][d["tok_ids"]]                              # [Q, templates, D]
+    T2 = OF.text_embeddings(rows)
+    T1 = OF.text_embeddings(rows[:, :1])
+    np.testing.assert_allclose(OF.similarity(d["feats"], T1), d["sim_single"], atol=2e-6, rtol=0)
+    sim = OF.similarity(d["feats"], T2)
+    np.testing.assert_allclose(sim, d["sim_ensemble"], atol=2e-6, rtol=0)
+    cls, conf = OF.classify(d["sim_ensemble"], float(d["th"]))
+    assert np.array_equal(cls, d["classes"])
+    np.testing.assert_allclose(conf, d["conf"], atol=0, rtol=0)

@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by RUNNING the reference's own pure-torch code on CPU.
+
+Usage (build container only; /root/reference does not exist on the GPU box):
+    python tools/gen_golden.py --reference /root/reference --out tests/golden
+
+The reference has no tests, so these vectors are what pins the oracle: each .npz holds
+the inputs we fed and the outputs the reference returned. Third-party imports that are missing here
+(torchvision, open_clip, perception_models, open3d, wandb) are replaced by empty stub modules; no
+function that actually *calls* a stubbed symbol is used as an oracle, except `depth_filter`, for which
+we inject a documented 7x7 reflect-padded Gaussian so the surrounding tracking logic can be exercised
+with `depth_filter: True` (that fixture pins the tracking, not the blur).
+
+Nothing from the reference is copied: only arrays go to disk. Bytecode writing is disabled.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ovo_amd import synthetic as syn  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def gaussian_blur_7(img: torch.Tensor, k: int, sigma: float) -> torch.Tensor:
+    """Separable Gaussian, reflect padding, kernel from pdf at integer offsets (torchvision semantics)."""
+    half = (k - 1) * 0.5
+    x = torch.linspace(-half, half, k)
+    pdf = torch.exp(-0.5 * (x / sigma) ** 2)
+    k1 = (pdf / pdf.sum()).to(img.dtype)
+    p = k // 2
+    t = torch.nn.functional.pad(img[None], (p, p, p, p), mode="reflect")
+    kern = (k1[:, None] * k1[None, :])[None, None]
+    return torch.nn.functional.conv2d(t, kern)[0]
+
+
+def install_stubs():
+    class _T:  # placeholder transform classes
+        def __init__(self, *a, **k):
+            pass
+    tv = _stub("torchvision")
+    tvt = _stub("torchvision.transforms", Resize=_T, Normalize=_T, CenterCrop=_T, Compose=_T)
+    tvf = _stub("torchvision.transforms.functional")
+    tv2 = _stub("torchvision.transforms.v2")
+    tv2f = _stub("torchvision.transforms.v2.functional", gaussian_blur=gaussian_blur_7)
+    tv.transforms = tvt
+    tvt.functional = tvf
+    tvt.v2 = tv2
+    tv2.functional = tv2f
+    _stub("open_clip")
+    core = _stub("core")
+    ve = _stub("core.vision_encoder")
+    core.vision_encoder = ve
+    ve.pe = _stub("core.vision_encoder.pe")
+    ve.transforms = _stub("core.vision_encoder.transforms")
+    _stub("open3d")
+    _stub("wandb")
+
+
+def t2n(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def save(out, name, **arrays):
+    path = os.path.join(out, name + ".npz")
+    np.savez_compressed(path, **{k: t2n(v) for k, v in arrays.items()})
+    print(f"  wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_geometry(out, G):
+    scale = 0.35
+    h, w = syn.scannet_depth_hw(scale)
+    K = torch.from_numpy(syn.scannet_intrinsics(scale))
+    pts = torch.from_numpy(np.ascontiguousarray(syn.padded_map(24000, frames=2, scale=scale, seed=11)[::3]))
+    for t in (1, 2):
+        c2w = torch.from_numpy(syn.pose(t))
+        depth = torch.from_numpy(syn.render_depth(c2w.numpy(), K.numpy(), h, w, seed=11 + t))
+        corners = G.compute_camera_frustum_corners(depth, c2w, K)
+        ids = G.compute_frustum_point_ids(pts, corners, device="cpu")
+        w2c = torch.linalg.inv(c2w)
+        fpts = pts[ids]
+        mask, matches = G.match_3d_points_to_2d_pixels(depth, w2c, fpts, K, 0.05)
+        hom = torch.hstack([fpts, torch.ones((fpts.shape[0], 1))])
+        uv = G.project_3d_points(hom, K, w2c)
+        assert ids.shape[0] >= 1000, ids.shape
+        save(out, f"geometry_t{t}", pts=pts, depth=depth, c2w=c2w, w2c=w2c, K=K, corners=corners,
+             frustum_ids=ids, match_idx=mask, match_uv=matches, project_uv=uv, th=np.float32(0.05))
+
+
+def gen_mapper(out, VM):
+    scale = 0.35
+    h, w = syn.scannet_depth_hw(scale)
+    K = torch.from_numpy(syn.scannet_intrinsics(scale))
+    cfg = {"device": "cpu", "mapping": {"max_frame_points": 1e5, "k_pooling": 3, "downscale_ratio": 2}}
+    vm = VM(cfg, K)
+    arrays = {"K": K}
+    for i, t in enumerate((0, 1, 2)):
+        fid, rgb, depth, c2w = syn.frame(t, scale=scale, seed=21)
+        fd = [fid, rgb, depth, c2w]
+        vm.track_camera(fd)
+        vm.map(fd, vm.get_c2w(fid))
+        arrays.update({f"rgb{i}": rgb, f"depth{i}": depth, f"c2w{i}": c2w, f"n{i}": np.int64(vm.pcd.shape[0])})
+    arrays.update(pcd=vm.pcd, pcd_ids=vm.pcd_ids, pcd_obj_ids=vm.pcd_obj_ids, pcd_colors=vm.pcd_colors)
+    save(out, "vanilla_mapper", **arrays)
+
+
+def gen_tracking(out, OVOcls, I3D, VM, depth_filter: bool, tag: str):
+    """3 keyframes through VanillaMapper.map + OVO._match_and_track_instances with synthetic masks."""
+    scale = 0.35
+    h, w = syn.scannet_depth_hw(scale)
+    K = torch.from_numpy(syn.scannet_intrinsics(scale))
+    vm = VM({"device": "cpu", "mapping": {}}, K)
+    ovo = OVOcls.__new__(OVOcls)
+    ovo.cam_intrinsics = K
+    ovo.config = {"match_distance_th": 0.05, "track_th": 40, "depth_filter": depth_filter, "log": False}
+    ovo.device = "cpu"
+    ovo.n_top_views = 3
+    I3D.n_top_kf = 3
+    I3D.set_fusion("avg_pooling")
+    ovo.objects = {}
+    ovo.next_ins_id = 0
+    ovo.kf_id = 0
+    ovo.keyframes = {"ins_descriptors": {}, "frame_id": [], "ins_maps": []}
+    arrays = {"K": K, "track_th": np.int64(40), "n_top_views": np.int64(3)}
+    for i, t in enumerate((0, 1, 2, 3)):
+        fid, rgb, depth, c2w = syn.frame(t, scale=scale, seed=31)
+        fd = [fid, rgb, depth, c2w]
+        vm.track_camera(fd)
+        c2w_t = vm.get_c2w(fid)
+        vm.map(fd, c2w_t)
+        masks = syn.make_masks(h, w, grid=(3, 4), n_blobs=4, seed=31 + t)
+        seg = syn.masks_to_segmap(masks)
+        pcd, pcd_ids, obj_ids = vm.get_map()
+        ins_before = obj_ids.clone()
+        matched_ins_ids, bmaps, n_matched, updated = ovo._match_and_track_instances(
+            (rgb, depth, ()), (pcd, pcd_ids, obj_ids), c2w_t, torch.from_numpy(seg), torch.from_numpy(masks.copy()))
+        vm.update_pcd_obj_ids(updated)
+        ovo.kf_id += 1
+        arrays.update({
+            f"rgb{i}": rgb, f"depth{i}": depth, f"c2w{i}": c2w, f"masks{i}": np.packbits(masks, axis=-1),
+            f"seg{i}": seg, f"pcd_n{i}": np.int64(pcd.shape[0]), f"ins_before{i}": ins_before,
+            f"updated{i}": updated, f"matched_ins_ids{i}": np.asarray(matched_ins_ids, dtype=np.int64),
+            f"bmaps{i}": np.packbits(t2n(bmaps), axis=-1), f"n_matched{i}": np.int64(n_matched),
+            f"next_ins_id{i}": np.int64(ovo.next_ins_id),
+        })
+    arrays["pcd"] = vm.pcd
+    arrays["mask_w"] = np.int64(w)
+    ids = sorted(ovo.objects.keys())
+    arrays["obj_ids"] = np.asarray(ids, dtype=np.int64)
+    for j in ids:
+        o = ovo.objects[j]
+        arrays[f"obj{j}_kfs"] = np.asarray(o.kfs_ids, dtype=np.int64)
+        arrays[f"obj{j}_points"] = np.asarray(o.points_ids, dtype=np.int64)
+        arrays[f"obj{j}_topkf"] = np.asarray(sorted(o.top_kf), dtype=np.int64).reshape(-1, 2)
+    save(out, f"tracking_{tag}", **arrays)
+
+
+def gen_fusion(out, I3Dmod):
+    g = torch.Generator().manual_seed(41)
+    clips = torch.randn(1, 7, 64, generator=g)
+    a, ka = I3Dmod.l1_medoid(None, clips)
+    b, kb = I3Dmod.cossim_medoid(None, clips)
+    c, _ = I3Dmod.avg_pooling(None, clips)
+    # Instance3D.update_clip flow with a top-k heap
+    I3D = I3Dmod.Instance3D
+    I3D.n_top_kf = 3
+    I3D.set_fusion("avg_pooling")
+    inst = I3D(5)
+    kf_clips = {}
+    areas = [50, 10, 70, 30, 90]
+    feats = torch.randn(5, 64, generator=g)
+    trace = []
+    for kf, area in enumerate(areas):
+        inst.update([kf * 10], kf, area)
+        kf_clips[kf] = {5: feats[kf]}
+        inst.update_clip(kf_clips)
+        trace.append(inst.clip_feature.clone().reshape(-1))
+    save(out, "fusion", clips=clips, l1=a.reshape(-1), l1_kf=np.int64(int(kb * 0 + ka)), cos=b.reshape(-1), cos_kf=np.int64(int(kb)),
+         avg=c.reshape(-1), areas=np.asarray(areas), feats=feats, trace=torch.stack(trace),
+         top_kf=np.asarray(sorted(inst.top_kf), dtype=np.int64))
+
+
+def gen_similarity(out, CU):
+    g = torch.Generator().manual_seed(51)
+    F = torch.nn.functional.normalize(torch.randn(300, 96, generator=g), dim=-1)
+    T = torch.nn.functional.normalize(torch.randn(17, 96, generator=g), dim=-1)
+    s_clip = CU.clip_cosine_similarity(T, F)
+    scale = torch.tensor([float(np.log(100.0))])
+    s_sig = CU.siglip_cosine_similarity(T, F, scale, -10.0)
+    arrays = dict(F=F, T=T, clip=s_clip, siglip=s_sig, logit_scale=scale, logit_bias=np.float32(-10.0))
+    cg, cs, cb = (torch.nn.functional.normalize(torch.randn(9, 96, generator=g), dim=-1) for _ in range(3))
+    arrays.update(cg=cg, cs=cs, cb=cb)
+    for et in ("fixed_weights", "hovsg", "adaptive_weights", "concept_fusion", "vanilla"):
+        arrays["fuse_" + et] = CU.fuse_clips(cg, cs, cb, et, 0.4418, 0.1)
+    save(out, "similarity", **arrays)
+
+
+def gen_textregion(out, TR):
+    torch.manual_seed(61)
+    D, P, patch = 64, 6, 14          # crop 84 = 6 patches of 14
+    crop = P * patch
+
+    class Pool(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.probe = torch.nn.Parameter(torch.randn(1, 1, D))
+            self.attn = torch.nn.MultiheadAttention(D, 4, batch_first=True)
+            self.layernorm = torch.nn.LayerNorm(D)
+
+    class Visual(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.patch_size = patch
+            self.use_cls_token = True
+            self.attn_pool = Pool()
+            self.proj = torch.nn.Parameter(torch.randn(D, D) * D ** -0.5)
+            self.tokens = None
+
+        def forward_features(self, x, norm=True):
+            self.seen_shape = tuple(x.shape)
+            return self.tokens[: x.shape[0]]
+
+    class VLM(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.visual = Visual()
+
+    vlm = VLM().eval()
+    # non-trivial bias / LN params
+    with torch.no_grad():
+        vlm.visual.attn_pool.attn.in_proj_bias.normal_(0, 0.1)
+        vlm.visual.attn_pool.attn.out_proj.bias.normal_(0, 0.1)
+        vlm.visual.attn_pool.layernorm.weight.normal_(1, 0.1)
+        vlm.visual.attn_pool.layernorm.bias.normal_(0, 0.1)
+    pre = lambda img: torch.nn.functional.interpolate(img[None], (crop, crop), mode="bilinear")[0]
+    arrays = {}
+    for tag, (H, W) in {"a": (100, 150), "b": (170, 260)}.items():   # 1x1 tiles and 2x3 tiles
+        tr = TR.PETextRegion(vlm, "PE-fake-%03d" % crop, pre, remove_global_patch=False, device="cpu", dtype="fp32")
+        nh, nw = max(H // crop, 1), max(W // crop, 1)
+        vlm.visual.tokens = torch.randn(1 + nh * nw, 1 + P * P, D)
+        img = torch.rand(3, H, W)
+        masks = torch.from_numpy(syn.make_masks(H, W, grid=(2, 3), n_blobs=3, seed=61))
+        with torch.no_grad():
+            feats = tr.get_img_features(img)
+            fm = tr.get_features_mask(masks)
+            xin = TR.resize_features(feats[:, 1:], crop, patch, tr.points_per_h, tr.points_per_w, tr.crop_num_h, tr.crop_num_w)
+            outv = tr.pe_value_with_sam2_attn(fm.clone(), feats)
+        arrays.update({f"{tag}_tokens": vlm.visual.tokens, f"{tag}_masks": np.packbits(masks.numpy(), axis=-1),
+                       f"{tag}_mask_w": np.int64(W), f"{tag}_feature_masks": fm, f"{tag}_x_input": xin,
+                       f"{tag}_out": outv, f"{tag}_grid": np.asarray([tr.points_per_h, tr.points_per_w, nh, nw]),
+                       f"{tag}_batch": np.asarray(vlm.visual.seen_shape)})
+    ap = vlm.visual.attn_pool
+    arrays.update(in_proj_weight=ap.attn.in_proj_weight, in_proj_bias=ap.attn.in_proj_bias,
+                  out_proj_weight=ap.attn.out_proj.weight, out_proj_bias=ap.attn.out_proj.bias,
+                  ln_weight=ap.layernorm.weight, ln_bias=ap.layernorm.bias, probe=ap.probe, proj=vlm.visual.proj,
+                  patch=np.int64(patch), crop=np.int64(crop), heads=np.int64(4))
+    save(out, "textregion", **arrays)
+
+
+def gen_segment(out, SU):
+    H, W = 60, 80
+    for tag, with_big, seed in (("a", True, 71), ("b", False, 72), ("c", False, 73)):
+        rng = np.random.default_rng(seed)
+        base = syn.make_masks(H, W, grid=(2, 3), n_blobs=10, seed=seed)
+        # add near-duplicates and nested masks so every NMS rule fires
+        extra = []
+        m = base[0].copy(); m[:2] = False; extra.append(m)                      # IoU > 0.8 with base[0]
+        m = np.zeros((H, W), bool); m[5:15, 5:15] = True; extra.append(m)        # small mask inside base[0]
+        if with_big:
+            m = np.zeros((H, W), bool); m[2:58, 2:78] = True; extra.append(m)    # big mask containing many
+        masks = np.concatenate([base, np.stack(extra)])
+        n = masks.shape[0]
+        pred_iou = rng.uniform(0.82, 1.0, n).astype(np.float32)
+        stab = rng.uniform(0.82, 1.0, n).astype(np.float32)
+        dicts = [{"segmentation": masks[i], "predicted_iou": pred_iou[i], "stability_score": stab[i]} for i in range(n)]
+        keep = SU.mask_nms(torch.from_numpy(masks), torch.from_numpy(stab * pred_iou), iou_thr=0.8, score_thr=0.7, inner_thr=0.5)
+        kept, = SU.masks_update(dicts, iou_thr=0.8, score_thr=0.7, inner_thr=0.5)
+        seg_map, bmaps = SU.mask2segmap(kept, np.zeros((H, W, 3), np.uint8))
+        boxes = SU.batched_mask_to_box(torch.from_numpy(masks))
+        print("   nms", tag, "kept", len(kept), "of", n)
+        save(out, "segment_" + tag, masks=np.packbits(masks, axis=-1), mask_w=np.int64(W), pred_iou=pred_iou, stability=stab,
+             keep=keep, seg_map=seg_map, bmaps=np.packbits(bmaps, axis=-1), boxes=boxes)
+
+
+def gen_query(out, OVOcls, CG, I3D):
+    """OVO.query / classify_instances / capture_dict with a fake text tower (lookup table)."""
+    g = torch.Generator().manual_seed(81)
+    D = 48
+    vocab = {}
+
+    def tokenizer(phrase):
+        return torch.tensor([[vocab.setdefault(phrase, len(vocab))]])
+
+    table = torch.randn(64, D, generator=g)
+
+    class M:
+        def encode_text(self, tok):
+            return table[tok[:, 0]].clone()
+
+    cg = CG.__new__(CG)
+    cg.config, cg.device, cg.model, cg.tokenizer, cg.clip_dim = {}, "cpu", M(), tokenizer, D
+    from ovo.utils import clip_utils as CU
+    cg.get_similarity, cg.similarity_args = CU.clip_cosine_similarity, ()
+    ovo = OVOcls.__new__(OVOcls)
+    ovo.device, ovo.clip_generator, ovo.objects = "cpu", cg, {}
+    ovo.keyframes = {"ins_descriptors": {}, "frame_id": [], "ins_maps": []}
+    feats = torch.nn.functional.normalize(torch.randn(11, D, generator=g), dim=-1)
+    for i, j in enumerate([3, 0, 7, 8, 12, 13, 20, 21, 22, 30, 31]):
+        o = I3D(j)
+        o.clip_feature, o.clip_feature_kf = feats[i], 0
+        ovo.objects[j] = o
+    classes = ["chair", "table", "sofa", "lamp", "floor"]
+    templates = ["This is a photo of a {}", "a {} in a room"]
+    sim1 = ovo.query(classes, "This is a photo of a {}")
+    sim2 = ovo.query(classes, templates)
+    info = ovo.classify_instances(classes, templates, th=0.05)
+    phrases = [[t.format(c) for t in templates] for c in classes]
+    tok_ids = np.asarray([[vocab[p] for p in row] for row in phrases])
+    cap = ovo.capture_dict(False)
+    save(out, "query", feats=feats, obj_ids=np.asarray(list(ovo.objects.keys())), table=table, tok_ids=tok_ids,
+         sim_single=sim1, sim_ensemble=sim2, classes=info["classes"], conf=info["conf"], th=np.float32(0.05),
+         capture_keys=np.asarray(sorted(cap.keys())))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    args = ap.parse_args()
+    if not os.path.isdir(os.path.join(args.reference, "ovo")):
+        print("reference not present: nothing to do (fixtures are committed)")
+        return
+    os.makedirs(args.out, exist_ok=True)
+    install_stubs()
+    sys.path.insert(0, args.reference)
+    torch.set_num_threads(1)
+    from ovo.utils import geometry_utils as G, clip_utils as CU, segment_utils as SU
+    from ovo.slam.vanilla_mapper import VanillaMapper as VM
+    from ovo.entities import instance3d as I3Dmod, textregion as TR
+    from ovo.entities.ovo import OVO as OVOcls
+    from ovo.entities.clip_generator import CLIPGenerator as CG
+    print("torch", torch.__version__, "numpy", np.__version__)
+    gen_geometry(args.out, G)
+    gen_mapper(args.out, VM)
+    gen_tracking(args.out, OVOcls, I3Dmod.Instance3D, VM, False, "nofilter")
+    gen_tracking(args.out, OVOcls, I3Dmod.Instance3D, VM, True, "filter")
+    gen_fusion(args.out, I3Dmod)
+    gen_similarity(args.out, CU)
+    gen_textregion(args.out, TR)
+    gen_segment(args.out, SU)
+    gen_query(args.out, OVOcls, CG, I3Dmod.Instance3D)
+
+
+if __name__ == "__main__":
+    main()
