@@ -1,0 +1,162 @@
+/*
+ * ovo_hip.h -- C ABI of libovo_hip.so, the MI355X (gfx950) implementation of OVO's per-frame
+ * open-vocabulary feature path.
+ *
+ * The reference (tberriel/OVO) is pure Python/PyTorch and has NO FFI of its own:
+ * its boundary is a set of duck-typed Python classes.  This header is the boundary we add underneath
+ * those classes; every entry point names the reference function(s) it replaces (paths relative to the
+ * reference checkout).  The Python side (ovo_amd/) binds it with ctypes: raw device pointers from
+ * tensor.data_ptr(), sizes, and the caller's hipStream_t -- no torch types cross this line.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative OVO_E_* code otherwise; ovo_hip_last_error()
+ *     returns a thread-local message for the last failure.
+ *   - pointers are DEVICE pointers unless the parameter is a small by-value struct or says "host".
+ *   - nothing allocates: scratch comes from the caller (sizes from the *_workspace_bytes() queries).
+ *   - all launches go to `stream`; no function synchronises the device.
+ *   - row-major, C-contiguous arrays; "f32[N,3]" means N rows of 3 floats.
+ */
+#ifndef OVO_HIP_H
+#define OVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OVO_OK 0
+#define OVO_E_ARG (-1)     /* bad argument (null pointer, negative size, unsupported shape) */
+#define OVO_E_LAUNCH (-2)  /* hip launch / runtime error                                     */
+#define OVO_E_UNSUPPORTED (-3)
+
+typedef void *ovo_stream_t; /* hipStream_t */
+
+const char *ovo_hip_last_error(void);
+int ovo_hip_abi_version(void); /* bumped when a signature changes */
+
+/* ---------------------------------------------------------------------------------------------
+ * Camera / frustum parameters for one frame.  Filled on the host (8-corner and 6-plane math is tiny
+ * and stays in torch-CPU, see DESIGN.md "bit-exactness").
+ *   aabb   = min xyz, max xyz of the 8 frustum corners      geometry_utils.py:205-215
+ *   planes = 6 rows (a,b,c,d), inside <=> a x + b y + c z + d <= 0      geometry_utils.py:163-202,233-249
+ *   w2c    = inverse camera pose, row-major 4x4                   ovo.py:216, vanilla_mapper.py:59
+ *   K      = intrinsics, row-major 3x3
+ *   th     = |z - depth[v,u]| threshold in metres                 ovo.yaml:25 / vanilla_mapper.py:17
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    float aabb[6];
+    float planes[24];
+    float w2c[16];
+    float K[9];
+    float th;
+    int32_t h, w; /* depth image size */
+} ovo_camera_t;
+
+/* rgb_depth_ratio of ovo.py:218-221: pixel (u,v) of the depth frame -> pixel of the colour/seg frame:
+ * u' = trunc((u + crop_edge) * r_w), v' = trunc((v + crop_edge) * r_h).  enabled = 0 -> identity. */
+typedef struct {
+    int32_t enabled;
+    float r_h, r_w;
+    int32_t crop_edge;
+} ovo_ratio_t;
+
+/* ---- a2: compute_frustum_point_ids (geometry_utils.py:252-276) ------------------------------
+ * out_idx receives the ascending indices of points inside the AABB and all six planes;
+ * *out_count (device int64) their number.  ws: ovo_compact_workspace_bytes(n). */
+size_t ovo_compact_workspace_bytes(int64_t n);
+int ovo_frustum_ids(const float *pts, int64_t n, const ovo_camera_t *cam, int64_t *out_idx,
+                    int64_t *out_count, void *ws, size_t ws_bytes, ovo_stream_t stream);
+
+/* ---- a3: project_3d_points / match_3d_points_to_2d_pixels (geometry_utils.py:26-89) ----------
+ * pts has `stride` floats per point (3: w := 1, or 4 homogeneous).  No frustum test here: like the
+ * reference it assumes the caller already culled.  ovo_project_points writes i32[n,2] (u,v).
+ * ovo_match_points writes the ascending indices (into pts) and pixels of the points whose pixel is
+ * inside the image, |z - depth| < th and depth != 0. */
+int ovo_project_points(const float *pts, int64_t n, int stride, const ovo_camera_t *cam, int32_t *out_uv,
+                       ovo_stream_t stream);
+int ovo_match_points(const float *pts, int64_t n, int stride, const ovo_camera_t *cam, const float *depth,
+                     int64_t *out_idx, int32_t *out_uv, int64_t *out_count, void *ws, size_t ws_bytes,
+                     ovo_stream_t stream);
+
+/* ---- a4: depth_filter (geometry_utils.py:92-96) ----------------------------------------------
+ * 7x7 Gaussian (sigma 2.5, reflect padding, torchvision kernel), |d - blur| > th -> -1. */
+int ovo_depth_filter(const float *depth, int h, int w, int ksize, float sigma, float th, float *out,
+                     ovo_stream_t stream);
+
+/* ---- a2+a3+a5 fused, tracking form (ovo.py:208-222) --------------------------------------------
+ * One pass over the whole map: cull, project, depth-test, colour-frame remap, seg_map gather.
+ *   point_seg  i16[n]: -2 = not matched, -1 = matched on an unlabelled pixel, >=0 = mask index.
+ *   hist       i32[n_masks, hist_cols] (zeroed here): votes[mask][ins_id+1], column 0 = unassigned
+ *              points; hist_cols must be > max instance id + 1            (ovo.py:257-264 inputs)
+ *   counters   i64[2]: {points in frustum, points matched}  (zeroed here)
+ * point_ins: i32[n] current instance id per point (-1 = none). */
+int ovo_track_project(const float *pts, const int32_t *point_ins, int64_t n, const ovo_camera_t *cam,
+                      const float *depth, const int32_t *seg_map, int seg_h, int seg_w, ovo_ratio_t ratio,
+                      int16_t *point_seg, int32_t *hist, int n_masks, int hist_cols, int64_t *counters,
+                      ovo_stream_t stream);
+
+/* ---- a6 (device half): per-mask vote statistics (ovo.py:255-264) -------------------------------
+ * stats i32[n_masks,4] = {matched points, of which already assigned, mode of their instance ids
+ * (smallest id among ties, -1 if none), mask area in seg_map pixels}. */
+int ovo_vote_stats(const int32_t *hist, int n_masks, int hist_cols, const int32_t *seg_map, int64_t seg_pixels,
+                   int32_t *stats, ovo_stream_t stream);
+
+/* ---- a6 (write half) + a8: ovo.py:228-229,280 -----------------------------------------------------
+ * out_ins = point_ins, except points with point_seg = m >= 0, no instance yet and mask_target[m] > -1,
+ * which receive mask_target[m].  In-place (out_ins == point_ins) is allowed.
+ * new_count (device int64, optional) counts the re-labelled points. */
+int ovo_assign_instances(const int32_t *point_ins, const int16_t *point_seg, int64_t n,
+                         const int32_t *mask_target, int n_masks, int32_t *out_ins, int64_t *new_count,
+                         ovo_stream_t stream);
+
+/* ---- a9: VanillaMapper.map (vanilla_mapper.py:46-85) -------------------------------------------
+ * Step 1 (only when the map is non-empty): mark depth pixels already explained by a map point.
+ *   explained u8[h,w] is zeroed here, then set to 1 at every matched pixel.
+ * Step 2: erode the valid mask (3x3, only when `erode`), subsample [::ds, ::ds], unproject and
+ *   transform by c2w (row-major 4x4, by value in cam2world), append in row-major pixel order at row
+ *   `base` of the capacity buffers: xyz f32[cap,3], ids i32[cap] (= first_id + k), ins i32[cap] (-1),
+ *   rgb u8[cap,3].  *out_count (device int64) = number of appended points.
+ *   ws: ovo_compact_workspace_bytes(ceil(h/ds)*ceil(w/ds)). */
+int ovo_map_explained(const float *pts, int64_t n, const ovo_camera_t *cam, const float *depth,
+                      uint8_t *explained, ovo_stream_t stream);
+int ovo_map_backproject(const float *depth, const uint8_t *rgb, const uint8_t *explained, int h, int w,
+                        int erode, int ds, const float *K9_host, const float *c2w16_host, int64_t base,
+                        int32_t first_id, float *xyz, int32_t *ids, int32_t *ins, uint8_t *out_rgb,
+                        int64_t *out_count, void *ws, size_t ws_bytes, ovo_stream_t stream);
+
+/* ---- a20: multi-view descriptor fusion (instance3d.py:9-21,157-189) -----------------------------
+ * store f32[R,D]: every per-(keyframe, instance) descriptor ever produced (append-only).
+ * For update k, rows csr_rows[csr_off[k] .. csr_off[k+1]) are that instance's views in the order the
+ * reference stacks them.  mode 0 = avg_pooling (mean, NOT re-normalised), 1 = l1_medoid,
+ * 2 = cossim_medoid.  table f32[cap,D] row table_rows[k] receives the fused descriptor; out_view[k]
+ * the medoid's position in the view list (-1 for avg; 0 for a single view). */
+int ovo_fuse_views(const float *store, int D, const int32_t *csr_off, const int32_t *csr_rows, int n_updates,
+                   int mode, float *table, const int32_t *table_rows, int32_t *out_view, ovo_stream_t stream);
+
+/* ---- dense ("voxel") fusion, BASELINE.json configs 3-4 -----------------------------------------
+ * For every point with point_seg = m >= 0 and mask_row[m] >= 0:
+ *   acc[i,:] += desc[mask_row[m],:]; cnt[i] += 1.      acc f32[n,D], cnt i32[n], desc f32[*,D]. */
+int ovo_scatter_accum(const int16_t *point_seg, int64_t n, const int32_t *mask_row, int n_masks,
+                      const float *desc, int D, float *acc, int32_t *cnt, ovo_stream_t stream);
+
+/* ---- a21 + a22: similarity query (clip_utils.py:10-19, ovo.py:487-491) ---------------------------
+ * S[i,q] = row_scale(i) * sum_k F[i,k] T[q,k];  siglip: S = sigmoid(S * exp(logit_scale) + logit_bias).
+ * F is f32 or f16 ([n,D], feat_dtype 0 = f32, 1 = f16, 2 = bf16); T f32[Q,D].
+ * cnt (optional i32[n]): row_scale = 1/cnt (0 rows give 0) -- the dense accumulator form.
+ * out_sim (optional) f32[n,Q]; out_cls (optional) i64[n] first-max argmax, -1 when conf <= th;
+ * out_conf (optional) f32[n] (0 when conf <= th).  Q <= 64 here; larger Q goes through ovo_gemm. */
+int ovo_similarity(const void *F, int feat_dtype, int64_t n, int D, const float *T, int Q, const int32_t *cnt,
+                   int siglip, float logit_scale, float logit_bias, float th, float *out_sim,
+                   int64_t *out_cls, float *out_conf, ovo_stream_t stream);
+
+/* ---- a11: mask NMS intersections (segment_utils.py:218-230) --------------------------------------
+ * bits u64[n, words] bit-packed masks (little-endian bit order, zero padded); inter i32[n,n]. */
+int ovo_mask_intersections(const uint64_t *bits, int n, int64_t words, int32_t *inter, ovo_stream_t stream);
+int ovo_pack_masks(const uint8_t *masks, int n, int64_t pixels, uint64_t *bits, int64_t words, ovo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVO_HIP_H */

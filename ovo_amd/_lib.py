@@ -1,0 +1,118 @@
+"""ctypes binding of libovo_hip.so (the C ABI declared in include/ovo_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this module raises.  Tensors cross
+the boundary as raw device pointers (`tensor.data_ptr()`) plus sizes and torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libovo_hip.so")
+ABI_VERSION = 1
+
+
+class OvoHipError(RuntimeError):
+    pass
+
+
+class Camera(C.Structure):
+    """ovo_camera_t"""
+    _fields_ = [("aabb", C.c_float * 6), ("planes", C.c_float * 24), ("w2c", C.c_float * 16),
+                ("K", C.c_float * 9), ("th", C.c_float), ("h", C.c_int32), ("w", C.c_int32)]
+
+
+class Ratio(C.Structure):
+    """ovo_ratio_t"""
+    _fields_ = [("enabled", C.c_int32), ("r_h", C.c_float), ("r_w", C.c_float), ("crop_edge", C.c_int32)]
+
+
+_P, _I64, _I32, _F32, _SZ = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+_CAM = C.POINTER(Camera)
+
+_SIGNATURES = {
+    "ovo_hip_last_error": (C.c_char_p, []),
+    "ovo_hip_abi_version": (_I32, []),
+    "ovo_compact_workspace_bytes": (_SZ, [_I64]),
+    "ovo_frustum_ids": (_I32, [_P, _I64, _CAM, _P, _P, _P, _SZ, _P]),
+    "ovo_project_points": (_I32, [_P, _I64, _I32, _CAM, _P, _P]),
+    "ovo_match_points": (_I32, [_P, _I64, _I32, _CAM, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ovo_depth_filter": (_I32, [_P, _I32, _I32, _I32, _F32, _F32, _P, _P]),
+    "ovo_track_project": (_I32, [_P, _P, _I64, _CAM, _P, _P, _I32, _I32, Ratio, _P, _P, _I32, _I32, _P, _P]),
+    "ovo_vote_stats": (_I32, [_P, _I32, _I32, _P, _I64, _P, _P]),
+    "ovo_assign_instances": (_I32, [_P, _P, _I64, _P, _I32, _P, _P, _P]),
+    "ovo_map_explained": (_I32, [_P, _I64, _CAM, _P, _P, _P]),
+    "ovo_map_backproject": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ovo_fuse_views": (_I32, [_P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P]),
+    "ovo_scatter_accum": (_I32, [_P, _I64, _P, _I32, _P, _I32, _P, _P, _P]),
+    "ovo_similarity": (_I32, [_P, _I32, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P, _P]),
+    "ovo_mask_intersections": (_I32, [_P, _I32, _I64, _P, _P]),
+    "ovo_pack_masks": (_I32, [_P, _I32, _I64, _P, _I64, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load() -> C.CDLL:
+    """Load the library (no compute, works without a GPU).  Raises OvoHipError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise OvoHipError(f"{SO_PATH} is missing: run `python -m ovo_amd.build` (needs hipcc). "
+                          "ovo_amd has no CPU fallback.")
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library disagree
+        fn.restype, fn.argtypes = res, args
+    if lib.ovo_hip_abi_version() != ABI_VERSION:
+        raise OvoHipError(f"ABI mismatch: library {lib.ovo_hip_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise OvoHipError(f"libovo_hip error {status}: {load().ovo_hip_last_error().decode()}")
+
+
+def stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def dev(t: torch.Tensor, dtype: torch.dtype, name: str = "tensor") -> torch.Tensor:
+    """Validate a tensor that is about to cross the C ABI."""
+    if not t.is_cuda:
+        raise OvoHipError(f"{name} must live on the GPU (got {t.device}); ovo_amd has no CPU path")
+    if t.dtype != dtype:
+        raise OvoHipError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise OvoHipError(f"{name} must be contiguous")
+    return t
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only per-device scratch buffer (u8)."""
+    key = str(device)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

@@ -1,0 +1,57 @@
+// Internal helpers shared by the HIP translation units of libovo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ovo_hip.h"
+
+#define OVO_WAVE 64
+
+void ovo_set_error(const char *fmt, ...);
+
+#define OVO_REQUIRE(cond, msg)                                   \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            ovo_set_error("%s: %s", __func__, msg);              \
+            return OVO_E_ARG;                                    \
+        }                                                        \
+    } while (0)
+
+#define OVO_CHECK_LAUNCH()                                                        \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            ovo_set_error("%s: %s", __func__, hipGetErrorString(e__));            \
+            return OVO_E_LAUNCH;                                                  \
+        }                                                                         \
+    } while (0)
+
+#define OVO_HIP(call)                                                             \
+    do {                                                                          \
+        hipError_t e__ = (call);                                                  \
+        if (e__ != hipSuccess) {                                                  \
+            ovo_set_error("%s: %s -> %s", __func__, #call, hipGetErrorString(e__)); \
+            return OVO_E_LAUNCH;                                                  \
+        }                                                                         \
+    } while (0)
+
+static inline int ovo_grid(int64_t work_items, int block, int cap = 256 * 8) {
+    int64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

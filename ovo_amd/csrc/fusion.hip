@@ -1,0 +1,129 @@
+// fusion.hip -- multi-view descriptor fusion (instance form) and dense per-point scatter-accumulate.
+#include <float.h>
+
+#include "common.h"
+
+namespace {
+
+// One workgroup (256 threads) per instance update.  V = number of views, D = descriptor length.
+// mode 0: mean over views (sequential sum in view order, then one divide -- torch.mean's order for
+//         a short strided reduction), 1: l1 medoid, 2: cosine medoid (instance3d.py:9-21).
+__global__ void __launch_bounds__(256) k_fuse_views(const float *__restrict__ store, int D, const int32_t *__restrict__ csr_off,
+                                                    const int32_t *__restrict__ csr_rows, int mode, float *__restrict__ table,
+                                                    const int32_t *__restrict__ table_rows, int32_t *__restrict__ out_view) {
+    const int k = blockIdx.x, t = threadIdx.x;
+    const int lo = csr_off[k], V = csr_off[k + 1] - lo;
+    float *dst = table + (int64_t)table_rows[k] * D;
+    if (V <= 0) return;
+    if (V == 1 || mode == 0) {
+        for (int d = t; d < D; d += 256) {
+            float s = store[(int64_t)csr_rows[lo] * D + d];
+            for (int v = 1; v < V; ++v) s += store[(int64_t)csr_rows[lo + v] * D + d];
+            dst[d] = V == 1 ? s : s / (float)V;
+        }
+        if (t == 0 && out_view) out_view[k] = V == 1 ? 0 : -1;
+        return;
+    }
+    // medoids: score[i] = sum_j dist(i, j); pick argmin (l1) / argmax (cos), first index on ties
+    __shared__ float red[256];
+    __shared__ float s_best;
+    __shared__ int s_arg;
+    if (t == 0) { s_best = mode == 1 ? FLT_MAX : -FLT_MAX; s_arg = 0; }
+    __syncthreads();
+    for (int i = 0; i < V; ++i) {
+        const float *a = store + (int64_t)csr_rows[lo + i] * D;
+        float score = 0.f;
+        for (int j = 0; j < V; ++j) {
+            const float *b = store + (int64_t)csr_rows[lo + j] * D;
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+            for (int d = t; d < D; d += 256) {
+                const float x = a[d], y = b[d];
+                if (mode == 1) p0 += fabsf(x - y);
+                else { p0 += x * y; p1 += x * x; p2 += y * y; }
+            }
+            for (int r = 0; r < (mode == 1 ? 1 : 3); ++r) {
+                red[t] = r == 0 ? p0 : (r == 1 ? p1 : p2);
+                __syncthreads();
+                for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+                const float tot = red[0];
+                __syncthreads();
+                if (r == 0) p0 = tot; else if (r == 1) p1 = tot; else p2 = tot;
+            }
+            if (mode == 1) score += p0;
+            else score += p0 / (fmaxf(sqrtf(p1), 1e-8f) * fmaxf(sqrtf(p2), 1e-8f));   // torch.cosine_similarity eps
+        }
+        if (t == 0) {
+            const bool better = mode == 1 ? score < s_best : score > s_best;
+            if (better) { s_best = score; s_arg = i; }
+        }
+        __syncthreads();
+    }
+    const float *src = store + (int64_t)csr_rows[lo + s_arg] * D;
+    for (int d = t; d < D; d += 256) dst[d] = src[d];
+    if (t == 0 && out_view) out_view[k] = s_arg;
+}
+
+// Dense fusion: one wave per point slot; lanes stride the descriptor with float4.
+// HBM traffic per matched point: D*4 read-modify-write of acc (desc rows stay in L2).
+__global__ void __launch_bounds__(256) k_scatter_accum(const int16_t *__restrict__ point_seg, int64_t n,
+                                                       const int32_t *__restrict__ mask_row, int n_masks,
+                                                       const float *__restrict__ desc, int D, float *__restrict__ acc,
+                                                       int32_t *__restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int D4 = D >> 2;
+    for (int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64; base < n; base += waves * 64) {
+        // each lane inspects one point of the 64-point chunk, then the wave serves the hits one by one
+        const int64_t i = base + lane;
+        int row = -1;
+        if (i < n) {
+            const int s = point_seg[i];
+            if (s >= 0 && s < n_masks) row = mask_row[s];
+        }
+        unsigned long long hits = __ballot(row >= 0);
+        while (hits) {
+            const int src = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const int r = __shfl(row, src, 64);
+            const int64_t p = base + src;
+            const float4 *d4 = (const float4 *)(desc + (int64_t)r * D);
+            float4 *a4 = (float4 *)(acc + p * D);
+            for (int k = lane; k < D4; k += 64) {
+                float4 a = a4[k];
+                const float4 b = d4[k];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                a4[k] = a;
+            }
+            for (int k = (D4 << 2) + lane; k < D; k += 64) acc[p * D + k] += desc[(int64_t)r * D + k];
+            if (lane == 0) cnt[p] += 1;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ovo_fuse_views(const float *store, int D, const int32_t *csr_off, const int32_t *csr_rows, int n_updates, int mode,
+                   float *table, const int32_t *table_rows, int32_t *out_view, ovo_stream_t stream) {
+    OVO_REQUIRE(n_updates >= 0 && D > 0 && mode >= 0 && mode <= 2, "bad argument");
+    if (n_updates == 0) return OVO_OK;
+    OVO_REQUIRE(store && csr_off && csr_rows && table && table_rows, "null pointer");
+    k_fuse_views<<<n_updates, 256, 0, (hipStream_t)stream>>>(store, D, csr_off, csr_rows, mode, table, table_rows, out_view);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_scatter_accum(const int16_t *point_seg, int64_t n, const int32_t *mask_row, int n_masks, const float *desc,
+                      int D, float *acc, int32_t *cnt, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && D > 0 && n_masks > 0, "bad argument");
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(point_seg && mask_row && desc && acc && cnt, "null pointer");
+    OVO_REQUIRE((((uintptr_t)desc | (uintptr_t)acc) & 15) == 0 && D % 4 == 0, "acc/desc must be 16-byte aligned, D % 4 == 0");
+    k_scatter_accum<<<ovo_grid((n + 63) / 64 * 64, 256), 256, 0, (hipStream_t)stream>>>(point_seg, n, mask_row, n_masks,
+                                                                                       desc, D, acc, cnt);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,497 @@
+// geometry.hip -- frustum cull, projection, depth matching, back-projection, instance voting.
+//
+// Bandwidth-bound integer/float32 work over the point map (12 B per point read).  Numerics are pinned:
+// every 3- or 4-term product is a left-to-right FMA chain, divisions are IEEE, rounding to pixels is
+// half-to-even -- the exact sequence oracle/ovo_oracle.c uses, which is bit-identical to the reference's
+// torch-CPU einsum (tests/golden/geometry_*.npz).  This file is compiled with -ffp-contract=off.
+#include <limits.h>
+
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float dot3(const float *m, float x, float y, float z) {
+    float a = __fmul_rn(m[0], x);
+    a = __fmaf_rn(m[1], y, a);
+    a = __fmaf_rn(m[2], z, a);
+    return a;
+}
+__device__ __forceinline__ float dot4(const float *m, float x, float y, float z, float w) {
+    float a = __fmul_rn(m[0], x);
+    a = __fmaf_rn(m[1], y, a);
+    a = __fmaf_rn(m[2], z, a);
+    a = __fmaf_rn(m[3], w, a);
+    return a;
+}
+// tensor.int() of the reference's CPU path: truncation, INT_MIN when unrepresentable.
+__device__ __forceinline__ int f2i(float v) {
+    if (!(v > -2147483904.0f && v < 2147483648.0f)) return INT_MIN;
+    return (int)v;
+}
+
+__device__ __forceinline__ bool in_frustum(const ovo_camera_t &c, float x, float y, float z) {
+    if (!(x >= c.aabb[0] && x <= c.aabb[3] && y >= c.aabb[1] && y <= c.aabb[4] && z >= c.aabb[2] && z <= c.aabb[5]))
+        return false;
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) ok = ok && (dot4(c.planes + 4 * p, x, y, z, 1.0f) <= 0.0f);
+    return ok;
+}
+
+__device__ __forceinline__ void project(const ovo_camera_t &c, float x, float y, float z, float w, float &zc,
+                                        int &u, int &v) {
+    float lx = dot4(c.w2c, x, y, z, w), ly = dot4(c.w2c + 4, x, y, z, w);
+    float lz = dot4(c.w2c + 8, x, y, z, w), lw = dot4(c.w2c + 12, x, y, z, w);
+    zc = lz;
+    float cx = __fdiv_rn(lx, lw), cy = __fdiv_rn(ly, lw), cz = __fdiv_rn(lz, lw);
+    float pu = dot3(c.K, cx, cy, cz), pv = dot3(c.K + 3, cx, cy, cz), pw = dot3(c.K + 6, cx, cy, cz);
+    u = f2i(rintf(__fdiv_rn(pu, pw)));
+    v = f2i(rintf(__fdiv_rn(pv, pw)));
+}
+
+__device__ __forceinline__ bool depth_match(const ovo_camera_t &c, const float *__restrict__ depth, float zc, int u,
+                                            int v) {
+    if (!(u < c.w && v < c.h && u >= 0 && v >= 0)) return false;
+    float d = depth[(int64_t)v * c.w + u];
+    return (fabsf(__fsub_rn(zc, d)) < c.th) && (d != 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ordered stream compaction: (A) one ballot word per 64 items, (B) single-block exclusive scan of the
+// word popcounts, (C) emit at offset + rank-in-word.  Output order == input order, which the reference's
+// boolean-mask indexing guarantees and pcd_ids depend on.
+// ws layout: u64 words[n_words] | i64 offs[n_words]
+struct CompactWs {
+    unsigned long long *words;
+    long long *offs;
+    int64_t n_words;
+};
+
+__host__ CompactWs carve(void *ws, int64_t n) {
+    CompactWs c;
+    c.n_words = (n + 63) / 64;
+    c.words = (unsigned long long *)ws;
+    c.offs = (long long *)(c.words + c.n_words);
+    return c;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_words(const unsigned long long *__restrict__ words, long long *__restrict__ offs,
+                                                     int64_t n_words, long long *__restrict__ total) {
+    __shared__ long long part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (n_words + 1023) / 1024;
+    const int64_t lo = t * per, hi = lo + per < n_words ? lo + per : n_words;
+    long long s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += __popcll(words[i]);
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
+        long long v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    long long run = part[t] - s;
+    for (int64_t i = lo; i < hi; ++i) {
+        offs[i] = run;
+        run += __popcll(words[i]);
+    }
+    if (t == 1023 && total) *total = part[1023];
+}
+
+template <typename Pred>
+__device__ __forceinline__ void flag_words(int64_t n, unsigned long long *words, Pred pred) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t n_words = (n + 63) >> 6;
+    for (int64_t wd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wd < n_words; wd += waves) {
+        const int64_t i = wd * 64 + lane;
+        const bool p = i < n && pred(i);
+        const unsigned long long m = __ballot(p);
+        if (lane == 0) words[wd] = m;
+    }
+}
+
+template <typename Emit>
+__device__ __forceinline__ void emit_words(int64_t n, const unsigned long long *words, const long long *offs, Emit emit) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t n_words = (n + 63) >> 6;
+    for (int64_t wd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wd < n_words; wd += waves) {
+        const unsigned long long m = words[wd];
+        if ((m >> lane) & 1ull) {
+            const long long pos = offs[wd] + __popcll(m & ((1ull << lane) - 1ull));
+            emit(wd * 64 + lane, pos);
+        }
+    }
+}
+
+// ---- a2 ----
+__global__ void __launch_bounds__(256) k_frustum_flag(const float *__restrict__ pts, int64_t n, ovo_camera_t cam,
+                                                      unsigned long long *words) {
+    flag_words(n, words, [&](int64_t i) { return in_frustum(cam, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]); });
+}
+__global__ void __launch_bounds__(256) k_frustum_emit(int64_t n, const unsigned long long *words, const long long *offs,
+                                                      int64_t *out_idx) {
+    emit_words(n, words, offs, [&](int64_t i, long long pos) { out_idx[pos] = i; });
+}
+
+// ---- a3 ----
+__global__ void __launch_bounds__(256) k_project(const float *__restrict__ pts, int64_t n, int stride, ovo_camera_t cam,
+                                                 int32_t *__restrict__ out_uv) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float *p = pts + i * stride;
+        float zc; int u, v;
+        project(cam, p[0], p[1], p[2], stride == 4 ? p[3] : 1.0f, zc, u, v);
+        out_uv[2 * i] = u;
+        out_uv[2 * i + 1] = v;
+    }
+}
+__global__ void __launch_bounds__(256) k_match_flag(const float *__restrict__ pts, int64_t n, int stride, ovo_camera_t cam,
+                                                    const float *__restrict__ depth, unsigned long long *words) {
+    flag_words(n, words, [&](int64_t i) {
+        const float *p = pts + i * stride;
+        float zc; int u, v;
+        project(cam, p[0], p[1], p[2], stride == 4 ? p[3] : 1.0f, zc, u, v);
+        return depth_match(cam, depth, zc, u, v);
+    });
+}
+__global__ void __launch_bounds__(256) k_match_emit(const float *__restrict__ pts, int64_t n, int stride, ovo_camera_t cam,
+                                                    const unsigned long long *words, const long long *offs,
+                                                    int64_t *out_idx, int32_t *out_uv) {
+    emit_words(n, words, offs, [&](int64_t i, long long pos) {
+        const float *p = pts + i * stride;
+        float zc; int u, v;
+        project(cam, p[0], p[1], p[2], stride == 4 ? p[3] : 1.0f, zc, u, v);
+        out_idx[pos] = i;
+        out_uv[2 * pos] = u;
+        out_uv[2 * pos + 1] = v;
+    });
+}
+
+// ---- fused tracking pass (a2+a3+a5 + vote histogram) ----
+// Wave-aggregated histogram: neighbouring map points come from neighbouring pixels and mostly share the
+// (mask, instance) cell, so one atomic per distinct cell per wave instead of one per point.
+__device__ __forceinline__ void wave_hist_add(int32_t *hist, int cell, bool active) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(cell, leader, 64);
+        const unsigned long long same = __ballot(active && cell == k);
+        if (lane == leader) atomicAdd(hist + k, (int)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_track_project(const float *__restrict__ pts, const int32_t *__restrict__ point_ins,
+                                                       int64_t n, ovo_camera_t cam, const float *__restrict__ depth,
+                                                       const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
+                                                       ovo_ratio_t ratio, int16_t *__restrict__ point_seg,
+                                                       int32_t *__restrict__ hist, int n_masks, int hist_cols,
+                                                       unsigned long long *__restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    long long n_in = 0, n_match = 0;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n_round = ((n + 63) / 64) * 64;      // keep whole waves in the loop (ballots inside)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += step) {
+        int seg = -2;
+        int cell = 0;
+        bool vote = false;
+        if (i < n) {
+            const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+            if (in_frustum(cam, x, y, z)) {
+                ++n_in;
+                float zc; int u, v;
+                project(cam, x, y, z, 1.0f, zc, u, v);
+                if (depth_match(cam, depth, zc, u, v)) {
+                    ++n_match;
+                    if (ratio.enabled) {
+                        u = f2i(__fmul_rn((float)(u + ratio.crop_edge), ratio.r_w));
+                        v = f2i(__fmul_rn((float)(v + ratio.crop_edge), ratio.r_h));
+                    }
+                    seg = -1;
+                    if (u >= 0 && v >= 0 && u < seg_w && v < seg_h) seg = seg_map[(int64_t)v * seg_w + u];
+                    if (seg >= n_masks) seg = -1;
+                    if (seg >= 0) {
+                        int ins = point_ins[i];
+                        if (ins + 1 >= hist_cols) ins = -1;   // never taken: the host sizes hist_cols > max id + 1
+                        cell = seg * hist_cols + (ins < 0 ? 0 : ins + 1);
+                        vote = true;
+                    }
+                }
+            }
+            point_seg[i] = (int16_t)seg;
+        }
+        wave_hist_add(hist, cell, vote);
+    }
+    // per-wave reduction of the two counters, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) {
+        n_in += __shfl_xor(n_in, o, 64);
+        n_match += __shfl_xor(n_match, o, 64);
+    }
+    if (lane == 0) {
+        if (n_in) atomicAdd(counters, (unsigned long long)n_in);
+        if (n_match) atomicAdd(counters + 1, (unsigned long long)n_match);
+    }
+}
+
+// ---- a6: per-mask statistics ----
+__global__ void __launch_bounds__(256) k_seg_area(const int32_t *__restrict__ seg_map, int64_t pixels, int n_masks,
+                                                  int32_t *__restrict__ stats) {
+    extern __shared__ int area[];
+    for (int i = threadIdx.x; i < n_masks; i += blockDim.x) area[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = seg_map[i];
+        if (s >= 0 && s < n_masks) atomicAdd(area + s, 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_masks; i += blockDim.x)
+        if (area[i]) atomicAdd(stats + 4 * i + 3, area[i]);
+}
+
+__global__ void __launch_bounds__(256) k_vote_stats(const int32_t *__restrict__ hist, int hist_cols, int32_t *__restrict__ stats) {
+    // one block per mask: total, assigned, mode with smallest-id tie break (torch.mode on CPU)
+    __shared__ long long s_cnt[256];
+    __shared__ int s_best[256], s_arg[256];
+    const int m = blockIdx.x, t = threadIdx.x;
+    const int32_t *row = hist + (int64_t)m * hist_cols;
+    long long assigned = 0;
+    int best = 0, arg = -1;
+    for (int c = 1 + t; c < hist_cols; c += 256) {
+        const int v = row[c];
+        assigned += v;
+        if (v > best) { best = v; arg = c - 1; }     // ascending c per thread => first hit is the smallest id
+    }
+    s_cnt[t] = assigned; s_best[t] = best; s_arg[t] = arg;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            s_cnt[t] += s_cnt[t + o];
+            const int b2 = s_best[t + o], a2 = s_arg[t + o];
+            if (b2 > s_best[t] || (b2 == s_best[t] && b2 > 0 && (s_arg[t] < 0 || a2 < s_arg[t]))) {
+                s_best[t] = b2; s_arg[t] = a2;
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        stats[4 * m + 0] = (int)(s_cnt[0] + row[0]);
+        stats[4 * m + 1] = (int)s_cnt[0];
+        stats[4 * m + 2] = s_arg[0];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_assign(const int32_t *__restrict__ point_ins, const int16_t *__restrict__ point_seg,
+                                                int64_t n, const int32_t *__restrict__ mask_target, int n_masks,
+                                                int32_t *__restrict__ out_ins, unsigned long long *__restrict__ new_count) {
+    long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int ins = point_ins[i];
+        const int s = point_seg[i];
+        if (s >= 0 && s < n_masks && ins == -1) {
+            const int tgt = mask_target[s];
+            if (tgt > -1) { ins = tgt; ++c; }
+        }
+        out_ins[i] = ins;
+    }
+    if (new_count) {
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(new_count, (unsigned long long)c);
+    }
+}
+
+// ---- a9 ----
+__global__ void __launch_bounds__(256) k_map_explained(const float *__restrict__ pts, int64_t n, ovo_camera_t cam,
+                                                       const float *__restrict__ depth, uint8_t *__restrict__ explained) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        if (!in_frustum(cam, x, y, z)) continue;
+        float zc; int u, v;
+        project(cam, x, y, z, 1.0f, zc, u, v);
+        if (depth_match(cam, depth, zc, u, v)) explained[(int64_t)v * cam.w + u] = 1;
+    }
+}
+
+struct BackprojArgs {
+    float K[9];
+    float c2w[16];
+    int h, w, ds, ws_w, erode;
+};
+
+__device__ __forceinline__ bool px_valid(const float *depth, const uint8_t *explained, int64_t i) {
+    return depth[i] > 0.0f && !(explained && explained[i]);
+}
+
+__global__ void __launch_bounds__(256) k_backproj_flag(const float *__restrict__ depth, const uint8_t *__restrict__ explained,
+                                                       BackprojArgs a, int64_t n_sub, unsigned long long *words) {
+    flag_words(n_sub, words, [&](int64_t k) {
+        const int y = (int)(k / a.ws_w) * a.ds, x = (int)(k % a.ws_w) * a.ds;
+        if (!px_valid(depth, explained, (int64_t)y * a.w + x)) return false;
+        if (a.erode) {
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if (yy < 0 || yy >= a.h || xx < 0 || xx >= a.w) continue;
+                    if (!px_valid(depth, explained, (int64_t)yy * a.w + xx)) return false;
+                }
+        }
+        return true;
+    });
+}
+
+__global__ void __launch_bounds__(256) k_backproj_emit(const float *__restrict__ depth, const uint8_t *__restrict__ rgb, BackprojArgs a,
+                                                       int64_t n_sub, const unsigned long long *words, const long long *offs,
+                                                       int64_t base, int32_t first_id, float *xyz, int32_t *ids, int32_t *ins,
+                                                       uint8_t *out_rgb) {
+    emit_words(n_sub, words, offs, [&](int64_t k, long long pos) {
+        const int y = (int)(k / a.ws_w) * a.ds, x = (int)(k % a.ws_w) * a.ds;
+        const int64_t px = (int64_t)y * a.w + x;
+        const float d = depth[px];
+        const float x3 = __fdiv_rn(__fmul_rn(__fsub_rn((float)x, a.K[2]), d), a.K[0]);
+        const float y3 = __fdiv_rn(__fmul_rn(__fsub_rn((float)y, a.K[5]), d), a.K[4]);
+        const int64_t r = base + pos;
+        xyz[3 * r + 0] = dot4(a.c2w, x3, y3, d, 1.0f);
+        xyz[3 * r + 1] = dot4(a.c2w + 4, x3, y3, d, 1.0f);
+        xyz[3 * r + 2] = dot4(a.c2w + 8, x3, y3, d, 1.0f);
+        ids[r] = first_id + (int32_t)pos;
+        ins[r] = -1;
+        if (rgb) {
+            out_rgb[3 * r + 0] = rgb[3 * px + 0];
+            out_rgb[3 * r + 1] = rgb[3 * px + 1];
+            out_rgb[3 * r + 2] = rgb[3 * px + 2];
+        }
+    });
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+size_t ovo_compact_workspace_bytes(int64_t n) {
+    const int64_t w = (n + 63) / 64 + 1;
+    return (size_t)w * 16;
+}
+
+int ovo_frustum_ids(const float *pts, int64_t n, const ovo_camera_t *cam, int64_t *out_idx, int64_t *out_count,
+                    void *ws, size_t ws_bytes, ovo_stream_t stream) {
+    OVO_REQUIRE(cam && out_count && n >= 0, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { OVO_HIP(hipMemsetAsync(out_count, 0, 8, s)); return OVO_OK; }
+    OVO_REQUIRE(pts && out_idx && ws && ws_bytes >= ovo_compact_workspace_bytes(n), "workspace too small");
+    CompactWs c = carve(ws, n);
+    const int g = ovo_grid(n, 256);
+    k_frustum_flag<<<g, 256, 0, s>>>(pts, n, *cam, c.words);
+    k_scan_words<<<1, 1024, 0, s>>>(c.words, c.offs, c.n_words, (long long *)out_count);
+    k_frustum_emit<<<g, 256, 0, s>>>(n, c.words, c.offs, out_idx);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_project_points(const float *pts, int64_t n, int stride, const ovo_camera_t *cam, int32_t *out_uv,
+                       ovo_stream_t stream) {
+    OVO_REQUIRE(cam && n >= 0 && (stride == 3 || stride == 4), "bad argument");
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(pts && out_uv, "null pointer");
+    k_project<<<ovo_grid(n, 256), 256, 0, (hipStream_t)stream>>>(pts, n, stride, *cam, out_uv);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_match_points(const float *pts, int64_t n, int stride, const ovo_camera_t *cam, const float *depth,
+                     int64_t *out_idx, int32_t *out_uv, int64_t *out_count, void *ws, size_t ws_bytes,
+                     ovo_stream_t stream) {
+    OVO_REQUIRE(cam && out_count && n >= 0 && (stride == 3 || stride == 4), "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) { OVO_HIP(hipMemsetAsync(out_count, 0, 8, s)); return OVO_OK; }
+    OVO_REQUIRE(pts && depth && out_idx && out_uv && ws && ws_bytes >= ovo_compact_workspace_bytes(n), "null / workspace");
+    CompactWs c = carve(ws, n);
+    const int g = ovo_grid(n, 256);
+    k_match_flag<<<g, 256, 0, s>>>(pts, n, stride, *cam, depth, c.words);
+    k_scan_words<<<1, 1024, 0, s>>>(c.words, c.offs, c.n_words, (long long *)out_count);
+    k_match_emit<<<g, 256, 0, s>>>(pts, n, stride, *cam, c.words, c.offs, out_idx, out_uv);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_track_project(const float *pts, const int32_t *point_ins, int64_t n, const ovo_camera_t *cam,
+                      const float *depth, const int32_t *seg_map, int seg_h, int seg_w, ovo_ratio_t ratio,
+                      int16_t *point_seg, int32_t *hist, int n_masks, int hist_cols, int64_t *counters,
+                      ovo_stream_t stream) {
+    OVO_REQUIRE(cam && depth && seg_map && hist && counters && n >= 0, "null argument");
+    OVO_REQUIRE(n_masks > 0 && n_masks < 32767 && hist_cols >= 1, "bad mask / histogram shape");
+    hipStream_t s = (hipStream_t)stream;
+    OVO_HIP(hipMemsetAsync(hist, 0, (size_t)n_masks * hist_cols * sizeof(int32_t), s));
+    OVO_HIP(hipMemsetAsync(counters, 0, 16, s));
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(pts && point_ins && point_seg, "null pointer");
+    k_track_project<<<ovo_grid(n, 256), 256, 0, s>>>(pts, point_ins, n, *cam, depth, seg_map, seg_h, seg_w, ratio,
+                                                      point_seg, hist, n_masks, hist_cols,
+                                                      (unsigned long long *)counters);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_vote_stats(const int32_t *hist, int n_masks, int hist_cols, const int32_t *seg_map, int64_t seg_pixels,
+                   int32_t *stats, ovo_stream_t stream) {
+    OVO_REQUIRE(hist && seg_map && stats && n_masks > 0 && hist_cols >= 1, "bad argument");
+    OVO_REQUIRE(n_masks <= 8192, "more than 8192 masks");
+    hipStream_t s = (hipStream_t)stream;
+    OVO_HIP(hipMemsetAsync(stats, 0, (size_t)n_masks * 4 * sizeof(int32_t), s));
+    k_seg_area<<<ovo_grid(seg_pixels, 256, 256), 256, n_masks * sizeof(int), s>>>(seg_map, seg_pixels, n_masks, stats);
+    k_vote_stats<<<n_masks, 256, 0, s>>>(hist, hist_cols, stats);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_assign_instances(const int32_t *point_ins, const int16_t *point_seg, int64_t n, const int32_t *mask_target,
+                         int n_masks, int32_t *out_ins, int64_t *new_count, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && mask_target && n_masks > 0, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (new_count) OVO_HIP(hipMemsetAsync(new_count, 0, 8, s));
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(point_ins && point_seg && out_ins, "null pointer");
+    k_assign<<<ovo_grid(n, 256), 256, 0, s>>>(point_ins, point_seg, n, mask_target, n_masks, out_ins,
+                                               (unsigned long long *)new_count);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_map_explained(const float *pts, int64_t n, const ovo_camera_t *cam, const float *depth, uint8_t *explained,
+                      ovo_stream_t stream) {
+    OVO_REQUIRE(cam && depth && explained && n >= 0, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    OVO_HIP(hipMemsetAsync(explained, 0, (size_t)cam->h * cam->w, s));
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(pts, "null pointer");
+    k_map_explained<<<ovo_grid(n, 256), 256, 0, s>>>(pts, n, *cam, depth, explained);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_map_backproject(const float *depth, const uint8_t *rgb, const uint8_t *explained, int h, int w, int erode,
+                        int ds, const float *K9_host, const float *c2w16_host, int64_t base, int32_t first_id,
+                        float *xyz, int32_t *ids, int32_t *ins, uint8_t *out_rgb, int64_t *out_count, void *ws,
+                        size_t ws_bytes, ovo_stream_t stream) {
+    OVO_REQUIRE(depth && K9_host && c2w16_host && xyz && ids && ins && out_count && ws, "null argument");
+    OVO_REQUIRE(h > 0 && w > 0 && ds >= 1 && base >= 0, "bad shape");
+    BackprojArgs a;
+    for (int i = 0; i < 9; ++i) a.K[i] = K9_host[i];
+    for (int i = 0; i < 16; ++i) a.c2w[i] = c2w16_host[i];
+    a.h = h; a.w = w; a.ds = ds; a.erode = erode;
+    a.ws_w = (w + ds - 1) / ds;
+    const int64_t n_sub = (int64_t)((h + ds - 1) / ds) * a.ws_w;
+    OVO_REQUIRE(ws_bytes >= ovo_compact_workspace_bytes(n_sub), "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    CompactWs c = carve(ws, n_sub);
+    const int g = ovo_grid(n_sub, 256);
+    k_backproj_flag<<<g, 256, 0, s>>>(depth, explained, a, n_sub, c.words);
+    k_scan_words<<<1, 1024, 0, s>>>(c.words, c.offs, c.n_words, (long long *)out_count);
+    k_backproj_emit<<<g, 256, 0, s>>>(depth, rgb, a, n_sub, c.words, c.offs, base, first_id, xyz, ids, ins, out_rgb);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// image.hip -- per-frame image-space helpers: depth high-pass filter (geometry_utils.py:92-96),
+// mask bit-packing and pairwise mask intersections for NMS (segment_utils.py:195-230).
+#include "common.h"
+
+namespace {
+
+struct BlurTaps { float w[15 * 15]; int k; };
+
+__device__ __forceinline__ int reflect(int i, int n) {   // torch 'reflect' padding (no edge repeat)
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+__global__ void __launch_bounds__(256) k_depth_filter(const float *__restrict__ depth, int h, int w, BlurTaps taps, float th,
+                                                      float *__restrict__ out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int k = taps.k, p = k >> 1;
+    float acc = 0.f;
+    for (int dy = 0; dy < k; ++dy) {
+        const int yy = reflect(y + dy - p, h);
+        for (int dx = 0; dx < k; ++dx) {
+            const int xx = reflect(x + dx - p, w);
+            acc = fmaf(taps.w[dy * k + dx], depth[(int64_t)yy * w + xx], acc);
+        }
+    }
+    const float d = depth[(int64_t)y * w + x];
+    out[(int64_t)y * w + x] = fabsf(d - acc) > th ? -1.0f : d;
+}
+
+__global__ void __launch_bounds__(256) k_pack_masks(const uint8_t *__restrict__ masks, int64_t pixels, unsigned long long *__restrict__ bits,
+                                                    int64_t words) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.y;
+    const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t wd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wd < words; wd += waves) {
+        const int64_t px = wd * 64 + lane;
+        const bool b = px < pixels && masks[(int64_t)m * pixels + px] != 0;
+        const unsigned long long v = __ballot(b);
+        if (lane == 0) bits[(int64_t)m * words + wd] = v;
+    }
+}
+
+// inter[i][j] = popcount(mask_i & mask_j); block = one i and a strip of 4 j's (one wave each).
+__global__ void __launch_bounds__(256) k_mask_inter(const unsigned long long *__restrict__ bits, int n, int64_t words,
+                                                    int32_t *__restrict__ inter) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= n || j < i) return;
+    const unsigned long long *a = bits + (int64_t)i * words, *b = bits + (int64_t)j * words;
+    int c = 0;
+    for (int64_t k = lane; k < words; k += 64) c += __popcll(a[k] & b[k]);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) { inter[(int64_t)i * n + j] = c; inter[(int64_t)j * n + i] = c; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ovo_depth_filter(const float *depth, int h, int w, int ksize, float sigma, float th, float *out, ovo_stream_t stream) {
+    OVO_REQUIRE(depth && out && h > 0 && w > 0, "null / empty image");
+    OVO_REQUIRE(ksize >= 1 && ksize <= 15 && (ksize & 1) && sigma > 0.f, "ksize must be odd and <= 15");
+    OVO_REQUIRE(h > ksize / 2 && w > ksize / 2, "image smaller than the reflect padding");
+    BlurTaps t;
+    t.k = ksize;
+    // torchvision _get_gaussian_kernel1d: pdf at linspace(-(k-1)/2, (k-1)/2, k), normalised, in fp32
+    float k1[15], sum = 0.f;
+    const float half = (ksize - 1) * 0.5f;
+    for (int i = 0; i < ksize; ++i) {
+        const float x = ksize == 1 ? 0.f : -half + (2.f * half) * (float)i / (float)(ksize - 1);
+        const float r = x / sigma;
+        k1[i] = expf(-0.5f * r * r);
+        sum += k1[i];
+    }
+    for (int i = 0; i < ksize; ++i) k1[i] /= sum;
+    for (int a = 0; a < ksize; ++a)
+        for (int b = 0; b < ksize; ++b) t.w[a * ksize + b] = k1[a] * k1[b];
+    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    k_depth_filter<<<grid, 256, 0, (hipStream_t)stream>>>(depth, h, w, t, th, out);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_pack_masks(const uint8_t *masks, int n, int64_t pixels, uint64_t *bits, int64_t words, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && pixels > 0 && words * 64 >= pixels, "bad shape");
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(masks && bits && n <= 65535, "null pointer / too many masks");
+    dim3 grid(ovo_grid(words * 64, 256, 64), n);
+    k_pack_masks<<<grid, 256, 0, (hipStream_t)stream>>>(masks, pixels, (unsigned long long *)bits, words);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_mask_intersections(const uint64_t *bits, int n, int64_t words, int32_t *inter, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && words > 0, "bad shape");
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(bits && inter && n <= 65535, "null pointer / too many masks");
+    dim3 grid((n + 3) / 4, n);
+    k_mask_inter<<<grid, 256, 0, (hipStream_t)stream>>>((const unsigned long long *)bits, n, words, inter);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,356 @@
+"""Semantic core of the open-vocabulary map on MI355X: mask <-> 3D-instance tracking, keyframe queue,
+descriptor fusion, text query.
+
+Mirror of the reference's `ovo/entities/ovo.py:OVO` -- the "entities update" API `OVOSemMap.run` and
+`run_eval.py` call: same constructor, same methods, same return types, same checkpoint
+keys.  What changed underneath:
+
+  reference (ovo.py)                                    here
+  ----------------------------------------------------  -------------------------------------------------
+  :209-222  cull, gather, project, depth-test, seg      ONE pass `ovo_track_project` over the map: writes a
+            lookup as ~15 torch ops + 4 compactions      per-point mask id and the [mask x instance] vote table
+  :255-280  python loop, >=3 device syncs per mask       `ovo_vote_stats` -> one 16 B/mask D2H, host decisions on
+                                                         that table (instance-id allocation order preserved)
+  :228-229,:280 clone + two scatters                     `ovo_assign_instances`
+  :349,:437 descriptors to CPU, dict of tensors          DescriptorBank rows on the GPU
+  :459-460  per-instance torch fusion on CPU             one `ovo_fuse_views` launch per keyframe
+  :513-527  re-stack + re-upload on every query          gather from the resident table, `ovo_similarity`
+"""
+from __future__ import annotations
+
+import time
+from collections import deque
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..utils import geometry_utils as G
+from .descriptor_bank import DescriptorBank, KeyframeView
+from .instance3d import Instance3D
+
+
+def _timed(slot: str):
+    """Per-stage wall clock like the reference's `profil` decorator (ovo.py:101-119), active when config['log']."""
+    def deco(fn):
+        def wrapper(self, *a, **k):
+            if not self.config.get("log", False):
+                return fn(self, *a, **k)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            out = fn(self, *a, **k)
+            torch.cuda.synchronize()
+            self._time_cache.append(time.time() - t0)
+            return out
+        return wrapper
+    return deco
+
+
+class OVO:
+    def __init__(self, config: Dict[str, Any], logger=None, scene_name: Optional[str] = None,
+                 cam_intrinsics: Optional[torch.Tensor] = None, eval: bool = False, device="cuda",
+                 clip_generator=None, mask_generator=None) -> None:
+        """Reference: ovo.py:24-69.  `clip_generator` / `mask_generator` may be injected (tests, bench)."""
+        if not eval:
+            assert cam_intrinsics is not None, "Camera intrinsics required for reconstruction!"
+        config.setdefault("sam", {})
+        config.setdefault("clip", {})
+        config["sam"]["multi_crop"] = config["clip"].get("embed_type", "vanilla") != "vanilla"
+        self.cam_intrinsics = cam_intrinsics
+        self._K_host = None if cam_intrinsics is None else G._cpu32(cam_intrinsics).contiguous()
+        self.config = config
+        self.logger = logger
+        self.debug_info = config.get("debug_info", False)
+        self.device = device
+        self.n_top_views = config["clip"].get("k_top_views", 0)
+        Instance3D.n_top_kf = self.n_top_views
+        Instance3D.set_fusion(config["clip"].get("fusion", "l1_medoid"), config["clip"].get("mv_fuser_ckpt"))
+        if "mask_res" in config["sam"] and "mask_res" not in config["clip"]:
+            config["clip"]["mask_res"] = config["sam"]["mask_res"]
+
+        if clip_generator is None:
+            from .clip_generator import CLIPGenerator
+            clip_generator = CLIPGenerator(config["clip"], device=device)
+        self.clip_generator = clip_generator
+        if not eval and mask_generator is None:
+            from .mask_generator import MaskGenerator
+            mask_generator = MaskGenerator(config["sam"], scene_name, device=device)
+        self.mask_generator = None if eval else mask_generator
+
+        self.bank = DescriptorBank(self.clip_generator.clip_dim, device)
+        self.keyframes = {"ins_descriptors": dict(), "frame_id": list(), "ins_maps": list()}
+        self.keyframes_queue = deque([])
+        self.objects: Dict[int, Instance3D] = dict()
+        self._time_cache: List[float] = []
+        self.next_ins_id = 0
+        self.kf_id = 0
+        self.last_point_seg: Optional[torch.Tensor] = None     # i16[N] mask id per map point of the last keyframe
+        self.last_mask_rows: Optional[List[int]] = None
+        # loop-closure thresholds (ovo.py:62-65); update_map itself is a "next" row
+        self.th_centroid = config.get("th_centroid", 1.5)
+        self.th_cossim = config.get("th_cossim", 0.81)
+        self.th_points = config.get("th_points", 0.1)
+
+    # ------------------------------------------------------------------ device moves (ovo.py:72-99)
+    def to(self, device: str) -> None:
+        return self.cuda() if "cuda" in device else self.cpu()
+
+    def cpu(self) -> None:
+        """The reference parks its models on the CPU here; this build's kernels only run on the GPU, so
+        the call releases nothing and only records the request."""
+        self.device = "cpu"
+
+    def cuda(self) -> None:
+        self.device = "cuda"
+
+    # ------------------------------------------------------------------ per-keyframe entry point
+    def detect_and_track_objects(self, frame_data, map_data, c2w: torch.Tensor):
+        """Reference: ovo.py:121-166.  Returns the updated i32[N] per-point instance ids, or None."""
+        frame_id, image = frame_data[:2]
+        seg_map, binary_maps = self._get_masks(image, frame_id)
+        if len(seg_map) == 0:
+            print(f"No mask segmented in {frame_id}!")
+            return None
+        first_new = self.next_ins_id
+        matched, binary_maps, n_matched, updated = self._match_and_track_instances(
+            frame_data[1:], map_data, c2w, seg_map, binary_maps)
+        self.keyframes_queue.append([matched, binary_maps, image, self.kf_id])
+        self.kf_id += 1
+        if self.config.get("log", False):
+            self.keyframes["frame_id"].append(frame_id)
+            if self.logger is not None:
+                self.logger.log_ovo_stats({"frame_id": frame_id, "n_obj": [self.next_ins_id - first_new],
+                                           "n_matches": n_matched, "t_sam": round(self._time_cache[0], 2),
+                                           "t_obj": round(self._time_cache[1], 3)}, print_output=True)
+            self._time_cache = []
+        return updated
+
+    @_timed("t_sam")
+    def _get_masks(self, image: np.ndarray, frame_id: int):
+        return self.mask_generator.get_masks(image, frame_id)
+
+    # ------------------------------------------------------------------ tracking
+    @_timed("t_obj")
+    def _match_and_track_instances(self, frame_data, map_data, c2w, seg_map: torch.Tensor, binary_maps: torch.Tensor):
+        """Reference: ovo.py:182-238 (with :240-324 inlined as device passes + a host decision loop)."""
+        kf_id = self.kf_id
+        image, depth_np, ratio = frame_data
+        points_3d, points_ids, points_ins_ids = map_data
+        dev = points_3d.device
+        lib = L.load()
+
+        depth_np = np.ascontiguousarray(depth_np, dtype=np.float32)
+        h, w = depth_np.shape
+        depth = torch.from_numpy(depth_np).to(dev, non_blocking=True)
+        pose = G._cpu32(c2w).contiguous()
+        near, far = G.depth_range(depth_np)                       # frustum uses the raw depth (:209)
+        corners = G.frustum_corners_from_range(near, far, h, w, pose, self._K_host)
+        cam = G.make_camera(corners, torch.linalg.inv(pose), self._K_host, self.config["match_distance_th"], h, w)
+        if self.config.get("depth_filter", False):
+            depth = G.depth_filter(depth)
+
+        pts = L.dev(points_3d, torch.float32, "points_3d")
+        ins = L.dev(points_ins_ids.reshape(-1), torch.int32, "points_ins_ids")
+        seg_map = L.dev(seg_map, torch.int32, "seg_map")
+        n, n_masks = pts.shape[0], int(binary_maps.shape[0])
+        # votes table columns: [unassigned | instance 0 .. max id]; restore_dict leaves next_ins_id at 0 like the reference
+        hist_cols = max(self.next_ins_id, max(self.objects) + 1 if self.objects else 0) + 1
+        r = L.Ratio(0, 1.0, 1.0, 0)
+        if len(ratio) > 0:
+            r = L.Ratio(1, float(ratio[0]), float(ratio[1]), int(ratio[2]))
+
+        point_seg = torch.empty(n, dtype=torch.int16, device=dev)
+        hist = torch.empty((n_masks, hist_cols), dtype=torch.int32, device=dev)
+        small = torch.empty(n_masks * 4 + 4, dtype=torch.int32, device=dev)        # stats | {in frustum, matched} as i64
+        stats, counters = small[:n_masks * 4], small[n_masks * 4:]
+        L.check(lib.ovo_track_project(L.ptr(pts), L.ptr(ins), n, cam, L.ptr(depth), L.ptr(seg_map), seg_map.shape[0],
+                                      seg_map.shape[1], r, L.ptr(point_seg), L.ptr(hist), n_masks, hist_cols,
+                                      L.ptr(counters), L.stream()))
+        L.check(lib.ovo_vote_stats(L.ptr(hist), n_masks, hist_cols, L.ptr(seg_map), seg_map.numel(), L.ptr(stats), L.stream()))
+        host = small.cpu()                                           # the one sync of the tracking stage
+        table = host[:n_masks * 4].view(n_masks, 4).tolist()
+        n_matched = int(host[n_masks * 4:].view(torch.int64)[1])
+
+        # ---- host decisions on the [n_masks x 4] table, in mask order (ovo.py:255-280)
+        track_th = self.config["track_th"]
+        target = [-1] * n_masks
+        matched_info: Dict[int, List[Tuple[int, int]]] = {}
+        fresh_masks: List[Tuple[int, int]] = []
+        for m, (n_pts, n_assigned, mode_id, area) in enumerate(table):
+            if n_pts <= track_th:
+                continue
+            n_fresh = n_pts - n_assigned
+            if n_assigned > track_th:
+                target[m] = mode_id
+                self.objects[mode_id].update([], kf_id, area)
+                matched_info.setdefault(mode_id, []).append((m, area))
+                fresh_masks.append((m, mode_id))
+            elif n_fresh > track_th:
+                new_id = self.next_ins_id
+                self.next_ins_id += 1
+                target[m] = new_id
+                self.objects[new_id] = Instance3D(new_id, kf_id=kf_id, points_ids=[], mask_area=area, bank=self.bank)
+                matched_info[new_id] = [(m, area)]
+                fresh_masks.append((m, new_id))
+
+        mask_target = torch.tensor(target, dtype=torch.int32).to(dev, non_blocking=True)
+        updated = torch.empty_like(ins)
+        L.check(lib.ovo_assign_instances(L.ptr(ins), L.ptr(point_seg), n, L.ptr(mask_target), n_masks, L.ptr(updated),
+                                         None, L.stream()))
+        if self.debug_info:                                        # point-id lists are only exported in debug checkpoints
+            pid = points_ids.reshape(-1)
+            was_free = ins == -1
+            for m, ins_id in fresh_masks:
+                sel = torch.nonzero((point_seg == m) & was_free).reshape(-1)
+                self.objects[ins_id].add_points_ids(pid[sel].reshape(-1, 1).cpu().tolist())
+
+        matched_ins_ids, binary_maps, mask_rows = self._fuse_masks_with_same_ins_id(binary_maps, matched_info, kf_id)
+        self.last_point_seg, self.last_mask_rows = point_seg, mask_rows
+
+        if self.debug_info:
+            ins_maps = torch.full(image.shape[:2], -1, dtype=torch.int32, device=dev)
+            for row, ins_id in enumerate(matched_ins_ids):
+                ins_maps[binary_maps[row]] = ins_id
+            self.keyframes["ins_maps"].append(ins_maps.cpu().numpy())
+        return matched_ins_ids, binary_maps, n_matched, updated
+
+    def _fuse_masks_with_same_ins_id(self, binary_maps: torch.Tensor, matched_info, kf_id: int):
+        """Reference: ovo.py:284-324.  Also returns, per ORIGINAL mask index, the row of the fused descriptor
+        it contributes to (-1 = dropped) for the dense accumulator."""
+        matched_ins_ids, keep_rows = [], []
+        mask_rows = [-1] * int(binary_maps.shape[0])
+        for ins_id, hits in matched_info.items():
+            first = hits[0][0]
+            if len(hits) > 1:
+                for other, _ in hits[1:]:
+                    binary_maps[first] = torch.logical_or(binary_maps[first], binary_maps[other])
+                if self.n_top_views > 0:
+                    self.objects[ins_id].add_top_kf(kf_id, int(binary_maps[first].sum().item()))
+            if self.n_top_views <= 0 or self.objects[ins_id].is_top_kf(kf_id):
+                for m, _ in hits:
+                    mask_rows[m] = len(matched_ins_ids)
+                matched_ins_ids.append(ins_id)
+                keep_rows.append(first)
+        idx = torch.tensor(keep_rows, dtype=torch.int64, device=binary_maps.device)
+        return matched_ins_ids, binary_maps.index_select(0, idx), mask_rows
+
+    # ------------------------------------------------------------------ descriptors
+    def compute_semantic_info(self) -> None:
+        if len(self.keyframes_queue) > self.config.get("kf_queue_delay", 0):
+            self._compute_semantic_info()
+
+    def complete_semantic_info(self) -> None:
+        while len(self.keyframes_queue) > 0:
+            self._compute_semantic_info()
+
+    def _compute_semantic_info(self) -> None:
+        """Reference: ovo.py:334-364."""
+        matched_ins_ids, binary_maps, image, kf_id = self.keyframes_queue.popleft()
+        if len(matched_ins_ids) == 0:
+            return
+        if self.n_top_views > 0:
+            rows = [j for j, i in enumerate(matched_ins_ids) if self.objects[i].is_top_kf(kf_id)]
+            if not rows:
+                return
+            if len(rows) != len(matched_ins_ids):
+                matched_ins_ids = [matched_ins_ids[j] for j in rows]
+                binary_maps = binary_maps[torch.tensor(rows, device=binary_maps.device)]
+        clip_embeds = self._extract_clip(image, binary_maps)
+        self._update_matched_objects_clip(clip_embeds, matched_ins_ids, kf_id)
+        if self.config.get("log", False) and self.logger is not None:
+            self.logger.log_ovo_stats({"frame_id": self.keyframes["frame_id"][kf_id],
+                                       "t_clip": round(self._time_cache[0], 2), "t_up": round(self._time_cache[1], 3)},
+                                      print_output=True)
+        self._time_cache = []
+
+    @_timed("t_clip")
+    def _extract_clip(self, image: np.ndarray, binary_maps: torch.Tensor) -> torch.Tensor:
+        """Reference: ovo.py:427-437 -- but the descriptors stay on the GPU."""
+        img = torch.from_numpy(np.ascontiguousarray(image.transpose((2, 0, 1)))).to(self.bank.device, non_blocking=True)
+        return self.clip_generator.extract_clip(img, binary_maps, self.config.get("return_all_clips", False))
+
+    @_timed("t_up")
+    def _update_matched_objects_clip(self, clip_embeds: torch.Tensor, matched_ins_ids: List[int], kf_id: int) -> None:
+        """Reference: ovo.py:440-461; all touched instances are fused in one launch."""
+        rows = self.bank.append(clip_embeds)
+        self.keyframes["ins_descriptors"][kf_id] = KeyframeView(
+            self.bank, {i: rows[j] for j, i in enumerate(matched_ins_ids) if i != -1})
+        updates = []
+        for ins_id in matched_ins_ids:
+            obj = self.objects[ins_id]
+            if not obj.to_update:
+                continue
+            views = [self.keyframes["ins_descriptors"][kf].row(ins_id) for kf in obj.fusion_views()
+                     if kf in self.keyframes["ins_descriptors"]]
+            if views:
+                updates.append((ins_id, views))
+                obj.to_update = False
+        self.bank.fuse(updates, Instance3D.mv_fusion)
+
+    def update_objects_clip(self, force_update: bool = False) -> None:
+        for obj in self.objects.values():
+            obj.update_clip(self.keyframes["ins_descriptors"], force_update=force_update)
+
+    def update_map(self, map_data, kfs):
+        """Loop-closure semantic update (ovo.py:366-424): a 'next' row; needs ORB-SLAM3."""
+        raise NotImplementedError("OVO.update_map (loop closure) is not part of this build yet")
+
+    # ------------------------------------------------------------------ query (ovo.py:473-527)
+    @torch.no_grad()
+    def get_objs_clips(self) -> torch.Tensor:
+        """f32[N_instances, D] on the GPU, rows in `self.objects` order."""
+        loose = [o for o in self.objects.values() if o._own_feature is not None or not self.bank.has_feature(o.id)]
+        for obj in loose:
+            if obj._own_feature is not None:                   # restored from a checkpoint: adopt into the table
+                feat, kf = obj._own_feature, obj._own_feature_kf
+                self.bank.set_feature(obj.id, feat)
+                obj._bank, obj._own_feature = self.bank, None
+                self.bank.medoid_of[self.bank.slot_of[obj.id]] = kf
+            else:                                              # "this should never happen" (ovo.py:523)
+                obj._bank, obj.to_update = self.bank, True
+                obj.update_clip(self.keyframes["ins_descriptors"])
+        return self.bank.gather(self.objects.keys())
+
+    @torch.no_grad()
+    def query(self, queries: List[str], templates=['{}'], ensemble: bool = False) -> torch.Tensor:
+        assert len(self.objects) > 0, "No 3D instances to query!"
+        return self.clip_generator.get_embed_txt_similarity(self.get_objs_clips(), queries, templates=templates)
+
+    @torch.no_grad()
+    def classify_instances(self, classes: List[str], template="This is a photo of a {}", th: float = 0):
+        """Reference: ovo.py:473-492; argmax / threshold fused into the similarity kernel's epilogue."""
+        assert len(self.objects) > 0, "No 3D instances to query!"
+        cls, conf = self.clip_generator.classify(self.get_objs_clips(), classes, templates=template, th=th)
+        return {"classes": cls.cpu().numpy(), "conf": conf.cpu().numpy()}
+
+    # ------------------------------------------------------------------ checkpoint (ovo.py:529-575)
+    def capture_dict(self, debug_info: bool) -> Dict[str, Any]:
+        scene = {"ins_3d_ids": np.asarray(list(self.objects.keys()))}
+        for obj in self.objects.values():
+            scene.update(obj.export(debug_info))
+        if debug_info:
+            scene["frame_id"] = np.array(self.keyframes["frame_id"])
+            scene["ins_map"] = np.array(self.keyframes["ins_maps"])
+            for kf_id, view in self.keyframes["ins_descriptors"].items():
+                for ins_id, desc in view.items():
+                    scene[f"kf_{kf_id}_ins3d_{ins_id}_clips"] = desc.cpu().numpy()
+        return scene
+
+    def restore_dict(self, scene_dict: Dict[str, Any], debug_info: bool = False) -> None:
+        for i in scene_dict["ins_3d_ids"]:
+            obj = Instance3D(int(i), bank=None)
+            obj.restore(scene_dict, debug_info)
+            self.objects[obj.id] = obj
+        if debug_info:
+            self.keyframes["frame_id"] = list(scene_dict["frame_id"])
+            n_kf = len(self.keyframes["frame_id"])
+            self.keyframes["ins_maps"] = [x.squeeze() for x in np.split(scene_dict["ins_map"], n_kf)] if n_kf else []
+            for k in range(n_kf):
+                rows = {}
+                for ins_id in self.objects:
+                    desc = scene_dict.get(f"kf_{k}_ins3d_{ins_id}_clips")
+                    if desc is not None:
+                        rows[ins_id] = self.bank.append(torch.as_tensor(desc).reshape(1, -1))[0]
+                self.keyframes["ins_descriptors"][k] = KeyframeView(self.bank, rows)
+            self.kf_id = n_kf

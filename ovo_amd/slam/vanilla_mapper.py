@@ -1,0 +1,179 @@
+"""GT-pose point-map builder on MI355X -- the "back-projection" half of the hot path.
+
+Host-side mirror of the reference's `ovo/slam/vanilla_mapper.py:VanillaMapper` (the canonical SLAM
+duck-type `OVOSemMap.run` drives: track_camera / get_c2w / map / get_map / update_pcd_obj_ids / ...).
+The map lives in capacity-doubling device buffers (the reference re-allocates the whole map with
+`torch.vstack` on every mapped frame, vanilla_mapper.py:81-85); per frame two HIP passes run:
+  1. ovo_map_explained   -- cull + project + depth-test every map point, mark explained pixels  (:56-61)
+  2. ovo_map_backproject -- erode, [::2,::2] subsample, unproject, c2w, ordered append           (:62-85)
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..utils import geometry_utils as G
+
+
+class VanillaMapper:
+    """Same constructor and methods as the reference class (vanilla_mapper.py:8-136)."""
+
+    def __init__(self, config: dict, cam_intrinsics: torch.Tensor) -> None:
+        self.cam_intrinsics = cam_intrinsics
+        self.config = config
+        self.device = config.get("device", "cuda")
+        mapping = config.get("mapping", {})
+        self.max_frame_points = mapping.get("max_frame_points", 1e5)
+        self.match_distance_th = 0.03                      # vanilla_mapper.py:17
+        self.max_id = 0
+        self.estimated_c2ws: Dict[int, torch.Tensor] = {}
+        self._c2w_host: Dict[int, torch.Tensor] = {}
+        self.kfs: Dict[int, Dict[str, Any]] = {}
+        self.map_updated = False
+        self.k_pooling = int(mapping.get("k_pooling", 3))
+        if self.k_pooling not in (1, 3):
+            raise NotImplementedError("k_pooling must be 1 or 3 (the reference default is 3)")
+        self.downscale = int(mapping.get("downscale_res", 2))   # sic: the yaml key `downscale_ratio` is never read (:32)
+        self._K_host = G._cpu32(cam_intrinsics).contiguous()
+        self._n = 0
+        self._cap = 0
+        self._xyz = self._ids = self._ins = self._rgb = None
+        self._reserve(1 << 16)
+
+    # ------------------------------------------------------------------ storage
+    def _reserve(self, cap: int) -> None:
+        if cap <= self._cap:
+            return
+        new_cap = max(cap, 2 * self._cap)
+        dev = self.device
+        xyz = torch.empty((new_cap, 3), dtype=torch.float32, device=dev)
+        ids = torch.empty((new_cap,), dtype=torch.int32, device=dev)
+        ins = torch.empty((new_cap,), dtype=torch.int32, device=dev)
+        rgb = torch.empty((new_cap, 3), dtype=torch.uint8, device=dev)
+        if self._n:
+            xyz[:self._n].copy_(self._xyz[:self._n])
+            ids[:self._n].copy_(self._ids[:self._n])
+            ins[:self._n].copy_(self._ins[:self._n])
+            rgb[:self._n].copy_(self._rgb[:self._n])
+        self._xyz, self._ids, self._ins, self._rgb, self._cap = xyz, ids, ins, rgb, new_cap
+
+    @property
+    def pcd(self) -> torch.Tensor:
+        return self._xyz[:self._n]
+
+    @property
+    def pcd_ids(self) -> torch.Tensor:
+        return self._ids[:self._n].unsqueeze(1)
+
+    @property
+    def pcd_obj_ids(self) -> torch.Tensor:
+        return self._ins[:self._n].unsqueeze(1)
+
+    @property
+    def pcd_colors(self) -> torch.Tensor:
+        return self._rgb[:self._n]
+
+    # ------------------------------------------------------------------ frame-callback API
+    def track_camera(self, frame_data: List[Any]) -> None:
+        frame_id, c2w = frame_data[0], frame_data[3]
+        if not np.isfinite(c2w).all():                     # skip NaN / Inf poses (:41-42)
+            return
+        host = torch.from_numpy(np.ascontiguousarray(c2w))
+        self._c2w_host[frame_id] = host
+        self.estimated_c2ws[frame_id] = host.to(self.device)
+
+    def get_c2w(self, frame_id: int):
+        c2w = self.estimated_c2ws.get(frame_id)
+        if c2w is not None and c2w.device.type != torch.device(self.device).type:
+            c2w = c2w.to(self.device)
+        return c2w
+
+    def cam_to_cpu(self, frame_id: int) -> None:
+        if frame_id in self.estimated_c2ws:
+            self.estimated_c2ws[frame_id] = self.estimated_c2ws[frame_id].cpu()
+
+    def _host_pose(self, frame_id, c2w) -> torch.Tensor:
+        host = self._c2w_host.get(frame_id)
+        return host if host is not None else c2w.detach().cpu()
+
+    def map(self, frame_data: List[Any], c2w: torch.Tensor) -> None:
+        """Reference: vanilla_mapper.py:46-85."""
+        frame_id, image, depth_np = frame_data[0], frame_data[1], frame_data[2]
+        depth_np = np.ascontiguousarray(depth_np, dtype=np.float32)
+        h, w = depth_np.shape
+        lib = L.load()
+        dev = self.device
+        depth = torch.from_numpy(depth_np).to(dev, non_blocking=True)
+        rgb = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8)).to(dev, non_blocking=True)
+        pose = self._host_pose(frame_id, c2w).float().contiguous()
+        explained = None
+        if self.max_id > 0:
+            if not (depth_np > 0).any():
+                return
+            near, far = G.depth_range(depth_np)
+            corners = G.frustum_corners_from_range(near, far, h, w, pose, self._K_host)
+            cam = G.make_camera(corners, torch.linalg.inv(pose), self._K_host, self.match_distance_th, h, w)
+            explained = torch.empty((h, w), dtype=torch.uint8, device=dev)
+            L.check(lib.ovo_map_explained(L.ptr(self._xyz), self._n, cam, L.ptr(depth), L.ptr(explained), L.stream()))
+        ds = self.downscale
+        n_sub = ((h + ds - 1) // ds) * ((w + ds - 1) // ds)
+        self._reserve(self._n + n_sub)
+        nb = lib.ovo_compact_workspace_bytes(n_sub)
+        ws = L.workspace(nb, depth.device)
+        cnt = torch.empty(1, dtype=torch.int64, device=dev)
+        K9 = (L.C.c_float * 9)(*self._K_host.reshape(-1).tolist())
+        T16 = (L.C.c_float * 16)(*pose.reshape(-1).tolist())
+        erode = int(self.max_id > 0 and self.k_pooling > 1)
+        L.check(lib.ovo_map_backproject(L.ptr(depth), L.ptr(rgb), L.ptr(explained), h, w, erode, ds, K9, T16, self._n,
+                                        self.max_id, L.ptr(self._xyz), L.ptr(self._ids), L.ptr(self._ins),
+                                        L.ptr(self._rgb), L.ptr(cnt), L.ptr(ws), nb, L.stream()))
+        m = int(cnt.item())
+        self._n += m
+        self.max_id += m
+
+    # ------------------------------------------------------------------ map access
+    def get_map(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(pcd f32[N,3], pcd_ids i32[N,1], pcd_obj_ids i32[N]) -- views of the live buffers (:98-100)."""
+        return self.pcd, self.pcd_ids, self._ins[:self._n]
+
+    def get_kfs(self) -> Dict[int, Dict[str, Any]]:
+        return self.kfs
+
+    def update_pcd_obj_ids(self, pcd_objs_ids: torch.Tensor) -> None:
+        ids = pcd_objs_ids.reshape(-1)
+        if ids.shape[0] != self._n:
+            raise ValueError(f"expected {self._n} instance ids, got {ids.shape[0]}")
+        if ids.data_ptr() != self._ins.data_ptr():
+            self._ins[:self._n].copy_(ids)
+
+    def get_pcd_colors(self) -> np.ndarray:
+        return self.pcd_colors.cpu().numpy()
+
+    # ------------------------------------------------------------------ checkpoint format (ovomapping.py:81-116)
+    def get_map_dict(self) -> Dict[str, Any]:
+        return {"xyz": self.pcd.detach().cpu().clone(), "obj_ids": self.pcd_obj_ids.detach().cpu().clone(),
+                "ids": self.pcd_ids.detach().cpu().clone(), "max_id": self.max_id,
+                "color": self.pcd_colors.detach().cpu().clone()}
+
+    def set_map_dict(self, map_dict: Dict[str, Any]) -> None:
+        n = map_dict["xyz"].shape[0]
+        self._n = 0
+        self._reserve(max(n, 1))
+        self._xyz[:n].copy_(map_dict["xyz"].to(self.device))
+        self._ins[:n].copy_(map_dict["obj_ids"].reshape(-1).to(self.device))
+        self._ids[:n].copy_(map_dict["ids"].reshape(-1).to(self.device))
+        self._rgb[:n].copy_(map_dict["color"].to(self.device))
+        self._n, self.max_id = n, map_dict["max_id"]
+
+    def get_cam_dict(self) -> Dict[str, Any]:
+        return {k: v.cpu().numpy() for k, v in self.estimated_c2ws.items()}
+
+    def set_cam_dict(self, cam_dict: Dict[str, Any]) -> None:
+        self.estimated_c2ws, self._c2w_host = {}, {}
+        for k, v in cam_dict.items():
+            host = torch.from_numpy(v)
+            self._c2w_host[int(k)] = host
+            self.estimated_c2ws[int(k)] = host.to(self.device)

@@ -1,0 +1,75 @@
+"""Similarity functions and crop-descriptor fusion on MI355X.
+
+Mirror of the similarity / fusion half of the reference's `ovo/utils/clip_utils.py` (:10-48).  The model
+loaders of that file (:51-115) pull checkpoints from the hub through open_clip / perception_models, neither
+of which exists offline; their replacement is `ovo_amd.encoders` (random-init or state-dict weights).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib as L
+
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def similarity(img_embed: torch.Tensor, txt_embeds: torch.Tensor, *, siglip: bool = False, logit_scale: float = 0.0,
+               logit_bias: float = 0.0, cnt: Optional[torch.Tensor] = None, want_sim: bool = True,
+               want_argmax: bool = False, th: float = 0.0) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """S = img_embed @ txt_embeds.T (+ SigLIP epilogue, + 1/cnt row scale, + fused argmax/threshold).
+
+    img_embed [N, D] f32 / f16 / bf16 on the GPU, txt_embeds [Q, D].  Returns (S f32[N,Q] | None,
+    classes i64[N] | None, conf f32[N] | None)."""
+    if img_embed.dtype not in _DTYPE_CODE:
+        raise L.OvoHipError(f"unsupported descriptor dtype {img_embed.dtype}")
+    feats = L.dev(img_embed, img_embed.dtype, "img_embed")
+    txt = L.dev(txt_embeds.to(device=feats.device, dtype=torch.float32).contiguous(), torch.float32, "txt_embeds")
+    n, d = feats.shape
+    q = txt.shape[0]
+    if txt.shape[1] != d:
+        raise L.OvoHipError(f"descriptor length mismatch: {d} vs {txt.shape[1]}")
+    sim = torch.empty((n, q), dtype=torch.float32, device=feats.device) if want_sim else None
+    cls = torch.empty(n, dtype=torch.int64, device=feats.device) if want_argmax else None
+    conf = torch.empty(n, dtype=torch.float32, device=feats.device) if want_argmax else None
+    if cnt is not None:
+        cnt = L.dev(cnt, torch.int32, "cnt")
+    L.check(L.load().ovo_similarity(L.ptr(feats), _DTYPE_CODE[feats.dtype], n, d, L.ptr(txt), q, L.ptr(cnt), int(siglip),
+                                    float(logit_scale), float(logit_bias), float(th), L.ptr(sim), L.ptr(cls), L.ptr(conf),
+                                    L.stream()))
+    return sim, cls, conf
+
+
+def clip_cosine_similarity(txt_embeds: torch.Tensor, img_embed: torch.Tensor) -> torch.Tensor:
+    """Reference: clip_utils.py:16-19 -> [N_obj, N_text]."""
+    return similarity(img_embed, txt_embeds)[0]
+
+
+def siglip_cosine_similarity(txt_embeds: torch.Tensor, img_embed: torch.Tensor, logit_scale, logit_bias) -> torch.Tensor:
+    """Reference: clip_utils.py:10-14 -> sigmoid(S * exp(scale) + bias)."""
+    return similarity(img_embed, txt_embeds, siglip=True, logit_scale=float(logit_scale), logit_bias=float(logit_bias))[0]
+
+
+def fuse_clips(clip_g: torch.Tensor, clip_seg: torch.Tensor, clip_bbox: torch.Tensor, embed_type: str,
+               w_masked: float, w_global: float) -> torch.Tensor:
+    """Reference: clip_utils.py:21-48.  [N, D] x 3 -> [N, D]; a few N*D elementwise ops on the device."""
+    def cos(a, b):
+        return F.cosine_similarity(a, b, dim=-1, eps=1e-6)
+
+    def unit(x):
+        return F.normalize(x, p=2, dim=-1)
+    if embed_type in ("hovsg", "fixed_weights"):
+        local = unit(clip_seg * w_masked + clip_bbox * (1 - w_masked))
+        wg = w_global if embed_type == "fixed_weights" else torch.softmax(cos(clip_g, local), dim=0).unsqueeze(1)
+        return unit(clip_g * wg + local * (1 - wg))
+    if embed_type == "adaptive_weights":
+        wl = (cos(clip_seg, clip_bbox) * w_masked).unsqueeze(-1)
+        local = unit(clip_seg * wl + clip_bbox * (1 - wl))
+        wg = (cos(clip_g, local) * w_global).unsqueeze(-1)
+        return unit(clip_g * wg + local * (1 - wg))
+    if embed_type == "concept_fusion":
+        wg = torch.softmax(cos(clip_g, clip_bbox), dim=0).unsqueeze(-1)
+        return unit(wg * clip_g + (1 - wg) * clip_bbox)
+    return clip_seg        # vanilla

@@ -1,0 +1,146 @@
+"""Frustum culling, projection, depth matching and the depth high-pass filter on MI355X.
+
+Host-side mirror of the reference's `ovo/utils/geometry_utils.py` (same function names, argument meaning
+and return layout) over libovo_hip.so.  The per-point arithmetic runs in HIP (csrc/geometry.hip); only the
+8-corner / 6-plane set-up, a few dozen flops per frame, stays on the host in torch-CPU so that it is the
+same arithmetic the reference's CPU path performs (DESIGN.md "bit-exactness").
+
+Reference lines each function replaces are given in its docstring.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+# corner order of the reference (near plane first): (0,0) (w,0) (0,h) (w,h), then the same at far depth
+_CORNER_X = (0.0, 1.0, 0.0, 1.0)
+_CORNER_Y = (0.0, 0.0, 1.0, 1.0)
+# plane i = cross(c[a]-c[b], c[c]-c[d]); near, far, left, right, top, bottom
+_PLANE_DEF = ((2, 0, 1, 0), (6, 4, 5, 4), (4, 0, 2, 0), (7, 3, 1, 3), (5, 1, 3, 1), (6, 2, 0, 2))
+
+
+def _cpu32(t) -> torch.Tensor:
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(t)
+    return t.detach().to(device="cpu", dtype=torch.float32)
+
+
+def depth_range(depth) -> Tuple[float, float]:
+    """min / max of the valid (> 0) depths; numpy input costs no device sync."""
+    if isinstance(depth, np.ndarray):
+        v = depth[depth > 0]
+        return float(v.min()), float(v.max())
+    big = torch.where(depth > 0, depth, torch.full_like(depth, float("inf"))).min()
+    top = depth.max()
+    lo, hi = torch.stack([big, top]).tolist()
+    return lo, hi
+
+
+def frustum_corners_from_range(near: float, far: float, h: int, w: int, pose, intrinsics) -> torch.Tensor:
+    """8 world-frame frustum corners, f32[8,3] on the CPU (geometry_utils.py:99-129)."""
+    K, T = _cpu32(intrinsics), _cpu32(pose)
+    px = torch.tensor(_CORNER_X * 2, dtype=torch.float32) * float(w)
+    py = torch.tensor(_CORNER_Y * 2, dtype=torch.float32) * float(h)
+    z = torch.tensor([near] * 4 + [far] * 4, dtype=torch.float32)
+    cam = torch.stack([(px - K[0, 2]) * z / K[0, 0], (py - K[1, 2]) * z / K[1, 1], z, torch.ones(8)], dim=1)
+    return torch.einsum("ij,mj->mi", T, cam)[:, :3].contiguous()
+
+
+def compute_camera_frustum_corners(depth_map, pose, intrinsics) -> torch.Tensor:
+    """Reference: geometry_utils.py:99-129.  Returns f32[8,3] on `pose`'s device."""
+    near, far = depth_range(depth_map)
+    h, w = depth_map.shape
+    out = frustum_corners_from_range(near, far, h, w, pose, intrinsics)
+    return out.to(pose.device) if isinstance(pose, torch.Tensor) else out
+
+
+def compute_camera_frustum_planes(frustum_corners) -> torch.Tensor:
+    """Reference: geometry_utils.py:163-202.  f32[6,4] rows (a,b,c,d), inside <=> plane.(p,1) <= 0."""
+    c = _cpu32(frustum_corners)
+    n = torch.stack([torch.linalg.cross(c[a] - c[b], c[e] - c[f]) for a, b, e, f in _PLANE_DEF])
+    d = torch.stack([-torch.dot(n[i], c[i]) for i in range(6)])      # offset from corner i (sic, :201)
+    return torch.cat([n, d[:, None]], dim=1).float()
+
+
+def compute_frustum_aabb(frustum_corners) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Reference: geometry_utils.py:205-215."""
+    c = frustum_corners
+    return c.min(dim=0).values, c.max(dim=0).values
+
+
+def make_camera(frustum_corners, w2c, intrinsics, th: float, h: int, w: int) -> L.Camera:
+    """Pack the per-frame parameters of csrc/geometry.hip (ovo_camera_t)."""
+    cam = L.Camera()
+    if frustum_corners is not None:
+        c = _cpu32(frustum_corners)
+        lo, hi = compute_frustum_aabb(c)
+        cam.aabb[:] = torch.cat([lo, hi]).tolist()
+        cam.planes[:] = compute_camera_frustum_planes(c).reshape(-1).tolist()
+    cam.w2c[:] = _cpu32(w2c).reshape(-1).tolist() if w2c is not None else torch.eye(4).reshape(-1).tolist()
+    cam.K[:] = _cpu32(intrinsics).reshape(-1).tolist()
+    cam.th, cam.h, cam.w = float(th), int(h), int(w)
+    return cam
+
+
+def _count(t: torch.Tensor) -> int:
+    return int(t.item())
+
+
+def compute_frustum_point_ids(pts: torch.Tensor, frustum_corners: torch.Tensor, device: str = "cuda") -> torch.Tensor:
+    """Reference: geometry_utils.py:252-276.  Ascending i64 indices of the points inside the frustum."""
+    if pts.shape[0] == 0:
+        return torch.zeros(0, dtype=torch.int64, device=device)
+    pts = L.dev(pts.to(device), torch.float32, "pts")
+    n = pts.shape[0]
+    cam = make_camera(frustum_corners, None, torch.eye(3), 0.0, 1, 1)
+    lib = L.load()
+    out = torch.empty(n, dtype=torch.int64, device=pts.device)
+    cnt = torch.empty(1, dtype=torch.int64, device=pts.device)
+    nb = lib.ovo_compact_workspace_bytes(n)
+    ws = L.workspace(nb, pts.device)
+    L.check(lib.ovo_frustum_ids(L.ptr(pts), n, cam, L.ptr(out), L.ptr(cnt), L.ptr(ws), nb, L.stream()))
+    return out[:_count(cnt)]
+
+
+def project_3d_points(points_3d: torch.Tensor, intrinsics: torch.Tensor, w2c: torch.Tensor = None) -> torch.Tensor:
+    """Reference: geometry_utils.py:26-43.  points_3d f32[N,4] homogeneous -> i32[N,2] pixel (u,v)."""
+    pts = L.dev(points_3d, torch.float32, "points_3d")
+    n = pts.shape[0]
+    cam = make_camera(None, w2c, intrinsics, 0.0, 1, 1)
+    out = torch.empty((n, 2), dtype=torch.int32, device=pts.device)
+    L.check(L.load().ovo_project_points(L.ptr(pts), n, pts.shape[1], cam, L.ptr(out), L.stream()))
+    return out
+
+
+def match_3d_points_to_2d_pixels(depth: torch.Tensor, w2c: torch.Tensor, points_3d: torch.Tensor,
+                                 intrinsics: torch.Tensor, th_dist: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Reference: geometry_utils.py:46-89.  Returns (i64[M] indices into points_3d, i32[M,2] (u,v))."""
+    depth = L.dev(depth, torch.float32, "depth")
+    pts = L.dev(points_3d, torch.float32, "points_3d")
+    n = pts.shape[0]
+    h, w = depth.shape
+    cam = make_camera(None, w2c, intrinsics, th_dist, h, w)
+    lib = L.load()
+    idx = torch.empty(n, dtype=torch.int64, device=pts.device)
+    uv = torch.empty((n, 2), dtype=torch.int32, device=pts.device)
+    cnt = torch.empty(1, dtype=torch.int64, device=pts.device)
+    nb = lib.ovo_compact_workspace_bytes(max(n, 1))
+    ws = L.workspace(nb, pts.device)
+    stride = pts.shape[1] if n else 3
+    L.check(lib.ovo_match_points(L.ptr(pts), n, stride, cam, L.ptr(depth), L.ptr(idx), L.ptr(uv), L.ptr(cnt),
+                                 L.ptr(ws), nb, L.stream()))
+    m = _count(cnt)
+    return idx[:m], uv[:m]
+
+
+def depth_filter(depth: torch.Tensor, k_size: int = 7, sigma: float = 2.5, th: float = 0.05) -> torch.Tensor:
+    """Reference: geometry_utils.py:92-96.  Pixels whose high-pass response exceeds `th` become -1."""
+    depth = L.dev(depth, torch.float32, "depth")
+    out = torch.empty_like(depth)
+    h, w = depth.shape
+    L.check(L.load().ovo_depth_filter(L.ptr(depth), h, w, int(k_size), float(sigma), float(th), L.ptr(out), L.stream()))
+    return out

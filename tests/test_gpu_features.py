@@ -1,0 +1,141 @@
+"""-m gpu: descriptor fusion, dense scatter-accumulate, similarity query and mask NMS kernels vs the oracle.
+
+Floating-point tolerances are written next to each comparison; integer results are bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, unpack
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t if dtype is None else t.to(dtype)).to(DEV)
+
+
+def test_similarity_golden_and_argmax():
+    from ovo_amd.utils import clip_utils as CU
+    d = golden("similarity")
+    F, T = _t(d["F"]), _t(d["T"])
+    np.testing.assert_allclose(CU.clip_cosine_similarity(T, F).cpu().numpy(), d["clip"], atol=1e-6, rtol=0)
+    s = CU.siglip_cosine_similarity(T, F, float(d["logit_scale"][0]), float(d["logit_bias"]))
+    np.testing.assert_allclose(s.cpu().numpy(), d["siglip"], atol=1e-6, rtol=1e-5)
+    # fused argmax == argmax of the kernel's own scores (bit-exact given S), with threshold semantics of ovo.py:487-491
+    sim, cls, conf = CU.similarity(F, T, want_argmax=True, th=0.25)
+    sim = sim.cpu().numpy()
+    ref_cls = sim.argmax(1)
+    ref_conf = sim.max(1)
+    ref_cls[ref_conf <= 0.25] = -1
+    ref_conf[ref_conf <= 0.25] = 0
+    assert np.array_equal(cls.cpu().numpy(), ref_cls) and np.array_equal(conf.cpu().numpy(), ref_conf)
+    assert (ref_cls == -1).any() and (ref_cls >= 0).any()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("q", [1, 10, 16, 17, 100])
+def test_similarity_vs_oracle(dtype, tol, q):
+    from oracle import features as OF
+    from ovo_amd import synthetic as syn
+    from ovo_amd.utils import clip_utils as CU
+    n, d = 4099, 768
+    F = syn.unit_vectors(n, d, seed=1)
+    T = syn.unit_vectors(q, d, seed=2)
+    Fd = _t(F).to(dtype)
+    sim, cls, conf = CU.similarity(Fd, _t(T), want_argmax=True)
+    ref = OF.similarity(Fd.float().cpu().numpy(), T)         # oracle on the same (rounded) inputs: tolerance = accumulation only
+    np.testing.assert_allclose(sim.cpu().numpy(), ref, atol=2e-6, rtol=0)
+    np.testing.assert_allclose(sim.cpu().numpy(), OF.similarity(F, T), atol=tol, rtol=0)   # <= 1e-3 in fp16 (north_star)
+    assert np.array_equal(cls.cpu().numpy(), sim.argmax(1).cpu().numpy())
+
+
+def test_dense_query_row_scale():
+    from oracle import features as OF
+    from ovo_amd.utils import clip_utils as CU
+    rng = np.random.default_rng(0)
+    acc = rng.standard_normal((1000, 64)).astype(np.float32)
+    cnt = rng.integers(0, 4, 1000).astype(np.int32)
+    T = rng.standard_normal((10, 64)).astype(np.float32)
+    sim = CU.similarity(_t(acc), _t(T), cnt=_t(cnt))[0].cpu().numpy()
+    ref = OF.similarity(acc, T) * np.where(cnt > 0, 1.0 / np.maximum(cnt, 1), 0)[:, None].astype(np.float32)
+    np.testing.assert_allclose(sim, ref, atol=1e-5, rtol=1e-5)
+
+
+def test_fuse_views_golden_and_bank():
+    from ovo_amd.entities.descriptor_bank import DescriptorBank
+    from ovo_amd.entities.instance3d import Instance3D
+    d = golden("fusion")
+    rows = _t(d["clips"][0])
+    bank = DescriptorBank(rows.shape[1], DEV, rows=2, slots=1)      # tiny capacities: exercise growth
+    r = bank.append(rows)
+    for mode, key, kfkey in (("avg_pooling", "avg", None), ("l1_medoid", "l1", None), ("cossim_medoid", "cos", "cos_kf")):
+        kf = bank.fuse([(7, r), (9, r[:1])], mode)
+        np.testing.assert_allclose(bank.feature(7).reshape(-1).cpu().numpy(), d[key], atol=1e-6, rtol=0)
+        assert bank.feature(7).shape == (1, rows.shape[1]) and bank.feature(9).shape == (rows.shape[1],)
+        assert kf[9] == 0
+        if kfkey:
+            assert kf[7] == int(d[kfkey])
+    # Instance3D.update_clip flow with a top-3 heap (instance3d.py:105-189)
+    Instance3D.n_top_kf = 3
+    Instance3D.set_fusion("avg_pooling")
+    from ovo_amd.entities.descriptor_bank import KeyframeView
+    inst = Instance3D(5, bank=bank)
+    views = {}
+    for kf, area in enumerate(d["areas"].tolist()):
+        inst.update([kf * 10], kf, area)
+        views[kf] = KeyframeView(bank, {5: bank.append(_t(d["feats"][kf:kf + 1]))[0]})
+        inst.update_clip(views)
+        np.testing.assert_allclose(inst.clip_feature.reshape(-1).cpu().numpy(), d["trace"][kf], atol=1e-6, rtol=0)
+    assert sorted(inst.top_kf) == [tuple(x) for x in d["top_kf"].tolist()]
+    exp = inst.export(True)
+    assert exp["ins3d_5_clip_feature"].device.type == "cpu" and exp["ins3d_5_keyframes_ids"].tolist() == [0, 1, 2, 3, 4]
+
+
+def test_scatter_accum_linearity():
+    """acc += desc[row(seg)] for matched points only; two passes == 2x one pass; counts exact."""
+    from ovo_amd import _lib as L
+    rng = np.random.default_rng(4)
+    n, D, n_masks = 50_001, 768, 32
+    seg = rng.integers(-2, n_masks, n).astype(np.int16)
+    mask_row = np.where(np.arange(n_masks) % 5 == 0, -1, rng.permutation(n_masks)).astype(np.int32)
+    desc = rng.standard_normal((n_masks, D)).astype(np.float32)
+    acc = torch.zeros((n, D), dtype=torch.float32, device=DEV)
+    cnt = torch.zeros(n, dtype=torch.int32, device=DEV)
+    lib = L.load()
+    for _ in range(2):
+        L.check(lib.ovo_scatter_accum(L.ptr(_t(seg)), n, L.ptr(_t(mask_row)), n_masks, L.ptr(_t(desc)), D, L.ptr(acc),
+                                      L.ptr(cnt), L.stream()))
+    rows = np.where(seg >= 0, mask_row[np.clip(seg, 0, None)], -1)
+    hit = rows >= 0
+    ref = np.zeros((n, D), np.float32)
+    ref[hit] = 2 * desc[rows[hit]]
+    assert np.array_equal(acc.cpu().numpy(), ref)              # x + x is exact
+    assert np.array_equal(cnt.cpu().numpy(), 2 * hit.astype(np.int32))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_mask_nms_golden(tag):
+    from ovo_amd.utils import segment_utils as SU
+    d = golden(f"segment_{tag}")
+    masks = unpack(d["masks"], int(d["mask_w"]))
+    keep = SU.mask_nms(_t(masks), _t(d["stability"] * d["pred_iou"]), iou_thr=0.8, score_thr=0.7, inner_thr=0.5)
+    assert keep.cpu().tolist() == d["keep"].tolist()
+    dicts = [{"segmentation": masks[i], "predicted_iou": d["pred_iou"][i], "stability_score": d["stability"][i]}
+             for i in range(masks.shape[0])]
+    kept, = SU.masks_update(dicts, iou_thr=0.8, score_thr=0.7, inner_thr=0.5)
+    seg, bm = SU.mask2segmap(kept, np.zeros(masks.shape[1:] + (3,), np.uint8))
+    assert seg.dtype == np.int32 and np.array_equal(seg, d["seg_map"])
+    assert np.array_equal(bm, unpack(d["bmaps"], int(d["mask_w"])))
+    assert np.array_equal(SU.batched_mask_to_box(_t(masks)).cpu().numpy(), d["boxes"])
+
+
+def test_mask_intersections_full_res():
+    from oracle import features as OF
+    from ovo_amd import synthetic as syn
+    from ovo_amd.utils import segment_utils as SU
+    masks = syn.make_masks(480, 640, grid=(6, 8), n_blobs=40, seed=2)
+    inter = SU.mask_intersections(_t(masks)).cpu().numpy()
+    assert np.array_equal(inter, OF.mask_intersections(masks))

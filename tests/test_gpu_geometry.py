@@ -1,0 +1,213 @@
+"""-m gpu: HIP geometry / mapping / tracking path vs the oracle and the reference's golden vectors.
+
+Integer and index outputs (and fp32 coordinates produced by the FMA chain) are compared bit-exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, unpack
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t if dtype is None else t.to(dtype)).to(DEV)
+
+
+# ------------------------------------------------------------------ golden (reference outputs)
+@pytest.mark.parametrize("t", [1, 2])
+def test_frustum_project_match_golden(t):
+    from ovo_amd.utils import geometry_utils as G
+    d = golden(f"geometry_t{t}")
+    pts = _t(d["pts"])
+    corners = G.compute_camera_frustum_corners(d["depth"], torch.from_numpy(d["c2w"]), torch.from_numpy(d["K"]))
+    assert np.array_equal(corners.numpy(), d["corners"])
+    ids = G.compute_frustum_point_ids(pts, torch.from_numpy(d["corners"]), device=DEV)
+    assert ids.dtype == torch.int64 and np.array_equal(ids.cpu().numpy(), d["frustum_ids"])
+    fp = pts[ids]
+    hom = torch.hstack([fp, torch.ones((fp.shape[0], 1), device=DEV)]).contiguous()
+    uv = G.project_3d_points(hom, torch.from_numpy(d["K"]), torch.from_numpy(d["w2c"]))
+    assert uv.dtype == torch.int32 and np.array_equal(uv.cpu().numpy(), d["project_uv"])
+    mi, muv = G.match_3d_points_to_2d_pixels(_t(d["depth"]), torch.from_numpy(d["w2c"]), fp.contiguous(),
+                                             torch.from_numpy(d["K"]), float(d["th"]))
+    assert np.array_equal(mi.cpu().numpy(), d["match_idx"]) and np.array_equal(muv.cpu().numpy(), d["match_uv"])
+    # homogeneous input gives the same answer
+    mi4, muv4 = G.match_3d_points_to_2d_pixels(_t(d["depth"]), torch.from_numpy(d["w2c"]), hom, torch.from_numpy(d["K"]), float(d["th"]))
+    assert torch.equal(mi, mi4) and torch.equal(muv, muv4)
+
+
+def test_vanilla_mapper_golden():
+    from ovo_amd.slam.vanilla_mapper import VanillaMapper
+    d = golden("vanilla_mapper")
+    vm = VanillaMapper({"device": DEV, "mapping": {"k_pooling": 3}}, torch.from_numpy(d["K"]).to(DEV))
+    for i in range(3):
+        fd = [i, d[f"rgb{i}"], d[f"depth{i}"], d[f"c2w{i}"]]
+        vm.track_camera(fd)
+        vm.map(fd, vm.get_c2w(i))
+        assert vm.pcd.shape[0] == int(d[f"n{i}"])
+    assert np.array_equal(vm.pcd.cpu().numpy(), d["pcd"])
+    assert np.array_equal(vm.pcd_ids.cpu().numpy(), d["pcd_ids"])
+    assert np.array_equal(vm.pcd_obj_ids.cpu().numpy(), d["pcd_obj_ids"])
+    assert np.array_equal(vm.pcd_colors.cpu().numpy(), d["pcd_colors"])
+    md = vm.get_map_dict()
+    assert md["xyz"].shape == (vm.max_id, 3) and md["obj_ids"].shape == (vm.max_id, 1) and md["ids"].dtype == torch.int32
+
+
+class _FixedMasks:
+    def __init__(self):
+        self.next = None
+
+    def get_masks(self, image, frame_id):
+        seg, masks = self.next
+        return torch.from_numpy(seg).to(DEV), torch.from_numpy(masks).to(DEV)
+
+
+class _NoClip:
+    clip_dim = 16
+
+
+@pytest.mark.parametrize("tag,filt", [("nofilter", False), ("filter", True)])
+def test_tracking_golden(tag, filt):
+    from ovo_amd.entities.ovo import OVO
+    from ovo_amd.slam.vanilla_mapper import VanillaMapper
+    d = golden(f"tracking_{tag}")
+    w = int(d["mask_w"])
+    K = torch.from_numpy(d["K"]).to(DEV)
+    cfg = {"match_distance_th": 0.05, "track_th": int(d["track_th"]), "depth_filter": filt, "log": False,
+           "debug_info": True, "clip": {"k_top_views": int(d["n_top_views"]), "fusion": "avg_pooling"}, "sam": {}}
+    mg = _FixedMasks()
+    ovo = OVO(cfg, None, None, K, device=DEV, clip_generator=_NoClip(), mask_generator=mg)
+    vm = VanillaMapper({"device": DEV, "mapping": {}}, K)
+    for i in range(4):
+        fd = [i, d[f"rgb{i}"], d[f"depth{i}"], d[f"c2w{i}"]]
+        vm.track_camera(fd)
+        vm.map(fd, vm.get_c2w(i))
+        assert vm.pcd.shape[0] == int(d[f"pcd_n{i}"])
+        assert np.array_equal(vm.get_map()[2].cpu().numpy(), d[f"ins_before{i}"])
+        masks = unpack(d[f"masks{i}"], w)
+        mg.next = (d[f"seg{i}"], masks)
+        updated = ovo.detect_and_track_objects([i, d[f"rgb{i}"], d[f"depth{i}"], ()], vm.get_map(), vm.get_c2w(i))
+        assert updated.dtype == torch.int32 and np.array_equal(updated.cpu().numpy(), d[f"updated{i}"])
+        vm.update_pcd_obj_ids(updated)
+        matched, fused, _, kf = ovo.keyframes_queue[-1]
+        assert kf == i and matched == d[f"matched_ins_ids{i}"].tolist()
+        assert np.array_equal(fused.cpu().numpy(), unpack(d[f"bmaps{i}"], w))
+        assert ovo.next_ins_id == int(d[f"next_ins_id{i}"])
+    assert sorted(ovo.objects) == d["obj_ids"].tolist()
+    for j, o in ovo.objects.items():
+        assert o.kfs_ids == d[f"obj{j}_kfs"].tolist()
+        assert sorted(o.top_kf) == [tuple(r) for r in d[f"obj{j}_topkf"].tolist()]
+        assert np.asarray(o.points_ids).reshape(-1).tolist() == d[f"obj{j}_points"].reshape(-1).tolist()
+
+
+# ------------------------------------------------------------------ oracle at full size
+def _scene(n_points, scale=1.0, t=2, seed=5):
+    from ovo_amd import synthetic as syn
+    h, w = syn.scannet_depth_hw(scale)
+    K = syn.scannet_intrinsics(scale)
+    c2w = syn.pose(t)
+    depth = syn.render_depth(c2w, K, h, w, seed=seed)
+    pts = syn.padded_map(n_points, frames=3, scale=scale, seed=seed)
+    return pts, depth, c2w, K
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 100_003, 1_000_000])
+def test_frustum_and_match_vs_oracle_sizes(n):
+    from oracle import geometry as OG
+    from ovo_amd.utils import geometry_utils as G
+    pts, depth, c2w, K = _scene(max(n, 1))
+    pts = pts[:n]
+    corners = OG.frustum_corners(depth, c2w, K)
+    ids = G.compute_frustum_point_ids(_t(pts).reshape(-1, 3), torch.from_numpy(corners), device=DEV)
+    ref = OG.frustum_point_ids(pts, corners)
+    assert np.array_equal(ids.cpu().numpy(), ref)
+    if n == 0:
+        return
+    w2c = torch.linalg.inv(torch.from_numpy(c2w))
+    fp = np.ascontiguousarray(pts[ref])
+    mi, muv = G.match_3d_points_to_2d_pixels(_t(depth), w2c, _t(fp).reshape(-1, 3), torch.from_numpy(K), 0.05)
+    ri, ruv = OG.match(depth, w2c.numpy(), fp, K, 0.05)
+    assert np.array_equal(mi.cpu().numpy(), ri) and np.array_equal(muv.cpu().numpy(), ruv)
+    if n >= 100_000:
+        assert ri.shape[0] > 1000          # the scene really exercises the matcher
+        assert (np.diff(mi.cpu().numpy()) > 0).all()      # ascending, unique
+
+
+def test_depth_filter_vs_oracle():
+    from oracle import geometry as OG
+    from ovo_amd.utils import geometry_utils as G
+    _, depth, _, _ = _scene(1)
+    depth[100:140, 200:260] += 0.4            # a step edge so the filter fires
+    out = G.depth_filter(_t(depth)).cpu().numpy()
+    ref = OG.depth_filter(depth)
+    diff = out != ref
+    # fp32 vs fp64 accumulation: only pixels within 1e-5 of the threshold may flip
+    assert diff.mean() < 1e-4
+    assert (ref == -1).sum() > 100 and (out == -1).sum() > 100
+    same = ~diff
+    assert np.array_equal(out[same], ref[same])
+
+
+def test_track_project_matches_unfused_oracle_full_size():
+    """Fused cull+project+match+seg-lookup+vote pass == oracle composition, 1M-point map, with colour/depth ratio."""
+    from oracle import geometry as OG
+    from ovo_amd import _lib as L, synthetic as syn
+    from ovo_amd.utils import geometry_utils as G
+    n = 1_000_000
+    pts, depth, c2w, K = _scene(n)
+    h, w = depth.shape
+    H, W = 480, 640
+    masks = syn.make_masks(H, W, seed=9)
+    seg = syn.masks_to_segmap(masks)
+    rng = np.random.default_rng(3)
+    ins = np.where(rng.random(n) < 0.3, -1, rng.integers(0, 2000, n)).astype(np.int32)
+    ratio = (1.0, 1.0, 12)
+    corners = OG.frustum_corners(depth, c2w, K)
+    w2c = torch.linalg.inv(torch.from_numpy(c2w))
+    cam = G.make_camera(torch.from_numpy(corners), w2c, torch.from_numpy(K), 0.05, h, w)
+    n_masks, cols = masks.shape[0], 2001
+    point_seg = torch.empty(n, dtype=torch.int16, device=DEV)
+    hist = torch.empty((n_masks, cols), dtype=torch.int32, device=DEV)
+    counters = torch.empty(2, dtype=torch.int64, device=DEV)
+    lib = L.load()
+    L.check(lib.ovo_track_project(L.ptr(_t(pts)), L.ptr(_t(ins)), n, cam, L.ptr(_t(depth)), L.ptr(_t(seg)), H, W,
+                                  L.Ratio(1, ratio[0], ratio[1], ratio[2]), L.ptr(point_seg), L.ptr(hist), n_masks, cols,
+                                  L.ptr(counters), L.stream()))
+    stats = torch.empty((n_masks, 4), dtype=torch.int32, device=DEV)
+    L.check(lib.ovo_vote_stats(L.ptr(hist), n_masks, cols, L.ptr(_t(seg)), seg.size, L.ptr(stats), L.stream()))
+    # oracle composition
+    fids = OG.frustum_point_ids(pts, corners)
+    midx, uv = OG.match(depth, w2c.numpy(), pts[fids], K, 0.05)
+    uv = uv + 12
+    ref_seg = np.full(n, -2, np.int16)
+    ref_seg[fids[midx]] = seg[uv[:, 1], uv[:, 0]]
+    assert counters.tolist() == [fids.shape[0], midx.shape[0]]
+    assert np.array_equal(point_seg.cpu().numpy(), ref_seg)
+    ref_hist = np.zeros((n_masks, cols), np.int64)
+    sel = ref_seg >= 0
+    np.add.at(ref_hist, (ref_seg[sel].astype(np.int64), ins[sel].astype(np.int64) + 1), 1)
+    assert np.array_equal(hist.cpu().numpy(), ref_hist)
+    st = stats.cpu().numpy()
+    assert np.array_equal(st[:, 0], ref_hist.sum(1)) and np.array_equal(st[:, 1], ref_hist[:, 1:].sum(1))
+    assert np.array_equal(st[:, 3], np.bincount(seg[seg >= 0], minlength=n_masks))
+    for m in range(n_masks):
+        row = ref_hist[m, 1:]
+        exp = -1 if row.max() == 0 else int(np.flatnonzero(row == row.max())[0])
+        assert st[m, 2] == exp
+    # write half: idempotent, only touches free points of targeted masks
+    target = np.where(np.arange(n_masks) % 2 == 0, 5000 + np.arange(n_masks), -1).astype(np.int32)
+    out = torch.empty(n, dtype=torch.int32, device=DEV)
+    cnt = torch.empty(1, dtype=torch.int64, device=DEV)
+    L.check(lib.ovo_assign_instances(L.ptr(_t(ins)), L.ptr(point_seg), n, L.ptr(_t(target)), n_masks, L.ptr(out), L.ptr(cnt), L.stream()))
+    exp = ins.copy()
+    hit = (ref_seg >= 0) & (ins == -1)
+    tg = target[np.clip(ref_seg, 0, None)]
+    exp[hit & (tg > -1)] = tg[hit & (tg > -1)]
+    assert np.array_equal(out.cpu().numpy(), exp) and int(cnt) == int((exp != ins).sum())
+    out2 = torch.empty_like(out)
+    L.check(lib.ovo_assign_instances(L.ptr(out), L.ptr(point_seg), n, L.ptr(_t(target)), n_masks, L.ptr(out2), None, L.stream()))
+    assert torch.equal(out, out2)
