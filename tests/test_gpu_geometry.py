@@ -174,11 +174,12 @@ def test_track_project_matches_unfused_oracle_full_size():
     hist = torch.empty((n_masks, cols), dtype=torch.int32, device=DEV)
     counters = torch.empty(2, dtype=torch.int64, device=DEV)
     lib = L.load()
-    L.check(lib.ovo_track_project(L.ptr(_t(pts)), L.ptr(_t(ins)), n, cam, L.ptr(_t(depth)), L.ptr(_t(seg)), H, W,
+    d_pts, d_ins, d_depth, d_seg = _t(pts), _t(ins), _t(depth), _t(seg)     # keep alive: raw pointers cross the ABI
+    L.check(lib.ovo_track_project(L.ptr(d_pts), L.ptr(d_ins), n, cam, L.ptr(d_depth), L.ptr(d_seg), H, W,
                                   L.Ratio(1, ratio[0], ratio[1], ratio[2]), L.ptr(point_seg), L.ptr(hist), n_masks, cols,
                                   L.ptr(counters), L.stream()))
     stats = torch.empty((n_masks, 4), dtype=torch.int32, device=DEV)
-    L.check(lib.ovo_vote_stats(L.ptr(hist), n_masks, cols, L.ptr(_t(seg)), seg.size, L.ptr(stats), L.stream()))
+    L.check(lib.ovo_vote_stats(L.ptr(hist), n_masks, cols, L.ptr(d_seg), seg.size, L.ptr(stats), L.stream()))
     # oracle composition
     fids = OG.frustum_point_ids(pts, corners)
     midx, uv = OG.match(depth, w2c.numpy(), pts[fids], K, 0.05)
@@ -202,12 +203,13 @@ def test_track_project_matches_unfused_oracle_full_size():
     target = np.where(np.arange(n_masks) % 2 == 0, 5000 + np.arange(n_masks), -1).astype(np.int32)
     out = torch.empty(n, dtype=torch.int32, device=DEV)
     cnt = torch.empty(1, dtype=torch.int64, device=DEV)
-    L.check(lib.ovo_assign_instances(L.ptr(_t(ins)), L.ptr(point_seg), n, L.ptr(_t(target)), n_masks, L.ptr(out), L.ptr(cnt), L.stream()))
+    d_target = _t(target)
+    L.check(lib.ovo_assign_instances(L.ptr(d_ins), L.ptr(point_seg), n, L.ptr(d_target), n_masks, L.ptr(out), L.ptr(cnt), L.stream()))
     exp = ins.copy()
     hit = (ref_seg >= 0) & (ins == -1)
     tg = target[np.clip(ref_seg, 0, None)]
     exp[hit & (tg > -1)] = tg[hit & (tg > -1)]
     assert np.array_equal(out.cpu().numpy(), exp) and int(cnt) == int((exp != ins).sum())
     out2 = torch.empty_like(out)
-    L.check(lib.ovo_assign_instances(L.ptr(out), L.ptr(point_seg), n, L.ptr(_t(target)), n_masks, L.ptr(out2), None, L.stream()))
+    L.check(lib.ovo_assign_instances(L.ptr(out), L.ptr(point_seg), n, L.ptr(d_target), n_masks, L.ptr(out2), None, L.stream()))
     assert torch.equal(out, out2)
