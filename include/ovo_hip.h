@@ -156,6 +156,132 @@ int ovo_similarity(const void *F, int feat_dtype, int64_t n, int D, const float 
 int ovo_mask_intersections(const uint64_t *bits, int n, int64_t words, int32_t *inter, ovo_stream_t stream);
 int ovo_pack_masks(const uint8_t *masks, int n, int64_t pixels, uint64_t *bits, int64_t words, ovo_stream_t stream);
 
+/* =============================================================================================
+ * Encoder building blocks (a10, a12, a13): the reference calls these through third-party nn.Modules
+ * (open_clip / perception_models ViT: clip_generator.py:112-122, textregion.py:141-142; sam2 Hiera:
+ * mask_generator.py:113).  bf16 (or f16) activations and weights, fp32 accumulation, fp32 residual stream.
+ * ============================================================================================= */
+
+/* C[M,N] = act(alpha * A[M,K] . W[N,K]^T + bias[N]) + add[M,N]      (nn.Linear layout: W is [out, in])
+ *   in_dtype : 1 = f16, 2 = bf16 (A and W);  out_dtype: 0 = f32, 1 = f16, 2 = bf16
+ *   act      : 0 none, 1 GELU (erf), 2 QuickGELU x*sigmoid(1.702x)      (open_clip "-qg" cards)
+ *   add      : optional f32 [M,N] (residual stream / position embedding); may alias C when out_dtype = 0
+ *   K % 32 == 0, N % 4 == 0, lda/ldw multiples of 8 elements, 16-byte aligned bases. */
+typedef struct {
+    const void *A; int64_t lda;
+    const void *W; int64_t ldw;
+    const float *bias;
+    void *C; int64_t ldc;
+    const float *add; int64_t ld_add;
+    int32_t M, N, K;
+    int32_t in_dtype, out_dtype, act;
+    float alpha;
+} ovo_gemm_t;
+int ovo_gemm(const ovo_gemm_t *g, ovo_stream_t stream);
+
+/* O = softmax(Q K^T * scale) V per (batch, head); bf16 in/out, fp32 softmax and accumulation.
+ * Element (b, h, t, d) of X lives at X + b*x_sb + h*x_sh + t*x_st + d (strides in ELEMENTS, d contiguous), so
+ * the packed QKV GEMM output [B, T, 3, H, hd] is consumed in place.  hd % 8 == 0, hd <= 128.
+ * Windowed attention (Hiera) = windows folded into B; pooled queries = Tq < Tk. */
+typedef struct {
+    const void *q, *k, *v;
+    void *o;
+    int64_t q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st;
+    int32_t B, H, Tq, Tk, hd;
+    float scale;
+} ovo_attention_t;
+int ovo_attention(const ovo_attention_t *a, ovo_stream_t stream);
+
+/* y = LayerNorm(x) * gamma + beta over the last dim (biased variance, eps inside the sqrt).
+ * x f32 rows at x + r*x_stride; y rows at y + r*y_stride, out_dtype 0 = f32, 2 = bf16.  d % 4 == 0. */
+int ovo_layernorm(const float *x, int64_t x_stride, int64_t rows, int d, const float *gamma, const float *beta,
+                  float eps, void *y, int64_t y_stride, int out_dtype, ovo_stream_t stream);
+
+/* ViT token assembly: x[b, t, :] = (t < n_prefix ? prefix[t] : patch[b, t - n_prefix]) + pos[t], then an optional
+ * LayerNorm (open_clip ln_pre).  patch f32 [B, P, d], prefix f32 [n_prefix, d] (class token) or NULL,
+ * pos f32 [n_prefix + P, d] or NULL, x f32 [B, n_prefix + P, d]. */
+int ovo_vit_embed(const float *patch, const float *prefix, int n_prefix, const float *pos, int B, int P, int d,
+                  const float *gamma, const float *beta, float eps, float *x, ovo_stream_t stream);
+
+/* Non-overlapping (stride == patch) or overlapping im2col of NCHW f32 images into bf16 rows
+ * [B * oh * ow, kpad], column (c, ky, kx) = c*ksz*ksz + ky*ksz + kx, zero padded to kpad (kpad % 32 == 0),
+ * zero outside the image (conv padding `pad`). */
+int ovo_im2col(const float *img, int B, int C, int H, int W, int ksz, int stride, int pad, void *out, int kpad,
+               ovo_stream_t stream);
+
+/* Crop + resize (bilinear, align_corners = False, optional antialias exactly as torch's
+ * F.interpolate(..., antialias=True)) + per-channel normalise: out[c] = (resize(src[c]) * scale - mean[c]) / std[c].
+ * src is CHW, u8 (src_dtype 3) or f32 (0); the crop is rows [y0, y0+ch) x cols [x0, x0+cw). out f32 [C, oh, ow]. */
+int ovo_resize_normalize(const void *src, int src_dtype, int C, int H, int W, int y0, int x0, int ch, int cw,
+                         float *out, int oh, int ow, int antialias, float scale, const float *mean3_host,
+                         const float *std3_host, ovo_stream_t stream);
+
+/* 2-D rotary embedding on q and k of a packed QKV buffer (perception_models Rope2D), in place.
+ * qkv bf16 [B, T, 3, H, hd]; cos/sin f32 [T, hd]; pairs (2i, 2i+1) rotate together (interleaved form);
+ * rows t < t0 (class token) are left alone. */
+int ovo_rope_qk(void *qkv, int B, int T, int H, int hd, const float *cos_t, const float *sin_t, int t0,
+                ovo_stream_t stream);
+
+/* ---- a15: PETextRegion.get_features_mask (textregion.py:145-161) ------------------------------------
+ * masks u8/bool [N, H, W] -> w bf16 [N, gpad] with w = 1 where the bilinear (align_corners = False) sample of the
+ * mask at token cell (gy, gx) is > 0, else 0; columns >= gh*gw are zero; cnt f32[N] = number of ones. */
+int ovo_feature_masks(const uint8_t *masks, int N, int H, int W, int gh, int gw, void *w, int gpad, float *cnt,
+                      ovo_stream_t stream);
+
+/* ---- a16: resize_features (textregion.py:9-28), written TRANSPOSED for the pooling GEMM --------------
+ * tokens f32 [1 + nh*nw, tstride rows of d] (row 0 = global crop, then tiles); each crop has P*P patch tokens
+ * starting at token `t0` (1 when a class token is present).  out bf16 [d, gpad]:
+ * out[:, gy*gw + gx] = 0.5 * bilinear(global grid)(gy, gx) + tile(gy / P, gx / P) token (gy % P, gx % P). */
+int ovo_stitch_tokens_t(const float *tokens, int tokens_per_crop, int t0, int d, int P, int nh, int nw, void *out,
+                        int gpad, ovo_stream_t stream);
+
+/* rows of f32 [N, d] scaled by 1 / cnt[row] -> bf16 [N, d] (masked mean);  y = x / ||x||_2 per row (f32). */
+int ovo_scale_rows_bf16(const float *x, const float *cnt, int N, int d, void *y, ovo_stream_t stream);
+int ovo_l2_normalize_rows(const float *x, int64_t N, int d, float *y, ovo_stream_t stream);
+/* f32 -> bf16 (dtype 2) / f16 (dtype 1) conversion of n elements (n % 4 == 0). */
+int ovo_cast_f32(const float *x, int64_t n, void *y, int dtype, ovo_stream_t stream);
+
+/* ---- a12 / a13: ViT forward (open_clip VisionTransformer / perception_models pe.VisionTransformer) -----
+ * Replaces `model.encode_image` (clip_generator.py:122) and `visual.forward_features(x, norm=True)`
+ * (textregion.py:142).  The whole layer loop runs inside the library (one C call per forward, graph-capturable).
+ * Weights: bf16 matrices in nn.Linear layout [out, in]; fp32 vectors (biases, LayerNorm, class / position
+ * embeddings).  LayerScale, if a model has it, is folded into out_w/out_b and fc2_w/fc2_b at load time. */
+typedef struct {
+    int32_t image_size, patch, width, layers, heads, mlp_dim, out_dim;
+    int32_t n_prefix;  /* 1 = class token, 0 = none                                             */
+    int32_t act;       /* 1 = GELU, 2 = QuickGELU                                               */
+    int32_t pre_ln;    /* ln_pre present                                                        */
+    int32_t use_rope;  /* 2-D rotary embedding on q, k (PE)                                     */
+    int32_t pool;      /* 0: all tokens after ln_post -> f32 [B, T, width] (forward_features);  */
+                       /* 1: ln_post(class token) @ proj -> f32 [B, out_dim] (encode_image)     */
+    int32_t kpad;      /* 3*patch*patch rounded up to a multiple of 32                          */
+    float ln_eps;
+} ovo_vit_config_t;
+
+typedef struct {
+    const float *ln1_g, *ln1_b;
+    const void *qkv_w; const float *qkv_b;   /* [3*width, width], [3*width]  (q | k | v)  */
+    const void *out_w; const float *out_b;   /* [width, width]                              */
+    const float *ln2_g, *ln2_b;
+    const void *fc1_w; const float *fc1_b;   /* [mlp_dim, width]                            */
+    const void *fc2_w; const float *fc2_b;   /* [width, mlp_dim]                            */
+} ovo_vit_layer_t;
+
+typedef struct {
+    const void *patch_w; const float *patch_b;        /* [width, kpad] (conv1 flattened, zero padded), bias or NULL */
+    const float *prefix;                              /* [n_prefix, width] class embedding                           */
+    const float *pos;                                 /* [n_prefix + P, width] or NULL                                */
+    const float *ln_pre_g, *ln_pre_b, *ln_post_g, *ln_post_b;
+    const void *proj_w;                               /* [out_dim, width] (= proj^T) when pool = 1                    */
+    const float *rope_cos, *rope_sin;                 /* [n_prefix + P, head_dim] when use_rope                       */
+    const ovo_vit_layer_t *layers;                    /* HOST array of cfg.layers entries                            */
+} ovo_vit_weights_t;
+
+size_t ovo_vit_workspace_bytes(const ovo_vit_config_t *cfg, int B);
+/* images f32 [B, 3, S, S] already resized + normalised (ovo_resize_normalize); out as described by cfg.pool. */
+int ovo_vit_forward(const ovo_vit_config_t *cfg, const ovo_vit_weights_t *w, const float *images, int B, float *out,
+                    void *ws, size_t ws_bytes, ovo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

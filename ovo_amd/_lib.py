@@ -34,6 +34,41 @@ class Ratio(C.Structure):
 _P, _I64, _I32, _F32, _SZ = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 _CAM = C.POINTER(Camera)
 
+
+class Gemm(C.Structure):
+    """ovo_gemm_t"""
+    _fields_ = [("A", _P), ("lda", _I64), ("W", _P), ("ldw", _I64), ("bias", _P), ("C", _P), ("ldc", _I64),
+                ("add", _P), ("ld_add", _I64), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("act", C.c_int32), ("alpha", _F32)]
+
+
+class Attention(C.Structure):
+    """ovo_attention_t"""
+    _fields_ = [("q", _P), ("k", _P), ("v", _P), ("o", _P)] + \
+               [(n, _I64) for n in ("q_sb", "q_sh", "q_st", "k_sb", "k_sh", "k_st", "v_sb", "v_sh", "v_st", "o_sb", "o_sh", "o_st")] + \
+               [(n, C.c_int32) for n in ("B", "H", "Tq", "Tk", "hd")] + [("scale", _F32)]
+
+
+class VitConfig(C.Structure):
+    """ovo_vit_config_t"""
+    _fields_ = [(n, C.c_int32) for n in ("image_size", "patch", "width", "layers", "heads", "mlp_dim", "out_dim", "n_prefix",
+                                          "act", "pre_ln", "use_rope", "pool", "kpad")] + [("ln_eps", _F32)]
+
+
+class VitLayer(C.Structure):
+    """ovo_vit_layer_t"""
+    _fields_ = [(n, _P) for n in ("ln1_g", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_g", "ln2_b",
+                                   "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class VitWeights(C.Structure):
+    """ovo_vit_weights_t"""
+    _fields_ = [(n, _P) for n in ("patch_w", "patch_b", "prefix", "pos", "ln_pre_g", "ln_pre_b", "ln_post_g", "ln_post_b",
+                                   "proj_w", "rope_cos", "rope_sin")] + [("layers", C.POINTER(VitLayer))]
+
+
+DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.uint8: 3}
+
 _SIGNATURES = {
     "ovo_hip_last_error": (C.c_char_p, []),
     "ovo_hip_abi_version": (_I32, []),
@@ -52,6 +87,21 @@ _SIGNATURES = {
     "ovo_similarity": (_I32, [_P, _I32, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P, _P]),
     "ovo_mask_intersections": (_I32, [_P, _I32, _I64, _P, _P]),
     "ovo_pack_masks": (_I32, [_P, _I32, _I64, _P, _I64, _P]),
+    "ovo_gemm": (_I32, [C.POINTER(Gemm), _P]),
+    "ovo_attention": (_I32, [C.POINTER(Attention), _P]),
+    "ovo_layernorm": (_I32, [_P, _I64, _I64, _I32, _P, _P, _F32, _P, _I64, _I32, _P]),
+    "ovo_vit_embed": (_I32, [_P, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _F32, _P, _P]),
+    "ovo_im2col": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "ovo_resize_normalize": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _F32,
+                                    C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
+    "ovo_rope_qk": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P, _I32, _P]),
+    "ovo_feature_masks": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P, _P]),
+    "ovo_stitch_tokens_t": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "ovo_scale_rows_bf16": (_I32, [_P, _P, _I32, _I32, _P, _P]),
+    "ovo_l2_normalize_rows": (_I32, [_P, _I64, _I32, _P, _P]),
+    "ovo_cast_f32": (_I32, [_P, _I64, _P, _I32, _P]),
+    "ovo_vit_workspace_bytes": (_SZ, [C.POINTER(VitConfig), _I32]),
+    "ovo_vit_forward": (_I32, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _I32, _P, _P, _SZ, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

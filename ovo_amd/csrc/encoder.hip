@@ -1,0 +1,370 @@
+// encoder.hip -- the bandwidth-bound glue of the ViT / Hiera forward passes and of TextRegion region pooling:
+// LayerNorm, token assembly, im2col, crop+resize+normalise, rotary embedding, mask -> token-grid resampling,
+// multi-resolution token stitching, row scaling / L2 normalisation.  One wave per row wherever a row is
+// reduced (64-lane shuffles, no LDS), 16-byte accesses along the contiguous dimension.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ uint16_t f2bf(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) {
+    return make_uint2((uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16), (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16));
+}
+
+// ---- LayerNorm: one wave per row, three passes over an L1-resident row ----
+__device__ __forceinline__ void ln_row(const float *__restrict__ x, int d, const float *__restrict__ gamma,
+                                       const float *__restrict__ beta, float eps, void *__restrict__ y, int out_bf16, int lane,
+                                       const float *__restrict__ extra_add = nullptr) {
+    const int d4 = d >> 2;
+    float s = 0.f;
+    for (int i = lane; i < d4; i += 64) {
+        float4 v = ((const float4 *)x)[i];
+        if (extra_add) { const float4 e = ((const float4 *)extra_add)[i]; v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+    for (int i = lane; i < d4; i += 64) {
+        float4 v = ((const float4 *)x)[i];
+        if (extra_add) { const float4 e = ((const float4 *)extra_add)[i]; v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e2 = v.w - mean;
+        q += (a * a + b * b) + (c * c + e2 * e2);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+    for (int i = lane; i < d4; i += 64) {
+        float4 v = ((const float4 *)x)[i];
+        if (extra_add) { const float4 e = ((const float4 *)extra_add)[i]; v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
+        const float4 g = ((const float4 *)gamma)[i], b = ((const float4 *)beta)[i];
+        const float o0 = (v.x - mean) * rstd * g.x + b.x, o1 = (v.y - mean) * rstd * g.y + b.y;
+        const float o2 = (v.z - mean) * rstd * g.z + b.z, o3 = (v.w - mean) * rstd * g.w + b.w;
+        if (out_bf16) ((uint2 *)y)[i] = pack4_bf16(o0, o1, o2, o3);
+        else ((float4 *)y)[i] = make_float4(o0, o1, o2, o3);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_layernorm(const float *__restrict__ x, long long xs, long long rows, int d,
+                                                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                   char *__restrict__ y, long long ys, int out_bf16) {
+    const int lane = threadIdx.x & 63;
+    const long long waves = (long long)gridDim.x * 4;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += waves)
+        ln_row(x + r * xs, d, gamma, beta, eps, y + r * ys * (out_bf16 ? 2 : 4), out_bf16, lane);
+}
+
+__global__ void __launch_bounds__(256) k_vit_embed(const float *__restrict__ patch, const float *__restrict__ prefix, int n_prefix,
+                                                   const float *__restrict__ pos, int B, int P, int d, const float *__restrict__ gamma,
+                                                   const float *__restrict__ beta, float eps, float *__restrict__ x) {
+    const int lane = threadIdx.x & 63;
+    const int T = n_prefix + P;
+    const long long rows = (long long)B * T, waves = (long long)gridDim.x * 4;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += waves) {
+        const int b = (int)(r / T), t = (int)(r % T);
+        const float *src = t < n_prefix ? prefix + (long long)t * d : patch + ((long long)b * P + (t - n_prefix)) * d;
+        const float *pe = pos ? pos + (long long)t * d : nullptr;
+        float *dst = x + r * d;
+        if (gamma) ln_row(src, d, gamma, beta, eps, dst, 0, lane, pe);
+        else
+            for (int i = lane; i < (d >> 2); i += 64) {
+                float4 v = ((const float4 *)src)[i];
+                if (pe) { const float4 e = ((const float4 *)pe)[i]; v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w; }
+                ((float4 *)dst)[i] = v;
+            }
+    }
+}
+
+// ---- im2col ----
+__global__ void __launch_bounds__(256) k_im2col(const float *__restrict__ img, int B, int C, int H, int W, int ksz, int stride, int pad,
+                                                int oh, int ow, uint16_t *__restrict__ out, int kpad) {
+    const long long total = (long long)B * oh * ow * kpad;
+    const int kk = ksz * ksz, kreal = C * kk;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % kpad);
+        const long long row = i / kpad;
+        float v = 0.f;
+        if (k < kreal) {
+            const int c = k / kk, ky = (k % kk) / ksz, kx = k % ksz;
+            const int ox = (int)(row % ow), oy = (int)((row / ow) % oh), b = (int)(row / ((long long)ow * oh));
+            const int y = oy * stride - pad + ky, x = ox * stride - pad + kx;
+            if (y >= 0 && y < H && x >= 0 && x < W) v = img[(((long long)b * C + c) * H + y) * W + x];
+        }
+        out[i] = f2bf(v);
+    }
+}
+
+// ---- crop + resize + normalise ----
+struct ResizeArgs {
+    const void *src; int src_u8; int C, H, W, y0, x0, ch, cw, oh, ow, aa;
+    float scale, mean[4], std[4];
+};
+__device__ __forceinline__ float src_px(const ResizeArgs &a, int c, int y, int x) {
+    const long long i = ((long long)c * a.H + (a.y0 + y)) * a.W + (a.x0 + x);
+    return a.src_u8 ? (float)((const uint8_t *)a.src)[i] : ((const float *)a.src)[i];
+}
+__device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
+
+__global__ void __launch_bounds__(256) k_resize_norm(ResizeArgs a, float *__restrict__ out) {
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= a.ow || oy >= a.oh) return;
+    const float sy = (float)a.ch / (float)a.oh, sx = (float)a.cw / (float)a.ow;
+    for (int c = 0; c < a.C; ++c) {
+        float v;
+        if (!a.aa) {                                    // torch upsample_bilinear2d, align_corners = False
+            float fy = sy * ((float)oy + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+            float fx = sx * ((float)ox + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < a.ch - 1 ? 1 : 0), x1 = x0 + (x0 < a.cw - 1 ? 1 : 0);
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            v = (1.f - ly) * ((1.f - lx) * src_px(a, c, y0, x0) + lx * src_px(a, c, y0, x1)) +
+                ly * ((1.f - lx) * src_px(a, c, y1, x0) + lx * src_px(a, c, y1, x1));
+        } else {                                        // torch _upsample_bilinear2d_aa (separable triangle filter)
+            const float supy = sy >= 1.f ? sy : 1.f, supx = sx >= 1.f ? sx : 1.f;
+            const float ivy = sy >= 1.f ? 1.f / sy : 1.f, ivx = sx >= 1.f ? 1.f / sx : 1.f;
+            const float cy = sy * ((float)oy + 0.5f), cx = sx * ((float)ox + 0.5f);
+            int ymin = (int)(cy - supy + 0.5f); ymin = ymin < 0 ? 0 : ymin;
+            int ymax = (int)(cy + supy + 0.5f); ymax = ymax > a.ch ? a.ch : ymax;
+            int xmin = (int)(cx - supx + 0.5f); xmin = xmin < 0 ? 0 : xmin;
+            int xmax = (int)(cx + supx + 0.5f); xmax = xmax > a.cw ? a.cw : xmax;
+            float wy_tot = 0.f, wx_tot = 0.f;
+            for (int y = ymin; y < ymax; ++y) wy_tot += tri(((float)y - cy + 0.5f) * ivy);
+            for (int x = xmin; x < xmax; ++x) wx_tot += tri(((float)x - cx + 0.5f) * ivx);
+            float acc = 0.f;
+            for (int y = ymin; y < ymax; ++y) {
+                const float wy = tri(((float)y - cy + 0.5f) * ivy) / wy_tot;
+                float rowacc = 0.f;
+                for (int x = xmin; x < xmax; ++x) rowacc += (tri(((float)x - cx + 0.5f) * ivx) / wx_tot) * src_px(a, c, y, x);
+                acc += wy * rowacc;
+            }
+            v = acc;
+        }
+        out[((long long)c * a.oh + oy) * a.ow + ox] = (v * a.scale - a.mean[c]) / a.std[c];
+    }
+}
+
+// ---- rotary embedding on q, k of a packed [B, T, 3, H, hd] bf16 buffer ----
+__global__ void __launch_bounds__(256) k_rope_qk(uint32_t *__restrict__ qkv, int B, int T, int H, int hd, const float *__restrict__ cos_t,
+                                                 const float *__restrict__ sin_t, int t0) {
+    const int hp = hd >> 1;                                    // pairs per head
+    const long long total = (long long)B * T * 2 * H * hp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % hp);
+        long long r = i / hp;
+        const int h = (int)(r % H); r /= H;
+        const int which = (int)(r % 2); r /= 2;                 // 0 = q, 1 = k
+        const int t = (int)(r % T);
+        const int b = (int)(r / T);
+        if (t < t0) continue;
+        uint32_t *w = qkv + ((((long long)b * T + t) * 3 + which) * H + h) * hp + p;
+        const uint32_t raw = *w;
+        const float x0 = __uint_as_float(raw << 16), x1 = __uint_as_float(raw & 0xffff0000u);
+        const float c0 = cos_t[(long long)t * hd + 2 * p], c1 = cos_t[(long long)t * hd + 2 * p + 1];
+        const float s0 = sin_t[(long long)t * hd + 2 * p], s1 = sin_t[(long long)t * hd + 2 * p + 1];
+        const float y0 = x0 * c0 - x1 * s0, y1 = x1 * c1 + x0 * s1;
+        *w = (uint32_t)f2bf(y0) | ((uint32_t)f2bf(y1) << 16);
+    }
+}
+
+// ---- a15: masks -> token-grid weights ----
+__global__ void __launch_bounds__(256) k_feature_masks(const uint8_t *__restrict__ masks, int N, int H, int W, int gh, int gw,
+                                                       uint16_t *__restrict__ w, int gpad, float *__restrict__ cnt) {
+    const int n = blockIdx.x;
+    const uint8_t *m = masks + (long long)n * H * W;
+    const float sy = (float)H / (float)gh, sx = (float)W / (float)gw;
+    int local = 0;
+    for (int g = threadIdx.x; g < gpad; g += blockDim.x) {
+        float v = 0.f;
+        if (g < gh * gw) {
+            const int gy = g / gw, gx = g % gw;
+            float fy = sy * ((float)gy + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+            float fx = sx * ((float)gx + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            const float a = m[(long long)y0 * W + x0] ? 1.f : 0.f, b = m[(long long)y0 * W + x1] ? 1.f : 0.f;
+            const float c = m[(long long)y1 * W + x0] ? 1.f : 0.f, d = m[(long long)y1 * W + x1] ? 1.f : 0.f;
+            v = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * c + lx * d);
+        }
+        const bool on = v > 0.f;
+        w[(long long)n * gpad + g] = on ? 0x3f80 : 0;      // bf16 1.0 / 0.0
+        local += on;
+    }
+    __shared__ int red[256];
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) cnt[n] = (float)red[0];
+}
+
+// ---- a16: multi-resolution stitch, transposed output [d, gpad] ----
+__global__ void __launch_bounds__(256) k_stitch_t(const float *__restrict__ tokens, int tpc, int t0, int d, int P, int nh, int nw,
+                                                  uint16_t *__restrict__ out, int gpad) {
+    const int gh = P * nh, gw = P * nw, G = gh * gw;
+    const long long total = (long long)d * gpad;
+    const float sy = (float)P / (float)gh, sx = (float)P / (float)gw;
+    // thread -> (g fastest across lanes for coalesced writes; reads of a token row stride d are served by L2)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % gpad), c = (int)(i / gpad);
+        float v = 0.f;
+        if (g < G) {
+            const int gy = g / gw, gx = g % gw;
+            float fy = sy * ((float)gy + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+            float fx = sx * ((float)gx + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < P - 1 ? 1 : 0), x1 = x0 + (x0 < P - 1 ? 1 : 0);
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            const float *glob = tokens + (long long)t0 * d + c;                        // crop 0
+            const float a = glob[(long long)(y0 * P + x0) * d], b = glob[(long long)(y0 * P + x1) * d];
+            const float e = glob[(long long)(y1 * P + x0) * d], f = glob[(long long)(y1 * P + x1) * d];
+            const float up = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * e + lx * f);
+            const int tile = 1 + (gy / P) * nw + (gx / P);
+            const float loc = tokens[((long long)tile * tpc + t0 + (gy % P) * P + (gx % P)) * d + c];
+            v = 0.5f * up + loc;
+        }
+        out[i] = f2bf(v);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scale_rows(const float *__restrict__ x, const float *__restrict__ cnt, int N, int d,
+                                                    uint16_t *__restrict__ y) {
+    const long long total = (long long)N * d;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        y[i] = f2bf(x[i] / cnt[i / d]);
+}
+
+__global__ void __launch_bounds__(256) k_l2norm(const float *__restrict__ x, long long N, int d, float *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long long waves = (long long)gridDim.x * 4;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < N; r += waves) {
+        const float *row = x + r * d;
+        float s = 0.f;
+        for (int i = lane; i < d; i += 64) s += row[i] * row[i];
+        const float inv = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);      // F.normalize eps
+        for (int i = lane; i < d; i += 64) y[r * d + i] = row[i] * inv;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cast(const float4 *__restrict__ x, long long n4, uint2 *__restrict__ y, int dtype) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        if (dtype == 2) y[i] = pack4_bf16(v.x, v.y, v.z, v.w);
+        else {
+            const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+            y[i] = make_uint2(*(const uint32_t *)&a, *(const uint32_t *)&b);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ovo_layernorm(const float *x, int64_t x_stride, int64_t rows, int d, const float *gamma, const float *beta, float eps,
+                  void *y, int64_t y_stride, int out_dtype, ovo_stream_t stream) {
+    OVO_REQUIRE(rows >= 0 && d > 0 && d % 4 == 0, "d must be a multiple of 4");
+    OVO_REQUIRE(out_dtype == 0 || out_dtype == 2, "out_dtype: 0 = f32, 2 = bf16");
+    if (rows == 0) return OVO_OK;
+    OVO_REQUIRE(x && gamma && beta && y && x_stride % 4 == 0 && y_stride % 4 == 0, "null pointer / misaligned stride");
+    k_layernorm<<<ovo_grid(rows * 64, 256), 256, 0, (hipStream_t)stream>>>(x, x_stride, rows, d, gamma, beta, eps, (char *)y,
+                                                                          y_stride, out_dtype == 2);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_vit_embed(const float *patch, const float *prefix, int n_prefix, const float *pos, int B, int P, int d,
+                  const float *gamma, const float *beta, float eps, float *x, ovo_stream_t stream) {
+    OVO_REQUIRE(patch && x && B > 0 && P > 0 && d > 0 && d % 4 == 0 && n_prefix >= 0, "bad argument");
+    OVO_REQUIRE(n_prefix == 0 || prefix, "prefix tokens missing");
+    OVO_REQUIRE((gamma == nullptr) == (beta == nullptr), "gamma and beta go together");
+    k_vit_embed<<<ovo_grid((long long)B * (n_prefix + P) * 64, 256), 256, 0, (hipStream_t)stream>>>(patch, prefix, n_prefix, pos, B, P, d,
+                                                                                                    gamma, beta, eps, x);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_im2col(const float *img, int B, int C, int H, int W, int ksz, int stride, int pad, void *out, int kpad,
+               ovo_stream_t stream) {
+    OVO_REQUIRE(img && out && B > 0 && C > 0 && H > 0 && W > 0 && ksz > 0 && stride > 0 && pad >= 0, "bad argument");
+    OVO_REQUIRE(kpad >= C * ksz * ksz && kpad % 32 == 0, "kpad must cover C*k*k and be a multiple of 32");
+    const int oh = (H + 2 * pad - ksz) / stride + 1, ow = (W + 2 * pad - ksz) / stride + 1;
+    OVO_REQUIRE(oh > 0 && ow > 0, "empty output");
+    k_im2col<<<ovo_grid((long long)B * oh * ow * kpad, 256), 256, 0, (hipStream_t)stream>>>(img, B, C, H, W, ksz, stride, pad, oh, ow,
+                                                                                           (uint16_t *)out, kpad);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_resize_normalize(const void *src, int src_dtype, int C, int H, int W, int y0, int x0, int ch, int cw, float *out,
+                         int oh, int ow, int antialias, float scale, const float *mean3_host, const float *std3_host,
+                         ovo_stream_t stream) {
+    OVO_REQUIRE(src && out && (src_dtype == 0 || src_dtype == 3), "src_dtype: 0 = f32, 3 = u8");
+    OVO_REQUIRE(C >= 1 && C <= 4 && ch > 0 && cw > 0 && oh > 0 && ow > 0, "bad shape");
+    OVO_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + ch <= H && x0 + cw <= W, "crop outside the image");
+    ResizeArgs a;
+    a.src = src; a.src_u8 = src_dtype == 3; a.C = C; a.H = H; a.W = W; a.y0 = y0; a.x0 = x0; a.ch = ch; a.cw = cw;
+    a.oh = oh; a.ow = ow; a.aa = antialias; a.scale = scale;
+    for (int c = 0; c < 4; ++c) { a.mean[c] = mean3_host && c < C ? mean3_host[c] : 0.f; a.std[c] = std3_host && c < C ? std3_host[c] : 1.f; }
+    dim3 grid((ow + 63) / 64, (oh + 3) / 4);
+    k_resize_norm<<<grid, 256, 0, (hipStream_t)stream>>>(a, out);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_rope_qk(void *qkv, int B, int T, int H, int hd, const float *cos_t, const float *sin_t, int t0, ovo_stream_t stream) {
+    OVO_REQUIRE(qkv && cos_t && sin_t && B > 0 && T > 0 && H > 0 && hd > 0 && hd % 2 == 0 && t0 >= 0, "bad argument");
+    k_rope_qk<<<ovo_grid((long long)B * T * H * hd, 256), 256, 0, (hipStream_t)stream>>>((uint32_t *)qkv, B, T, H, hd, cos_t, sin_t, t0);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_feature_masks(const uint8_t *masks, int N, int H, int W, int gh, int gw, void *w, int gpad, float *cnt,
+                      ovo_stream_t stream) {
+    OVO_REQUIRE(N >= 0 && H > 0 && W > 0 && gh > 0 && gw > 0 && gpad >= gh * gw && gpad % 32 == 0, "bad shape");
+    if (N == 0) return OVO_OK;
+    OVO_REQUIRE(masks && w && cnt, "null pointer");
+    k_feature_masks<<<N, 256, 0, (hipStream_t)stream>>>(masks, N, H, W, gh, gw, (uint16_t *)w, gpad, cnt);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_stitch_tokens_t(const float *tokens, int tokens_per_crop, int t0, int d, int P, int nh, int nw, void *out, int gpad,
+                        ovo_stream_t stream) {
+    OVO_REQUIRE(tokens && out && d > 0 && P > 0 && nh > 0 && nw > 0 && t0 >= 0, "bad argument");
+    OVO_REQUIRE(tokens_per_crop >= t0 + P * P && gpad >= P * P * nh * nw && gpad % 32 == 0, "bad token / grid shape");
+    k_stitch_t<<<ovo_grid((long long)d * gpad, 256), 256, 0, (hipStream_t)stream>>>(tokens, tokens_per_crop, t0, d, P, nh, nw,
+                                                                                   (uint16_t *)out, gpad);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_scale_rows_bf16(const float *x, const float *cnt, int N, int d, void *y, ovo_stream_t stream) {
+    OVO_REQUIRE(N >= 0 && d > 0, "bad shape");
+    if (N == 0) return OVO_OK;
+    OVO_REQUIRE(x && cnt && y, "null pointer");
+    k_scale_rows<<<ovo_grid((long long)N * d, 256), 256, 0, (hipStream_t)stream>>>(x, cnt, N, d, (uint16_t *)y);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_l2_normalize_rows(const float *x, int64_t N, int d, float *y, ovo_stream_t stream) {
+    OVO_REQUIRE(N >= 0 && d > 0, "bad shape");
+    if (N == 0) return OVO_OK;
+    OVO_REQUIRE(x && y, "null pointer");
+    k_l2norm<<<ovo_grid(N * 64, 256), 256, 0, (hipStream_t)stream>>>(x, N, d, y);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_cast_f32(const float *x, int64_t n, void *y, int dtype, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && n % 4 == 0 && (dtype == 1 || dtype == 2), "n % 4 == 0, dtype 1 (f16) or 2 (bf16)");
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(x && y && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 7) == 0), "null / misaligned pointer");
+    k_cast<<<ovo_grid(n / 4, 256), 256, 0, (hipStream_t)stream>>>((const float4 *)x, n / 4, (uint2 *)y, dtype);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+// gemm.hip -- C[M,N] = act(alpha * A[M,K] . W[N,K]^T + bias) (+ add), bf16/f16 inputs, fp32 accumulate on MFMA.
+//
+// The workhorse of the ViT / Hiera forward passes (QKV, projection, MLP, patch-embed, FPN 1x1 convs) and of
+// the large-Q similarity query (BASELINE.json config 5).  Both operands are K-contiguous (activations
+// [tokens, K], nn.Linear weights [out, K]), so A and W tiles are staged the same way.
+//
+// Structure (gfx950):
+//   * block = 256 threads = 4 waves in a 2x2 arrangement; block tile BM x BN in {64,128}^2, BK in {32,64};
+//     each wave owns (BM/2) x (BN/2) as 16x16 MFMA tiles (v_mfma_f32_16x16x32_{bf16,f16}).
+//   * global -> LDS with global_load_lds_dwordx4 (16 B per lane, no VGPR round trip), two LDS stages:
+//     tile t+1 streams in while tile t is multiplied.
+//   * the DMA writes LDS lane-linearly, so the bank-conflict swizzle (16-byte chunk index XOR a row
+//     function) is applied to the per-lane SOURCE address and again when fragments are read (ds_read_b128).
+//   * operands are swapped (a = W fragment, b = activation fragment): the accumulator holds C^T tiles, i.e.
+//     each lane owns 4 consecutive output columns of one output row -> 8/16-byte epilogue stores.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct GemmArgs {
+    const char *A; long long lda;
+    const char *W; long long ldw;
+    const float *bias;
+    void *C; long long ldc;
+    const float *add; long long ld_add;
+    int M, N, K;
+    int out_dtype, act;
+    float alpha;
+    int nbn;
+};
+
+template <typename VT> struct Mfma;
+template <> struct Mfma<bf16x8> {
+    __device__ static f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma<f16x8> {
+    __device__ static f32x4 run(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+template <int BK> __device__ __forceinline__ int swz(int row) {
+    return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+}
+
+__device__ __forceinline__ void glds16(const void *src, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float act_fn(float x, int act) {
+    if (act == 1) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    if (act == 2) return x / (1.0f + __expf(-1.702f * x));
+    return x;
+}
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+    const uint32_t ra = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;         // round-to-nearest-even (finite values)
+    const uint32_t rb = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
+    return ra | (rb << 16);
+}
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+    const __half2 h = __floats2half2_rn(a, b);
+    return *(const uint32_t *)&h;
+}
+
+template <int BM, int BN, int BK, typename VT>
+__global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CPR = BK / 8;                       // 16-byte chunks per tile row
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16, KS = BK / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int m0 = (blockIdx.x / g.nbn) * BM, n0 = (blockIdx.x % g.nbn) * BN;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int buf, int kt) {
+        char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
+#pragma unroll
+        for (int it = 0; it < A_BYTES / 4096; ++it) {
+            const int id = it * 256 + tid, row = id / CPR, c = (id % CPR) ^ swz<BK>(row);
+            int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
+            glds16(g.A + ((long long)gr * g.lda + (long long)kt * BK + c * 8) * 2, sa + (it * 256 + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int it = 0; it < B_BYTES / 4096; ++it) {
+            const int id = it * 256 + tid, row = id / CPR, c = (id % CPR) ^ swz<BK>(row);
+            int gr = n0 + row; gr = gr < g.N ? gr : g.N - 1;
+            glds16(g.W + ((long long)gr * g.ldw + (long long)kt * BK + c * 8) * 2, sb + (it * 256 + wave * 64) * 16);
+        }
+    };
+    auto frag = [&](const char *tile, int row, int chunk) -> VT {
+        return *(const VT *)(tile + (row * CPR + (chunk ^ swz<BK>(row))) * 16);
+    };
+    auto compute = [&](int buf) {
+        const char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            VT xf[TM], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xf[i] = frag(sa, wm0 + i * 16 + fr, ks * 4 + fq);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = frag(sb, wn0 + j * 16 + fr, ks * 4 + fq);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<VT>::run(wf[j], xf[i], acc[i][j]);
+        }
+    };
+
+    const int nt = g.K / BK;
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < nt - 1; ++t) {
+        stage((t + 1) & 1, t + 1);
+        compute(t & 1);
+        __syncthreads();
+    }
+    compute((nt - 1) & 1);
+
+    // epilogue: acc[i][j][r] = C[m = m0+wm0+16i+fr][n = n0+wn0+16j+4fq+r]
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm0 + i * 16 + fr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * 16 + fq * 4;
+            if (n >= g.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
+            if (g.bias) {
+                const float4 b = *(const float4 *)(g.bias + n);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (g.act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = act_fn(v[r], g.act);
+            }
+            if (g.add) {
+                const float4 a = *(const float4 *)(g.add + (long long)m * g.ld_add + n);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            }
+            if (g.out_dtype == 0) {
+                *(float4 *)((float *)g.C + (long long)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 p;
+                if (g.out_dtype == 2) { p.x = pack_bf16(v[0], v[1]); p.y = pack_bf16(v[2], v[3]); }
+                else { p.x = pack_f16(v[0], v[1]); p.y = pack_f16(v[2], v[3]); }
+                *(uint2 *)((uint16_t *)g.C + (long long)m * g.ldc + n) = p;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, typename VT>
+int launch(const GemmArgs &g0, hipStream_t s) {
+    GemmArgs g = g0;
+    g.nbn = (g.N + BN - 1) / BN;
+    const int nbm = (g.M + BM - 1) / BM;
+    const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+    static bool attr_done = false;              // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_gemm<BM, BN, BK, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { ovo_set_error("ovo_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
+        attr_done = true;
+    }
+    k_gemm<BM, BN, BK, VT><<<nbm * g.nbn, 256, lds, s>>>(g);
+    return OVO_OK;
+}
+
+template <typename VT>
+int dispatch(const GemmArgs &g, hipStream_t s) {
+    const bool k64 = g.K % 64 == 0;
+    auto blocks = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
+    // largest tile that still gives every CU (256) something to do
+    int bm = 64, bn = 64;
+    if (blocks(128, 128) >= 200) { bm = 128; bn = 128; }
+    else if (blocks(64, 128) >= 200) { bm = 64; bn = 128; }
+    else if (blocks(128, 64) >= 200) { bm = 128; bn = 64; }
+#define GO(BM, BN)                                                          \
+    if (bm == BM && bn == BN) return k64 ? launch<BM, BN, 64, VT>(g, s) : launch<BM, BN, 32, VT>(g, s);
+    GO(128, 128) GO(64, 128) GO(128, 64) GO(64, 64)
+#undef GO
+    return OVO_E_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int ovo_gemm(const ovo_gemm_t *p, ovo_stream_t stream) {
+    OVO_REQUIRE(p, "null descriptor");
+    OVO_REQUIRE(p->M >= 0 && p->N > 0 && p->K > 0, "bad shape");
+    if (p->M == 0) return OVO_OK;
+    OVO_REQUIRE(p->A && p->W && p->C, "null pointer");
+    OVO_REQUIRE(p->K % 32 == 0, "K must be a multiple of 32 (pad activations and weights with zeros)");
+    OVO_REQUIRE(p->N % 4 == 0, "N must be a multiple of 4");
+    OVO_REQUIRE(p->in_dtype == 1 || p->in_dtype == 2, "in_dtype: 1 = f16, 2 = bf16");
+    OVO_REQUIRE(p->out_dtype >= 0 && p->out_dtype <= 2, "out_dtype: 0 = f32, 1 = f16, 2 = bf16");
+    OVO_REQUIRE(p->lda % 8 == 0 && p->ldw % 8 == 0 && (((uintptr_t)p->A | (uintptr_t)p->W) & 15) == 0, "A/W rows must be 16-byte aligned");
+    OVO_REQUIRE(p->ldc % 4 == 0 && ((uintptr_t)p->C & 15) == 0, "C rows must be 16-byte aligned");
+    OVO_REQUIRE(!p->add || (p->ld_add % 4 == 0 && ((uintptr_t)p->add & 15) == 0), "add rows must be 16-byte aligned");
+    OVO_REQUIRE(!p->bias || ((uintptr_t)p->bias & 15) == 0, "bias must be 16-byte aligned");
+    GemmArgs g;
+    g.A = (const char *)p->A; g.lda = p->lda; g.W = (const char *)p->W; g.ldw = p->ldw; g.bias = p->bias;
+    g.C = p->C; g.ldc = p->ldc; g.add = p->add; g.ld_add = p->ld_add;
+    g.M = p->M; g.N = p->N; g.K = p->K; g.out_dtype = p->out_dtype; g.act = p->act; g.alpha = p->alpha; g.nbn = 0;
+    const int rc = p->in_dtype == 2 ? dispatch<bf16x8>(g, (hipStream_t)stream) : dispatch<f16x8>(g, (hipStream_t)stream);
+    if (rc != OVO_OK) return rc;
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}

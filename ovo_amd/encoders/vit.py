@@ -1,0 +1,241 @@
+"""Vision transformer image encoder on MI355X.
+
+Replaces the third-party towers the reference calls -- open_clip `model.encode_image`
+(clip_generator.py:112-122) and perception_models `visual.forward_features(x, norm=True)`
+(textregion.py:141-142) -- with `ovo_vit_forward` from libovo_hip.so (MFMA GEMMs, fused attention, fp32
+residual stream).  Weights use open_clip's VisionTransformer state-dict names, so a real checkpoint's
+`visual.*` tensors load unchanged; offline (no hub access) `random_state` gives seeded weights of the same
+architecture, which is all throughput and parity-vs-oracle need.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import _lib as L
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+@dataclass(frozen=True)
+class ViTSpec:
+    name: str
+    image_size: int
+    patch: int
+    width: int
+    layers: int
+    heads: int
+    mlp_dim: int
+    out_dim: int
+    act: str = "gelu"                 # "gelu" | "quick_gelu" (DFN "-qg" cards, clip_utils.py:57-60)
+    pre_ln: bool = True
+    use_rope: bool = False            # perception_models Rope2D
+    cls_token: bool = True
+    ln_eps: float = 1e-5
+    mean: Tuple[float, float, float] = CLIP_MEAN
+    std: Tuple[float, float, float] = CLIP_STD
+    attn_pool_heads: int = 0          # > 0: PE attention-pool head (only W_v / W_o / proj are used by TextRegion)
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch
+
+    @property
+    def tokens(self) -> int:
+        return self.grid * self.grid + int(self.cls_token)
+
+    @property
+    def kpad(self) -> int:
+        return (3 * self.patch * self.patch + 31) // 32 * 32
+
+    def flops_per_image(self) -> float:
+        """Dense FLOPs of one forward (SURVEY.md §8d formula: 24 N d^2 L + 4 N^2 d L + patch embed)."""
+        n, d, l = self.tokens, self.width, self.layers
+        r = self.mlp_dim / d
+        return (2 * n * d * d * (4 + 2 * r) + 4 * n * n * d) * l + 2 * (self.grid ** 2) * 3 * self.patch ** 2 * d
+
+
+# model cards the reference can select (clip_utils.py:53-75, ovo.yaml:46)
+SPECS: Dict[str, ViTSpec] = {
+    "ViT-B-16-qg": ViTSpec("ViT-B-16-qg", 224, 16, 768, 12, 12, 3072, 512, act="quick_gelu"),
+    "ViT-L-14-qg": ViTSpec("ViT-L-14-qg", 224, 14, 1024, 24, 16, 4096, 768, act="quick_gelu"),
+    "ViT-H-14": ViTSpec("ViT-H-14", 224, 14, 1280, 32, 16, 5120, 1024),
+    "ViT-H-14-qg": ViTSpec("ViT-H-14-qg", 224, 14, 1280, 32, 16, 5120, 1024, act="quick_gelu"),
+    "PE-Core-L14-336": ViTSpec("PE-Core-L14-336", 336, 14, 1024, 24, 16, 4096, 1024, use_rope=True,
+                               mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), attn_pool_heads=8),
+    # reduced shapes for tests
+    "tiny-clip": ViTSpec("tiny-clip", 64, 16, 128, 2, 4, 512, 64, act="quick_gelu"),
+    "tiny-pe": ViTSpec("tiny-pe", 84, 14, 128, 2, 4, 512, 128, use_rope=True, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5),
+                       attn_pool_heads=4),
+}
+
+
+def random_state(spec: ViTSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded fp32 CPU weights with open_clip VisionTransformer names (+ `attn_pool.*` for PE)."""
+    g = torch.Generator().manual_seed(seed)
+    d, t = spec.width, spec.tokens
+
+    def rn(*shape, std=0.02):
+        return torch.randn(*shape, generator=g) * std
+    sd = {"conv1.weight": rn(d, 3, spec.patch, spec.patch, std=0.05), "positional_embedding": rn(t, d),
+          "ln_post.weight": 1 + rn(d, std=0.05), "ln_post.bias": rn(d, std=0.05), "proj": rn(d, spec.out_dim, std=d ** -0.5)}
+    if spec.cls_token:
+        sd["class_embedding"] = rn(d)
+    if spec.pre_ln:
+        sd["ln_pre.weight"], sd["ln_pre.bias"] = 1 + rn(d, std=0.05), rn(d, std=0.05)
+    for i in range(spec.layers):
+        p = f"transformer.resblocks.{i}."
+        sd[p + "ln_1.weight"], sd[p + "ln_1.bias"] = 1 + rn(d, std=0.05), rn(d, std=0.05)
+        sd[p + "ln_2.weight"], sd[p + "ln_2.bias"] = 1 + rn(d, std=0.05), rn(d, std=0.05)
+        sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"] = rn(3 * d, d, std=d ** -0.5), rn(3 * d)
+        sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"] = rn(d, d, std=d ** -0.5), rn(d)
+        sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"] = rn(spec.mlp_dim, d, std=d ** -0.5), rn(spec.mlp_dim)
+        sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"] = rn(d, spec.mlp_dim, std=spec.mlp_dim ** -0.5), rn(d)
+    if spec.attn_pool_heads:
+        sd["attn_pool.probe"] = rn(1, 1, d)
+        sd["attn_pool.attn.in_proj_weight"], sd["attn_pool.attn.in_proj_bias"] = rn(3 * d, d, std=d ** -0.5), rn(3 * d)
+        sd["attn_pool.attn.out_proj.weight"], sd["attn_pool.attn.out_proj.bias"] = rn(d, d, std=d ** -0.5), rn(d)
+        sd["attn_pool.layernorm.weight"], sd["attn_pool.layernorm.bias"] = 1 + rn(d, std=0.05), rn(d, std=0.05)
+    return sd
+
+
+def rope_tables(spec: ViTSpec, theta: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cos / sin f32 [T, head_dim] of a 2-D axial rotary embedding in interleaved-pair form.
+
+    perception_models' Rope2D is not available offline ([upstream-knowledge]): this follows
+    its published design -- half of each head's channels rotate with the patch row, half with the column,
+    frequencies theta^(-2i/(hd/2)), pairs (2i, 2i+1) share an angle, the class token is not rotated."""
+    hd = spec.width // spec.heads
+    quarter = hd // 4
+    freqs = theta ** (-torch.arange(quarter, dtype=torch.float32) / quarter)
+    pos = torch.arange(spec.grid, dtype=torch.float32)
+    ang = pos[:, None] * freqs[None, :]                                   # [G, hd/4]
+    ang = ang.repeat_interleave(2, dim=1)                                 # pairs share the angle -> [G, hd/2]
+    ay = ang[:, None, :].expand(spec.grid, spec.grid, hd // 2)
+    ax = ang[None, :, :].expand(spec.grid, spec.grid, hd // 2)
+    full = torch.cat([ay, ax], dim=-1).reshape(spec.grid * spec.grid, hd)
+    if spec.cls_token:
+        full = torch.cat([torch.zeros(1, hd), full], dim=0)
+    return full.cos().contiguous(), full.sin().contiguous()
+
+
+class HipViT:
+    """A ViT whose forward pass is one call into libovo_hip.so."""
+
+    def __init__(self, spec: ViTSpec, state: Optional[Dict[str, torch.Tensor]] = None, device="cuda", seed: int = 0):
+        self.spec, self.device = spec, torch.device(device)
+        sd = state if state is not None else random_state(spec, seed)
+        self._keep: List[torch.Tensor] = []                # device tensors referenced by raw pointers
+        d = spec.width
+
+        def mat(t):                                       # bf16 matrix [out, in]
+            x = t.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
+            self._keep.append(x)
+            return L.ptr(x)
+
+        def vec(t):
+            x = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            self._keep.append(x)
+            return L.ptr(x)
+
+        conv = sd["conv1.weight"].reshape(d, -1).float()
+        pw = torch.zeros(d, spec.kpad)
+        pw[:, :conv.shape[1]] = conv
+        self._layers = (L.VitLayer * spec.layers)()
+        for i in range(spec.layers):
+            p = f"transformer.resblocks.{i}."
+            ls1 = sd.get(p + "ls_1.gamma")                 # LayerScale (if any) folds into the projection
+            ls2 = sd.get(p + "ls_2.gamma")
+            ow, ob = sd[p + "attn.out_proj.weight"].float(), sd[p + "attn.out_proj.bias"].float()
+            fw, fb = sd[p + "mlp.c_proj.weight"].float(), sd[p + "mlp.c_proj.bias"].float()
+            if ls1 is not None:
+                ow, ob = ow * ls1.float()[:, None], ob * ls1.float()
+            if ls2 is not None:
+                fw, fb = fw * ls2.float()[:, None], fb * ls2.float()
+            ly = self._layers[i]
+            ly.ln1_g, ly.ln1_b = vec(sd[p + "ln_1.weight"]), vec(sd[p + "ln_1.bias"])
+            ly.qkv_w, ly.qkv_b = mat(sd[p + "attn.in_proj_weight"]), vec(sd[p + "attn.in_proj_bias"])
+            ly.out_w, ly.out_b = mat(ow), vec(ob)
+            ly.ln2_g, ly.ln2_b = vec(sd[p + "ln_2.weight"]), vec(sd[p + "ln_2.bias"])
+            ly.fc1_w, ly.fc1_b = mat(sd[p + "mlp.c_fc.weight"]), vec(sd[p + "mlp.c_fc.bias"])
+            ly.fc2_w, ly.fc2_b = mat(fw), vec(fb)
+        w = L.VitWeights()
+        w.patch_w = mat(pw)
+        w.patch_b = vec(sd["conv1.bias"]) if "conv1.bias" in sd else None
+        w.prefix = vec(sd["class_embedding"].reshape(1, d)) if spec.cls_token else None
+        w.pos = vec(sd["positional_embedding"]) if "positional_embedding" in sd else None
+        if spec.pre_ln:
+            w.ln_pre_g, w.ln_pre_b = vec(sd["ln_pre.weight"]), vec(sd["ln_pre.bias"])
+        w.ln_post_g, w.ln_post_b = vec(sd["ln_post.weight"]), vec(sd["ln_post.bias"])
+        w.proj_w = mat(sd["proj"].float().t())
+        if spec.use_rope:
+            cos, sin = rope_tables(spec)
+            w.rope_cos, w.rope_sin = vec(cos), vec(sin)
+        w.layers = C.cast(self._layers, C.POINTER(L.VitLayer))
+        self._weights = w
+        self._cfg = {}
+        self._ws: Optional[torch.Tensor] = None
+        self.proj = sd["proj"].detach().to(self.device, torch.float32)
+        self.pool_weights = None
+        if spec.attn_pool_heads:
+            self.pool_weights = {k[len("attn_pool."):]: v.detach().float() for k, v in sd.items() if k.startswith("attn_pool.")}
+
+    def _config(self, pool: int) -> L.VitConfig:
+        c = self._cfg.get(pool)
+        if c is None:
+            s = self.spec
+            c = L.VitConfig(s.image_size, s.patch, s.width, s.layers, s.heads, s.mlp_dim, s.out_dim, int(s.cls_token),
+                            2 if s.act == "quick_gelu" else 1, int(s.pre_ln), int(s.use_rope), pool, s.kpad, s.ln_eps)
+            self._cfg[pool] = c
+        return c
+
+    def _workspace(self, cfg, batch: int):
+        need = L.load().ovo_vit_workspace_bytes(C.byref(cfg), batch)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws, need
+
+    # ---------------------------------------------------------------- preprocessing
+    def preprocess(self, image: torch.Tensor, crops: Optional[Sequence[Tuple[int, int, int, int]]] = None,
+                   scale: float = 1.0, antialias: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """CHW image (u8 0..255 or f32) -> f32 [len(crops), 3, S, S]: squash-resize each crop (y0, x0, h, w) to the
+        model resolution (bilinear, antialiased like torchvision's tensor Resize) and normalise with mean / std.
+        `scale` multiplies pixel values first (1/255 for u8 input expected in [0, 1])."""
+        s = self.spec
+        img = L.dev(image, image.dtype, "image")
+        if img.dtype not in (torch.uint8, torch.float32):
+            raise L.OvoHipError("image must be u8 or f32")
+        _, h, w = img.shape
+        crops = list(crops) if crops is not None else [(0, 0, h, w)]
+        if out is None:
+            out = torch.empty((len(crops), 3, s.image_size, s.image_size), dtype=torch.float32, device=img.device)
+        mean, std = (C.c_float * 3)(*s.mean), (C.c_float * 3)(*s.std)
+        lib = L.load()
+        for i, (y0, x0, ch, cw) in enumerate(crops):
+            L.check(lib.ovo_resize_normalize(L.ptr(img), L.DTYPE_CODE[img.dtype], 3, h, w, y0, x0, ch, cw, L.ptr(out[i]),
+                                             s.image_size, s.image_size, int(antialias), float(scale), mean, std, L.stream()))
+        return out
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, images: torch.Tensor, tokens: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """images f32 [B, 3, S, S] (preprocessed).  tokens=False -> f32 [B, out_dim] = ln_post(cls) @ proj
+        (open_clip encode_image); tokens=True -> f32 [B, T, width] after ln_post (PE forward_features(norm=True))."""
+        s = self.spec
+        x = L.dev(images, torch.float32, "images")
+        b = x.shape[0]
+        if tuple(x.shape[1:]) != (3, s.image_size, s.image_size):
+            raise L.OvoHipError(f"expected [B, 3, {s.image_size}, {s.image_size}], got {tuple(x.shape)}")
+        cfg = self._config(0 if tokens else 1)
+        ws, need = self._workspace(cfg, b)
+        if out is None:
+            shape = (b, s.tokens, s.width) if tokens else (b, s.out_dim)
+            out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        L.check(L.load().ovo_vit_forward(C.byref(cfg), C.byref(self._weights), L.ptr(x), b, L.ptr(out), L.ptr(ws), need, L.stream()))
+        return out
+
+    encode_image = forward

@@ -1,0 +1,241 @@
+"""-m gpu: MFMA GEMM, fused attention, LayerNorm / embedding / resize kernels and the full ViT forward vs fp32
+references (plain torch on the same inputs, and oracle/vit.py pinned against HuggingFace CLIP).
+
+Tolerances: bf16 operands carry 8 mantissa bits; products are accumulated in fp32.  Each check states its bound.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, unpack
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _gemm(a, w, bias=None, add=None, act=0, alpha=1.0, out_dtype=torch.float32):
+    from ovo_amd import _lib as L
+    m, k = a.shape
+    n = w.shape[0]
+    out = torch.empty((m, n), dtype=out_dtype, device=DEV)
+    g = L.Gemm()
+    g.A, g.lda, g.W, g.ldw = a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0)
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.C, g.ldc = out.data_ptr(), out.stride(0)
+    g.add, g.ld_add = (add.data_ptr(), add.stride(0)) if add is not None else (None, 0)
+    g.M, g.N, g.K = m, n, k
+    g.in_dtype, g.out_dtype, g.act, g.alpha = L.DTYPE_CODE[a.dtype], L.DTYPE_CODE[out_dtype], act, alpha
+    L.check(L.load().ovo_gemm(C.byref(g), L.stream()))
+    return out
+
+
+@pytest.mark.parametrize("m,n,k", [(1154, 3072, 1024), (1154, 1024, 4096), (1154, 1024, 1024), (64, 64, 32), (1, 4, 32),
+                                   (130, 132, 96), (4097, 336, 224), (300, 1000, 768), (2, 768, 1024), (65536, 112, 160)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_vs_torch(m, n, k, dtype):
+    g = torch.Generator(device="cpu").manual_seed(m * 7 + n * 3 + k)
+    a = torch.randn(m, k, generator=g).to(DEV, dtype)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(DEV, dtype)
+    bias = torch.randn(n, generator=g).to(DEV)
+    ref = a.float() @ w.float().T + bias                      # same rounded operands, fp32 math
+    out = _gemm(a, w, bias)
+    # fp32 accumulation in a different order: |err| <= ~1e-5 * sum|a||w| ~ 1e-5 * sqrt(k)
+    torch.testing.assert_close(out, ref, atol=2e-4, rtol=2e-4)
+
+
+def test_gemm_epilogues_and_padding():
+    g = torch.Generator().manual_seed(1)
+    m, n, k = 577, 256, 128
+    a = torch.randn(m, k + 32, generator=g).to(DEV, torch.bfloat16)[:, :k]            # lda > K
+    w = (torch.randn(n, k, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    bias, add = torch.randn(n, generator=g).to(DEV), torch.randn(m, n, generator=g).to(DEV)
+    z = a.float() @ w.float().T
+    for act, fn in ((1, torch.nn.functional.gelu), (2, lambda x: x * torch.sigmoid(1.702 * x))):
+        torch.testing.assert_close(_gemm(a, w, bias, act=act), fn(z + bias), atol=3e-4, rtol=3e-4)
+    torch.testing.assert_close(_gemm(a, w, bias, add=add, alpha=0.5), 0.5 * z + bias + add, atol=3e-4, rtol=3e-4)
+    x = add.clone()                                          # in-place residual: C aliases add
+    from ovo_amd import _lib as L
+    gg = L.Gemm()
+    gg.A, gg.lda, gg.W, gg.ldw, gg.bias = a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr()
+    gg.C, gg.ldc, gg.add, gg.ld_add = x.data_ptr(), n, x.data_ptr(), n
+    gg.M, gg.N, gg.K, gg.in_dtype, gg.out_dtype, gg.act, gg.alpha = m, n, k, 2, 0, 0, 1.0
+    L.check(L.load().ovo_gemm(C.byref(gg), L.stream()))
+    torch.testing.assert_close(x, add + z + bias, atol=3e-4, rtol=3e-4)
+    ob = _gemm(a, w, bias, out_dtype=torch.bfloat16)         # bf16 store = RNE of the fp32 result
+    assert torch.equal(ob, _gemm(a, w, bias).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,hd", [(2, 16, 577, 577, 64), (1, 4, 197, 197, 64), (64, 2, 16, 64, 56), (3, 1, 49, 196, 96),
+                                          (2, 2, 1, 1, 8), (1, 2, 130, 70, 72), (1, 1, 4096, 4096, 56), (2, 8, 257, 257, 128)])
+def test_attention_vs_torch(B, H, Tq, Tk, hd):
+    from ovo_amd import _lib as L
+    g = torch.Generator().manual_seed(B + H + Tq + Tk + hd)
+    D = H * hd
+    T = max(Tq, Tk)
+    qkv = torch.randn(B, T, 3, H, hd, generator=g).to(DEV, torch.bfloat16)          # packed like the QKV GEMM output
+    qkv[:, :, 0] *= 2.0                                                              # peaked softmax rows
+    out = torch.zeros(B, Tq, D, dtype=torch.bfloat16, device=DEV)
+    a = L.Attention()
+    base, esz = qkv.data_ptr(), 2
+    a.q, a.k, a.v, a.o = base, base + D * esz, base + 2 * D * esz, out.data_ptr()
+    a.q_sb = a.k_sb = a.v_sb = T * 3 * D
+    a.q_sh = a.k_sh = a.v_sh = hd
+    a.q_st = a.k_st = a.v_st = 3 * D
+    a.o_sb, a.o_sh, a.o_st = Tq * D, hd, D
+    a.B, a.H, a.Tq, a.Tk, a.hd, a.scale = B, H, Tq, Tk, hd, hd ** -0.5
+    L.check(L.load().ovo_attention(C.byref(a), L.stream()))
+    q, k, v = (qkv[:, :n, i].float().permute(0, 2, 1, 3) for i, n in ((0, Tq), (1, Tk), (2, Tk)))
+    ref = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1) @ v
+    ref = ref.permute(0, 2, 1, 3).reshape(B, Tq, D)
+    # P is rounded to bf16 before P.V (rel 2^-9) and O is stored in bf16
+    torch.testing.assert_close(out.float(), ref, atol=2e-2, rtol=2e-2)
+    assert (out.float() - ref).abs().mean() < 2e-3
+
+
+def test_layernorm_embed_im2col_rope():
+    from ovo_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    rows, d = 1154, 1024
+    x = (torch.randn(rows, d, generator=g) * 3 + 1).to(DEV)
+    gm, bt = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    y = torch.empty_like(x)
+    L.check(lib.ovo_layernorm(L.ptr(x), d, rows, d, L.ptr(gm), L.ptr(bt), 1e-5, L.ptr(y), d, 0, L.stream()))
+    ref = torch.nn.functional.layer_norm(x, (d,), gm, bt, 1e-5)
+    torch.testing.assert_close(y, ref, atol=2e-5, rtol=2e-5)
+    yb = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.ovo_layernorm(L.ptr(x), d, rows, d, L.ptr(gm), L.ptr(bt), 1e-5, L.ptr(yb), d, 2, L.stream()))
+    assert (yb.float() - ref).abs().max() < 0.04 and torch.equal(yb, y.to(torch.bfloat16))     # bf16 ulp at |y| ~ 8 is 0.03
+    # token assembly + ln_pre
+    B, P = 2, 576
+    patch = torch.randn(B, P, d, generator=g).to(DEV)
+    cls, pos = torch.randn(1, d, generator=g).to(DEV), torch.randn(P + 1, d, generator=g).to(DEV)
+    out = torch.empty(B, P + 1, d, device=DEV)
+    L.check(lib.ovo_vit_embed(L.ptr(patch), L.ptr(cls), 1, L.ptr(pos), B, P, d, L.ptr(gm), L.ptr(bt), 1e-5, L.ptr(out), L.stream()))
+    tok = torch.cat([cls[None].expand(B, 1, d), patch], 1) + pos
+    torch.testing.assert_close(out, torch.nn.functional.layer_norm(tok, (d,), gm, bt, 1e-5), atol=2e-5, rtol=2e-5)
+    L.check(lib.ovo_vit_embed(L.ptr(patch), L.ptr(cls), 1, L.ptr(pos), B, P, d, None, None, 0.0, L.ptr(out), L.stream()))
+    assert torch.equal(out, tok)
+    # im2col == unfold (non-overlapping 14x14 and overlapping 7x7 / stride 4 / pad 3)
+    img = torch.randn(2, 3, 56, 56, generator=g).to(DEV)
+    for ksz, stride, pad in ((14, 14, 0), (7, 4, 3)):
+        kreal = 3 * ksz * ksz
+        kpad = (kreal + 31) // 32 * 32
+        oh = (56 + 2 * pad - ksz) // stride + 1
+        col = torch.full((2 * oh * oh, kpad), 7.0, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.ovo_im2col(L.ptr(img), 2, 3, 56, 56, ksz, stride, pad, L.ptr(col), kpad, L.stream()))
+        ref = torch.nn.functional.unfold(img, ksz, padding=pad, stride=stride).transpose(1, 2).reshape(-1, kreal)
+        assert torch.equal(col[:, :kreal], ref.to(torch.bfloat16)) and (col[:, kreal:] == 0).all()
+    # rope: rotation is norm preserving per pair, identity on the class token, matches the oracle formula
+    from oracle import vit as OV
+    Bq, T, H, hd = 2, 37, 4, 32
+    qkv = torch.randn(Bq, T, 3, H, hd, generator=g).to(DEV, torch.bfloat16)
+    ang = torch.rand(T, hd // 2, generator=g).repeat_interleave(2, 1) * 6
+    ang[0] = 0
+    cos, sin = ang.cos().to(DEV), ang.sin().to(DEV)
+    before = qkv.clone()
+    L.check(lib.ovo_rope_qk(L.ptr(qkv), Bq, T, H, hd, L.ptr(cos), L.ptr(sin), 1, L.stream()))
+    for i in (0, 1):
+        ref = OV._rope(before[:, :, i].float().permute(0, 2, 1, 3).cpu(), ang.cos(), ang.sin()).permute(0, 2, 1, 3)
+        ref[:, 0] = before[:, 0, i].float().cpu()
+        torch.testing.assert_close(qkv[:, :, i].float().cpu(), ref, atol=0.03, rtol=0.01)
+    assert torch.equal(qkv[:, :, 2], before[:, :, 2]) and torch.equal(qkv[:, 0], before[:, 0])
+
+
+@pytest.mark.parametrize("aa", [True, False])
+@pytest.mark.parametrize("src,crop,out", [((480, 640), None, 336), ((480, 640), (0, 320, 480, 320), 336), ((480, 640), None, 1024),
+                                          ((968, 1296), (484, 432, 484, 432), 336), ((37, 53), None, 84)])
+def test_resize_normalize_vs_torch(aa, src, crop, out):
+    from oracle import vit as OV
+    from ovo_amd.encoders.vit import SPECS, HipViT, ViTSpec
+    import dataclasses
+    spec = dataclasses.replace(SPECS["tiny-pe"], image_size=out)      # preprocess only reads image_size / mean / std
+    g = torch.Generator().manual_seed(3)
+    img = (torch.rand(3, *src, generator=g) * 255).to(torch.uint8)
+    vit = object.__new__(HipViT)
+    vit.spec, vit.device = spec, torch.device(DEV)
+    got = HipViT.preprocess(vit, img.to(DEV), [crop or (0, 0, *src)], scale=1 / 255.0, antialias=aa)[0].cpu()
+    ref = OV.resize_normalize(img, out, spec.mean, spec.std, crop, scale=1 / 255.0, antialias=aa)
+    torch.testing.assert_close(got, ref, atol=2e-5, rtol=1e-5)
+    got_f = HipViT.preprocess(vit, img.float().to(DEV), [crop or (0, 0, *src)], scale=1 / 255.0, antialias=aa)[0].cpu()
+    assert torch.equal(got, got_f)
+
+
+def test_vit_forward_vs_hf_golden():
+    """HIP bf16 forward vs HuggingFace CLIP (fp32) on the golden weights/input: width 64, 2 layers, 10 tokens."""
+    from oracle import vit as OV
+    from ovo_amd.encoders.vit import HipViT, ViTSpec
+    d = golden("hf_clip_vit")
+    sd = OV.hf_clip_to_openclip({k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")})
+    spec = ViTSpec("hf-golden", 48, 16, 64, 2, 4, 256, 32, act="quick_gelu")
+    vit = HipViT(spec, sd, device=DEV)
+    x = torch.from_numpy(d["x"]).to(DEV)
+    emb = vit.forward(x).cpu().numpy()
+    # bf16 operands through 2 blocks: observed ~3e-3 abs on outputs of magnitude ~1
+    np.testing.assert_allclose(emb, d["image_embeds"], atol=3e-2, rtol=3e-2)
+    cos = (emb * d["image_embeds"]).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(d["image_embeds"], axis=1)
+    assert cos.min() > 0.9995
+    tok = vit.forward(x, tokens=True).cpu()
+    ref = OV.vit_forward(sd, torch.from_numpy(d["x"]), patch=16, heads=4, act="quick_gelu", tokens=True)
+    torch.testing.assert_close(tok, ref, atol=5e-2, rtol=5e-2)
+
+
+@pytest.mark.parametrize("card,batch", [("tiny-pe", 3), ("ViT-B-16-qg", 2), ("PE-Core-L14-336", 2)])
+def test_vit_forward_vs_oracle_full_size(card, batch):
+    """Unit-normalised descriptor error vs the fp32 oracle: north_star bound 1e-3 (features) on ViT-B/16 and PE-L/14-336."""
+    from oracle import vit as OV
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state, rope_tables
+    spec = SPECS[card]
+    sd = random_state(spec, seed=11)
+    vit = HipViT(spec, sd, device=DEV)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(batch, 3, spec.image_size, spec.image_size, generator=g)
+    rope = rope_tables(spec) if spec.use_rope else None
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    ref = OV.vit_forward(sd, x, patch=spec.patch, heads=spec.heads, act=spec.act, rope=rope)
+    out = vit.forward(x.to(DEV)).cpu()
+    nr, no = torch.nn.functional.normalize(ref, dim=-1), torch.nn.functional.normalize(out, dim=-1)
+    err = (nr - no).abs().max().item()
+    cos = (nr * no).sum(-1).min().item()
+    print(f"{card}: max |unit feature error| = {err:.2e}, min cosine = {cos:.6f}")
+    # bound scales with the element magnitude 1/sqrt(out_dim): 1e-3 at out_dim >= 512 (the BASELINE models)
+    assert err < 1e-3 * max(1.0, (512 / spec.out_dim) ** 0.5 * 1.5) and cos > 0.9999
+
+
+@pytest.mark.parametrize("hw", [(100, 150), (170, 260)])
+def test_textregion_predict_vs_oracle(hw):
+    """Full region-descriptor path (crops -> ViT tokens -> mask resample -> stitch -> masked-mean pooling -> proj -> L2)."""
+    from oracle import features as OF, vit as OV
+    from ovo_amd import synthetic as syn
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state, rope_tables
+    from ovo_amd.entities.textregion import PETextRegion
+    spec = SPECS["tiny-pe"]
+    sd = random_state(spec, seed=4)
+    vit = HipViT(spec, sd, device=DEV)
+    tr = PETextRegion(vit, "PE-tiny-084", remove_global_patch=False)
+    H, W = hw
+    g = torch.Generator().manual_seed(8)
+    img = (torch.rand(3, H, W, generator=g) * 255).to(torch.uint8)
+    masks = syn.make_masks(H, W, grid=(2, 3), n_blobs=3, seed=6)
+    out = tr.predict(img.to(DEV), torch.from_numpy(masks).to(DEV), scale=1 / 255.0).cpu().numpy()
+    # oracle pipeline in fp32
+    crops = tr._crops(H, W)
+    batch = torch.stack([OV.resize_normalize(img, spec.image_size, spec.mean, spec.std, c, scale=1 / 255.0) for c in crops])
+    tok = OV.vit_forward(sd, batch, patch=spec.patch, heads=spec.heads, act=spec.act, rope=rope_tables(spec), tokens=True)
+    P, nh, nw = spec.grid, tr.crop_num_h, tr.crop_num_w
+    x = OF.stitch_tokens(tok[:, 1:].numpy(), P, P * nh, P * nw, nh, nw)
+    fm = OF.feature_masks(masks, P * nh, P * nw)
+    dd = spec.width
+    ref = OF.region_pool(x, fm, sd["attn_pool.attn.in_proj_weight"][2 * dd:], sd["attn_pool.attn.in_proj_bias"][2 * dd:],
+                         sd["attn_pool.attn.out_proj.weight"], sd["attn_pool.attn.out_proj.bias"], sd["proj"])
+    w_dev, cnt = tr.get_features_mask(torch.from_numpy(masks).to(DEV))
+    assert np.array_equal(w_dev[:, :fm.shape[1]].float().cpu().numpy(), (fm > 0).astype(np.float32))     # {0,1} weights: exact
+    assert np.array_equal(cnt.cpu().numpy(), (fm > 0).sum(1).astype(np.float32))
+    empty = (fm > 0).sum(1) == 0              # a mask that covers no token: NaN in the reference (softmax of all -inf), NaN here
+    assert np.isnan(out[empty]).all() and np.isnan(ref[empty]).all() and not np.isnan(out[~empty]).any()
+    err = np.abs(out[~empty] - ref[~empty]).max()
+    print(f"textregion {hw}: max |unit descriptor error| = {err:.2e} ({int(empty.sum())} empty masks)")
+    assert err < 3e-3 and out.shape == (masks.shape[0], spec.out_dim)
+    np.testing.assert_allclose(np.linalg.norm(out[~empty], axis=1), 1.0, atol=1e-5)
