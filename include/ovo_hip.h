@@ -282,6 +282,47 @@ size_t ovo_vit_workspace_bytes(const ovo_vit_config_t *cfg, int B);
 int ovo_vit_forward(const ovo_vit_config_t *cfg, const ovo_vit_weights_t *w, const float *images, int B, float *out,
                     void *ws, size_t ws_bytes, ovo_stream_t stream);
 
+/* ---- a10: SAM2 image encoder (Hiera trunk + FPN neck) ------------------------------------------------
+ * Replaces the encoder half of `SAM2AutomaticMaskGenerator.generate(image)` (mask_generator.py:113,
+ * segment_utils.py:291-308; sam2 `forward_image`).  Architecture per the SAM2 paper / sam2 repo
+ * (SURVEY.md App. A): 7x7/4 patch embed + (bicubic background + tiled window) position embedding, 4 stages of
+ * windowed multi-head attention blocks with 2x2 max-pool query pooling at stage changes and a few global
+ * blocks, FPN 1x1 laterals with nearest top-down on the coarse levels, optional decoder conv_s0 / conv_s1.
+ * Outputs are NHWC f32: feat0 [B, S/4, S/4, c0], feat1 [B, S/8, S/8, c1], feat2 [B, S/16, S/16, fpn_dim]
+ * with (c0, c1) = (32, 64) when hi_res else (fpn_dim, fpn_dim). */
+typedef struct {
+    int32_t image_size;            /* 1024 */
+    int32_t dims[4], heads[4], blocks[4], window[4];
+    int32_t n_global, global_blocks[8];
+    int32_t fpn_dim;               /* 256 */
+    int32_t hi_res;                /* apply conv_s0 (->32) / conv_s1 (->64) to the two fine levels */
+    float ln_eps;                  /* 1e-6 */
+} ovo_hiera_config_t;
+
+typedef struct {
+    const float *ln1_g, *ln1_b;
+    const void *qkv_w; const float *qkv_b;   /* [3*dim_out, pad32(dim)]      */
+    const void *out_w; const float *out_b;   /* [dim_out, pad32(dim_out)]    */
+    const float *ln2_g, *ln2_b;
+    const void *fc1_w; const float *fc1_b;   /* [4*dim_out, pad32(dim_out)]  */
+    const void *fc2_w; const float *fc2_b;   /* [dim_out, 4*dim_out]         */
+    const void *res_w; const float *res_b;   /* [dim_out, pad32(dim)] at stage changes, else NULL */
+} ovo_hiera_block_t;
+
+typedef struct {
+    const void *patch_w; const float *patch_b;   /* [dims[0], 160] (3*7*7 = 147 padded), [dims[0]] */
+    const float *pos;                            /* [(S/4)^2, dims[0]] precomputed position embedding */
+    const ovo_hiera_block_t *blocks;             /* HOST array, sum(blocks) entries */
+    const void *neck_w[4]; const float *neck_b[4]; /* level i (fine -> coarse): [fpn_dim, pad32(dims[i])] */
+    const void *s0_w; const float *s0_b;         /* [32, fpn_dim] */
+    const void *s1_w; const float *s1_b;         /* [64, fpn_dim] */
+} ovo_hiera_weights_t;
+
+size_t ovo_hiera_workspace_bytes(const ovo_hiera_config_t *cfg, int B);
+/* images f32 [B, 3, S, S], already resized + normalised. */
+int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *w, const float *images, int B,
+                      float *feat0, float *feat1, float *feat2, void *ws, size_t ws_bytes, ovo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

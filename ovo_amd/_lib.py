@@ -67,6 +67,25 @@ class VitWeights(C.Structure):
                                    "proj_w", "rope_cos", "rope_sin")] + [("layers", C.POINTER(VitLayer))]
 
 
+class HieraConfig(C.Structure):
+    """ovo_hiera_config_t"""
+    _fields_ = [("image_size", C.c_int32), ("dims", C.c_int32 * 4), ("heads", C.c_int32 * 4), ("blocks", C.c_int32 * 4),
+                ("window", C.c_int32 * 4), ("n_global", C.c_int32), ("global_blocks", C.c_int32 * 8), ("fpn_dim", C.c_int32),
+                ("hi_res", C.c_int32), ("ln_eps", _F32)]
+
+
+class HieraBlock(C.Structure):
+    """ovo_hiera_block_t"""
+    _fields_ = [(n, _P) for n in ("ln1_g", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_g", "ln2_b",
+                                   "fc1_w", "fc1_b", "fc2_w", "fc2_b", "res_w", "res_b")]
+
+
+class HieraWeights(C.Structure):
+    """ovo_hiera_weights_t"""
+    _fields_ = [("patch_w", _P), ("patch_b", _P), ("pos", _P), ("blocks", C.POINTER(HieraBlock)),
+                ("neck_w", _P * 4), ("neck_b", _P * 4), ("s0_w", _P), ("s0_b", _P), ("s1_w", _P), ("s1_b", _P)]
+
+
 DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.uint8: 3}
 
 _SIGNATURES = {
@@ -102,6 +121,8 @@ _SIGNATURES = {
     "ovo_cast_f32": (_I32, [_P, _I64, _P, _I32, _P]),
     "ovo_vit_workspace_bytes": (_SZ, [C.POINTER(VitConfig), _I32]),
     "ovo_vit_forward": (_I32, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _I32, _P, _P, _SZ, _P]),
+    "ovo_hiera_workspace_bytes": (_SZ, [C.POINTER(HieraConfig), _I32]),
+    "ovo_hiera_forward": (_I32, [C.POINTER(HieraConfig), C.POINTER(HieraWeights), _P, _I32, _P, _P, _P, _P, _SZ, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

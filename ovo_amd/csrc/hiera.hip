@@ -1,0 +1,346 @@
+// hiera.hip -- SAM2 image encoder forward (Hiera trunk + FPN neck) as one C call.
+//
+// Tokens live in an fp32 residual stream x[B, H, W, C] (NHWC).  Per block:
+//   k_ln_window   LayerNorm + window partition (+ zero rows for the padding windows, zero K-padding columns)
+//   ovo_gemm      QKV (bf16, MFMA)                         [rows, 3*dim_out]
+//   k_qpool       2x2 max-pool of q inside each window     (stage-change blocks only)
+//   ovo_attention per-window (or global) fused attention, windows folded into the batch dimension
+//   ovo_gemm      output projection -> fp32 rows in window order
+//   k_unwindow_add  window order -> spatial order, + residual (the pooled projected skip at stage changes)
+//   k_ln_window(identity) -> FC1 GEMM(+GELU) -> FC2 GEMM(+bias, += x)
+// All GEMM operands have K padded to a multiple of 32 with zeros (dims 112 / 144 of hiera_b+ / hiera_l).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ uint16_t f2bf(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+
+struct Grid {           // window partition geometry of an [B, H, W] token grid
+    int B, H, W, ws;    // ws == 0: one window = whole image (global attention)
+    int nwh, nww, wh, ww;   // windows per image (rows, cols) and window height / width
+    long long rows;     // B * nwh * nww * wh * ww (including padding rows)
+};
+__host__ __device__ inline Grid make_grid(int B, int H, int W, int ws) {
+    Grid g; g.B = B; g.H = H; g.W = W; g.ws = ws;
+    if (ws > 0) { g.wh = g.ww = ws; g.nwh = (H + ws - 1) / ws; g.nww = (W + ws - 1) / ws; }
+    else { g.wh = H; g.ww = W; g.nwh = g.nww = 1; }
+    g.rows = (long long)B * g.nwh * g.nww * g.wh * g.ww;
+    return g;
+}
+// window-order row of spatial token (b, y, x)
+__device__ __forceinline__ long long row_of(const Grid &g, int b, int y, int x) {
+    const int wy = y / g.wh, wx = x / g.ww;
+    return ((((long long)b * g.nwh + wy) * g.nww + wx) * g.wh + (y - wy * g.wh)) * g.ww + (x - wx * g.ww);
+}
+
+// LayerNorm of x[b, y, x, :d] written as bf16 row `r` (window order) of width kp; padding rows / columns = 0.
+__global__ void __launch_bounds__(256) k_ln_window(const float *__restrict__ x, Grid g, int d, int kp, const float *__restrict__ gamma,
+                                                   const float *__restrict__ beta, float eps, uint16_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long waves = (long long)gridDim.x * 4;
+    const int per_win = g.wh * g.ww;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < g.rows; r += waves) {
+        const long long win = r / per_win;
+        const int in = (int)(r % per_win), ly = in / g.ww, lx = in % g.ww;
+        const int wx = (int)(win % g.nww), wy = (int)((win / g.nww) % g.nwh), b = (int)(win / ((long long)g.nww * g.nwh));
+        const int y = wy * g.wh + ly, xx = wx * g.ww + lx;
+        uint16_t *o = out + r * kp;
+        if (y >= g.H || xx >= g.W) {
+            for (int i = lane; i < kp; i += 64) o[i] = 0;
+            continue;
+        }
+        const float *src = x + (((long long)b * g.H + y) * g.W + xx) * d;
+        float s = 0.f;
+        for (int i = lane; i < d; i += 64) s += src[i];
+        const float mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+        for (int i = lane; i < d; i += 64) { const float t = src[i] - mean; q += t * t; }
+        const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+        for (int i = lane; i < kp; i += 64) o[i] = i < d ? f2bf((src[i] - mean) * rstd * gamma[i] + beta[i]) : (uint16_t)0;
+    }
+}
+
+// q of a packed qkv buffer [rows, 3*C] (window order, window wh x ww) -> pooled q [rows/4, C]: 2x2 max.
+__global__ void __launch_bounds__(256) k_qpool(const uint16_t *__restrict__ qkv, long long n_windows, int wh, int ww, int C,
+                                               uint16_t *__restrict__ qp) {
+    const int oh = wh / 2, ow = ww / 2;
+    const long long total = n_windows * oh * ow * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int ox = (int)(t % ow); t /= ow;
+        const int oy = (int)(t % oh);
+        const long long win = t / oh;
+        const uint16_t *base = qkv + (win * wh * ww) * 3 * C + c;
+        float m = -3.0e38f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) m = fmaxf(m, bf2f(base[((long long)(2 * oy + dy) * ww + (2 * ox + dx)) * 3 * C]));
+        qp[i] = f2bf(m);
+    }
+}
+
+// out[b, y, x, :] = (res ? res[b, y, x, :] : 0) + rows[row_of(b, y, x), :]      (window order -> spatial)
+__global__ void __launch_bounds__(256) k_unwindow_add(const float *__restrict__ rows, Grid g, int C, const float *__restrict__ res,
+                                                      float *__restrict__ out) {
+    const int c4 = C >> 2;
+    const long long total = (long long)g.B * g.H * g.W * c4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4);
+        long long t = i / c4;
+        const int x = (int)(t % g.W); t /= g.W;
+        const int y = (int)(t % g.H);
+        const int b = (int)(t / g.H);
+        float4 v = ((const float4 *)(rows + row_of(g, b, y, x) * C))[c];
+        if (res) { const float4 r = ((const float4 *)res)[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        ((float4 *)out)[i] = v;
+    }
+}
+
+// skip path at a stage change: out[b, y2, x2, :] = max over the 2x2 block of rows[row_of(b, 2y2+dy, 2x2+dx), :]
+__global__ void __launch_bounds__(256) k_pool_unwindow(const float *__restrict__ rows, Grid g, int C, float *__restrict__ out) {
+    const int oh = g.H / 2, ow = g.W / 2;
+    const long long total = (long long)g.B * oh * ow * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int x = (int)(t % ow); t /= ow;
+        const int y = (int)(t % oh);
+        const int b = (int)(t / oh);
+        float m = -3.0e38f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) m = fmaxf(m, rows[row_of(g, b, 2 * y + dy, 2 * x + dx) * C + c]);
+        out[i] = m;
+    }
+}
+
+// f32 [rows, C] -> bf16 [rows, kp] with zero padding columns
+__global__ void __launch_bounds__(256) k_cast_pad(const float *__restrict__ x, long long rows, int C, int kp, uint16_t *__restrict__ y) {
+    const long long total = rows * kp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % kp);
+        y[i] = c < C ? f2bf(x[(i / kp) * C + c]) : (uint16_t)0;
+    }
+}
+
+// fine[b, y, x, :] += coarse[b, y/2, x/2, :]   (nearest 2x top-down)
+__global__ void __launch_bounds__(256) k_topdown_add(float *__restrict__ fine, const float *__restrict__ coarse, int B, int H, int W, int C) {
+    const int c4 = C >> 2;
+    const long long total = (long long)B * H * W * c4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4);
+        long long t = i / c4;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        const float4 u = ((const float4 *)coarse)[(((long long)b * (H / 2) + y / 2) * (W / 2) + x / 2) * c4 + c];
+        float4 v = ((float4 *)fine)[i];
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        ((float4 *)fine)[i] = v;
+    }
+}
+
+inline int pad32(int v) { return (v + 31) / 32 * 32; }
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Plan {
+    int n_blocks;
+    int dim_in[64], dim_out[64], heads[64], ws[64], pool[64], Hin[64];
+    int stage_end[64];        // stage index if the block closes a stage, else -1
+};
+
+int make_plan(const ovo_hiera_config_t &c, Plan &p) {
+    int idx = 0, H = c.image_size / 4;
+    for (int s = 0; s < 4; ++s)
+        for (int b = 0; b < c.blocks[s]; ++b) {
+            if (idx >= 64) return -1;
+            const bool first = s > 0 && b == 0;
+            p.dim_in[idx] = first ? c.dims[s - 1] : c.dims[s];
+            p.dim_out[idx] = c.dims[s];
+            p.heads[idx] = c.heads[s];
+            int ws = first ? c.window[s - 1] : c.window[s];
+            for (int k = 0; k < c.n_global; ++k) if (c.global_blocks[k] == idx) ws = 0;
+            p.ws[idx] = ws;
+            p.pool[idx] = first;
+            p.Hin[idx] = H;
+            if (first) H /= 2;
+            p.stage_end[idx] = b == c.blocks[s] - 1 ? s : -1;
+            ++idx;
+        }
+    p.n_blocks = idx;
+    return 0;
+}
+
+struct Ws {
+    uint16_t *col; float *x, *xr, *tmp; uint16_t *h, *qkv, *qp, *att, *u, *cast; float *lat[4];
+    size_t bytes;
+};
+
+Ws carve(const ovo_hiera_config_t &c, const Plan &p, int B, void *base) {
+    size_t max_x = 0, max_h = 0, max_qkv = 0, max_att = 0, max_u = 0, max_tmp = 0, max_cast = 0;
+    for (int i = 0; i < p.n_blocks; ++i) {
+        const int H = p.Hin[i], Ho = p.pool[i] ? H / 2 : H;
+        const Grid g = make_grid(B, H, H, p.ws[i]);
+        const size_t tok_in = (size_t)B * H * H, tok_out = (size_t)B * Ho * Ho;
+        const size_t rows_out = p.pool[i] ? (size_t)g.rows / 4 : (size_t)g.rows;
+        max_x = max_x > tok_in * p.dim_in[i] ? max_x : tok_in * p.dim_in[i];
+        max_x = max_x > tok_out * p.dim_out[i] ? max_x : tok_out * p.dim_out[i];
+        size_t v = (size_t)g.rows * pad32(p.dim_in[i]); max_h = max_h > v ? max_h : v;
+        v = tok_out * pad32(p.dim_out[i]); max_h = max_h > v ? max_h : v;
+        v = (size_t)g.rows * 3 * p.dim_out[i]; max_qkv = max_qkv > v ? max_qkv : v;
+        v = rows_out * pad32(p.dim_out[i]); max_att = max_att > v ? max_att : v;
+        v = tok_out * 4 * p.dim_out[i]; max_u = max_u > v ? max_u : v;
+        v = (size_t)g.rows * p.dim_out[i]; max_tmp = max_tmp > v ? max_tmp : v;
+        v = tok_out * pad32(p.dim_out[i]); max_cast = max_cast > v ? max_cast : v;
+    }
+    const size_t T0 = (size_t)B * (c.image_size / 4) * (c.image_size / 4);
+    max_cast = max_cast > T0 * c.fpn_dim ? max_cast : T0 * c.fpn_dim;
+    Ws w;
+    char *b0 = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t n) { char *r = b0 ? b0 + off : nullptr; off += align256(n); return r; };
+    w.col = (uint16_t *)take(T0 * 160 * 2);
+    w.x = (float *)take(max_x * 4);
+    w.xr = (float *)take(max_x * 4);
+    w.tmp = (float *)take(max_tmp * 4);
+    w.h = (uint16_t *)take(max_h * 2);
+    w.qkv = (uint16_t *)take(max_qkv * 2);
+    w.qp = (uint16_t *)take(max_att * 2);
+    w.att = (uint16_t *)take(max_att * 2);
+    w.u = (uint16_t *)take(max_u * 2);
+    w.cast = (uint16_t *)take(max_cast * 2);
+    for (int s = 0; s < 4; ++s) { const size_t t = T0 >> (2 * s); w.lat[s] = (float *)take(t * c.fpn_dim * 4); }
+    w.bytes = off;
+    return w;
+}
+
+int gemm(const void *A, long long lda, const void *W, long long ldw, const float *bias, void *C, long long ldc, int out_dtype,
+         const float *add, long long ld_add, long long M, int N, int K, int act, ovo_stream_t s) {
+    ovo_gemm_t g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc; g.add = add; g.ld_add = ld_add;
+    g.M = (int)M; g.N = N; g.K = K; g.in_dtype = 2; g.out_dtype = out_dtype; g.act = act; g.alpha = 1.0f;
+    return ovo_gemm(&g, s);
+}
+
+}  // namespace
+
+#define TRY(call)                        \
+    do {                                 \
+        const int rc__ = (call);         \
+        if (rc__ != OVO_OK) return rc__; \
+    } while (0)
+#define LAUNCHED() OVO_CHECK_LAUNCH()
+
+extern "C" {
+
+size_t ovo_hiera_workspace_bytes(const ovo_hiera_config_t *cfg, int B) {
+    if (!cfg || B <= 0) return 0;
+    Plan p;
+    if (make_plan(*cfg, p) != 0) return 0;
+    return carve(*cfg, p, B, nullptr).bytes;
+}
+
+int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *w, const float *images, int B, float *feat0,
+                      float *feat1, float *feat2, void *ws, size_t ws_bytes, ovo_stream_t stream) {
+    OVO_REQUIRE(cfg && w && images && feat0 && feat1 && feat2 && ws && B > 0, "null argument");
+    const ovo_hiera_config_t &c = *cfg;
+    OVO_REQUIRE(c.image_size % 32 == 0 && c.fpn_dim % 32 == 0 && c.n_global >= 0 && c.n_global <= 8, "bad config");
+    for (int s = 0; s < 4; ++s)
+        OVO_REQUIRE(c.dims[s] % 8 == 0 && c.heads[s] > 0 && c.dims[s] % c.heads[s] == 0 && (c.dims[s] / c.heads[s]) % 8 == 0 &&
+                        c.blocks[s] > 0 && c.window[s] > 0, "bad stage config");
+    Plan p;
+    OVO_REQUIRE(make_plan(c, p) == 0, "too many blocks");
+    OVO_REQUIRE(w->patch_w && w->patch_b && w->pos && w->blocks, "missing weights");
+    Ws k = carve(c, p, B, ws);
+    OVO_REQUIRE(ws_bytes >= k.bytes, "workspace too small");
+    hipStream_t hs = (hipStream_t)stream;
+    const int S4 = c.image_size / 4;
+    const long long T0 = (long long)S4 * S4;
+
+    // patch embedding (+ position embedding through the GEMM epilogue), one image at a time (pos has no batch dim)
+    TRY(ovo_im2col(images, B, 3, c.image_size, c.image_size, 7, 4, 3, k.col, 160, stream));
+    for (int b = 0; b < B; ++b)
+        TRY(gemm(k.col + (size_t)b * T0 * 160, 160, w->patch_w, 160, w->patch_b, k.x + (size_t)b * T0 * c.dims[0], c.dims[0], 0, w->pos,
+                 c.dims[0], T0, c.dims[0], 160, 0, stream));
+
+    float *x = k.x, *spare = k.xr;
+    for (int i = 0; i < p.n_blocks; ++i) {
+        const ovo_hiera_block_t &L = w->blocks[i];
+        const int din = p.dim_in[i], dout = p.dim_out[i], H = p.Hin[i], Ho = p.pool[i] ? H / 2 : H;
+        const int kin = pad32(din), kout = pad32(dout), hd = dout / p.heads[i];
+        const Grid g = make_grid(B, H, H, p.ws[i]);
+        OVO_REQUIRE(!p.pool[i] || (g.wh % 2 == 0 && H % 2 == 0), "query pooling needs even windows");
+        const long long tok_out = (long long)B * Ho * Ho;
+
+        k_ln_window<<<ovo_grid(g.rows * 64, 256), 256, 0, hs>>>(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, k.h);
+        const float *residual = x;
+        if (din != dout) {                                   // skip = maxpool(proj(LN(x)))
+            OVO_REQUIRE(L.res_w && L.res_b && p.pool[i], "stage-change block without projection weights");
+            TRY(gemm(k.h, kin, L.res_w, kin, L.res_b, k.tmp, dout, 0, nullptr, 0, g.rows, dout, kin, 0, stream));
+            k_pool_unwindow<<<ovo_grid(tok_out * dout, 256), 256, 0, hs>>>(k.tmp, g, dout, spare);
+            residual = spare;
+        }
+        TRY(gemm(k.h, kin, L.qkv_w, kin, L.qkv_b, k.qkv, 3 * dout, 2, nullptr, 0, g.rows, 3 * dout, kin, 0, stream));
+        const long long n_win = (long long)B * g.nwh * g.nww;
+        const int tk = g.wh * g.ww, tq = p.pool[i] ? tk / 4 : tk;
+        ovo_attention_t a;
+        a.k = k.qkv + dout; a.v = k.qkv + 2 * dout; a.o = k.att;
+        a.k_sb = a.v_sb = (int64_t)tk * 3 * dout; a.k_sh = a.v_sh = hd; a.k_st = a.v_st = 3 * dout;
+        if (p.pool[i]) {
+            k_qpool<<<ovo_grid(n_win * tq * dout, 256), 256, 0, hs>>>(k.qkv, n_win, g.wh, g.ww, dout, k.qp);
+            a.q = k.qp; a.q_sb = (int64_t)tq * dout; a.q_sh = hd; a.q_st = dout;
+        } else {
+            a.q = k.qkv; a.q_sb = a.k_sb; a.q_sh = hd; a.q_st = 3 * dout;
+        }
+        if (kout != dout) OVO_HIP(hipMemsetAsync(k.att, 0, (size_t)n_win * tq * kout * 2, hs));      // K-padding columns stay zero
+        a.o_sb = (int64_t)tq * kout; a.o_sh = hd; a.o_st = kout;
+        a.B = (int)n_win; a.H = p.heads[i]; a.Tq = tq; a.Tk = tk; a.hd = hd; a.scale = 1.0f / sqrtf((float)hd);
+        TRY(ovo_attention(&a, stream));
+        TRY(gemm(k.att, kout, L.out_w, kout, L.out_b, k.tmp, dout, 0, nullptr, 0, n_win * tq, dout, kout, 0, stream));
+        // window order (pooled window size) -> spatial, + residual
+        const Grid go = make_grid(B, Ho, Ho, p.ws[i] > 0 ? (p.pool[i] ? p.ws[i] / 2 : p.ws[i]) : 0);
+        // in place: same-dim blocks add onto x; at a stage change the old x is dead (only LN1 read it) and the
+        // pooled skip lives in `spare`, so the smaller new stream is written over the old buffer
+        k_unwindow_add<<<ovo_grid(tok_out * (dout / 4), 256), 256, 0, hs>>>(k.tmp, go, dout, residual, x);
+        // MLP
+        const Grid gi = make_grid(B, Ho, Ho, 0);
+        k_ln_window<<<ovo_grid(gi.rows * 64, 256), 256, 0, hs>>>(x, gi, dout, kout, L.ln2_g, L.ln2_b, c.ln_eps, k.h);
+        TRY(gemm(k.h, kout, L.fc1_w, kout, L.fc1_b, k.u, 4 * dout, 2, nullptr, 0, tok_out, 4 * dout, kout, 1, stream));
+        TRY(gemm(k.u, 4 * dout, L.fc2_w, 4 * dout, L.fc2_b, x, dout, 0, x, dout, tok_out, dout, 4 * dout, 0, stream));
+        LAUNCHED();
+
+        if (p.stage_end[i] >= 0) {                           // FPN lateral 1x1 conv of this stage's output
+            const int s = p.stage_end[i];
+            OVO_REQUIRE(w->neck_w[s] && w->neck_b[s], "missing neck weights");
+            k_cast_pad<<<ovo_grid(tok_out * kout, 256), 256, 0, hs>>>(x, tok_out, dout, kout, k.cast);
+            TRY(gemm(k.cast, kout, w->neck_w[s], kout, w->neck_b[s], k.lat[s], c.fpn_dim, 0, nullptr, 0, tok_out, c.fpn_dim, kout, 0, stream));
+        }
+    }
+    // top-down on the coarse levels: level 2 += up(level 3); levels 0 and 1 are laterals only
+    const int S16 = c.image_size / 16;
+    k_topdown_add<<<ovo_grid((long long)B * S16 * S16 * (c.fpn_dim / 4), 256), 256, 0, hs>>>(k.lat[2], k.lat[3], B, S16, S16, c.fpn_dim);
+    LAUNCHED();
+    OVO_HIP(hipMemcpyAsync(feat2, k.lat[2], (size_t)B * S16 * S16 * c.fpn_dim * 4, hipMemcpyDeviceToDevice, hs));
+    const long long t0 = (long long)B * T0, t1 = t0 / 4;
+    if (c.hi_res) {
+        OVO_REQUIRE(w->s0_w && w->s0_b && w->s1_w && w->s1_b, "missing conv_s0 / conv_s1 weights");
+        k_cast_pad<<<ovo_grid(t0 * c.fpn_dim, 256), 256, 0, hs>>>(k.lat[0], t0, c.fpn_dim, c.fpn_dim, k.cast);
+        TRY(gemm(k.cast, c.fpn_dim, w->s0_w, c.fpn_dim, w->s0_b, feat0, 32, 0, nullptr, 0, t0, 32, c.fpn_dim, 0, stream));
+        k_cast_pad<<<ovo_grid(t1 * c.fpn_dim, 256), 256, 0, hs>>>(k.lat[1], t1, c.fpn_dim, c.fpn_dim, k.cast);
+        TRY(gemm(k.cast, c.fpn_dim, w->s1_w, c.fpn_dim, w->s1_b, feat1, 64, 0, nullptr, 0, t1, 64, c.fpn_dim, 0, stream));
+    } else {
+        OVO_HIP(hipMemcpyAsync(feat0, k.lat[0], (size_t)t0 * c.fpn_dim * 4, hipMemcpyDeviceToDevice, hs));
+        OVO_HIP(hipMemcpyAsync(feat1, k.lat[1], (size_t)t1 * c.fpn_dim * 4, hipMemcpyDeviceToDevice, hs));
+    }
+    LAUNCHED();
+    return OVO_OK;
+}
+
+}  // extern "C"

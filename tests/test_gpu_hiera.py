@@ -1,0 +1,64 @@
+"""-m gpu: SAM2 image encoder (Hiera + FPN) on the GPU vs the fp32 oracle and HuggingFace golden vectors.
+
+bf16 operands, fp32 accumulation and residual stream: errors are reported relative to the feature RMS.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    return ((a - b).abs().max() / b.pow(2).mean().sqrt()).item()
+
+
+def test_hiera_vs_hf_golden():
+    from oracle import hiera as OH
+    from ovo_amd.encoders.hiera import HieraSpec, HipHiera
+    d = golden("hf_sam2_hiera")
+    sd = OH.hf_sam2_to_sam2({k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")})
+    spec = HieraSpec("hf-golden", 16, 1, tuple(d["stages"].tolist()), tuple(d["global_blocks"].tolist()),
+                     tuple(d["window_spec"].tolist()), (5, 5), image_size=128, fpn_dim=32, hi_res=False)
+    enc = HipHiera(spec, sd, device=DEV)
+    feats = enc.forward(torch.from_numpy(d["x"]).to(DEV))
+    for i, f in enumerate(feats):
+        ref = torch.from_numpy(d[f"fpn{i}"]).permute(0, 2, 3, 1)
+        assert f.shape == ref.shape
+        r = _rel(f.cpu(), ref)
+        print(f"level {i}: max err / rms = {r:.3e}")
+        assert r < 0.08
+
+
+@pytest.mark.parametrize("card,batch", [("hiera_test", 2), ("hiera_b+", 1)])
+def test_hiera_vs_oracle(card, batch):
+    from oracle import hiera as OH
+    from ovo_amd.encoders.hiera import SPECS, HipHiera, random_state
+    spec = SPECS[card]
+    sd = random_state(spec, seed=5)
+    enc = HipHiera(spec, sd, device=DEV)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(batch, 3, spec.image_size, spec.image_size, generator=g)
+    ref = OH.hiera_forward(sd, x, stages=spec.stages, heads=spec.heads, window_spec=spec.window_spec,
+                           global_blocks=spec.global_blocks, hi_res=True)
+    out = enc.forward(x.to(DEV))
+    for i, (f, r) in enumerate(zip(out, ref)):
+        assert f.shape == r.shape, (f.shape, r.shape)
+        e = _rel(f.cpu(), r)
+        cos = torch.nn.functional.cosine_similarity(f.cpu().flatten(), r.flatten(), dim=0).item()
+        print(f"{card} level {i} {tuple(f.shape)}: max err / rms = {e:.3e}, cosine = {cos:.6f}")
+        assert e < 0.1 and cos > 0.9995
+
+
+def test_hiera_preprocess_matches_torch():
+    from oracle import vit as OV
+    from ovo_amd.encoders.hiera import IMAGENET_MEAN, IMAGENET_STD, SPECS, HipHiera
+    enc = object.__new__(HipHiera)
+    enc.spec, enc.device = SPECS["hiera_b+"], torch.device(DEV)
+    img = (torch.rand(3, 480, 640, generator=torch.Generator().manual_seed(0)) * 255).to(torch.uint8)
+    got = HipHiera.preprocess(enc, img.to(DEV))[0].cpu()
+    ref = OV.resize_normalize(img, 1024, IMAGENET_MEAN, IMAGENET_STD, None, scale=1 / 255.0, antialias=True)
+    torch.testing.assert_close(got, ref, atol=3e-5, rtol=1e-5)
