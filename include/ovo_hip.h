@@ -36,6 +36,13 @@ typedef void *ovo_stream_t; /* hipStream_t */
 const char *ovo_hip_last_error(void);
 int ovo_hip_abi_version(void); /* bumped when a signature changes */
 
+/* Optional profiler for bench.py's roofline figures: between start and stop every launch of a profiled kernel
+ * family is bracketed by hipEvents on its own stream.  Kinds: 0 = 128x128-tile MFMA GEMM (work = flops),
+ * 1 = fused attention (flops), 2 = fused point-map tracking pass (bytes), 3 = smaller-tile GEMMs (flops).
+ * stop synchronises the device and returns, per kind, total milliseconds, total work and launch count. */
+int ovo_profile_start(void);
+int ovo_profile_stop(double *ms, double *work, int64_t *launches, int n_kinds);
+
 /* ---------------------------------------------------------------------------------------------
  * Camera / frustum parameters for one frame.  Filled on the host (8-corner and 6-plane math is tiny
  * and stays in torch-CPU, see DESIGN.md "bit-exactness").

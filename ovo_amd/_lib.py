@@ -91,6 +91,8 @@ DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.uint8
 _SIGNATURES = {
     "ovo_hip_last_error": (C.c_char_p, []),
     "ovo_hip_abi_version": (_I32, []),
+    "ovo_profile_start": (_I32, []),
+    "ovo_profile_stop": (_I32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
     "ovo_compact_workspace_bytes": (_SZ, [_I64]),
     "ovo_frustum_ids": (_I32, [_P, _I64, _CAM, _P, _P, _P, _SZ, _P]),
     "ovo_project_points": (_I32, [_P, _I64, _I32, _CAM, _P, _P]),

@@ -188,6 +188,9 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     a.scale_log2e = p->scale * 1.4426950408889634f;
     dim3 grid((p->Tq + 63) / 64, p->B * p->H);
     hipStream_t s = (hipStream_t)stream;
+    const bool prof = ovo_prof_enabled();
+    if (prof) ovo_prof_begin(1, 4.0 * p->B * p->H * (double)p->Tq * p->Tk * p->hd, s);
+    struct Done { bool on; hipStream_t s; ~Done() { if (on) ovo_prof_end(s); } } done{prof, s};
     if (p->hd <= 64) k_attention<64><<<grid, 256, 0, s>>>(a);
     else if (p->hd <= 96) k_attention<96><<<grid, 256, 0, s>>>(a);
     else k_attention<128><<<grid, 256, 0, s>>>(a);

@@ -10,6 +10,12 @@
 
 void ovo_set_error(const char *fmt, ...);
 
+// optional hipEvent profiler (core.hip): kinds 0 = MFMA GEMM (work = flops), 1 = attention (flops), 2 = point-map passes (bytes)
+#define OVO_PROF_KINDS 4
+bool ovo_prof_enabled();
+void ovo_prof_begin(int kind, double work, hipStream_t s);
+void ovo_prof_end(hipStream_t s);
+
 #define OVO_REQUIRE(cond, msg)                                   \
     do {                                                         \
         if (!(cond)) {                                           \

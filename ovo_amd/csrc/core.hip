@@ -1,5 +1,7 @@
-// core.hip -- error reporting and ABI version of libovo_hip.so.
+// core.hip -- error reporting, ABI version and the optional per-kernel-family event profiler of libovo_hip.so.
 #include <stdarg.h>
+
+#include <vector>
 
 #include "common.h"
 
@@ -12,7 +14,57 @@ void ovo_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// ---- profiler: hipEvent pairs around the launches of a kernel family, on the launch stream --------------
+namespace {
+struct Rec { hipEvent_t a, b; int kind; double work; };
+struct Prof {
+    bool on = false;
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+        return pool[used++];
+    }
+} g_prof;
+}  // namespace
+
+bool ovo_prof_enabled() { return g_prof.on; }
+void ovo_prof_begin(int kind, double work, hipStream_t s) {
+    if (!g_prof.on || g_prof.recs.size() >= (1u << 20)) return;
+    Rec r; r.kind = kind; r.work = work; r.a = g_prof.get(); r.b = g_prof.get();
+    if (!r.a || !r.b) return;
+    hipEventRecord(r.a, s);
+    g_prof.recs.push_back(r);
+}
+void ovo_prof_end(hipStream_t s) {
+    if (!g_prof.on || g_prof.recs.empty()) return;
+    hipEventRecord(g_prof.recs.back().b, s);
+}
+
 extern "C" {
 const char *ovo_hip_last_error(void) { return g_err; }
 int ovo_hip_abi_version(void) { return 1; }
+
+int ovo_profile_start(void) {
+    g_prof.recs.clear();
+    g_prof.used = 0;
+    g_prof.on = true;
+    return OVO_OK;
+}
+
+int ovo_profile_stop(double *ms, double *work, int64_t *launches, int n_kinds) {
+    g_prof.on = false;
+    OVO_REQUIRE(ms && work && launches && n_kinds > 0 && n_kinds <= OVO_PROF_KINDS, "bad argument");
+    for (int i = 0; i < n_kinds; ++i) { ms[i] = 0; work[i] = 0; launches[i] = 0; }
+    OVO_HIP(hipDeviceSynchronize());
+    for (const Rec &r : g_prof.recs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess || r.kind >= n_kinds) continue;
+        ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1;
+    }
+    g_prof.recs.clear();
+    g_prof.used = 0;
+    return OVO_OK;
+}
 }

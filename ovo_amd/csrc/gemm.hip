@@ -179,7 +179,10 @@ int launch(const GemmArgs &g0, hipStream_t s) {
         if (e != hipSuccess) { ovo_set_error("ovo_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
         attr_done = true;
     }
+    const bool prof = ovo_prof_enabled();
+    if (prof) ovo_prof_begin(BM == 128 && BN == 128 ? 0 : 3, 2.0 * g.M * (double)g.N * g.K, s);   // kind 0: the 128x128 tile kernel
     k_gemm<BM, BN, BK, VT><<<nbm * g.nbn, 256, lds, s>>>(g);
+    if (prof) ovo_prof_end(s);
     return OVO_OK;
 }
 

@@ -427,9 +427,12 @@ int ovo_track_project(const float *pts, const int32_t *point_ins, int64_t n, con
     OVO_HIP(hipMemsetAsync(counters, 0, 16, s));
     if (n == 0) return OVO_OK;
     OVO_REQUIRE(pts && point_ins && point_seg, "null pointer");
+    const bool prof = ovo_prof_enabled();
+    if (prof) ovo_prof_begin(2, 14.0 * (double)n, s);          // 12 B xyz read + 2 B mask id written per map point
     k_track_project<<<ovo_grid(n, 256), 256, 0, s>>>(pts, point_ins, n, *cam, depth, seg_map, seg_h, seg_w, ratio,
                                                       point_seg, hist, n_masks, hist_cols,
                                                       (unsigned long long *)counters);
+    if (prof) ovo_prof_end(s);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

@@ -135,16 +135,15 @@ class OVO:
     def _match_and_track_instances(self, frame_data, map_data, c2w, seg_map: torch.Tensor, binary_maps: torch.Tensor):
         """Reference: ovo.py:182-238 (with :240-324 inlined as device passes + a host decision loop)."""
         kf_id = self.kf_id
-        image, depth_np, ratio = frame_data
+        image, depth_in, ratio = frame_data
         points_3d, points_ids, points_ins_ids = map_data
         dev = points_3d.device
         lib = L.load()
 
-        depth_np = np.ascontiguousarray(depth_np, dtype=np.float32)
-        h, w = depth_np.shape
-        depth = torch.from_numpy(depth_np).to(dev, non_blocking=True)
-        pose = G._cpu32(c2w).contiguous()
-        near, far = G.depth_range(depth_np)                       # frustum uses the raw depth (:209)
+        h, w = depth_in.shape
+        depth = G.to_device(depth_in, torch.float32, dev)
+        pose = self._pose_host(c2w)
+        near, far = G.depth_range(depth_in)                       # frustum uses the raw depth (:209)
         corners = G.frustum_corners_from_range(near, far, h, w, pose, self._K_host)
         cam = G.make_camera(corners, torch.linalg.inv(pose), self._K_host, self.config["match_distance_th"], h, w)
         if self.config.get("depth_filter", False):
@@ -215,6 +214,11 @@ class OVO:
             self.keyframes["ins_maps"].append(ins_maps.cpu().numpy())
         return matched_ins_ids, binary_maps, n_matched, updated
 
+    @staticmethod
+    def _pose_host(c2w) -> torch.Tensor:
+        """4x4 pose on the host for the frustum set-up (a CPU tensor costs nothing, a device tensor one 64-byte D2H)."""
+        return G._cpu32(c2w).contiguous()
+
     def _fuse_masks_with_same_ins_id(self, binary_maps: torch.Tensor, matched_info, kf_id: int):
         """Reference: ovo.py:284-324.  Also returns, per ORIGINAL mask index, the row of the fused descriptor
         it contributes to (-1 = dropped) for the dense accumulator."""
@@ -224,7 +228,7 @@ class OVO:
             first = hits[0][0]
             if len(hits) > 1:
                 for other, _ in hits[1:]:
-                    binary_maps[first] = torch.logical_or(binary_maps[first], binary_maps[other])
+                    binary_maps[first].logical_or_(binary_maps[other])          # in place: no allocation on the hot path
                 if self.n_top_views > 0:
                     self.objects[ins_id].add_top_kf(kf_id, int(binary_maps[first].sum().item()))
             if self.n_top_views <= 0 or self.objects[ins_id].is_top_kf(kf_id):
@@ -257,6 +261,7 @@ class OVO:
                 matched_ins_ids = [matched_ins_ids[j] for j in rows]
                 binary_maps = binary_maps[torch.tensor(rows, device=binary_maps.device)]
         clip_embeds = self._extract_clip(image, binary_maps)
+        self.last_clip_embeds, self.last_clip_ins_ids, self.last_clip_kf = clip_embeds, matched_ins_ids, kf_id
         self._update_matched_objects_clip(clip_embeds, matched_ins_ids, kf_id)
         if self.config.get("log", False) and self.logger is not None:
             self.logger.log_ovo_stats({"frame_id": self.keyframes["frame_id"][kf_id],
@@ -267,7 +272,10 @@ class OVO:
     @_timed("t_clip")
     def _extract_clip(self, image: np.ndarray, binary_maps: torch.Tensor) -> torch.Tensor:
         """Reference: ovo.py:427-437 -- but the descriptors stay on the GPU."""
-        img = torch.from_numpy(np.ascontiguousarray(image.transpose((2, 0, 1)))).to(self.bank.device, non_blocking=True)
+        if isinstance(image, torch.Tensor):                      # already resident: HWC u8 -> CHW
+            img = image.to(self.bank.device).permute(2, 0, 1).contiguous()
+        else:
+            img = torch.from_numpy(np.ascontiguousarray(image.transpose((2, 0, 1)))).to(self.bank.device, non_blocking=True)
         return self.clip_generator.extract_clip(img, binary_maps, self.config.get("return_all_clips", False))
 
     @_timed("t_up")

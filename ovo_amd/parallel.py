@@ -1,0 +1,84 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm) / gloo on CPU.
+
+The reference is single-process (no collective anywhere).  The path shards at frame granularity
+(SURVEY.md §8e): the heavy per-frame work -- SAM2 encoder, ViT forward, region pooling, project / match / vote --
+is independent per frame, so rank r takes frames r, r+N, ...  The ONE exchange step is a sum-reduce of the
+descriptor accumulators (`avg_pooling` fusion is a mean = sum / count, instance3d.py:19-21, hence all-reducible):
+    * per step  : instance-level delta tables  sum f32[S, D] + cnt f32[S]   (a few MB -- latency bound)
+    * on demand : the dense per-point accumulators acc f32[N, D] + cnt i32[N] (GBs; bucketed so that every xGMI
+                  link carries 1/N of each bucket -- RCCL picks the direct all-to-all algorithm on a fully
+                  connected 8-GPU node; we only choose the bucket size)
+No NCCL call pattern is translated from anywhere: there is none in the reference.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+DENSE_BUCKET_BYTES = 256 << 20     # per all_reduce call for the dense merge (large buckets: 288 GB HBM, per-link bound)
+
+
+def env_world() -> tuple:
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_distributed(backend: Optional[str] = None) -> tuple:
+    """Initialise the default process group from torchrun's environment.  Returns (rank, local_rank, world)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def barrier() -> None:
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def allreduce_sum_(tensors: Sequence[torch.Tensor]) -> None:
+    """In-place sum over ranks of a few small tensors, packed into ONE collective."""
+    if world_size() == 1 or not tensors:
+        return
+    flat = torch.cat([t.reshape(-1).float() for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
+        off += n
+
+
+def allreduce_dense_(acc: torch.Tensor, cnt: torch.Tensor, bucket_bytes: int = DENSE_BUCKET_BYTES) -> int:
+    """Merge per-GPU dense accumulators (acc f32[N, D], cnt i32[N]) by bucketed in-place sum.  Returns #collectives."""
+    if world_size() == 1:
+        return 0
+    calls = 0
+    flat = acc.reshape(-1)
+    step = max(1, bucket_bytes // flat.element_size())
+    for s in range(0, flat.numel(), step):
+        dist.all_reduce(flat[s:s + step], op=dist.ReduceOp.SUM)
+        calls += 1
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    return calls + 1
+
+
+def max_over_ranks(value: float, device) -> float:
+    if world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,157 @@
+"""One keyframe of OVO's open-vocabulary feature path, end to end on one GPU.
+
+This is the frame loop body of the reference's `OVOSemMap.run` (ovomapping.py:139-187) with every frame a semantic
+keyframe (map_every = segment_every = 1, kf_queue_delay = 0), wired from this package's drop-in classes:
+
+    slam.track_camera / slam.map          back-projection into the point map                     (a9)
+    SAM2 image encoder                    Hiera + FPN on the 1024^2 resized frame                (a10)
+    ovo.detect_and_track_objects          masks (precomputed-mask seam) -> cull / project / match / vote / assign (a1-a8)
+    ovo.compute_semantic_info             ViT tokens -> region pooling -> multi-view fusion      (a12, a15-a17, a20)
+    dense ("voxel") fusion                per-point scatter-accumulate of the mask descriptors   (BASELINE configs 3-4)
+    query                                 instance table x texts (+argmax) and dense map x texts (a21-a22)
+
+It is what bench.py times and what smoke() runs small; it adds no arithmetic of its own.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import parallel, synthetic as syn
+from .encoders.hiera import SPECS as HIERA_SPECS, HipHiera
+from .encoders.vit import SPECS as VIT_SPECS, HipViT
+from .entities.clip_generator import CLIPGenerator
+from .entities.ovo import OVO
+from .slam.vanilla_mapper import VanillaMapper
+from .utils import clip_utils
+
+
+@dataclass
+class Frame:
+    index: int
+    rgb: torch.Tensor          # u8 [H, W, 3]      colour frame (640x480 for ScanNet)
+    rgb_lr: torch.Tensor       # u8 [h, w, 3]      colour at depth resolution (crop_edge applied)
+    depth: torch.Tensor        # f32 [h, w]        metres, 0 = invalid
+    c2w: np.ndarray            # f32 [4, 4]
+    seg_map: torch.Tensor      # i32 [H, W]        -1 = no mask
+    masks: torch.Tensor        # bool [N, H, W]
+
+
+class ResidentMasks:
+    """The reference's precomputed-mask seam (mask_generator.py:94-95) with the masks already in HBM."""
+
+    def __init__(self):
+        self.frames: Dict[int, Frame] = {}
+        self.precomputed = True
+
+    def get_masks(self, image, frame_id):
+        f = self.frames[frame_id]
+        return f.seg_map, f.masks.clone()        # OVO fuses masks in place (ovo.py:303): hand out a copy
+
+
+def synthetic_frames(n: int, device, scale: float = 1.0, n_masks_grid=(4, 6), n_blobs: int = 8, seed: int = 0, start: int = 0) -> List[Frame]:
+    """Deterministic 640x480-style RGB-D frames with consistent geometry, resident on `device`."""
+    h, w = syn.scannet_depth_hw(scale)
+    e = int(round(syn.SCANNET["crop_edge"] * scale))
+    H, W = h + 2 * e, w + 2 * e
+    K = syn.scannet_intrinsics(scale)
+    out = []
+    for t in range(start, start + n):
+        c2w = syn.pose(t % 24)                                     # the trajectory loops inside the room
+        rgb = syn.render_rgb(H, W, seed + t)
+        depth = syn.render_depth(c2w, K, h, w, seed + t)
+        masks = syn.make_masks(H, W, grid=n_masks_grid, n_blobs=n_blobs, seed=seed + t)
+        out.append(Frame(t, torch.from_numpy(rgb).to(device), torch.from_numpy(np.ascontiguousarray(rgb[e:H - e, e:W - e])).to(device),
+                         torch.from_numpy(depth).to(device), c2w, torch.from_numpy(syn.masks_to_segmap(masks)).to(device),
+                         torch.from_numpy(masks).to(device)))
+    return out
+
+
+class FramePipeline:
+    def __init__(self, device="cuda", vit_card: str = "PE-Core-L14-336", sam_card: Optional[str] = "hiera_b+",
+                 n_map: int = 1_000_000, n_text: int = 10, dense: bool = True, scale: float = 1.0, extra_capacity: int = 4_000_000,
+                 seed: int = 0, depth_filter: bool = True, track_th: int = 100):
+        self.device = torch.device(device)
+        self.scale = scale
+        self.crop_edge = int(round(syn.SCANNET["crop_edge"] * scale))
+        K = torch.from_numpy(syn.scannet_intrinsics(scale)).to(self.device)
+        self.slam = VanillaMapper({"device": str(self.device), "mapping": {"k_pooling": 3}}, K)
+        if n_map > 0:
+            pts = torch.from_numpy(syn.padded_map(n_map, frames=4, scale=scale, seed=seed))
+            self.slam.set_map_dict({"xyz": pts, "obj_ids": torch.full((n_map, 1), -1, dtype=torch.int32),
+                                    "ids": torch.arange(n_map, dtype=torch.int32)[:, None], "max_id": n_map,
+                                    "color": torch.zeros((n_map, 3), dtype=torch.uint8)})
+        self.slam._reserve(n_map + extra_capacity)
+        self.masks = ResidentMasks()
+        clip_cfg = {"embed_type": "TextRegion", "model_card": vit_card, "k_top_views": 10000, "fusion": "avg_pooling", "seed": seed}
+        self.clip = CLIPGenerator(clip_cfg, device=str(self.device), encoder=HipViT(VIT_SPECS[vit_card], None, self.device, seed))
+        cfg = {"match_distance_th": 0.05, "track_th": track_th, "depth_filter": depth_filter, "log": False, "kf_queue_delay": 0,
+               "debug_info": False, "clip": clip_cfg, "sam": {"precomputed": True}}
+        self.ovo = OVO(cfg, None, "synthetic", K, device=str(self.device), clip_generator=self.clip, mask_generator=self.masks)
+        self.sam = HipHiera(HIERA_SPECS[sam_card], None, self.device, seed) if sam_card else None
+        self.sam_out = None
+        self.D = self.clip.clip_dim
+        self.texts = torch.from_numpy(syn.unit_vectors(n_text, self.D, seed=seed + 7)).to(self.device)
+        self.dense = dense
+        if dense:
+            cap = self.slam._cap
+            self.acc = torch.zeros((cap, self.D), dtype=torch.float32, device=self.device)
+            self.cnt = torch.zeros(cap, dtype=torch.int32, device=self.device)
+        self.inst_delta = torch.zeros((4096, self.D), dtype=torch.float32, device=self.device)
+        self.inst_delta_cnt = torch.zeros(4096, dtype=torch.float32, device=self.device)
+        self.last: Dict[str, object] = {}
+
+    # ------------------------------------------------------------------ one keyframe
+    def step(self, f: Frame) -> Dict[str, object]:
+        lib = L.load()
+        self.masks.frames = {f.index: f}
+        fd = [f.index, f.rgb_lr, f.depth, f.c2w]
+        self.slam.track_camera(fd)
+        c2w = self.slam._c2w_host[f.index]                         # host copy: no D2H for the frustum set-up
+        self.slam.map(fd, c2w)
+        if self.sam is not None:                                   # SAM2 image encoder (masks come from the seam)
+            self.sam_out = self.sam.forward(self.sam.preprocess(f.rgb.permute(2, 0, 1).contiguous()))
+        ratio = (1.0, 1.0, self.crop_edge) if self.crop_edge else ()
+        updated = self.ovo.detect_and_track_objects([f.index, f.rgb, f.depth, ratio], self.slam.get_map(), c2w)
+        if updated is not None:
+            self.slam.update_pcd_obj_ids(updated)
+        self.ovo.compute_semantic_info()
+        n = self.slam._n
+        desc = getattr(self.ovo, "last_clip_embeds", None)
+        if desc is not None and self.ovo.last_clip_kf == self.ovo.kf_id - 1 and desc.shape[0] > 0:
+            if self.dense:
+                rows = torch.tensor(self.ovo.last_mask_rows, dtype=torch.int32).to(self.device, non_blocking=True)
+                L.check(lib.ovo_scatter_accum(L.ptr(self.ovo.last_point_seg), self.ovo.last_point_seg.shape[0], L.ptr(rows), rows.shape[0],
+                                              L.ptr(desc), self.D, L.ptr(self.acc), L.ptr(self.cnt), L.stream()))
+            if parallel.world_size() > 1:                          # the one exchange step: sum-reduce of the fusion accumulators
+                slots = torch.tensor([self.ovo.bank.slot_of[i] % 4096 for i in self.ovo.last_clip_ins_ids], device=self.device)
+                self.inst_delta.zero_(); self.inst_delta_cnt.zero_()
+                self.inst_delta.index_add_(0, slots, desc)
+                self.inst_delta_cnt.index_add_(0, slots, torch.ones(slots.shape[0], device=self.device))
+                parallel.allreduce_sum_([self.inst_delta, self.inst_delta_cnt])
+        out: Dict[str, object] = {"n_points": n, "n_instances": len(self.ovo.objects)}
+        if len(self.ovo.objects) > 0:                              # query: instances x texts, fused argmax
+            table = self.ovo.get_objs_clips()
+            out["sim"], out["cls"], out["conf"] = clip_utils.similarity(table, self.texts, want_argmax=True)
+        if self.dense:                                             # dense query: per-point mean descriptor x texts
+            _, out["dense_cls"], out["dense_conf"] = clip_utils.similarity(self.acc[:n], self.texts, cnt=self.cnt[:n], want_sim=False,
+                                                                           want_argmax=True)
+        self.last = out
+        return out
+
+    def merge_dense(self) -> int:
+        """Merge the per-GPU dense accumulators over xGMI (called once per batch of frames / before a global query)."""
+        return parallel.allreduce_dense_(self.acc[:self.slam._n], self.cnt[:self.slam._n]) if self.dense else 0
+
+    # ------------------------------------------------------------------ workload accounting
+    def flops_per_frame(self, h: int, w: int) -> Dict[str, float]:
+        spec = self.clip.model.spec
+        crops = 1 + max(h // spec.image_size, 1) * max(w // spec.image_size, 1)
+        out = {"vit": crops * spec.flops_per_image()}
+        if self.sam is not None:
+            out["sam2"] = self.sam.spec.flops_per_image()
+        return out

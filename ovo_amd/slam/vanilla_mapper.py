@@ -101,19 +101,18 @@ class VanillaMapper:
 
     def map(self, frame_data: List[Any], c2w: torch.Tensor) -> None:
         """Reference: vanilla_mapper.py:46-85."""
-        frame_id, image, depth_np = frame_data[0], frame_data[1], frame_data[2]
-        depth_np = np.ascontiguousarray(depth_np, dtype=np.float32)
-        h, w = depth_np.shape
+        frame_id, image, depth_in = frame_data[0], frame_data[1], frame_data[2]
+        h, w = depth_in.shape
         lib = L.load()
         dev = self.device
-        depth = torch.from_numpy(depth_np).to(dev, non_blocking=True)
-        rgb = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8)).to(dev, non_blocking=True)
+        depth = G.to_device(depth_in, torch.float32, dev)
+        rgb = G.to_device(image, torch.uint8, dev)
         pose = self._host_pose(frame_id, c2w).float().contiguous()
         explained = None
         if self.max_id > 0:
-            if not (depth_np > 0).any():
+            near, far = G.depth_range(depth_in)
+            if not far > 0:
                 return
-            near, far = G.depth_range(depth_np)
             corners = G.frustum_corners_from_range(near, far, h, w, pose, self._K_host)
             cam = G.make_camera(corners, torch.linalg.inv(pose), self._K_host, self.match_distance_th, h, w)
             explained = torch.empty((h, w), dtype=torch.uint8, device=dev)

@@ -29,10 +29,21 @@ def _cpu32(t) -> torch.Tensor:
     return t.detach().to(device="cpu", dtype=torch.float32)
 
 
+def to_device(arr, dtype: torch.dtype, device) -> torch.Tensor:
+    """Frame arrays arrive as numpy (the reference's dataset tuples) or as tensors already resident on the GPU."""
+    if isinstance(arr, torch.Tensor):
+        t = arr if arr.dtype == dtype else arr.to(dtype)
+        return (t if t.is_cuda else t.to(device, non_blocking=True)).contiguous()
+    np_dtype = {torch.float32: np.float32, torch.uint8: np.uint8, torch.int32: np.int32}[dtype]
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np_dtype)).to(device, non_blocking=True)
+
+
 def depth_range(depth) -> Tuple[float, float]:
-    """min / max of the valid (> 0) depths; numpy input costs no device sync."""
+    """min / max of the valid (> 0) depths (inf, <= 0 when there is none); numpy input costs no device sync."""
     if isinstance(depth, np.ndarray):
         v = depth[depth > 0]
+        if v.size == 0:
+            return float("inf"), 0.0
         return float(v.min()), float(v.max())
     big = torch.where(depth > 0, depth, torch.full_like(depth, float("inf"))).min()
     top = depth.max()

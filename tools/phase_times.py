@@ -1,0 +1,42 @@
+"""Per-phase wall clock of one keyframe (each phase followed by a device sync) -- a diagnosis tool, not a benchmark."""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import torch
+from ovo_amd import _lib as L
+from ovo_amd.pipeline import FramePipeline, synthetic_frames
+from ovo_amd.utils import clip_utils
+
+torch.set_num_threads(int(os.environ.get("OVO_THREADS", "1")))
+dev = torch.device("cuda", 0)
+pipe = FramePipeline(dev, extra_capacity=40 * 72000)
+frames = synthetic_frames(16, dev)
+for f in frames[:4]:
+    pipe.step(f)
+torch.cuda.synchronize()
+acc = {}
+def tick(name, t0):
+    torch.cuda.synchronize()
+    acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+    return time.perf_counter()
+n = 0
+for f in frames[4:14]:
+    n += 1
+    t = time.perf_counter()
+    pipe.masks.frames = {f.index: f}
+    fd = [f.index, f.rgb_lr, f.depth, f.c2w]
+    pipe.slam.track_camera(fd); t = tick("track_camera", t)
+    c2w = pipe.slam._c2w_host[f.index]
+    pipe.slam.map(fd, c2w); t = tick("map", t)
+    x = pipe.sam.preprocess(f.rgb.permute(2, 0, 1).contiguous()); t = tick("sam_pre", t)
+    pipe.sam.forward(x); t = tick("sam_fwd", t)
+    upd = pipe.ovo.detect_and_track_objects([f.index, f.rgb, f.depth, (1.0, 1.0, 12)], pipe.slam.get_map(), c2w); t = tick("track", t)
+    pipe.slam.update_pcd_obj_ids(upd); t = tick("writeback", t)
+    pipe.ovo.compute_semantic_info(); t = tick("clip", t)
+    nn = pipe.slam._n
+    rows = torch.tensor(pipe.ovo.last_mask_rows, dtype=torch.int32).to(dev)
+    L.check(L.load().ovo_scatter_accum(L.ptr(pipe.ovo.last_point_seg), pipe.ovo.last_point_seg.shape[0], L.ptr(rows), rows.shape[0],
+                                       L.ptr(pipe.ovo.last_clip_embeds), pipe.D, L.ptr(pipe.acc), L.ptr(pipe.cnt), L.stream())); t = tick("scatter", t)
+    table = pipe.ovo.get_objs_clips(); t = tick("gather", t)
+    clip_utils.similarity(table, pipe.texts, want_argmax=True); t = tick("query_inst", t)
+    clip_utils.similarity(pipe.acc[:nn], pipe.texts, cnt=pipe.cnt[:nn], want_sim=False, want_argmax=True); t = tick("query_dense", t)
+print({k: round(1e3 * v / n, 3) for k, v in acc.items()}, "total ms", round(1e3 * sum(acc.values()) / n, 2))
