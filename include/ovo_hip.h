@@ -163,6 +163,12 @@ int ovo_similarity(const void *F, int feat_dtype, int64_t n, int D, const float 
 int ovo_mask_intersections(const uint64_t *bits, int n, int64_t words, int32_t *inter, ovo_stream_t stream);
 int ovo_pack_masks(const uint8_t *masks, int n, int64_t pixels, uint64_t *bits, int64_t words, ovo_stream_t stream);
 
+/* ---- a7: _fuse_masks_with_same_ins_id (ovo.py:284-324) -------------------------------------------------
+ * masks u8/bool [n, pixels] (pixels % 16 == 0): masks[dst] |= masks[src] for each (dst, src) of pairs i32[n_pairs, 2];
+ * ovo_mask_area: area[k] = number of set pixels of masks[rows[k]]. */
+int ovo_mask_or(uint8_t *masks, int64_t pixels, const int32_t *pairs, int n_pairs, ovo_stream_t stream);
+int ovo_mask_area(const uint8_t *masks, int64_t pixels, const int32_t *rows, int n_rows, int32_t *area, ovo_stream_t stream);
+
 /* =============================================================================================
  * Encoder building blocks (a10, a12, a13): the reference calls these through third-party nn.Modules
  * (open_clip / perception_models ViT: clip_generator.py:112-122, textregion.py:141-142; sam2 Hiera:

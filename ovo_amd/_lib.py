@@ -108,6 +108,8 @@ _SIGNATURES = {
     "ovo_similarity": (_I32, [_P, _I32, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P, _P]),
     "ovo_mask_intersections": (_I32, [_P, _I32, _I64, _P, _P]),
     "ovo_pack_masks": (_I32, [_P, _I32, _I64, _P, _I64, _P]),
+    "ovo_mask_or": (_I32, [_P, _I64, _P, _I32, _P]),
+    "ovo_mask_area": (_I32, [_P, _I64, _P, _I32, _P, _P]),
     "ovo_gemm": (_I32, [C.POINTER(Gemm), _P]),
     "ovo_attention": (_I32, [C.POINTER(Attention), _P]),
     "ovo_layernorm": (_I32, [_P, _I64, _I64, _I32, _P, _P, _F32, _P, _I64, _I32, _P]),

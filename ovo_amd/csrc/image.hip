@@ -57,9 +57,51 @@ __global__ void __launch_bounds__(256) k_mask_inter(const unsigned long long *__
     if (lane == 0) { inter[(int64_t)i * n + j] = c; inter[(int64_t)j * n + i] = c; }
 }
 
+// masks[dst] |= masks[src] for every (dst, src) pair (a mask is never both), 16 pixels per thread
+__global__ void __launch_bounds__(256) k_mask_or(uint4 *__restrict__ masks, long long px16, const int32_t *__restrict__ pairs, int n_pairs) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < px16; i += (long long)gridDim.x * blockDim.x)
+        for (int p = 0; p < n_pairs; ++p) {
+            const long long d = pairs[2 * p] * px16 + i, s = pairs[2 * p + 1] * px16 + i;
+            uint4 a = masks[d];
+            const uint4 b = masks[s];
+            a.x |= b.x; a.y |= b.y; a.z |= b.z; a.w |= b.w;
+            masks[d] = a;
+        }
+}
+
+// area[k] = number of non-zero bytes of masks[rows[k]]
+__global__ void __launch_bounds__(256) k_mask_area(const uint8_t *__restrict__ masks, long long pixels, const int32_t *__restrict__ rows,
+                                                   int32_t *__restrict__ area) {
+    const uint8_t *m = masks + (long long)rows[blockIdx.y] * pixels;
+    int c = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += (long long)gridDim.x * blockDim.x) c += m[i] != 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(area + blockIdx.y, c);
+}
+
 }  // namespace
 
 extern "C" {
+
+int ovo_mask_or(uint8_t *masks, int64_t pixels, const int32_t *pairs, int n_pairs, ovo_stream_t stream) {
+    OVO_REQUIRE(n_pairs >= 0 && pixels > 0 && pixels % 16 == 0, "pixels must be a multiple of 16");
+    if (n_pairs == 0) return OVO_OK;
+    OVO_REQUIRE(masks && pairs && ((uintptr_t)masks & 15) == 0, "null / misaligned pointer");
+    k_mask_or<<<ovo_grid(pixels / 16, 256, 512), 256, 0, (hipStream_t)stream>>>((uint4 *)masks, pixels / 16, pairs, n_pairs);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_mask_area(const uint8_t *masks, int64_t pixels, const int32_t *rows, int n_rows, int32_t *area, ovo_stream_t stream) {
+    OVO_REQUIRE(n_rows >= 0 && pixels > 0, "bad shape");
+    if (n_rows == 0) return OVO_OK;
+    OVO_REQUIRE(masks && rows && area && n_rows <= 65535, "null pointer");
+    OVO_HIP(hipMemsetAsync(area, 0, (size_t)n_rows * sizeof(int32_t), (hipStream_t)stream));
+    dim3 grid(ovo_grid(pixels, 256, 64), n_rows);
+    k_mask_area<<<grid, 256, 0, (hipStream_t)stream>>>(masks, pixels, rows, area);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
 
 int ovo_depth_filter(const float *depth, int h, int w, int ksize, float sigma, float th, float *out, ovo_stream_t stream) {
     OVO_REQUIRE(depth && out && h > 0 && w > 0, "null / empty image");

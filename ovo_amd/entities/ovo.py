@@ -222,21 +222,33 @@ class OVO:
     def _fuse_masks_with_same_ins_id(self, binary_maps: torch.Tensor, matched_info, kf_id: int):
         """Reference: ovo.py:284-324.  Also returns, per ORIGINAL mask index, the row of the fused descriptor
         it contributes to (-1 = dropped) for the dense accumulator."""
+        lib = L.load()
+        n_all = int(binary_maps.shape[0])
+        pixels = binary_maps[0].numel() if n_all else 0
+        maps_u8 = binary_maps.view(torch.uint8) if binary_maps.dtype == torch.bool else binary_maps
+        pairs = [(hits[0][0], other) for hits in matched_info.values() for other, _ in hits[1:]]
+        fused_area = {}
+        if pairs:                                               # all ORs of the keyframe in one launch
+            flat = torch.tensor(pairs, dtype=torch.int32).reshape(-1).to(maps_u8.device, non_blocking=True)
+            L.check(lib.ovo_mask_or(L.ptr(maps_u8), pixels, L.ptr(flat), len(pairs), L.stream()))
+            if self.n_top_views > 0:                           # fused areas feed the top-k view heap (:305-309)
+                dst = sorted({d for d, _ in pairs})
+                rows = torch.tensor(dst, dtype=torch.int32).to(maps_u8.device, non_blocking=True)
+                area = torch.empty(len(dst), dtype=torch.int32, device=maps_u8.device)
+                L.check(lib.ovo_mask_area(L.ptr(maps_u8), pixels, L.ptr(rows), len(dst), L.ptr(area), L.stream()))
+                fused_area = dict(zip(dst, area.tolist()))
         matched_ins_ids, keep_rows = [], []
-        mask_rows = [-1] * int(binary_maps.shape[0])
+        mask_rows = [-1] * n_all
         for ins_id, hits in matched_info.items():
             first = hits[0][0]
-            if len(hits) > 1:
-                for other, _ in hits[1:]:
-                    binary_maps[first].logical_or_(binary_maps[other])          # in place: no allocation on the hot path
-                if self.n_top_views > 0:
-                    self.objects[ins_id].add_top_kf(kf_id, int(binary_maps[first].sum().item()))
+            if len(hits) > 1 and self.n_top_views > 0:
+                self.objects[ins_id].add_top_kf(kf_id, int(fused_area[first]))
             if self.n_top_views <= 0 or self.objects[ins_id].is_top_kf(kf_id):
                 for m, _ in hits:
                     mask_rows[m] = len(matched_ins_ids)
                 matched_ins_ids.append(ins_id)
                 keep_rows.append(first)
-        idx = torch.tensor(keep_rows, dtype=torch.int64, device=binary_maps.device)
+        idx = torch.tensor(keep_rows, dtype=torch.int64).to(binary_maps.device, non_blocking=True)
         return matched_ins_ids, binary_maps.index_select(0, idx), mask_rows
 
     # ------------------------------------------------------------------ descriptors
