@@ -1,0 +1,50 @@
+"""Host-side logic that needs no GPU: Instance3D top-k heap semantics vs the reference, crop tiling, configs."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+
+def test_instance3d_heap_matches_reference():
+    from ovo_amd.entities.instance3d import Instance3D
+    d = golden("fusion")
+    Instance3D.n_top_kf = 3
+    inst = Instance3D(5)
+    flags = []
+    for kf, area in enumerate(d["areas"].tolist()):
+        inst.to_update = False
+        inst.update([kf * 10], kf, area)
+        flags.append(inst.to_update)
+    assert sorted(inst.top_kf) == [tuple(r) for r in d["top_kf"].tolist()]
+    assert inst.kfs_ids == [0, 1, 2, 3, 4] and inst.points_ids == [0, 10, 20, 30, 40]
+    assert flags == [True, True, True, True, True]          # areas 50,10,70,30,90: 30 evicts 10, 90 evicts 30
+    assert inst.fusion_views() == [4, 2, 0]                 # nlargest by area
+    inst.add_top_kf(4, 95)                                   # same keyframe, larger fused mask (ovo.py:308-309)
+    assert (95, 4) in inst.top_kf
+    Instance3D.n_top_kf = 0
+    free = Instance3D(6, kf_id=2, points_ids=[1], mask_area=9)
+    assert free.top_kf == [] and free.to_update and free.fusion_views() == [2]
+
+
+def test_tracking_golden_state_keys():
+    d = golden("query")
+    keys = d["capture_keys"].tolist()
+    assert "ins_3d_ids" in keys and all(k.startswith("ins3d_") for k in keys if k != "ins_3d_ids")
+
+
+def test_textregion_tiling_matches_reference_rule():
+    from ovo_amd.entities.textregion import PETextRegion
+    tr = object.__new__(PETextRegion)
+    tr.resize_method, tr.crop_size, tr.patch_size = "multi_resolution", 336, 14
+    assert tr._crops(480, 640) == [(0, 0, 480, 640), (0, 0, 480, 640)] and (tr.points_per_h, tr.points_per_w) == (24, 24)
+    crops = tr._crops(968, 1296)                              # ScanNet full-res colour: 2 x 3 tiles
+    assert len(crops) == 7 and (tr.points_per_h, tr.points_per_w) == (48, 72)
+    assert crops[1] == (0, 0, 484, 432) and crops[-1] == (484, 864, 484, 432)
+
+
+def test_specs_flops():
+    from ovo_amd.encoders.hiera import SPECS as H
+    from ovo_amd.encoders.vit import SPECS as V
+    assert abs(V["ViT-B-16-qg"].flops_per_image() / 1e9 - 35.1) < 0.5
+    assert abs(V["PE-Core-L14-336"].flops_per_image() / 1e9 - 381) < 3         # per 336^2 crop
+    assert H["hiera_b+"].dims == (112, 224, 448, 896) and H["hiera_l"].heads == (2, 4, 8, 16)

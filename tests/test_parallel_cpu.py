@@ -1,0 +1,58 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercising ovo_amd.parallel (the collectives bench.py uses)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ovo_amd import parallel
+    r, lr, w = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world) and parallel.world_size() == world
+    # per-step exchange: packed sum-reduce of the instance delta tables
+    g = torch.Generator().manual_seed(rank)
+    delta = torch.randn(64, 16, generator=g)
+    cnt = torch.full((64,), float(rank + 1))
+    mine = delta.clone()
+    parallel.allreduce_sum_([delta, cnt])
+    # dense merge: bucketed in-place reduce (tiny bucket -> several collectives), i32 counts
+    acc = torch.full((1000, 8), float(rank + 1))
+    c = torch.full((1000,), rank + 1, dtype=torch.int32)
+    calls = parallel.allreduce_dense_(acc, c, bucket_bytes=4096)
+    t = parallel.max_over_ranks(10.0 + rank, "cpu")
+    parallel.barrier()
+    out[rank] = (mine, delta, cnt, acc, c, calls, t)
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_reduce():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    total = out[0][0] + out[1][0]
+    for r in range(world):
+        mine, delta, cnt, acc, c, calls, t = out[r]
+        torch.testing.assert_close(delta, total)
+        assert torch.equal(cnt, torch.full((64,), 3.0))
+        assert torch.equal(acc, torch.full((1000, 8), 3.0)) and torch.equal(c, torch.full((1000,), 3, dtype=torch.int32))
+        assert calls == 8 + 1 and t == 11.0
+
+
+def test_single_process_is_a_noop():
+    from ovo_amd import parallel
+    x = torch.ones(4)
+    parallel.allreduce_sum_([x])
+    assert parallel.world_size() == 1 and torch.equal(x, torch.ones(4)) and parallel.max_over_ranks(2.5, "cpu") == 2.5
+    assert parallel.allreduce_dense_(torch.ones(4, 2), torch.ones(4, dtype=torch.int32)) == 0
