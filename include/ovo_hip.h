@@ -37,8 +37,8 @@ const char *ovo_hip_last_error(void);
 int ovo_hip_abi_version(void); /* bumped when a signature changes */
 
 /* Optional profiler for bench.py's roofline figures: between start and stop every launch of a profiled kernel
- * family is bracketed by hipEvents on its own stream.  Kinds: 0 = 128x128-tile MFMA GEMM (work = flops),
- * 1 = fused attention (flops), 2 = fused point-map tracking pass (bytes), 3 = smaller-tile GEMMs (flops).
+ * family is bracketed by hipEvents on its own stream.  Kinds (n_kinds <= 8): 1 = fused attention (work = flops),
+ * 2 = fused point-map tracking pass (bytes), 4..7 = MFMA GEMM with tile 128x128 / 128x64 / 64x128 / 64x64 (flops).
  * stop synchronises the device and returns, per kind, total milliseconds, total work and launch count. */
 int ovo_profile_start(void);
 int ovo_profile_stop(double *ms, double *work, int64_t *launches, int n_kinds);
@@ -167,6 +167,9 @@ int ovo_pack_masks(const uint8_t *masks, int n, int64_t pixels, uint64_t *bits, 
  * masks u8/bool [n, pixels] (pixels % 16 == 0): masks[dst] |= masks[src] for each (dst, src) of pairs i32[n_pairs, 2];
  * ovo_mask_area: area[k] = number of set pixels of masks[rows[k]]. */
 int ovo_mask_or(uint8_t *masks, int64_t pixels, const int32_t *pairs, int n_pairs, ovo_stream_t stream);
+/* dst[k, :] = src[idx[k], :] for rows of row_bytes bytes (multiple of 16): the kept-mask reorder of ovo.py:322 and the
+ * instance-table gather of ovo.py:513-527. */
+int ovo_gather_rows(const void *src, int64_t row_bytes, const int32_t *idx, int n, void *dst, ovo_stream_t stream);
 int ovo_mask_area(const uint8_t *masks, int64_t pixels, const int32_t *rows, int n_rows, int32_t *area, ovo_stream_t stream);
 
 /* =============================================================================================

@@ -109,6 +109,7 @@ _SIGNATURES = {
     "ovo_mask_intersections": (_I32, [_P, _I32, _I64, _P, _P]),
     "ovo_pack_masks": (_I32, [_P, _I32, _I64, _P, _I64, _P]),
     "ovo_mask_or": (_I32, [_P, _I64, _P, _I32, _P]),
+    "ovo_gather_rows": (_I32, [_P, _I64, _P, _I32, _P, _P]),
     "ovo_mask_area": (_I32, [_P, _I64, _P, _I32, _P, _P]),
     "ovo_gemm": (_I32, [C.POINTER(Gemm), _P]),
     "ovo_attention": (_I32, [C.POINTER(Attention), _P]),
@@ -178,6 +179,19 @@ def dev(t: torch.Tensor, dtype: torch.dtype, name: str = "tensor") -> torch.Tens
     if not t.is_contiguous():
         raise OvoHipError(f"{name} must be contiguous")
     return t
+
+
+def gather_rows(src: torch.Tensor, rows) -> torch.Tensor:
+    """src[rows] along dim 0 through `ovo_gather_rows` (torch's index_select picks size-dependent kernel variants whose
+    first use lazily loads a code object: a 100+ ms stall in the middle of a sequence on ROCm)."""
+    n = len(rows)
+    out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    if n == 0:
+        return out
+    row_bytes = src[0].numel() * src.element_size()
+    idx = torch.tensor(list(rows), dtype=torch.int32).to(src.device, non_blocking=True)
+    check(load().ovo_gather_rows(ptr(src), row_bytes, ptr(idx), n, ptr(out), stream()))
+    return out
 
 
 _ws_cache = {}

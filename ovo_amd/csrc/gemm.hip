@@ -7,14 +7,18 @@
 // Structure (gfx950):
 //   * block = 256 threads = 4 waves in a 2x2 arrangement; block tile BM x BN in {64,128}^2, BK in {32,64};
 //     each wave owns (BM/2) x (BN/2) as 16x16 MFMA tiles (v_mfma_f32_16x16x32_{bf16,f16}).
-//   * global -> LDS with global_load_lds_dwordx4 (16 B per lane, no VGPR round trip), two LDS stages:
-//     tile t+1 streams in while tile t is multiplied.
+//   * global -> LDS with global_load_lds_dwordx4 (16 B per lane, no VGPR round trip) into a ring of 3-4 LDS stages:
+//     tiles t+1..t+2 stay in flight across the (raw) barrier behind a COUNTED s_waitcnt vmcnt while tile t is
+//     multiplied -- these GEMMs are small (1 workgroup per CU), so exposed load latency, not MFMA rate, was the bound
+//     (28 us -> see DESIGN.md for the measured effect).
 //   * the DMA writes LDS lane-linearly, so the bank-conflict swizzle (16-byte chunk index XOR a row
 //     function) is applied to the per-lane SOURCE address and again when fragments are read (ds_read_b128).
 //   * operands are swapped (a = W fragment, b = activation fragment): the accumulator holds C^T tiles, i.e.
 //     each lane owns 4 consecutive output columns of one output row -> 8/16-byte epilogue stores.
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
+
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -70,7 +74,7 @@ __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
     return *(const uint32_t *)&h;
 }
 
-template <int BM, int BN, int BK, typename VT>
+template <int BM, int BN, int BK, int NS, typename VT>
 __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CPR = BK / 8;                       // 16-byte chunks per tile row
@@ -87,20 +91,28 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // per-lane source pointers of the DMA pieces (swizzled chunk of a clamped row), advanced by BK elements per tile
+    constexpr int AI = A_BYTES / 4096, BI = B_BYTES / 4096;
+    const char *a_src[AI], *b_src[BI];
+#pragma unroll
+    for (int it = 0; it < AI; ++it) {
+        const int id = it * 256 + tid, row = id / CPR, c = (id % CPR) ^ swz<BK>(row);
+        int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
+        a_src[it] = g.A + ((long long)gr * g.lda + c * 8) * 2;
+    }
+#pragma unroll
+    for (int it = 0; it < BI; ++it) {
+        const int id = it * 256 + tid, row = id / CPR, c = (id % CPR) ^ swz<BK>(row);
+        int gr = n0 + row; gr = gr < g.N ? gr : g.N - 1;
+        b_src[it] = g.W + ((long long)gr * g.ldw + c * 8) * 2;
+    }
     auto stage = [&](int buf, int kt) {
         char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
+        const long long koff = (long long)kt * BK * 2;
 #pragma unroll
-        for (int it = 0; it < A_BYTES / 4096; ++it) {
-            const int id = it * 256 + tid, row = id / CPR, c = (id % CPR) ^ swz<BK>(row);
-            int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
-            glds16(g.A + ((long long)gr * g.lda + (long long)kt * BK + c * 8) * 2, sa + (it * 256 + wave * 64) * 16);
-        }
+        for (int it = 0; it < AI; ++it) glds16(a_src[it] + koff, sa + (it * 256 + wave * 64) * 16);
 #pragma unroll
-        for (int it = 0; it < B_BYTES / 4096; ++it) {
-            const int id = it * 256 + tid, row = id / CPR, c = (id % CPR) ^ swz<BK>(row);
-            int gr = n0 + row; gr = gr < g.N ? gr : g.N - 1;
-            glds16(g.W + ((long long)gr * g.ldw + (long long)kt * BK + c * 8) * 2, sb + (it * 256 + wave * 64) * 16);
-        }
+        for (int it = 0; it < BI; ++it) glds16(b_src[it] + koff, sb + (it * 256 + wave * 64) * 16);
     };
     auto frag = [&](const char *tile, int row, int chunk) -> VT {
         return *(const VT *)(tile + (row * CPR + (chunk ^ swz<BK>(row))) * 16);
@@ -121,15 +133,23 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
         }
     };
 
+    // NS-stage LDS ring: tiles t+1 .. t+NS-2 stay in flight (LDS-DMA) across the barrier while tile t is multiplied.
+    // A tile's DMA pieces are ordered for the ds_reads only by the issuing waves' counted vmcnt followed by a barrier,
+    // so: counted wait (leave the NEWER tiles' pieces outstanding) -> raw s_barrier -> restage the buffer tile t-1 used
+    // (every wave has finished reading it once it passes this barrier) -> multiply tile t.
     const int nt = g.K / BK;
-    stage(0, 0);
-    __syncthreads();
-    for (int t = 0; t < nt - 1; ++t) {
-        stage((t + 1) & 1, t + 1);
-        compute(t & 1);
-        __syncthreads();
+    constexpr int PIECES = AI + BI;                 // DMA instructions per thread per tile
+    constexpr int AHEAD = NS - 2;                   // tiles allowed to stay in flight behind the one being waited for
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nt) stage(s, s);
+    for (int t = 0; t < nt; ++t) {
+        if (t + AHEAD < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NS - 1 < nt) stage((t + NS - 1) % NS, t + NS - 1);
+        compute(t % NS);
     }
-    compute((nt - 1) & 1);
 
     // epilogue: acc[i][j][r] = C[m = m0+wm0+16i+fr][n = n0+wn0+16j+4fq+r]
 #pragma unroll
@@ -167,21 +187,24 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     }
 }
 
+template <int BM, int BN> struct Stages { static constexpr int value = (BM == 128 && BN == 128) || (BM == 64 && BN == 64) ? 4 : 3; };
+
 template <int BM, int BN, int BK, typename VT>
 int launch(const GemmArgs &g0, hipStream_t s) {
+    constexpr int NS = Stages<BM, BN>::value;
     GemmArgs g = g0;
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;
-    const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+    const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
     static bool attr_done = false;              // per instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_gemm<BM, BN, BK, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_gemm<BM, BN, BK, NS, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { ovo_set_error("ovo_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
         attr_done = true;
     }
     const bool prof = ovo_prof_enabled();
-    if (prof) ovo_prof_begin(BM == 128 && BN == 128 ? 0 : 3, 2.0 * g.M * (double)g.N * g.K, s);   // kind 0: the 128x128 tile kernel
-    k_gemm<BM, BN, BK, VT><<<nbm * g.nbn, 256, lds, s>>>(g);
+    if (prof) ovo_prof_begin(4 + (BM == 128 ? 0 : 2) + (BN == 128 ? 0 : 1), 2.0 * g.M * (double)g.N * g.K, s);   // kinds 4..7: 128x128, 128x64, 64x128, 64x64
+    k_gemm<BM, BN, BK, NS, VT><<<nbm * g.nbn, 256, lds, s>>>(g);
     if (prof) ovo_prof_end(s);
     return OVO_OK;
 }
@@ -190,12 +213,25 @@ template <typename VT>
 int dispatch(const GemmArgs &g, hipStream_t s) {
     const bool k64 = g.K % 64 == 0;
     auto blocks = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
-    // largest tile that still gives every CU (256) something to do
+    // Tile choice (tools/gemm_bench.py, MI355X): these GEMMs are a handful of workgroup "rounds" long, so round
+    // quantisation on 256 CUs decides.  128x128 (1 workgroup/CU, 128 KiB LDS ring) only pays for >= 4 full rounds of
+    // deep-K work; otherwise take the tile with the fewest rounds x area at 2 workgroups/CU, larger tile on ties.
     int bm = 64, bn = 64;
-    if (blocks(128, 128) >= 200) { bm = 128; bn = 128; }
-    else if (blocks(64, 128) >= 200) { bm = 64; bn = 128; }
-    else if (blocks(128, 64) >= 200) { bm = 128; bn = 64; }
-#define GO(BM, BN)                                                          \
+    if (blocks(128, 128) >= 1024 && g.K >= 1024) { bm = 128; bn = 128; }
+    else {
+        const int cand[3][2] = {{64, 128}, {128, 64}, {64, 64}};
+        long long best = -1;
+        for (int i = 0; i < 3; ++i) {
+            const long long rounds = (blocks(cand[i][0], cand[i][1]) + 511) / 512;
+            const long long cost = rounds * cand[i][0] * cand[i][1];
+            if (best < 0 || cost < best) { best = cost; bm = cand[i][0]; bn = cand[i][1]; }
+        }
+    }
+    if (const char *force = getenv("OVO_GEMM_TILE")) {           // tuning knob (tools/gemm_bench.py): "128x128", "64x128", ...
+        int fm = 0, fn = 0;
+        if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm == 64 || fm == 128) && (fn == 64 || fn == 128)) { bm = fm; bn = fn; }
+    }
+#define GO(BM, BN)                                                         \
     if (bm == BM && bn == BN) return k64 ? launch<BM, BN, 64, VT>(g, s) : launch<BM, BN, 32, VT>(g, s);
     GO(128, 128) GO(64, 128) GO(128, 64) GO(64, 64)
 #undef GO

@@ -79,9 +79,27 @@ __global__ void __launch_bounds__(256) k_mask_area(const uint8_t *__restrict__ m
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(area + blockIdx.y, c);
 }
 
+// dst[k] = src[idx[k]] for rows of row16 16-byte units
+__global__ void __launch_bounds__(256) k_gather_rows(const uint4 *__restrict__ src, long long row16, const int32_t *__restrict__ idx,
+                                                     uint4 *__restrict__ dst) {
+    const uint4 *s = src + (long long)idx[blockIdx.y] * row16;
+    uint4 *d = dst + (long long)blockIdx.y * row16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < row16; i += (long long)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 }  // namespace
 
 extern "C" {
+
+int ovo_gather_rows(const void *src, int64_t row_bytes, const int32_t *idx, int n, void *dst, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && row_bytes > 0 && row_bytes % 16 == 0, "row_bytes must be a multiple of 16");
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(src && idx && dst && n <= 65535 && ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0), "null / misaligned pointer");
+    dim3 grid(ovo_grid(row_bytes / 16, 256, 64), n);
+    k_gather_rows<<<grid, 256, 0, (hipStream_t)stream>>>((const uint4 *)src, row_bytes / 16, idx, (uint4 *)dst);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
 
 int ovo_mask_or(uint8_t *masks, int64_t pixels, const int32_t *pairs, int n_pairs, ovo_stream_t stream) {
     OVO_REQUIRE(n_pairs >= 0 && pixels > 0 && pixels % 16 == 0, "pixels must be a multiple of 16");

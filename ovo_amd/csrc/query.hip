@@ -1,14 +1,17 @@
 // query.hip -- text-similarity query over instance descriptors or dense per-point accumulators
-// (clip_utils.py:10-19, ovo.py:487-491).  Small-Q form: HBM-bound streaming of F, text matrix in LDS.
+// (clip_utils.py:10-19, ovo.py:487-491).  Small-Q form: HBM-bound streaming of F with the text matrix in LDS.
 // Large Q (BASELINE.json config 5, Q = 1000) is a GEMM and goes through gemm.hip.
+//
+// Each wave owns R = 4 consecutive rows per iteration: per 16-byte column chunk it issues 4 independent global
+// loads (one per row, 1 KiB per wave-instruction, fully coalesced) and reuses the QC text-vector chunks it
+// reads from LDS for all 4 rows, so LDS traffic and load latency are amortised 4x; the chunk loop is unrolled
+// so ~16 loads per lane are in flight.  Epilogue per row: 1/cnt scale, SigLIP sigmoid, argmax + threshold.
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
 #include "common.h"
 
 namespace {
-
-constexpr int QC = 16;   // queries per LDS chunk
 
 template <int DT> struct Loader;
 template <> struct Loader<0> {   // f32: 4 values per 16-byte load
@@ -40,75 +43,132 @@ template <> struct Loader<2> {   // bf16
     __device__ static float one(const void *base, int64_t elem) { return __uint_as_float((uint32_t)((const uint16_t *)base)[elem] << 16); }
 };
 
-template <int DT>
+constexpr int R = 4;     // rows per wave iteration
+
+template <int DT, int QC>
 __global__ void __launch_bounds__(256) k_similarity(const void *__restrict__ F, int64_t n, int D, const float *__restrict__ T, int Q,
                                                     const int32_t *__restrict__ cnt, int siglip, float scale_exp, float bias,
                                                     float th, float *__restrict__ out_sim, long long *__restrict__ out_cls,
                                                     float *__restrict__ out_conf) {
-    extern __shared__ float sT[];                      // [QC][D]
+    extern __shared__ __attribute__((aligned(16))) float sT[];                      // [QC][D]
     using L = Loader<DT>;
     const int lane = threadIdx.x & 63;
     const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t rows_per_wave_iter = waves;
     const int DV = D / L::VEC;                          // vector chunks per row
+    const int64_t groups = (n + R - 1) / R;
 
     for (int q0 = 0; q0 < Q; q0 += QC) {
         const int qn = Q - q0 < QC ? Q - q0 : QC;
         __syncthreads();
         for (int i = threadIdx.x; i < QC * D; i += blockDim.x) sT[i] = i < qn * D ? T[(int64_t)q0 * D + i] : 0.f;
         __syncthreads();
-        for (int64_t r = wave0; r < n; r += rows_per_wave_iter) {
-            float acc[QC];
+        for (int64_t grp = wave0; grp < groups; grp += waves) {
+            const int64_t r0 = grp * R;
+            int64_t row[R];
 #pragma unroll
-            for (int q = 0; q < QC; ++q) acc[q] = 0.f;
+            for (int j = 0; j < R; ++j) row[j] = r0 + j < n ? r0 + j : n - 1;      // clamp: tail rows recompute the last row
+            float acc[R][QC];
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+#pragma unroll
+                for (int q = 0; q < QC; ++q) acc[j][q] = 0.f;
+#pragma unroll 2
             for (int c = lane; c < DV; c += 64) {
-                float v[L::VEC];
-                L::load(F, r * D + (int64_t)c * L::VEC, v);
+                float v[R][L::VEC];
+#pragma unroll
+                for (int j = 0; j < R; ++j) L::load(F, row[j] * D + (int64_t)c * L::VEC, v[j]);
 #pragma unroll
                 for (int q = 0; q < QC; ++q) {
-                    const float *t = sT + q * D + c * L::VEC;
+                    float t[L::VEC];
 #pragma unroll
-                    for (int e = 0; e < L::VEC; ++e) acc[q] = fmaf(v[e], t[e], acc[q]);
+                    for (int e = 0; e < L::VEC; e += 4) {
+                        const float4 tt = *(const float4 *)(sT + q * D + c * L::VEC + e);
+                        t[e] = tt.x; t[e + 1] = tt.y; t[e + 2] = tt.z; t[e + 3] = tt.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < R; ++j)
+#pragma unroll
+                        for (int e = 0; e < L::VEC; ++e) acc[j][q] = fmaf(v[j][e], t[e], acc[j][q]);
                 }
             }
             for (int k = DV * L::VEC + lane; k < D; k += 64) {      // tail when D % VEC != 0
-                const float v = L::one(F, r * D + k);
 #pragma unroll
-                for (int q = 0; q < QC; ++q) acc[q] = fmaf(v, sT[q * D + k], acc[q]);
-            }
-            const float rs = cnt ? (cnt[r] > 0 ? 1.0f / (float)cnt[r] : 0.f) : 1.0f;
-            float mine = 0.f;
+                for (int j = 0; j < R; ++j) {
+                    const float v = L::one(F, row[j] * D + k);
 #pragma unroll
-            for (int q = 0; q < QC; ++q) {
-                float s = wave_sum(acc[q]) * rs;
-                if (siglip) s = 1.0f / (1.0f + __expf(-(s * scale_exp + bias)));
-                if (lane == q) mine = s;
-            }
-            if (out_sim && lane < qn) out_sim[r * Q + q0 + lane] = mine;
-            if (out_cls || out_conf) {
-                // first-max argmax over this chunk, merged with previous chunks through out_conf/out_cls
-                float best = lane < qn ? mine : -3.0e38f;
-                int arg = lane < qn ? q0 + lane : 0x7fffffff;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ob = __shfl_xor(best, o, 64);
-                    const int oa = __shfl_xor(arg, o, 64);
-                    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+                    for (int q = 0; q < QC; ++q) acc[j][q] = fmaf(v, sT[q * D + k], acc[j][q]);
                 }
-                if (lane == 0) {
-                    if (q0 > 0) {
-                        const float pb = out_conf[r];
-                        if (!(best > pb)) { best = pb; arg = (int)out_cls[r]; }
+            }
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int64_t r = r0 + j;
+                if (r >= n) break;                                                 // wave-uniform
+                const float rs = cnt ? (cnt[r] > 0 ? 1.0f / (float)cnt[r] : 0.f) : 1.0f;
+                float mine = 0.f;
+#pragma unroll
+                for (int q = 0; q < QC; ++q) {
+                    float s = wave_sum(acc[j][q]) * rs;
+                    if (siglip) s = 1.0f / (1.0f + __expf(-(s * scale_exp + bias)));
+                    if (lane == q) mine = s;
+                }
+                if (out_sim && lane < qn) out_sim[r * Q + q0 + lane] = mine;
+                if (out_cls) {
+                    // first-max argmax over this chunk, merged with previous chunks through out_conf/out_cls
+                    float best = lane < qn ? mine : -3.0e38f;
+                    int arg = lane < qn ? q0 + lane : 0x7fffffff;
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) {                              // QC <= 16: lanes 0..15 hold the scores
+                        const float ob = __shfl_xor(best, o, 64);
+                        const int oa = __shfl_xor(arg, o, 64);
+                        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
                     }
-                    const bool last = q0 + QC >= Q;
-                    if (last && best <= th) { best = 0.f; arg = -1; }
-                    out_conf[r] = best;
-                    out_cls[r] = arg;
+                    if (lane == 0) {
+                        if (q0 > 0) {
+                            const float pb = out_conf[r];
+                            if (!(best > pb)) { best = pb; arg = (int)out_cls[r]; }
+                        }
+                        const bool last = q0 + QC >= Q;
+                        if (last && best <= th) { best = 0.f; arg = -1; }
+                        out_conf[r] = best;
+                        out_cls[r] = arg;
+                    }
                 }
             }
         }
     }
+}
+
+template <int DT, int QC>
+int launch(const void *F, int64_t n, int D, const float *T, int Q, const int32_t *cnt, int siglip, float se, float bias, float th,
+           float *out_sim, long long *cls, float *conf, hipStream_t s) {
+    const size_t lds = (size_t)QC * D * sizeof(float);
+    if (lds > 160 * 1024) { ovo_set_error("ovo_similarity: D too large for the LDS text tile"); return OVO_E_ARG; }
+    static bool attr_done = false;
+    if (lds > 64 * 1024 && !attr_done) {
+        if (hipFuncSetAttribute((const void *)k_similarity<DT, QC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            ovo_set_error("ovo_similarity: hipFuncSetAttribute failed");
+            return OVO_E_LAUNCH;
+        }
+        attr_done = true;
+    }
+    const int64_t groups = (n + R - 1) / R;
+    const int per_cu = lds > 0 ? (int)((160 * 1024) / lds) : 4;          // resident blocks per CU by LDS
+    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    if ((int64_t)grid * 4 > groups) grid = (int)((groups + 3) / 4);
+    if (grid < 1) grid = 1;
+    k_similarity<DT, QC><<<grid, 256, lds, s>>>(F, n, D, T, Q, cnt, siglip, se, bias, th, out_sim, cls, conf);
+    return OVO_OK;
+}
+
+template <int DT>
+int dispatch(const void *F, int64_t n, int D, const float *T, int Q, const int32_t *cnt, int siglip, float se, float bias, float th,
+             float *out_sim, long long *cls, float *conf, hipStream_t s) {
+    // smallest query chunk that covers Q in one pass (fewer wasted FMAs / LDS bytes), else 16-wide passes
+    if (Q <= 4) return launch<DT, 4>(F, n, D, T, Q, cnt, siglip, se, bias, th, out_sim, cls, conf, s);
+    if (Q <= 8) return launch<DT, 8>(F, n, D, T, Q, cnt, siglip, se, bias, th, out_sim, cls, conf, s);
+    if (Q <= 12) return launch<DT, 12>(F, n, D, T, Q, cnt, siglip, se, bias, th, out_sim, cls, conf, s);
+    return launch<DT, 16>(F, n, D, T, Q, cnt, siglip, se, bias, th, out_sim, cls, conf, s);
 }
 
 }  // namespace
@@ -121,22 +181,15 @@ extern "C" int ovo_similarity(const void *F, int feat_dtype, int64_t n, int D, c
     OVO_REQUIRE((out_cls == nullptr) == (out_conf == nullptr), "out_cls and out_conf go together");
     if (n == 0) return OVO_OK;
     OVO_REQUIRE(F && T, "null pointer");
-    OVO_REQUIRE(((uintptr_t)F & 15) == 0 && (D * (feat_dtype == 0 ? 4 : 2)) % 16 == 0, "F rows must be 16-byte aligned");
-    const size_t lds = (size_t)QC * D * sizeof(float);
-    OVO_REQUIRE(lds <= 160 * 1024, "D too large for the LDS text tile");
+    OVO_REQUIRE(((uintptr_t)F & 15) == 0 && (D * (feat_dtype == 0 ? 4 : 2)) % 16 == 0 && D % 4 == 0, "F rows must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    const int grid = ovo_grid((n + 3) / 4 * 256, 256, 256 * 4);
     const float se = expf(logit_scale);
     long long *cls = (long long *)out_cls;
-#define LAUNCH(DT)                                                                                                  \
-    do {                                                                                                            \
-        if (lds > 64 * 1024) OVO_HIP(hipFuncSetAttribute((const void *)k_similarity<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        k_similarity<DT><<<grid, 256, lds, s>>>(F, n, D, T, Q, cnt, siglip, se, logit_bias, th, out_sim, cls, out_conf); \
-    } while (0)
-    if (feat_dtype == 0) LAUNCH(0);
-    else if (feat_dtype == 1) LAUNCH(1);
-    else LAUNCH(2);
-#undef LAUNCH
+    int rc;
+    if (feat_dtype == 0) rc = dispatch<0>(F, n, D, T, Q, cnt, siglip, se, logit_bias, th, out_sim, cls, out_conf, s);
+    else if (feat_dtype == 1) rc = dispatch<1>(F, n, D, T, Q, cnt, siglip, se, logit_bias, th, out_sim, cls, out_conf, s);
+    else rc = dispatch<2>(F, n, D, T, Q, cnt, siglip, se, logit_bias, th, out_sim, cls, out_conf, s);
+    if (rc != OVO_OK) return rc;
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

@@ -143,5 +143,7 @@ class DescriptorBank:
 
     def gather(self, ins_ids: Iterable[int]) -> torch.Tensor:
         """f32[N, D] fused descriptors in the given order (the resident replacement of ovo.py:513-527)."""
-        idx = torch.tensor([self.slot_of[i] for i in ins_ids], dtype=torch.int64).to(self.device)
-        return self.table.index_select(0, idx)
+        slots = [self.slot_of[i] for i in ins_ids]
+        if (self.dim * 4) % 16 == 0:
+            return L.gather_rows(self.table, slots)
+        return self.table.index_select(0, torch.tensor(slots, dtype=torch.int64).to(self.device))

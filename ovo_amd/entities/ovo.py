@@ -228,7 +228,12 @@ class OVO:
         maps_u8 = binary_maps.view(torch.uint8) if binary_maps.dtype == torch.bool else binary_maps
         pairs = [(hits[0][0], other) for hits in matched_info.values() for other, _ in hits[1:]]
         fused_area = {}
-        if pairs:                                               # all ORs of the keyframe in one launch
+        if pairs and (pixels % 16 != 0 or not binary_maps.is_contiguous()):      # odd image sizes: plain torch
+            for d, s in pairs:
+                binary_maps[d].logical_or_(binary_maps[s])
+            if self.n_top_views > 0:
+                fused_area = {d: int(binary_maps[d].sum().item()) for d in {d for d, _ in pairs}}
+        elif pairs:                                             # all ORs of the keyframe in one launch
             flat = torch.tensor(pairs, dtype=torch.int32).reshape(-1).to(maps_u8.device, non_blocking=True)
             L.check(lib.ovo_mask_or(L.ptr(maps_u8), pixels, L.ptr(flat), len(pairs), L.stream()))
             if self.n_top_views > 0:                           # fused areas feed the top-k view heap (:305-309)
@@ -248,6 +253,8 @@ class OVO:
                     mask_rows[m] = len(matched_ins_ids)
                 matched_ins_ids.append(ins_id)
                 keep_rows.append(first)
+        if pixels % 16 == 0 and binary_maps.is_contiguous():
+            return matched_ins_ids, L.gather_rows(binary_maps, keep_rows), mask_rows
         idx = torch.tensor(keep_rows, dtype=torch.int64).to(binary_maps.device, non_blocking=True)
         return matched_ins_ids, binary_maps.index_select(0, idx), mask_rows
 

@@ -9,7 +9,7 @@ from ovo_amd.utils import clip_utils
 torch.set_num_threads(int(os.environ.get("OVO_THREADS", "1")))
 dev = torch.device("cuda", 0)
 pipe = FramePipeline(dev, extra_capacity=40 * 72000)
-frames = synthetic_frames(16, dev)
+frames = synthetic_frames(40, dev)
 for f in frames[:4]:
     pipe.step(f)
 torch.cuda.synchronize()
@@ -19,7 +19,9 @@ def tick(name, t0):
     acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
     return time.perf_counter()
 n = 0
-for f in frames[4:14]:
+steps = []
+for f in frames[3:38]:
+    before = dict(acc)
     n += 1
     t = time.perf_counter()
     pipe.masks.frames = {f.index: f}
@@ -39,4 +41,7 @@ for f in frames[4:14]:
     table = pipe.ovo.get_objs_clips(); t = tick("gather", t)
     clip_utils.similarity(table, pipe.texts, want_argmax=True); t = tick("query_inst", t)
     clip_utils.similarity(pipe.acc[:nn], pipe.texts, cnt=pipe.cnt[:nn], want_sim=False, want_argmax=True); t = tick("query_dense", t)
+    steps.append({k: round(1e3 * (acc[k] - before.get(k, 0.0)), 2) for k in acc})
+worst = max(steps, key=lambda d: sum(d.values()))
+print('worst step', steps.index(worst), worst)
 print({k: round(1e3 * v / n, 3) for k, v in acc.items()}, "total ms", round(1e3 * sum(acc.values()) / n, 2))
