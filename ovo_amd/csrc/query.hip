@@ -9,6 +9,8 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -161,9 +163,134 @@ int launch(const void *F, int64_t n, int D, const float *T, int Q, const int32_t
     return OVO_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// MFMA form (D % 16 == 0): S^T[q][row] += T[q][k] F[row][k] on v_mfma_f32_16x16x4_f32 -- exact f32 (bitwise an fmaf
+// chain), at the f32 vector rate, and NO cross-lane reduction: the k-sum happens inside the MFMA.  A wave owns 16
+// rows; lane (row = lane&15, g = lane>>4) streams 32-byte pieces F[row][k0 + 8g .. +8) (4 lanes cover one 128-byte
+// line per row) and pairs them with the same k of T from LDS (the k index of an MFMA is free as long as A and B
+// agree).  Accumulator register r of lane (row, g) is S[q = 4g + r][row]: the argmax is 3 in-lane compares + two
+// xor-shuffles.  HBM-bound: D*s bytes per row.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int DT> __device__ __forceinline__ void load8(const void *F, int64_t elem, float *v) {
+    if (DT == 0) { Loader<0>::load(F, elem, v); Loader<0>::load(F, elem + 4, v + 4); }
+    else Loader<DT>::load(F, elem, v);
+}
+template <int DT> __device__ __forceinline__ void load4(const void *F, int64_t elem, float *v) {
+    if (DT == 0) Loader<0>::load(F, elem, v);
+    else { for (int e = 0; e < 4; ++e) v[e] = Loader<DT>::one(F, elem + e); }
+}
+
+template <int DT>
+__global__ void __launch_bounds__(256) k_similarity_mfma(const void *__restrict__ F, int64_t n, int D, const float *__restrict__ T, int Q,
+                                                         const int32_t *__restrict__ cnt, int siglip, float scale_exp, float bias,
+                                                         float th, float *__restrict__ out_sim, long long *__restrict__ out_cls,
+                                                         float *__restrict__ out_conf) {
+    extern __shared__ __attribute__((aligned(16))) float sT[];                      // [min(Q, 16)][D]
+    const int lane = threadIdx.x & 63, rr = lane & 15, g = lane >> 4;
+    const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t groups = (n + 15) / 16;
+    const int D32 = D & ~31;
+
+    for (int q0 = 0; q0 < Q; q0 += 16) {
+        const int qn = Q - q0 < 16 ? Q - q0 : 16;
+        __syncthreads();
+        for (int i = threadIdx.x; i < qn * D; i += blockDim.x) sT[i] = T[(int64_t)q0 * D + i];
+        __syncthreads();
+        // this lane's text row (A operand: i = q); lanes past the last query re-read it -- their output rows are never used
+        const float *tq = sT + (rr < qn ? rr : qn - 1) * D;
+        for (int64_t grp = wave0; grp < groups; grp += waves) {
+            int64_t row = grp * 16 + rr;
+            const bool live = row < n;
+            if (!live) row = n - 1;
+            const int64_t base = row * D;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int k0 = 0; k0 < D32; k0 += 32) {
+                float f[8];
+                load8<DT>(F, base + k0 + g * 8, f);
+                const float4 t0 = *(const float4 *)(tq + k0 + g * 8), t1 = *(const float4 *)(tq + k0 + g * 8 + 4);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.x, f[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.y, f[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.z, f[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.w, f[3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.x, f[4], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.y, f[5], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.z, f[6], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.w, f[7], acc, 0, 0, 0);
+            }
+            if (D32 < D) {                                                           // one 16-wide tail step
+                float f[4];
+                load4<DT>(F, base + D32 + g * 4, f);
+                const float4 t0 = *(const float4 *)(tq + D32 + g * 4);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.x, f[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.y, f[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.z, f[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.w, f[3], acc, 0, 0, 0);
+            }
+            // lane (row rr, g): acc[r] = S[q0 + 4g + r][row]
+            const float rs = cnt ? (cnt[row] > 0 ? 1.0f / (float)cnt[row] : 0.f) : 1.0f;
+            float best = -3.0e38f;
+            int arg = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 4 * g + r;
+                float s = acc[r] * rs;
+                if (siglip) s = 1.0f / (1.0f + __expf(-(s * scale_exp + bias)));
+                if (q < qn) {
+                    if (out_sim && live) out_sim[row * Q + q0 + q] = s;
+                    if (s > best) { best = s; arg = q0 + q; }
+                }
+            }
+            if (out_cls) {
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const float ob = __shfl_xor(best, o, 64);
+                    const int oa = __shfl_xor(arg, o, 64);
+                    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+                }
+                if (g == 0 && live) {
+                    if (q0 > 0) {
+                        const float pb = out_conf[row];
+                        if (!(best > pb)) { best = pb; arg = (int)out_cls[row]; }
+                    }
+                    const bool last = q0 + 16 >= Q;
+                    if (last && best <= th) { best = 0.f; arg = -1; }
+                    out_conf[row] = best;
+                    out_cls[row] = arg;
+                }
+            }
+        }
+    }
+}
+
+template <int DT>
+int launch_mfma(const void *F, int64_t n, int D, const float *T, int Q, const int32_t *cnt, int siglip, float se, float bias, float th,
+                float *out_sim, long long *cls, float *conf, hipStream_t s) {
+    const size_t lds = (size_t)(Q < 16 ? Q : 16) * D * sizeof(float);
+    static bool attr_done = false;
+    if (lds > 64 * 1024 && !attr_done) {
+        if (hipFuncSetAttribute((const void *)k_similarity_mfma<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            ovo_set_error("ovo_similarity: hipFuncSetAttribute failed");
+            return OVO_E_LAUNCH;
+        }
+        attr_done = true;
+    }
+    const int64_t groups = (n + 15) / 16;
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    int64_t grid = 256 * per_cu;
+    if (grid * 4 > groups) grid = (groups + 3) / 4;
+    k_similarity_mfma<DT><<<(int)(grid < 1 ? 1 : grid), 256, lds, s>>>(F, n, D, T, Q, cnt, siglip, se, bias, th, out_sim, cls, conf);
+    return OVO_OK;
+}
+
 template <int DT>
 int dispatch(const void *F, int64_t n, int D, const float *T, int Q, const int32_t *cnt, int siglip, float se, float bias, float th,
              float *out_sim, long long *cls, float *conf, hipStream_t s) {
+    if (D % 16 == 0 && (size_t)16 * D * sizeof(float) <= 160 * 1024 && !getenv("OVO_SIM_VALU"))
+        return launch_mfma<DT>(F, n, D, T, Q, cnt, siglip, se, bias, th, out_sim, cls, conf, s);
     // smallest query chunk that covers Q in one pass (fewer wasted FMAs / LDS bytes), else 16-wide passes
     if (Q <= 4) return launch<DT, 4>(F, n, D, T, Q, cnt, siglip, se, bias, th, out_sim, cls, conf, s);
     if (Q <= 8) return launch<DT, 8>(F, n, D, T, Q, cnt, siglip, se, bias, th, out_sim, cls, conf, s);
