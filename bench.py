@@ -100,8 +100,9 @@ def main():
     from ovo_amd.pipeline import FramePipeline, synthetic_frames
     rank, local_rank, world = parallel.init_distributed()
     assert torch.cuda.is_available(), "bench.py needs a GPU (ovo_amd has no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = parallel.local_device(local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     lib = L.load()
 
     total = args.warmup + args.steps + (0 if args.no_roofline else args.profile_steps)

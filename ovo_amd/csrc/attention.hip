@@ -1,20 +1,25 @@
 // attention.hip -- fused softmax(Q K^T * scale) V for the ViT blocks and the Hiera (windowed / global) blocks.
 //
-// One workgroup = 4 waves = 64 query rows of one (batch, head); each wave owns 16 queries.  Keys/values are
-// walked in tiles of 64: K tile row-major and V tile TRANSPOSED in LDS (padded rows, conflict-free fragment
-// reads), online softmax kept in registers, never materialising the score matrix.
+// One workgroup = 4 waves; each wave owns QT q-tiles of 16 queries (QT = 1: 64 queries per workgroup, QT = 2: 128, used
+// for long sequences so that every K / V^T fragment read from LDS feeds two MFMAs).  Keys/values are walked in tiles of
+// 64: K tile row-major and V tile TRANSPOSED in LDS (padded rows, conflict-free fragment reads), online softmax kept in
+// registers, the score matrix never materialised.
 //   S^T tile  = mfma(a = K fragment [16 keys x 32 d], b = Q fragment [32 d x 16 queries])   -> lane owns one query
 //   O^T tile  = mfma(a = V^T fragment [16 d x 32 keys], b = P fragment [32 keys x 16 queries])
 // With this operand order a lane's accumulator registers all belong to the query (lane & 15), so the running
 // max / sum / rescale are per-lane scalars plus two xor-shuffles, and the P fragment feeds the second MFMA
 // straight from registers (the k index of an MFMA is free as long as a and b agree on it).
+// Global loads of tile t+1 are issued into registers before tile t is multiplied and written to LDS after it
+// (async-stage split), so HBM/L2 latency hides under the MFMAs even at one workgroup per CU.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 struct AttnArgs {
     const uint16_t *q, *k, *v;
@@ -27,141 +32,185 @@ struct AttnArgs {
     float scale_log2e;
 };
 
-__device__ __forceinline__ uint16_t f2bf(float x) {
-    const uint32_t u = __float_as_uint(x);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// float -> bf16 through the compiler's conversion (v_cvt_pk_bf16_f32 on gfx950: one instruction per pair, RNE)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    return *(const uint32_t *)&h;
 }
 
-template <int HD>
+template <int HD, int QT>
 __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
     constexpr int KT = 64;                 // keys per tile
     constexpr int KROW = HD + 8;           // padded K-tile row (elements)
-    constexpr int VROW = KT + 8;           // padded V^T-tile row (elements)
+    constexpr int VB = HD / 16 + 1;        // V blocks per key group (+1 block of padding: bank spread)
     constexpr int CH = HD / 8;             // 16-byte chunks per head row
-    __shared__ __attribute__((aligned(16))) uint16_t sK[KT * KROW];
-    __shared__ __attribute__((aligned(16))) uint16_t sV[HD * VROW];
+    constexpr int NLD = KT * CH / 256;     // 16-byte pieces per thread per tile (K and V each)
+    __shared__ __attribute__((aligned(16))) uint16_t smem[KT * KROW + (KT / 4) * VB * 64];
+    uint16_t *sK = smem, *sV = smem + KT * KROW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
-    const int q_row = blockIdx.x * 64 + wave * 16 + fr;       // this lane's query
     const uint16_t *qp = a.q + b * a.q_sb + h * a.q_sh;
     const uint16_t *kp = a.k + b * a.k_sb + h * a.k_sh;
     const uint16_t *vp = a.v + b * a.v_sb + h * a.v_sh;
 
     // Q fragments: lane (query fr, group fq) holds d = ks*32 + fq*8 .. +8
-    bf16x8 qf[HD / 32];
+    int q_row[QT];
+    bf16x8 qf[QT][HD / 32];
 #pragma unroll
-    for (int ks = 0; ks < HD / 32; ++ks) {
-        uint4 raw = make_uint4(0, 0, 0, 0);
-        const int d0 = ks * 32 + fq * 8;
-        if (q_row < a.Tq && d0 < a.hd) raw = *(const uint4 *)(qp + (long long)q_row * a.q_st + d0);
-        qf[ks] = *(bf16x8 *)&raw;
+    for (int t = 0; t < QT; ++t) {
+        q_row[t] = (blockIdx.x * 4 + wave) * (16 * QT) + t * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            const int d0 = ks * 32 + fq * 8;
+            if (q_row[t] < a.Tq && d0 < a.hd) raw = *(const uint4 *)(qp + (long long)q_row[t] * a.q_st + d0);
+            qf[t][ks] = *(bf16x8 *)&raw;
+        }
     }
 
-    f32x4 oacc[HD / 16];
+    f32x4 oacc[QT][HD / 16];
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int i = 0; i < HD / 16; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -1.0e30f, l_run = 0.f;
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = -1.0e30f; l_run[t] = 0.f;
+#pragma unroll
+        for (int i = 0; i < HD / 16; ++i) oacc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    for (int k0 = 0; k0 < a.Tk; k0 += KT) {
-        __syncthreads();                                        // previous tile fully consumed
-        // ---- stage K (row-major) ----
+    // two register sets: tiles t+1 and t+2 are in flight while tile t is multiplied (async-stage split, depth 2)
+    uint4 k0r[NLD], v0r[NLD], k1r[NLD], v1r[NLD];
+    auto fetch = [&](uint4 (&kr)[NLD], uint4 (&vr)[NLD], int k0) {      // global -> registers, thread -> (key row, 16-byte chunk)
 #pragma unroll
-        for (int it = 0; it < KT * CH / 256; ++it) {
+        for (int it = 0; it < NLD; ++it) {
             const int id = it * 256 + tid, row = id / CH, c = id % CH;
-            uint4 raw = make_uint4(0, 0, 0, 0);
-            if (k0 + row < a.Tk && c * 8 < a.hd) raw = *(const uint4 *)(kp + (long long)(k0 + row) * a.k_st + c * 8);
-            *(uint4 *)(sK + row * KROW + c * 8) = raw;
-        }
-        // ---- stage V transposed: consecutive lanes take consecutive keys -> contiguous LDS writes ----
-#pragma unroll
-        for (int it = 0; it < KT * CH / 256; ++it) {
-            const int id = it * 256 + tid, row = id % KT, c = id / KT;
-            uint4 raw = make_uint4(0, 0, 0, 0);
-            if (k0 + row < a.Tk && c * 8 < a.hd) raw = *(const uint4 *)(vp + (long long)(k0 + row) * a.v_st + c * 8);
-            const uint16_t *e = (const uint16_t *)&raw;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sV[(c * 8 + j) * VROW + row] = e[j];
-        }
-        __syncthreads();
-
-        // ---- S^T = K Q^T : 4 tiles of 16 keys ----
-        f32x4 s[4];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < HD / 32; ++ks) {
-                const bf16x8 kf = *(const bf16x8 *)(sK + (kt * 16 + fr) * KROW + ks * 32 + fq * 8);
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+            kr[it] = make_uint4(0, 0, 0, 0);
+            vr[it] = make_uint4(0, 0, 0, 0);
+            if (k0 + row < a.Tk && c * 8 < a.hd) {
+                kr[it] = *(const uint4 *)(kp + (long long)(k0 + row) * a.k_st + c * 8);
+                vr[it] = *(const uint4 *)(vp + (long long)(k0 + row) * a.v_st + c * 8);
             }
         }
-        // ---- online softmax for query fr; this lane holds keys kt*16 + fq*4 + r ----
-        float mx = -1.0e30f;
+    };
+    // registers -> LDS.  K row-major (padded rows).  V in [4 keys][16 d] blocks of 128 B (block (kg, dg) at (kg*VB + dg)*64
+    // elements, VB = HD/16 + 1 keeps the four key groups of a fragment read on disjoint banks): written with plain 16-byte
+    // stores, read back TRANSPOSED by ds_read_b64_tr_b16 -- no 2-byte scatter.
+    auto commit = [&](const uint4 (&kr)[NLD], const uint4 (&vr)[NLD]) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + kt * 16 + fq * 4 + r;
-                const float v = key < a.Tk ? s[kt][r] * a.scale_log2e : -1.0e30f;
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
-        float ps = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(s[kt][r] - m_new);
-                s[kt][r] = p;
-                ps += p;
-            }
-        ps += __shfl_xor(ps, 16, 64);
-        ps += __shfl_xor(ps, 32, 64);
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < HD / 16; ++i) {
-            oacc[i][0] *= alpha; oacc[i][1] *= alpha; oacc[i][2] *= alpha; oacc[i][3] *= alpha;
+        for (int it = 0; it < NLD; ++it) {
+            const int id = it * 256 + tid, row = id / CH, c = id % CH;
+            *(uint4 *)(sK + row * KROW + c * 8) = kr[it];
+            *(uint4 *)(sV + ((row >> 2) * VB + (c >> 1)) * 64 + (row & 3) * 16 + (c & 1) * 8) = vr[it];
         }
-        // ---- P fragments (bf16): element e of fragment kk <-> key (kk*2 + e/4)*16 + fq*4 + e%4 ----
-        bf16x8 pf[2];
+    };
+    auto compute = [&](int k0) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint16_t t[8];
+        for (int t = 0; t < QT; ++t) {
+            // ---- S^T = K Q^T : 4 tiles of 16 keys ----
+            f32x4 s[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = f2bf(s[kk * 2 + (e >> 2)][e & 3]);
-            pf[kk] = *(bf16x8 *)t;
-        }
-        // ---- O^T += V^T P^T ----
+            for (int kt = 0; kt < 4; ++kt) {
+                s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) {
+                for (int ks = 0; ks < HD / 32; ++ks) {
+                    const bf16x8 kf = *(const bf16x8 *)(sK + (kt * 16 + fr) * KROW + ks * 32 + fq * 8);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[kt], 0, 0, 0);
+                }
+            }
+            // ---- online softmax for query fr; this lane holds keys kt*16 + fq*4 + r ----
+            if (k0 + KT > a.Tk) {                                   // wave-uniform: only the last tile has keys to mask
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + kt * 16 + fq * 4 + r >= a.Tk) s[kt][r] = -3.0e38f;
+            }
+            float mx = -3.0e38f;                                    // max of the RAW scores (scale > 0 commutes with max)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[t], mx * a.scale_log2e);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], a.scale_log2e, -m_new));   // v_exp_f32, one FMA in front
+                    s[kt][r] = p;
+                    ps += p;
+                }
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            l_run[t] = l_run[t] * alpha + ps;
+            m_run[t] = m_new;
+            if (__any(alpha != 1.0f)) {                             // the running max settles after a few tiles
+#pragma unroll
+                for (int i = 0; i < HD / 16; ++i) {
+                    oacc[t][i][0] *= alpha; oacc[t][i][1] *= alpha; oacc[t][i][2] *= alpha; oacc[t][i][3] *= alpha;
+                }
+            }
+            // ---- P fragments (bf16): element e of fragment kk <-> key (kk*2 + e/4)*16 + fq*4 + e%4 ----
+            bf16x8 pf[2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const uint16_t *row = sV + (dt * 16 + fr) * VROW;
-                uint2 lo = *(const uint2 *)(row + (kk * 2) * 16 + fq * 4);
-                uint2 hi = *(const uint2 *)(row + (kk * 2 + 1) * 16 + fq * 4);
-                uint4 raw = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8 *)&raw, pf[kk], oacc[dt], 0, 0, 0);
+                uint32_t tmp[4];
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) tmp[e >> 1] = pack2(s[kk * 2 + (e >> 2)][e & 3], s[kk * 2 + (e >> 2)][(e & 3) + 1]);
+                pf[kk] = *(bf16x8 *)tmp;
+            }
+            // ---- O^T += V^T P^T ----
+#pragma unroll
+            for (int dt = 0; dt < HD / 16; ++dt) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    // lane (d = dt*16 + fr, fq) needs V[keys (kk*2+h)*16 + fq*4 .. +4][d], h = 0,1: the transposing read of
+                    // block (kg = (kk*2+h)*4 + fq, dg = dt) with every lane pointing at its own 8-byte slot of the block
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(sV + (((kk * 2) * 4 + fq) * VB + dt) * 64 + fr * 4));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4 *)(sV + (((kk * 2 + 1) * 4 + fq) * VB + dt) * 64 + fr * 4));
+                    const uint2 l2 = *(const uint2 *)&lo, h2 = *(const uint2 *)&hi;
+                    uint4 raw = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                    oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8 *)&raw, pf[kk], oacc[t][dt], 0, 0, 0);
+                }
             }
         }
+    };
+
+    const int n_tiles = (a.Tk + KT - 1) / KT;
+    fetch(k0r, v0r, 0);
+    if (n_tiles > 1) fetch(k1r, v1r, KT);
+    for (int t = 0; t < n_tiles; t += 2) {
+        __syncthreads();                                        // previous tile fully consumed
+        commit(k0r, v0r);
+        __syncthreads();
+        if (t + 2 < n_tiles) fetch(k0r, v0r, (t + 2) * KT);
+        compute(t * KT);
+        if (t + 1 >= n_tiles) break;
+        __syncthreads();
+        commit(k1r, v1r);
+        __syncthreads();
+        if (t + 3 < n_tiles) fetch(k1r, v1r, (t + 3) * KT);
+        compute((t + 1) * KT);
     }
     // ---- store: lane holds O[q_row][dt*16 + fq*4 + r] ----
-    if (q_row < a.Tq) {
-        const float inv = 1.0f / l_run;
-        uint16_t *op = a.o + b * a.o_sb + h * a.o_sh + (long long)q_row * a.o_st;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        if (q_row[t] >= a.Tq) continue;
+        const float inv = 1.0f / l_run[t];
+        uint16_t *op = a.o + b * a.o_sb + h * a.o_sh + (long long)q_row[t] * a.o_st;
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) {
             const int d0 = dt * 16 + fq * 4;
             if (d0 < a.hd) {
                 uint2 p;
-                p.x = (uint32_t)f2bf(oacc[dt][0] * inv) | ((uint32_t)f2bf(oacc[dt][1] * inv) << 16);
-                p.y = (uint32_t)f2bf(oacc[dt][2] * inv) | ((uint32_t)f2bf(oacc[dt][3] * inv) << 16);
+                p.x = pack2(oacc[t][dt][0] * inv, oacc[t][dt][1] * inv);
+                p.y = pack2(oacc[t][dt][2] * inv, oacc[t][dt][3] * inv);
                 *(uint2 *)(op + d0) = p;
             }
         }
@@ -186,14 +235,25 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     a.v_sb = p->v_sb; a.v_sh = p->v_sh; a.v_st = p->v_st; a.o_sb = p->o_sb; a.o_sh = p->o_sh; a.o_st = p->o_st;
     a.B = p->B; a.H = p->H; a.Tq = p->Tq; a.Tk = p->Tk; a.hd = p->hd;
     a.scale_log2e = p->scale * 1.4426950408889634f;
-    dim3 grid((p->Tq + 63) / 64, p->B * p->H);
     hipStream_t s = (hipStream_t)stream;
+    // two q-tiles per wave once there are enough 128-query workgroups to fill the chip
+    // (tools/attn_bench.py: 128-query workgroups win once there are >= 2 of them per CU; below that the 64-query form's
+    // 3 waves/SIMD hide more latency: 4096 x 4096, 8 heads, hd 56: 100 us narrow vs 114 us wide)
+    const bool wide = p->Tq >= 512 && (long long)((p->Tq + 127) / 128) * p->B * p->H >= 512 && !getenv("OVO_ATTN_NARROW");
+    const int qpb = wide ? 128 : 64;
+    dim3 grid((p->Tq + qpb - 1) / qpb, p->B * p->H);
     const bool prof = ovo_prof_enabled();
     if (prof) ovo_prof_begin(1, 4.0 * p->B * p->H * (double)p->Tq * p->Tk * p->hd, s);
     struct Done { bool on; hipStream_t s; ~Done() { if (on) ovo_prof_end(s); } } done{prof, s};
-    if (p->hd <= 64) k_attention<64><<<grid, 256, 0, s>>>(a);
-    else if (p->hd <= 96) k_attention<96><<<grid, 256, 0, s>>>(a);
-    else k_attention<128><<<grid, 256, 0, s>>>(a);
+#define GO(HD)                                                       \
+    do {                                                             \
+        if (wide) k_attention<HD, 2><<<grid, 256, 0, s>>>(a);        \
+        else k_attention<HD, 1><<<grid, 256, 0, s>>>(a);             \
+    } while (0)
+    if (p->hd <= 64) GO(64);
+    else if (p->hd <= 96) GO(96);
+    else GO(128);
+#undef GO
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

@@ -38,30 +38,62 @@ __device__ __forceinline__ long long row_of(const Grid &g, int b, int y, int x) 
 }
 
 // LayerNorm of x[b, y, x, :d] written as bf16 row `r` (window order) of width kp; padding rows / columns = 0.
+// LPR lanes cooperate on one row (16 for the narrow early stages: 4 rows per wave, 64 for wide rows); d % 4 == 0,
+// kp % 4 == 0; float4 reads, 8-byte bf16 writes.
+template <int LPR>
 __global__ void __launch_bounds__(256) k_ln_window(const float *__restrict__ x, Grid g, int d, int kp, const float *__restrict__ gamma,
                                                    const float *__restrict__ beta, float eps, uint16_t *__restrict__ out) {
-    const int lane = threadIdx.x & 63;
+    constexpr int RPW = 64 / LPR;                       // rows per wave
+    const int lane = threadIdx.x & 63, sl = lane % LPR, sub = lane / LPR;
     const long long waves = (long long)gridDim.x * 4;
-    const int per_win = g.wh * g.ww;
-    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < g.rows; r += waves) {
-        const long long win = r / per_win;
-        const int in = (int)(r % per_win), ly = in / g.ww, lx = in % g.ww;
-        const int wx = (int)(win % g.nww), wy = (int)((win / g.nww) % g.nwh), b = (int)(win / ((long long)g.nww * g.nwh));
-        const int y = wy * g.wh + ly, xx = wx * g.ww + lx;
-        uint16_t *o = out + r * kp;
-        if (y >= g.H || xx >= g.W) {
-            for (int i = lane; i < kp; i += 64) o[i] = 0;
-            continue;
+    const int per_win = g.wh * g.ww, d4 = d >> 2, kp4 = kp >> 2;
+    const long long n_iter = (g.rows + RPW - 1) / RPW;
+    for (long long it = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_iter; it += waves) {
+        const long long r = it * RPW + sub;
+        bool real = r < g.rows;
+        const float *src = x;
+        if (real) {
+            const long long win = r / per_win;
+            const int in = (int)(r % per_win), ly = in / g.ww, lx = in % g.ww;
+            const int wx = (int)(win % g.nww), wy = (int)((win / g.nww) % g.nwh), b = (int)(win / ((long long)g.nww * g.nwh));
+            const int y = wy * g.wh + ly, xx = wx * g.ww + lx;
+            if (y >= g.H || xx >= g.W) {                // padding row of a partial window: zeros
+                uint2 *o = (uint2 *)(out + r * kp);
+                for (int i = sl; i < kp4; i += LPR) o[i] = make_uint2(0, 0);
+                real = false;
+            } else src = x + (((long long)b * g.H + y) * g.W + xx) * d;
         }
-        const float *src = x + (((long long)b * g.H + y) * g.W + xx) * d;
         float s = 0.f;
-        for (int i = lane; i < d; i += 64) s += src[i];
-        const float mean = wave_sum(s) / (float)d;
+        if (real) for (int i = sl; i < d4; i += LPR) { const float4 v = ((const float4 *)src)[i]; s += (v.x + v.y) + (v.z + v.w); }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s / (float)d;
         float q = 0.f;
-        for (int i = lane; i < d; i += 64) { const float t = src[i] - mean; q += t * t; }
-        const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
-        for (int i = lane; i < kp; i += 64) o[i] = i < d ? f2bf((src[i] - mean) * rstd * gamma[i] + beta[i]) : (uint16_t)0;
+        if (real) for (int i = sl; i < d4; i += LPR) {
+            const float4 v = ((const float4 *)src)[i];
+            const float a = v.x - mean, b2 = v.y - mean, c2 = v.z - mean, e2 = v.w - mean;
+            q += (a * a + b2 * b2) + (c2 * c2 + e2 * e2);
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = rsqrtf(q / (float)d + eps);
+        if (!real) continue;
+        uint2 *o = (uint2 *)(out + r * kp);
+        for (int i = sl; i < kp4; i += LPR) {
+            if (i < d4) {
+                const float4 v = ((const float4 *)src)[i], gm = ((const float4 *)gamma)[i], bt = ((const float4 *)beta)[i];
+                const uint32_t lo = (uint32_t)f2bf((v.x - mean) * rstd * gm.x + bt.x) | ((uint32_t)f2bf((v.y - mean) * rstd * gm.y + bt.y) << 16);
+                const uint32_t hi = (uint32_t)f2bf((v.z - mean) * rstd * gm.z + bt.z) | ((uint32_t)f2bf((v.w - mean) * rstd * gm.w + bt.w) << 16);
+                o[i] = make_uint2(lo, hi);
+            } else o[i] = make_uint2(0, 0);
+        }
     }
+}
+
+void launch_ln_window(const float *x, const Grid &g, int d, int kp, const float *gamma, const float *beta, float eps, uint16_t *out,
+                      hipStream_t hs) {
+    if (d <= 256) k_ln_window<16><<<ovo_grid(g.rows * 16, 256), 256, 0, hs>>>(x, g, d, kp, gamma, beta, eps, out);
+    else k_ln_window<64><<<ovo_grid(g.rows * 64, 256), 256, 0, hs>>>(x, g, d, kp, gamma, beta, eps, out);
 }
 
 // q of a packed qkv buffer [rows, 3*C] (window order, window wh x ww) -> pooled q [rows/4, C]: 2x2 max.
@@ -279,7 +311,7 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         OVO_REQUIRE(!p.pool[i] || (g.wh % 2 == 0 && H % 2 == 0), "query pooling needs even windows");
         const long long tok_out = (long long)B * Ho * Ho;
 
-        k_ln_window<<<ovo_grid(g.rows * 64, 256), 256, 0, hs>>>(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, k.h);
+        launch_ln_window(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, k.h, hs);
         const float *residual = x;
         if (din != dout) {                                   // skip = maxpool(proj(LN(x)))
             OVO_REQUIRE(L.res_w && L.res_b && p.pool[i], "stage-change block without projection weights");
@@ -311,7 +343,7 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         k_unwindow_add<<<ovo_grid(tok_out * (dout / 4), 256), 256, 0, hs>>>(k.tmp, go, dout, residual, x);
         // MLP
         const Grid gi = make_grid(B, Ho, Ho, 0);
-        k_ln_window<<<ovo_grid(gi.rows * 64, 256), 256, 0, hs>>>(x, gi, dout, kout, L.ln2_g, L.ln2_b, c.ln_eps, k.h);
+        launch_ln_window(x, gi, dout, kout, L.ln2_g, L.ln2_b, c.ln_eps, k.h, hs);
         TRY(gemm(k.h, kout, L.fc1_w, kout, L.fc1_b, k.u, 4 * dout, 2, nullptr, 0, tok_out, 4 * dout, kout, 1, stream));
         TRY(gemm(k.u, 4 * dout, L.fc2_w, 4 * dout, L.fc2_b, x, dout, 0, x, dout, tok_out, dout, 4 * dout, 0, stream));
         LAUNCHED();

@@ -25,6 +25,13 @@ def env_world() -> tuple:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+def local_device(local_rank: int) -> int:
+    """GPU index of this rank.  OVO_FORCE_DEVICE pins every rank to one GPU: the way to exercise the N > 1 code path on a
+    single-GPU box (with OVO_DIST_BACKEND=gloo, since RCCL refuses two ranks on one device)."""
+    forced = os.environ.get("OVO_FORCE_DEVICE")
+    return int(forced) if forced is not None else local_rank
+
+
 def init_distributed(backend: Optional[str] = None) -> tuple:
     """Initialise the default process group from torchrun's environment.  Returns (rank, local_rank, world)."""
     rank, local_rank, world = env_world()
@@ -33,9 +40,9 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("OVO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_device(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 

@@ -97,6 +97,7 @@ class FramePipeline:
         self.D = self.clip.clip_dim
         self.texts = torch.from_numpy(syn.unit_vectors(n_text, self.D, seed=seed + 7)).to(self.device)
         self.dense = dense
+        self.n_shared = n_map
         if dense:
             cap = self.slam._cap
             self.acc = torch.zeros((cap, self.D), dtype=torch.float32, device=self.device)
@@ -127,12 +128,17 @@ class FramePipeline:
                 rows = torch.tensor(self.ovo.last_mask_rows, dtype=torch.int32).to(self.device, non_blocking=True)
                 L.check(lib.ovo_scatter_accum(L.ptr(self.ovo.last_point_seg), self.ovo.last_point_seg.shape[0], L.ptr(rows), rows.shape[0],
                                               L.ptr(desc), self.D, L.ptr(self.acc), L.ptr(self.cnt), L.stream()))
-            if parallel.world_size() > 1:                          # the one exchange step: sum-reduce of the fusion accumulators
+        else:
+            desc = None
+        if parallel.world_size() > 1:
+            # The one exchange step: sum-reduce of this keyframe's descriptor contributions (fixed-size tables, issued by
+            # EVERY rank on EVERY step -- a rank whose frame matched nothing contributes zeros, never skips the collective).
+            self.inst_delta.zero_(); self.inst_delta_cnt.zero_()
+            if desc is not None:
                 slots = torch.tensor([self.ovo.bank.slot_of[i] % 4096 for i in self.ovo.last_clip_ins_ids], device=self.device)
-                self.inst_delta.zero_(); self.inst_delta_cnt.zero_()
                 self.inst_delta.index_add_(0, slots, desc)
                 self.inst_delta_cnt.index_add_(0, slots, torch.ones(slots.shape[0], device=self.device))
-                parallel.allreduce_sum_([self.inst_delta, self.inst_delta_cnt])
+            parallel.allreduce_sum_([self.inst_delta, self.inst_delta_cnt])
         out: Dict[str, object] = {"n_points": n, "n_instances": len(self.ovo.objects)}
         if len(self.ovo.objects) > 0:                              # query: instances x texts, fused argmax
             table = self.ovo.get_objs_clips()
@@ -144,8 +150,10 @@ class FramePipeline:
         return out
 
     def merge_dense(self) -> int:
-        """Merge the per-GPU dense accumulators over xGMI (called once per batch of frames / before a global query)."""
-        return parallel.allreduce_dense_(self.acc[:self.slam._n], self.cnt[:self.slam._n]) if self.dense else 0
+        """Merge the per-GPU dense accumulators over xGMI (called once per batch of frames / before a global query).
+        Only the points every rank shares -- the map all replicas started from -- are merged: each rank appends its own
+        frames' points after them, so sizes beyond `n_shared` differ per rank and a collective over them would mismatch."""
+        return parallel.allreduce_dense_(self.acc[:self.n_shared], self.cnt[:self.n_shared]) if self.dense else 0
 
     # ------------------------------------------------------------------ workload accounting (DESIGN.md §5)
     def flops_per_frame(self, h: int, w: int) -> Dict[str, float]:

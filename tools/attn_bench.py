@@ -1,0 +1,30 @@
+"""Attention micro-benchmark over the ViT-L/14-336 and hiera_b+ shapes."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from ovo_amd import _lib as L
+dev = torch.device("cuda", 0); lib = L.load()
+def run(B, H, Tq, Tk, hd, iters=20):
+    D = H * hd; T = max(Tq, Tk)
+    qkv = torch.randn(B, T, 3, H, hd, device=dev).to(torch.bfloat16)
+    out = torch.zeros(B, Tq, D, dtype=torch.bfloat16, device=dev)
+    a = L.Attention(); base = qkv.data_ptr()
+    a.q, a.k, a.v, a.o = base, base + D * 2, base + 4 * D, out.data_ptr()
+    a.q_sb = a.k_sb = a.v_sb = T * 3 * D; a.q_sh = a.k_sh = a.v_sh = hd; a.q_st = a.k_st = a.v_st = 3 * D
+    a.o_sb, a.o_sh, a.o_st = Tq * D, hd, D
+    a.B, a.H, a.Tq, a.Tk, a.hd, a.scale = B, H, Tq, Tk, hd, hd ** -0.5
+    for _ in range(3): L.check(lib.ovo_attention(C.byref(a), L.stream()))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(iters): L.check(lib.ovo_attention(C.byref(a), L.stream()))
+    e1.record(); torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / iters
+    return us, 4.0 * B * H * Tq * Tk * hd / us / 1e6
+for shape in [(2, 16, 577, 577, 64), (1, 8, 4096, 4096, 56), (25, 8, 196, 196, 56), (1024, 2, 64, 64, 56), (1024, 4, 16, 64, 56), (8, 16, 2048, 2048, 128)]:
+    row = "%-28s" % str(shape)
+    for mode in ("auto", "narrow"):
+        if mode == "narrow": os.environ["OVO_ATTN_NARROW"] = "1"
+        else: os.environ.pop("OVO_ATTN_NARROW", None)
+        us, tf = run(*shape)
+        row += "  %s %8.1fus %6.0fTF" % (mode, us, tf)
+    print(row)
