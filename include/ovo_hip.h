@@ -153,9 +153,15 @@ int ovo_scatter_accum(const int16_t *point_seg, int64_t n, const int32_t *mask_r
  * F is f32 or f16 ([n,D], feat_dtype 0 = f32, 1 = f16, 2 = bf16); T f32[Q,D].
  * cnt (optional i32[n]): row_scale = 1/cnt (0 rows give 0) -- the dense accumulator form.
  * out_sim (optional) f32[n,Q]; out_cls (optional) i64[n] first-max argmax, -1 when conf <= th;
- * out_conf (optional) f32[n] (0 when conf <= th).  Q <= 64 here; larger Q goes through ovo_gemm. */
+ * out_conf (optional) f32[n] (0 when conf <= th).  Exact f32 products at any Q, but F is re-read once per 16 queries:
+ * meant for Q up to a few dozen (the instance table, the 10-prompt dense query). */
 int ovo_similarity(const void *F, int feat_dtype, int64_t n, int D, const float *T, int Q, const int32_t *cnt,
                    int siglip, float logit_scale, float logit_bias, float th, float *out_sim,
+                   int64_t *out_cls, float *out_conf, ovo_stream_t stream);
+/* Large vocabularies (BASELINE.json config 5, 1k texts x fp16 map): S f32[n,Q] = ovo_gemm(F, T) in f16/bf16 with fp32
+ * accumulation, then this pass: optional SigLIP epilogue in place, first-max argmax / confidence / threshold per row
+ * (same out_cls / out_conf meaning as ovo_similarity).  Q % 4 == 0. */
+int ovo_row_argmax(float *S, int64_t n, int Q, int siglip, float logit_scale, float logit_bias, float th,
                    int64_t *out_cls, float *out_conf, ovo_stream_t stream);
 
 /* ---- a11: mask NMS intersections (segment_utils.py:218-230) --------------------------------------

@@ -243,7 +243,7 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     const int qpb = wide ? 128 : 64;
     dim3 grid((p->Tq + qpb - 1) / qpb, p->B * p->H);
     const bool prof = ovo_prof_enabled();
-    if (prof) ovo_prof_begin(1, 4.0 * p->B * p->H * (double)p->Tq * p->Tk * p->hd, s);
+    if (prof) { ovo_prof_begin(1, 4.0 * p->B * p->H * (double)p->Tq * p->Tk * p->hd, s); ovo_prof_shape(p->B * p->H, p->Tq, p->Tk); }
     struct Done { bool on; hipStream_t s; ~Done() { if (on) ovo_prof_end(s); } } done{prof, s};
 #define GO(HD)                                                       \
     do {                                                             \

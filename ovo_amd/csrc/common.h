@@ -14,6 +14,7 @@ void ovo_set_error(const char *fmt, ...);
 #define OVO_PROF_KINDS 8
 bool ovo_prof_enabled();
 void ovo_prof_begin(int kind, double work, hipStream_t s);
+void ovo_prof_shape(int a, int b, int c);       // optional: shape of the launch just begun (OVO_PROF_DUMP lines)
 void ovo_prof_end(hipStream_t s);
 
 #define OVO_REQUIRE(cond, msg)                                   \

@@ -1,5 +1,7 @@
 // core.hip -- error reporting, ABI version and the optional per-kernel-family event profiler of libovo_hip.so.
 #include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -16,7 +18,7 @@ void ovo_set_error(const char *fmt, ...) {
 
 // ---- profiler: hipEvent pairs around the launches of a kernel family, on the launch stream --------------
 namespace {
-struct Rec { hipEvent_t a, b; int kind; double work; };
+struct Rec { hipEvent_t a, b; int kind; double work; int shape[3]; };
 struct Prof {
     bool on = false;
     std::vector<Rec> recs;
@@ -32,10 +34,15 @@ struct Prof {
 bool ovo_prof_enabled() { return g_prof.on; }
 void ovo_prof_begin(int kind, double work, hipStream_t s) {
     if (!g_prof.on || g_prof.recs.size() >= (1u << 20)) return;
-    Rec r; r.kind = kind; r.work = work; r.a = g_prof.get(); r.b = g_prof.get();
+    Rec r; r.kind = kind; r.work = work; r.shape[0] = r.shape[1] = r.shape[2] = 0; r.a = g_prof.get(); r.b = g_prof.get();
     if (!r.a || !r.b) return;
     hipEventRecord(r.a, s);
     g_prof.recs.push_back(r);
+}
+void ovo_prof_shape(int a, int b, int c) {
+    if (!g_prof.on || g_prof.recs.empty()) return;
+    Rec &r = g_prof.recs.back();
+    r.shape[0] = a; r.shape[1] = b; r.shape[2] = c;
 }
 void ovo_prof_end(hipStream_t s) {
     if (!g_prof.on || g_prof.recs.empty()) return;
@@ -58,11 +65,14 @@ int ovo_profile_stop(double *ms, double *work, int64_t *launches, int n_kinds) {
     OVO_REQUIRE(ms && work && launches && n_kinds > 0 && n_kinds <= OVO_PROF_KINDS, "bad argument");
     for (int i = 0; i < n_kinds; ++i) { ms[i] = 0; work[i] = 0; launches[i] = 0; }
     OVO_HIP(hipDeviceSynchronize());
+    FILE *dump = getenv("OVO_PROF_DUMP") ? fopen(getenv("OVO_PROF_DUMP"), "a") : nullptr;   // diagnosis: one line per launch
     for (const Rec &r : g_prof.recs) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess || r.kind >= n_kinds) continue;
         ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1;
+        if (dump) fprintf(dump, "%d %d %d %d %.0f %.4f\n", r.kind, r.shape[0], r.shape[1], r.shape[2], r.work, t);
     }
+    if (dump) fclose(dump);
     g_prof.recs.clear();
     g_prof.used = 0;
     return OVO_OK;

@@ -38,6 +38,7 @@ struct GemmArgs {
     int out_dtype, act;
     float alpha;
     int nbn;
+    int chunk, tiles;          // chunk > 0: XCD-chunked tile order (see launch())
 };
 
 template <typename VT> struct Mfma;
@@ -57,8 +58,23 @@ __device__ __forceinline__ void glds16(const void *src, void *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 before the hardware rcp / exp2 roundings, ~2e-7 after): one
+// v_rcp_f32, one v_exp_f32 and six FMAs instead of the library erff's branchy ~50 instructions -- the GELU sits on the
+// serial tail of every FC1 tile (the epilogue is not overlapped with MFMA work), where it cost ~20% of the GEMM.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float y = fmaf(-p * t, e, 1.0f);
+    return copysignf(y, x);
+}
+
 __device__ __forceinline__ float act_fn(float x, int act) {
-    if (act == 1) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    if (act == 1) return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f));
     if (act == 2) return x / (1.0f + __expf(-1.702f * x));
     return x;
 }
@@ -82,7 +98,15 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16, KS = BK / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    const int m0 = (blockIdx.x / g.nbn) * BM, n0 = (blockIdx.x % g.nbn) * BN;
+    // Workgroups go round-robin over the 8 XCDs (XCD = blockIdx % 8), each with its own L2.  In chunked order XCD x walks
+    // the contiguous tile range [x * chunk, (x + 1) * chunk) (m-major, n-minor): the n-tiles that share an A panel are
+    // co-resident on ONE L2 and the panel leaves HBM once instead of once per XCD.
+    int tile = blockIdx.x;
+    if (g.chunk > 0) {
+        tile = (blockIdx.x & 7) * g.chunk + (blockIdx.x >> 3);
+        if (tile >= g.tiles) return;
+    }
+    const int m0 = (tile / g.nbn) * BM, n0 = (tile % g.nbn) * BN;
     const int fr = lane & 15, fq = lane >> 4;
 
     f32x4 acc[TM][TN];
@@ -147,8 +171,12 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
         if (t + AHEAD < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifndef OVO_GEMM_PROBE_NO_LOAD
         if (t + NS - 1 < nt) stage((t + NS - 1) % NS, t + NS - 1);
+#endif
+#ifndef OVO_GEMM_PROBE_NO_MMA
         compute(t % NS);
+#endif
     }
 
     // epilogue: acc[i][j][r] = C[m = m0+wm0+16i+fr][n = n0+wn0+16j+4fq+r]
@@ -195,16 +223,25 @@ int launch(const GemmArgs &g0, hipStream_t s) {
     GemmArgs g = g0;
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;
-    const size_t lds = (size_t)NS * (BM + BN) * BK * 2;
+    const size_t lds_max = (size_t)NS * (BM + BN) * BK * 2;
+    // short-K GEMMs (the SAM2 stage-1/2 layers: K = 128..256) touch only their first K/BK ring stages: ask for just those,
+    // so that more workgroups fit a CU and cover each other's load and store latency (these GEMMs are HBM streams)
+    const int nt = g.K / BK;
+    const size_t lds = (size_t)(nt < NS ? nt : NS) * (BM + BN) * BK * 2;
     static bool attr_done = false;              // per instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_gemm<BM, BN, BK, NS, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_gemm<BM, BN, BK, NS, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e != hipSuccess) { ovo_set_error("ovo_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
         attr_done = true;
     }
     const bool prof = ovo_prof_enabled();
-    if (prof) ovo_prof_begin(4 + (BM == 128 ? 0 : 2) + (BN == 128 ? 0 : 1), 2.0 * g.M * (double)g.N * g.K, s);   // kinds 4..7: 128x128, 128x64, 64x128, 64x64
-    k_gemm<BM, BN, BK, NS, VT><<<nbm * g.nbn, 256, lds, s>>>(g);
+    if (prof) { ovo_prof_begin(4 + (BM == 128 ? 0 : 2) + (BN == 128 ? 0 : 1), 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); }   // kinds 4..7: 128x128, 128x64, 64x128, 64x64
+    // Chunked order pays when the A panels outweigh the weights (M > N: per-XCD fills A/8 + W instead of A + W/8) or when
+    // the n-tile count is not a multiple of 8 (round-robin then spreads every panel over every L2).
+    g.tiles = nbm * g.nbn;
+    g.chunk = (g.M > g.N || g.nbn % 8 != 0) && !getenv("OVO_GEMM_NO_CHUNK") ? (g.tiles + 7) / 8 : 0;
+    const int grid = g.chunk > 0 ? g.chunk * 8 : g.tiles;
+    k_gemm<BM, BN, BK, NS, VT><<<grid, 256, lds, s>>>(g);
     if (prof) ovo_prof_end(s);
     return OVO_OK;
 }

@@ -298,7 +298,62 @@ int dispatch(const void *F, int64_t n, int D, const float *T, int Q, const int32
     return launch<DT, 16>(F, n, D, T, Q, cnt, siglip, se, bias, th, out_sim, cls, conf, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Large vocabularies (Q in the hundreds .. thousands, BASELINE config 5): the score matrix comes from the f16/bf16
+// MFMA GEMM (ovo_gemm, S = F . T^T) and this pass finishes it -- optional SigLIP epilogue in place, then
+// max / first-argmax / threshold per row.  One wave per row, 16-byte loads; HBM-bound on 4*Q bytes per row.
+__global__ void __launch_bounds__(256) k_row_argmax(float *__restrict__ S, int64_t n, int Q, int siglip, float scale_exp, float bias, float th,
+                                                    long long *__restrict__ out_cls, float *__restrict__ out_conf) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < n; row += waves) {
+        float *s = S + row * Q;
+        float best = -3.0e38f;
+        int arg = 0x7fffffff;
+        for (int q = lane * 4; q < Q; q += 256) {                                    // Q % 4 == 0 (ovo_gemm's N constraint)
+            float4 v = *(const float4 *)(s + q);
+            if (siglip) {
+                v.x = 1.0f / (1.0f + __expf(-(v.x * scale_exp + bias)));
+                v.y = 1.0f / (1.0f + __expf(-(v.y * scale_exp + bias)));
+                v.z = 1.0f / (1.0f + __expf(-(v.z * scale_exp + bias)));
+                v.w = 1.0f / (1.0f + __expf(-(v.w * scale_exp + bias)));
+                *(float4 *)(s + q) = v;
+            }
+            if (v.x > best) { best = v.x; arg = q; }
+            if (v.y > best) { best = v.y; arg = q + 1; }
+            if (v.z > best) { best = v.z; arg = q + 2; }
+            if (v.w > best) { best = v.w; arg = q + 3; }
+        }
+        if (out_cls) {
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float ob = __shfl_xor(best, o, 64);
+                const int oa = __shfl_xor(arg, o, 64);
+                if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+            }
+            if (lane == 0) {
+                if (best <= th) { best = 0.f; arg = -1; }
+                out_conf[row] = best;
+                out_cls[row] = arg;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int ovo_row_argmax(float *S, int64_t n, int Q, int siglip, float logit_scale, float logit_bias, float th,
+                              int64_t *out_cls, float *out_conf, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && Q > 0 && Q % 4 == 0, "Q must be a positive multiple of 4");
+    OVO_REQUIRE((out_cls == nullptr) == (out_conf == nullptr), "out_cls and out_conf go together");
+    if (n == 0 || (!siglip && !out_cls)) return OVO_OK;
+    OVO_REQUIRE(S && ((uintptr_t)S & 15) == 0, "S must be 16-byte aligned");
+    int64_t grid = (n + 3) / 4;
+    if (grid > 256 * 16) grid = 256 * 16;
+    k_row_argmax<<<(int)grid, 256, 0, (hipStream_t)stream>>>(S, n, Q, siglip, expf(logit_scale), logit_bias, th, (long long *)out_cls, out_conf);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
 
 extern "C" int ovo_similarity(const void *F, int feat_dtype, int64_t n, int D, const float *T, int Q, const int32_t *cnt,
                               int siglip, float logit_scale, float logit_bias, float th, float *out_sim,

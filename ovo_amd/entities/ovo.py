@@ -48,6 +48,9 @@ def _timed(slot: str):
 
 
 class OVO:
+    _vit_stream = None      # side stream + pending result of prefetch_image_features()
+    _prefetched = None
+
     def __init__(self, config: Dict[str, Any], logger=None, scene_name: Optional[str] = None,
                  cam_intrinsics: Optional[torch.Tensor] = None, eval: bool = False, device="cuda",
                  clip_generator=None, mask_generator=None) -> None:
@@ -208,7 +211,7 @@ class OVO:
         self.last_point_seg, self.last_mask_rows = point_seg, mask_rows
 
         if self.debug_info:
-            ins_maps = torch.full(image.shape[:2], -1, dtype=torch.int32, device=dev)
+            ins_maps = torch.full(tuple(seg_map.shape), -1, dtype=torch.int32, device=dev)     # == image.shape[:2] (ovo.py:277)
             for row, ins_id in enumerate(matched_ins_ids):
                 ins_maps[binary_maps[row]] = ins_id
             self.keyframes["ins_maps"].append(ins_maps.cpu().numpy())
@@ -288,9 +291,34 @@ class OVO:
                                       print_output=True)
         self._time_cache = []
 
+    def prefetch_image_features(self, image) -> bool:
+        """MI355X extension (no counterpart in the reference): start the mask-independent half of `_extract_clip` -- the
+        TextRegion crops' ViT forward (textregion.py:141-142 via :197-199) -- for `image` NOW, on a side HIP stream, so that
+        it overlaps the tracking stage (whose host decisions wait on a device->host copy) and the SAM2 encoder.  The
+        matching `_extract_clip(image, ...)` call (same image object) picks the tokens up and only pools; any other
+        image takes the ordinary path.  Returns False when the configured embed type has no such half."""
+        tr = getattr(self.clip_generator, "textregion", None)
+        if tr is None or not isinstance(image, torch.Tensor) or not image.is_cuda:
+            return False
+        if self._vit_stream is None:
+            self._vit_stream = torch.cuda.Stream(device=image.device)
+        self._vit_stream.wait_stream(torch.cuda.current_stream())     # the previous keyframe's pooling read the same workspace
+        with torch.cuda.stream(self._vit_stream):
+            img = image.permute(2, 0, 1).contiguous()
+            feats = tr.get_img_features(img, scale=1.0 / 255.0)
+            done = torch.cuda.Event()
+            done.record(self._vit_stream)
+        self._prefetched = (image, img, feats, done)
+        return True
+
     @_timed("t_clip")
     def _extract_clip(self, image: np.ndarray, binary_maps: torch.Tensor) -> torch.Tensor:
         """Reference: ovo.py:427-437 -- but the descriptors stay on the GPU."""
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre[0] is image and binary_maps.shape[0] > 0:
+            torch.cuda.current_stream().wait_event(pre[3])
+            tr = self.clip_generator.textregion
+            return tr.pe_value_with_sam2_attn(tr.get_features_mask(binary_maps), pre[2])
         if isinstance(image, torch.Tensor):                      # already resident: HWC u8 -> CHW
             img = image.to(self.bank.device).permute(2, 0, 1).contiguous()
         else:

@@ -14,6 +14,7 @@ It is what bench.py times and what smoke() runs small; it adds no arithmetic of 
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -94,6 +95,8 @@ class FramePipeline:
         self.ovo = OVO(cfg, None, "synthetic", K, device=str(self.device), clip_generator=self.clip, mask_generator=self.masks)
         self.sam = HipHiera(HIERA_SPECS[sam_card], None, self.device, seed) if sam_card else None
         self.sam_out = None
+        self.prefetch = not os.environ.get("OVO_NO_PREFETCH")
+        self.sam_stream = torch.cuda.Stream(device=self.device) if (sam_card and not os.environ.get("OVO_SAM_SAME_STREAM")) else None
         self.D = self.clip.clip_dim
         self.texts = torch.from_numpy(syn.unit_vectors(n_text, self.D, seed=seed + 7)).to(self.device)
         self.dense = dense
@@ -115,7 +118,14 @@ class FramePipeline:
         c2w = self.slam._c2w_host[f.index]                         # host copy: no D2H for the frustum set-up
         self.slam.map(fd, c2w)
         if self.sam is not None:                                   # SAM2 image encoder (masks come from the seam)
-            self.sam_out = self.sam.forward(self.sam.preprocess(f.rgb.permute(2, 0, 1).contiguous()))
+            # Independent of the tracking / descriptor work of this frame: it runs on its own HIP stream so that the two
+            # kernel sequences fill each other's tails (most launches here are one or two workgroup rounds long).
+            side = self.sam_stream or torch.cuda.current_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.sam_out = self.sam.forward(self.sam.preprocess(f.rgb.permute(2, 0, 1).contiguous()))
+        if self.prefetch:                                          # ViT tokens do not depend on the masks: start them now
+            self.ovo.prefetch_image_features(f.rgb)
         ratio = (1.0, 1.0, self.crop_edge) if self.crop_edge else ()
         updated = self.ovo.detect_and_track_objects([f.index, f.rgb, f.depth, ratio], self.slam.get_map(), c2w)
         if updated is not None:
@@ -146,6 +156,10 @@ class FramePipeline:
         if self.dense:                                             # dense query: per-point mean descriptor x texts
             _, out["dense_cls"], out["dense_conf"] = clip_utils.similarity(self.acc[:n], self.texts, cnt=self.cnt[:n], want_sim=False,
                                                                            want_argmax=True)
+        if self.sam_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.sam_stream)   # the frame is done when every stream is
+        if self.ovo._vit_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.ovo._vit_stream)
         self.last = out
         return out
 

@@ -31,15 +31,44 @@ def similarity(img_embed: torch.Tensor, txt_embeds: torch.Tensor, *, siglip: boo
     q = txt.shape[0]
     if txt.shape[1] != d:
         raise L.OvoHipError(f"descriptor length mismatch: {d} vs {txt.shape[1]}")
-    sim = torch.empty((n, q), dtype=torch.float32, device=feats.device) if want_sim else None
     cls = torch.empty(n, dtype=torch.int64, device=feats.device) if want_argmax else None
     conf = torch.empty(n, dtype=torch.float32, device=feats.device) if want_argmax else None
+    if q >= LARGE_VOCABULARY and feats.dtype != torch.float32 and cnt is None and d % 32 == 0 and n > 0:
+        return _similarity_large(feats, txt, siglip, logit_scale, logit_bias, th, cls, conf)
+    sim = torch.empty((n, q), dtype=torch.float32, device=feats.device) if want_sim else None
     if cnt is not None:
         cnt = L.dev(cnt, torch.int32, "cnt")
     L.check(L.load().ovo_similarity(L.ptr(feats), _DTYPE_CODE[feats.dtype], n, d, L.ptr(txt), q, L.ptr(cnt), int(siglip),
                                     float(logit_scale), float(logit_bias), float(th), L.ptr(sim), L.ptr(cls), L.ptr(conf),
                                     L.stream()))
     return sim, cls, conf
+
+
+LARGE_VOCABULARY = 64     # from here on the f16/bf16 score matrix is an MFMA GEMM (BASELINE.json config 5: 1k texts)
+
+
+def _similarity_large(feats, txt, siglip, logit_scale, logit_bias, th, cls, conf):
+    """S = F . T^T on the MFMA GEMM (inputs in F's 16-bit dtype, fp32 accumulation, fp32 scores), then one row pass for
+    the SigLIP epilogue and the argmax.  The vocabulary is padded to a multiple of 4 with copies of its last text, which
+    can never win the first-max argmax; the padded columns are sliced away."""
+    lib = L.load()
+    n, d = feats.shape
+    q = txt.shape[0]
+    qp = (q + 3) // 4 * 4
+    if qp != q:
+        txt = torch.cat([txt, txt[-1:].expand(qp - q, d)]).contiguous()
+    t16 = torch.empty((qp, d), dtype=feats.dtype, device=feats.device)
+    L.check(lib.ovo_cast_f32(L.ptr(txt), qp * d, L.ptr(t16), _DTYPE_CODE[feats.dtype], L.stream()))
+    sim = torch.empty((n, qp), dtype=torch.float32, device=feats.device)
+    g = L.Gemm()
+    g.A, g.lda, g.W, g.ldw, g.bias = feats.data_ptr(), d, t16.data_ptr(), d, None
+    g.C, g.ldc, g.add, g.ld_add = sim.data_ptr(), qp, None, 0
+    g.M, g.N, g.K = n, qp, d
+    g.in_dtype, g.out_dtype, g.act, g.alpha = _DTYPE_CODE[feats.dtype], 0, 0, 1.0
+    L.check(lib.ovo_gemm(L.C.byref(g), L.stream()))
+    L.check(lib.ovo_row_argmax(L.ptr(sim), n, qp, int(siglip), float(logit_scale), float(logit_bias), float(th), L.ptr(cls), L.ptr(conf),
+                               L.stream()))
+    return (sim if qp == q else sim[:, :q]), cls, conf
 
 
 def clip_cosine_similarity(txt_embeds: torch.Tensor, img_embed: torch.Tensor) -> torch.Tensor:

@@ -46,10 +46,38 @@ def test_similarity_vs_oracle(dtype, tol, q):
     T = syn.unit_vectors(q, d, seed=2)
     Fd = _t(F).to(dtype)
     sim, cls, conf = CU.similarity(Fd, _t(T), want_argmax=True, th=-10.0)
-    ref = OF.similarity(Fd.float().cpu().numpy(), T)         # oracle on the same (rounded) inputs: tolerance = accumulation only
+    Tr = T if (dtype == torch.float32 or q < CU.LARGE_VOCABULARY) else torch.from_numpy(T).to(dtype).float().numpy()
+    ref = OF.similarity(Fd.float().cpu().numpy(), Tr)        # oracle on the same (rounded) inputs: tolerance = accumulation only
     np.testing.assert_allclose(sim.cpu().numpy(), ref, atol=2e-6, rtol=0)
     np.testing.assert_allclose(sim.cpu().numpy(), OF.similarity(F, T), atol=tol, rtol=0)   # <= 1e-3 in fp16 (north_star)
     assert np.array_equal(cls.cpu().numpy(), sim.argmax(1).cpu().numpy())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("q,siglip", [(64, False), (1000, False), (1001, False), (202, True)])
+def test_large_vocabulary_query(dtype, tol, q, siglip):
+    """BASELINE config 5's shape (1k texts x 16-bit map): MFMA GEMM + row argmax vs the f64-accumulating oracle."""
+    from oracle import features as OF
+    from ovo_amd import synthetic as syn
+    from ovo_amd.utils import clip_utils as CU
+    n, d = 20011, 768
+    F = syn.unit_vectors(n, d, seed=3)
+    T = syn.unit_vectors(q, d, seed=4)
+    Fd = _t(F).to(dtype)
+    ls, lb = (2.5, -1.0) if siglip else (0.0, 0.0)
+    sim, cls, conf = CU.similarity(Fd, _t(T), want_argmax=True, th=-10.0, siglip=siglip, logit_scale=ls, logit_bias=lb)
+    assert sim.shape == (n, q)
+    Tr = torch.from_numpy(T).to(dtype).float().numpy()
+    ref = OF.similarity(Fd.float().cpu().numpy(), Tr, siglip, ls, lb)
+    np.testing.assert_allclose(sim.cpu().numpy(), ref, atol=3e-6, rtol=0)                    # same rounded inputs: accumulation only
+    np.testing.assert_allclose(sim.cpu().numpy(), OF.similarity(F, T, siglip, ls, lb), atol=tol * (3 if siglip else 1), rtol=0)
+    s = sim.cpu().numpy()
+    assert np.array_equal(cls.cpu().numpy(), s.argmax(1)) and np.array_equal(conf.cpu().numpy(), s.max(1))
+    # threshold semantics (ovo.py:487-491): rows whose best score is <= th get class -1, confidence 0
+    th = float(np.median(s.max(1)))
+    _, cls2, conf2 = CU.similarity(Fd, _t(T), want_argmax=True, th=th, siglip=siglip, logit_scale=ls, logit_bias=lb)
+    below = s.max(1) <= th
+    assert np.array_equal(cls2.cpu().numpy(), np.where(below, -1, s.argmax(1))) and np.all(conf2.cpu().numpy()[below] == 0)
 
 
 def test_dense_query_row_scale():

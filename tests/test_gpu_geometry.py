@@ -70,12 +70,14 @@ class _NoClip:
     clip_dim = 16
 
 
-@pytest.mark.parametrize("tag,filt", [("nofilter", False), ("filter", True)])
+@pytest.mark.parametrize("tag,filt", [("nofilter", False), ("filter", True), ("ratio", True)])
 def test_tracking_golden(tag, filt):
     from ovo_amd.entities.ovo import OVO
     from ovo_amd.slam.vanilla_mapper import VanillaMapper
     d = golden(f"tracking_{tag}")
     w = int(d["mask_w"])
+    ratio = tuple(d["ratio"].tolist())
+    ratio = (ratio[0], ratio[1], int(ratio[2])) if ratio else ()
     K = torch.from_numpy(d["K"]).to(DEV)
     cfg = {"match_distance_th": 0.05, "track_th": int(d["track_th"]), "depth_filter": filt, "log": False,
            "debug_info": True, "clip": {"k_top_views": int(d["n_top_views"]), "fusion": "avg_pooling"}, "sam": {}}
@@ -90,7 +92,7 @@ def test_tracking_golden(tag, filt):
         assert np.array_equal(vm.get_map()[2].cpu().numpy(), d[f"ins_before{i}"])
         masks = unpack(d[f"masks{i}"], w)
         mg.next = (d[f"seg{i}"], masks)
-        updated = ovo.detect_and_track_objects([i, d[f"rgb{i}"], d[f"depth{i}"], ()], vm.get_map(), vm.get_c2w(i))
+        updated = ovo.detect_and_track_objects([i, d[f"rgb{i}"], d[f"depth{i}"], ratio], vm.get_map(), vm.get_c2w(i))
         assert updated.dtype == torch.int32 and np.array_equal(updated.cpu().numpy(), d[f"updated{i}"])
         vm.update_pcd_obj_ids(updated)
         matched, fused, _, kf = ovo.keyframes_queue[-1]

@@ -36,10 +36,12 @@ def test_vanilla_mapper_bit_exact():
     assert (d["pcd_obj_ids"] == -1).all()
 
 
-@pytest.mark.parametrize("tag,filt", [("nofilter", False), ("filter", True)])
+@pytest.mark.parametrize("tag,filt", [("nofilter", False), ("filter", True), ("ratio", True)])
 def test_tracking_bit_exact(tag, filt):
     d = golden(f"tracking_{tag}")
     w = int(d["mask_w"])
+    ratio = tuple(d["ratio"].tolist())
+    ratio = (ratio[0], ratio[1], int(ratio[2])) if ratio else ()
     pm = OS.PointMap(d["K"])
     tr = OS.SemanticTracker(d["K"], 0.05, int(d["track_th"]), filt, int(d["n_top_views"]))
     for i in range(4):
@@ -47,7 +49,7 @@ def test_tracking_bit_exact(tag, filt):
         assert pm.xyz.shape[0] == int(d[f"pcd_n{i}"])
         assert np.array_equal(pm.ins, d[f"ins_before{i}"])
         masks = unpack(d[f"masks{i}"], w)
-        matched, fused, n_matched, updated = tr.step(d[f"depth{i}"], (), pm.xyz, pm.ids, pm.ins,
+        matched, fused, n_matched, updated = tr.step(d[f"depth{i}"], ratio, pm.xyz, pm.ids, pm.ins,
                                                      d[f"c2w{i}"], d[f"seg{i}"], masks)
         pm.ins = updated
         assert n_matched == int(d[f"n_matched{i}"])

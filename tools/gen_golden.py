@@ -123,10 +123,12 @@ def gen_mapper(out, VM):
     save(out, "vanilla_mapper", **arrays)
 
 
-def gen_tracking(out, OVOcls, I3D, VM, depth_filter: bool, tag: str):
-    """3 keyframes through VanillaMapper.map + OVO._match_and_track_instances with synthetic masks."""
+def gen_tracking(out, OVOcls, I3D, VM, depth_filter: bool, tag: str, ratio=()):
+    """3 keyframes through VanillaMapper.map + OVO._match_and_track_instances with synthetic masks.
+    `ratio` = (r_h, r_w, crop_edge): masks live on the (h + 2*crop)*r colour grid (ovo.py:218-221)."""
     scale = 0.35
     h, w = syn.scannet_depth_hw(scale)
+    mh, mw = (int((h + 2 * ratio[2]) * ratio[0]), int((w + 2 * ratio[2]) * ratio[1])) if ratio else (h, w)
     K = torch.from_numpy(syn.scannet_intrinsics(scale))
     vm = VM({"device": "cpu", "mapping": {}}, K)
     ovo = OVOcls.__new__(OVOcls)
@@ -147,12 +149,12 @@ def gen_tracking(out, OVOcls, I3D, VM, depth_filter: bool, tag: str):
         vm.track_camera(fd)
         c2w_t = vm.get_c2w(fid)
         vm.map(fd, c2w_t)
-        masks = syn.make_masks(h, w, grid=(3, 4), n_blobs=4, seed=31 + t)
+        masks = syn.make_masks(mh, mw, grid=(3, 4), n_blobs=4, seed=31 + t)
         seg = syn.masks_to_segmap(masks)
         pcd, pcd_ids, obj_ids = vm.get_map()
         ins_before = obj_ids.clone()
         matched_ins_ids, bmaps, n_matched, updated = ovo._match_and_track_instances(
-            (rgb, depth, ()), (pcd, pcd_ids, obj_ids), c2w_t, torch.from_numpy(seg), torch.from_numpy(masks.copy()))
+            (rgb, depth, tuple(ratio)), (pcd, pcd_ids, obj_ids), c2w_t, torch.from_numpy(seg), torch.from_numpy(masks.copy()))
         vm.update_pcd_obj_ids(updated)
         ovo.kf_id += 1
         arrays.update({
@@ -163,7 +165,8 @@ def gen_tracking(out, OVOcls, I3D, VM, depth_filter: bool, tag: str):
             f"next_ins_id{i}": np.int64(ovo.next_ins_id),
         })
     arrays["pcd"] = vm.pcd
-    arrays["mask_w"] = np.int64(w)
+    arrays["mask_w"] = np.int64(mw)
+    arrays["ratio"] = np.asarray(ratio, dtype=np.float64)
     ids = sorted(ovo.objects.keys())
     arrays["obj_ids"] = np.asarray(ids, dtype=np.int64)
     for j in ids:
@@ -363,6 +366,7 @@ def main():
     gen_mapper(args.out, VM)
     gen_tracking(args.out, OVOcls, I3Dmod.Instance3D, VM, False, "nofilter")
     gen_tracking(args.out, OVOcls, I3Dmod.Instance3D, VM, True, "filter")
+    gen_tracking(args.out, OVOcls, I3Dmod.Instance3D, VM, True, "ratio", ratio=(2.0, 1.5, 4))
     gen_fusion(args.out, I3Dmod)
     gen_similarity(args.out, CU)
     gen_textregion(args.out, TR)
