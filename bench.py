@@ -94,6 +94,46 @@ def cpu_baseline(pipe_args, frame_np, map_xyz, texts):
     return 1.0 / (time.time() - t0), torch.get_num_threads()
 
 
+def pmc_traffic(tile: str):
+    """HBM bytes per launch of the dominant GEMM instantiation from the committed PMC reduction (profiles/pmc_traffic.json,
+    made by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    bm, bn = tile.split(",")
+    with open(path) as fh:
+        kernels = json.load(fh)["kernels"]
+    hits = [v for k, v in kernels.items() if f"k_gemmILi{bm}ELi{bn}ELi64E" in k and "DF16b" in k]
+    n = sum(v["launches"] for v in hits)
+    return round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n) if n else None
+
+
+def profile_pass(pipe, it, steps, lib):
+    """hipEvent pairs around every GEMM / attention / track_project launch of `steps` frames (on the launching streams)."""
+    from ovo_amd import _lib as L
+    L.check(lib.ovo_profile_start())
+    for _ in range(steps):
+        pipe.step(next(it))
+    ms, work, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
+    L.check(lib.ovo_profile_stop(ms, work, n, 8))
+    tiles = {4: "128,128", 5: "128,64", 6: "64,128", 7: "64,64"}
+    dom = max(tiles, key=lambda k: ms[k])                      # the GEMM instantiation with the most time = dominant kernel
+    tf = work[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+    gemm_ms, gemm_work = sum(ms[k] for k in tiles), sum(work[k] for k in tiles)
+    return {"bound": "mfma", "kernel": f"k_gemm<{tiles[dom]},64,bf16> (ovo_amd/csrc/gemm.hip)", "achieved": round(tf, 1),
+            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+            "traffic": pmc_traffic(tiles[dom]),
+            "launches_per_frame": n[dom] / steps, "avg_launch_us": round(1e3 * ms[dom] / max(n[dom], 1), 2),
+            "gemm_tiles_ms_per_frame": {tiles[k]: round(ms[k] / steps, 3) for k in tiles},
+            "gemm_all_ms_per_frame": round(gemm_ms / steps, 3),
+            "gemm_all_tflops": round(gemm_work / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms > 0 else 0.0,
+            "attention_ms_per_frame": round(ms[1] / steps, 3),
+            "attention_tflops": round(work[1] / (ms[1] * 1e-3) / 1e12, 1) if ms[1] > 0 else 0.0,
+            "track_project_ms_per_frame": round(ms[2] / steps, 4),
+            "track_project_gbs": round(work[2] / (ms[2] * 1e-3) / 1e9, 1) if ms[2] > 0 else 0.0,
+            "hbm_peak_gbs": HBM_PEAK_GBS}
+
+
 def main():
     args = parse()
     from ovo_amd import _lib as L, parallel
@@ -105,7 +145,7 @@ def main():
     dev = torch.device("cuda", dev_index)
     lib = L.load()
 
-    total = args.warmup + args.steps + (0 if args.no_roofline else args.profile_steps)
+    total = args.warmup + args.steps + (0 if args.no_roofline else 2 * args.profile_steps)
     sam = None if args.sam == "none" else args.sam
     pipe = FramePipeline(dev, vit_card=args.vit, sam_card=sam, n_map=args.map_points, n_text=args.texts, dense=not args.no_dense,
                          extra_capacity=(total + 2) * 72_000, seed=0)
@@ -142,26 +182,14 @@ def main():
 
     roof = None
     if not args.no_roofline and args.profile_steps > 0:
-        L.check(lib.ovo_profile_start())
-        for _ in range(args.profile_steps):
-            pipe.step(next(it))
-        ms, work, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
-        L.check(lib.ovo_profile_stop(ms, work, n, 8))
-        tiles = {4: "128,128", 5: "128,64", 6: "64,128", 7: "64,64"}
-        dom = max(tiles, key=lambda k: ms[k])                      # the GEMM instantiation with the most time = dominant kernel
-        tf = work[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
-        gemm_ms, gemm_work = sum(ms[k] for k in tiles), sum(work[k] for k in tiles)
-        roof = {"bound": "mfma", "kernel": f"k_gemm<{tiles[dom]},64,bf16> (ovo_amd/csrc/gemm.hip)", "achieved": round(tf, 1),
-                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                "launches_per_frame": n[dom] / args.profile_steps, "avg_launch_us": round(1e3 * ms[dom] / max(n[dom], 1), 2),
-                "gemm_tiles_ms_per_frame": {tiles[k]: round(ms[k] / args.profile_steps, 3) for k in tiles},
-                "gemm_all_ms_per_frame": round(gemm_ms / args.profile_steps, 3),
-                "gemm_all_tflops": round(gemm_work / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms > 0 else 0.0,
-                "attention_ms_per_frame": round(ms[1] / args.profile_steps, 3),
-                "attention_tflops": round(work[1] / (ms[1] * 1e-3) / 1e12, 1) if ms[1] > 0 else 0.0,
-                "track_project_ms_per_frame": round(ms[2] / args.profile_steps, 4),
-                "track_project_gbs": round(work[2] / (ms[2] * 1e-3) / 1e9, 1) if ms[2] > 0 else 0.0,
-                "hbm_peak_gbs": HBM_PEAK_GBS}
+        roof = profile_pass(pipe, it, args.profile_steps, lib)                 # as timed: three concurrent HIP streams
+        streams = (pipe.sam_stream, pipe.prefetch)
+        pipe.sam_stream, pipe.prefetch = None, False                           # one stream: every kernel has the chip to itself
+        iso = profile_pass(pipe, it, args.profile_steps, lib)
+        pipe.sam_stream, pipe.prefetch = streams
+        roof["isolated"] = {k: iso[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "gemm_all_ms_per_frame", "gemm_all_tflops",
+                                                "attention_ms_per_frame", "attention_tflops", "track_project_gbs")}
+        roof["isolated"]["note"] = "same kernels, second profiled pass with the SAM2 / ViT-prefetch streams folded into one"
 
     cpu = None
     if map0 is not None:

@@ -58,25 +58,41 @@ __device__ __forceinline__ void glds16(const void *src, void *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 before the hardware rcp / exp2 roundings, ~2e-7 after): one
-// v_rcp_f32, one v_exp_f32 and six FMAs instead of the library erff's branchy ~50 instructions -- the GELU sits on the
-// serial tail of every FC1 tile (the epilogue is not overlapped with MFMA work), where it cost ~20% of the GEMM.
-__device__ __forceinline__ float fast_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-    const float y = fmaf(-p * t, e, 1.0f);
-    return copysignf(y, x);
+// GELU(x) = x/2 (1 + erf(x/sqrt2)) on PACKED f32 (v_pk_fma_f32: two values per VALU slot) with a polynomial erf and no
+// transcendental op:  erf(z) ~ zc * P(s),  zc = clamp(z, +-3.5),  s = 2 zc^2 / 3.5^2 - 1,  P of degree 11 (Chebyshev-node
+// weighted least squares, tools/ history in DESIGN.md).  |erf error| <= 1.9e-6, |GELU error| <= 8.6e-6 absolute for every
+// x -- far below the bf16 rounding of the stored activation.  The library erff is ~50 branchy instructions and an
+// exp/rcp form still pays two quarter-rate transcendentals per value; the GELU sits on the serial tail of every FC1
+// tile (the epilogue does not overlap MFMA work), where it cost up to a quarter of the GEMM.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+    const f32x2 z = x * 0.70710678118654752f;
+    const f32x2 zc = __builtin_elementwise_min(__builtin_elementwise_max(z, (f32x2)(-3.5f)), (f32x2)(3.5f));
+    const f32x2 s = __builtin_elementwise_fma(zc * zc, (f32x2)(0.16326530612244897f), (f32x2)(-1.0f));
+    f32x2 p = (f32x2)(-3.398861796e-03f);
+    p = __builtin_elementwise_fma(p, s, (f32x2)(8.621919328e-03f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(-8.698635955e-03f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(1.271555869e-02f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(-2.870869786e-02f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(4.709060027e-02f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(-6.528488840e-02f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(8.795614477e-02f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(-1.145324569e-01f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(1.467849556e-01f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(-2.007044758e-01f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(4.038725490e-01f));
+    const f32x2 hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, p * zc, hx);
 }
 
-__device__ __forceinline__ float act_fn(float x, int act) {
-    if (act == 1) return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f));
-    if (act == 2) return x / (1.0f + __expf(-1.702f * x));
-    return x;
+__device__ __forceinline__ void act4(float *v, int act) {
+    if (act == 1) {
+        const f32x2 a = gelu2(f32x2{v[0], v[1]}), b = gelu2(f32x2{v[2], v[3]});
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    } else if (act == 2) {                                       // QuickGELU x * sigmoid(1.702 x)   (open_clip "-qg" cards)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+    }
 }
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -157,6 +173,28 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
         }
     };
 
+    // Epilogue operands (bias, residual) are fetched into registers during the LAST k-tile: issued after the main loop they
+    // sat on the serial tail of every workgroup (2-4 us of a 15-25 us GEMM).
+    float4 bias_r[TN], add_r[TM][TN];
+    auto fetch_epilogue = [&]() {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * 16 + fq * 4;
+            bias_r[j] = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (g.add) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm0 + i * 16 + fr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn0 + j * 16 + fq * 4;
+                    if (m < g.M && n < g.N) add_r[i][j] = *(const float4 *)(g.add + (long long)m * g.ld_add + n);
+                }
+            }
+        }
+    };
+
     // NS-stage LDS ring: tiles t+1 .. t+NS-2 stay in flight (LDS-DMA) across the barrier while tile t is multiplied.
     // A tile's DMA pieces are ordered for the ds_reads only by the issuing waves' counted vmcnt followed by a barrier,
     // so: counted wait (leave the NEWER tiles' pieces outstanding) -> raw s_barrier -> restage the buffer tile t-1 used
@@ -174,6 +212,7 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
 #ifndef OVO_GEMM_PROBE_NO_LOAD
         if (t + NS - 1 < nt) stage((t + NS - 1) % NS, t + NS - 1);
 #endif
+        if (t == nt - 1) fetch_epilogue();          // behind the last DMA wait: their latency hides under the last multiply
 #ifndef OVO_GEMM_PROBE_NO_MMA
         compute(t % NS);
 #endif
@@ -191,18 +230,9 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
-            if (g.bias) {
-                const float4 b = *(const float4 *)(g.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (g.act) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = act_fn(v[r], g.act);
-            }
-            if (g.add) {
-                const float4 a = *(const float4 *)(g.add + (long long)m * g.ld_add + n);
-                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-            }
+            v[0] += bias_r[j].x; v[1] += bias_r[j].y; v[2] += bias_r[j].z; v[3] += bias_r[j].w;
+            if (g.act) act4(v, g.act);
+            if (g.add) { v[0] += add_r[i][j].x; v[1] += add_r[i][j].y; v[2] += add_r[i][j].z; v[3] += add_r[i][j].w; }
             if (g.out_dtype == 0) {
                 *(float4 *)((float *)g.C + (long long)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             } else {

@@ -50,6 +50,7 @@ def _timed(slot: str):
 class OVO:
     _vit_stream = None      # side stream + pending result of prefetch_image_features()
     _prefetched = None
+    _tokens_free = None     # recorded on the main stream after the pooling that last read the ViT workspace
 
     def __init__(self, config: Dict[str, Any], logger=None, scene_name: Optional[str] = None,
                  cam_intrinsics: Optional[torch.Tensor] = None, eval: bool = False, device="cuda",
@@ -302,7 +303,12 @@ class OVO:
             return False
         if self._vit_stream is None:
             self._vit_stream = torch.cuda.Stream(device=image.device)
-        self._vit_stream.wait_stream(torch.cuda.current_stream())     # the previous keyframe's pooling read the same workspace
+        # the ViT workspace is shared between keyframes: wait for its last reader (the previous pooling), not for the whole
+        # main stream -- the previous keyframe's fusion / query tail then overlaps this forward
+        if self._tokens_free is not None:
+            self._vit_stream.wait_event(self._tokens_free)
+        else:
+            self._vit_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._vit_stream):
             img = image.permute(2, 0, 1).contiguous()
             feats = tr.get_img_features(img, scale=1.0 / 255.0)
@@ -315,10 +321,15 @@ class OVO:
     def _extract_clip(self, image: np.ndarray, binary_maps: torch.Tensor) -> torch.Tensor:
         """Reference: ovo.py:427-437 -- but the descriptors stay on the GPU."""
         pre, self._prefetched = self._prefetched, None
-        if pre is not None and pre[0] is image and binary_maps.shape[0] > 0:
-            torch.cuda.current_stream().wait_event(pre[3])
-            tr = self.clip_generator.textregion
-            return tr.pe_value_with_sam2_attn(tr.get_features_mask(binary_maps), pre[2])
+        if pre is not None:
+            torch.cuda.current_stream().wait_event(pre[3])       # also on the ordinary path: it reuses the same workspace
+            if pre[0] is image and binary_maps.shape[0] > 0:
+                tr = self.clip_generator.textregion
+                out = tr.pe_value_with_sam2_attn(tr.get_features_mask(binary_maps), pre[2])
+                self._tokens_free = torch.cuda.Event()
+                self._tokens_free.record()
+                return out
+            self._tokens_free = None
         if isinstance(image, torch.Tensor):                      # already resident: HWC u8 -> CHW
             img = image.to(self.bank.device).permute(2, 0, 1).contiguous()
         else:

@@ -40,6 +40,7 @@ class Frame:
     c2w: np.ndarray            # f32 [4, 4]
     seg_map: torch.Tensor      # i32 [H, W]        -1 = no mask
     masks: torch.Tensor        # bool [N, H, W]
+    ready: Optional[torch.cuda.Event] = None   # recorded after the frame's host->device upload (None: already resident)
 
 
 class ResidentMasks:
@@ -96,6 +97,7 @@ class FramePipeline:
         self.sam = HipHiera(HIERA_SPECS[sam_card], None, self.device, seed) if sam_card else None
         self.sam_out = None
         self.prefetch = not os.environ.get("OVO_NO_PREFETCH")
+        self.join_each_step = bool(os.environ.get("OVO_JOIN_EACH_STEP"))
         self.sam_stream = torch.cuda.Stream(device=self.device) if (sam_card and not os.environ.get("OVO_SAM_SAME_STREAM")) else None
         self.D = self.clip.clip_dim
         self.texts = torch.from_numpy(syn.unit_vectors(n_text, self.D, seed=seed + 7)).to(self.device)
@@ -113,19 +115,22 @@ class FramePipeline:
     def step(self, f: Frame) -> Dict[str, object]:
         lib = L.load()
         self.masks.frames = {f.index: f}
-        fd = [f.index, f.rgb_lr, f.depth, f.c2w]
-        self.slam.track_camera(fd)
-        c2w = self.slam._c2w_host[f.index]                         # host copy: no D2H for the frustum set-up
-        self.slam.map(fd, c2w)
+        # The two encoders first: nothing of theirs depends on the map, and the map update below ends in a host sync (the
+        # count of new points) behind which the host could not launch them.
         if self.sam is not None:                                   # SAM2 image encoder (masks come from the seam)
             # Independent of the tracking / descriptor work of this frame: it runs on its own HIP stream so that the two
             # kernel sequences fill each other's tails (most launches here are one or two workgroup rounds long).
             side = self.sam_stream or torch.cuda.current_stream()
-            side.wait_stream(torch.cuda.current_stream())
+            if f.ready is not None:                                # the frame's upload, if it is still in flight
+                side.wait_event(f.ready)
             with torch.cuda.stream(side):
                 self.sam_out = self.sam.forward(self.sam.preprocess(f.rgb.permute(2, 0, 1).contiguous()))
         if self.prefetch:                                          # ViT tokens do not depend on the masks: start them now
             self.ovo.prefetch_image_features(f.rgb)
+        fd = [f.index, f.rgb_lr, f.depth, f.c2w]
+        self.slam.track_camera(fd)
+        c2w = self.slam._c2w_host[f.index]                         # host copy: no D2H for the frustum set-up
+        self.slam.map(fd, c2w)
         ratio = (1.0, 1.0, self.crop_edge) if self.crop_edge else ()
         updated = self.ovo.detect_and_track_objects([f.index, f.rgb, f.depth, ratio], self.slam.get_map(), c2w)
         if updated is not None:
@@ -156,12 +161,16 @@ class FramePipeline:
         if self.dense:                                             # dense query: per-point mean descriptor x texts
             _, out["dense_cls"], out["dense_conf"] = clip_utils.similarity(self.acc[:n], self.texts, cnt=self.cnt[:n], want_sim=False,
                                                                            want_argmax=True)
-        if self.sam_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.sam_stream)   # the frame is done when every stream is
-        if self.ovo._vit_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.ovo._vit_stream)
+        if self.join_each_step:                                    # strict frame boundaries (tests); the stream of frames is
+            self.join()                                            # otherwise software-pipelined: tail(t) || encoders(t+1)
         self.last = out
         return out
+
+    def join(self) -> None:
+        """Make the main stream wait for the SAM2 and ViT streams (everything of the frames stepped so far)."""
+        for side in (self.sam_stream, self.ovo._vit_stream):
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
 
     def merge_dense(self) -> int:
         """Merge the per-GPU dense accumulators over xGMI (called once per batch of frames / before a global query).

@@ -7,31 +7,41 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _run(prefetch: bool, side_stream: bool, n_frames: int = 4):
+def _run(prefetch: bool, side_stream: bool, pipelined: bool = False, n_frames: int = 4):
     from ovo_amd.pipeline import FramePipeline, synthetic_frames
     pipe = FramePipeline(DEV, vit_card="tiny-pe", sam_card="hiera_test", n_map=60_000, n_text=7, scale=0.35, extra_capacity=200_000,
                          track_th=40)
     pipe.prefetch = prefetch
+    pipe.join_each_step = not pipelined
     if not side_stream:
         pipe.sam_stream = None
     frames = synthetic_frames(n_frames, DEV, scale=0.35, n_masks_grid=(3, 4), n_blobs=4)
     trace = []
     for f in frames:
         out = pipe.step(f)
-        torch.cuda.synchronize()
-        trace.append({"n_points": out["n_points"], "n_instances": out["n_instances"],
-                      "cls": out["cls"].cpu().numpy() if "cls" in out else None,
-                      "sim": out["sim"].cpu().numpy() if "sim" in out else None,
-                      "dense_cls": out["dense_cls"].cpu().numpy(), "dense_conf": out["dense_conf"].cpu().numpy(),
-                      "desc": pipe.ovo.last_clip_embeds.cpu().numpy() if pipe.ovo.last_clip_embeds is not None else None,
-                      "sam": [t.float().cpu().numpy() for t in pipe.sam_out]})
+        if not pipelined:
+            torch.cuda.synchronize()
+        with torch.cuda.stream(pipe.sam_stream or torch.cuda.current_stream()):      # the SAM2 features live in a reused workspace
+            sam = [t.clone() for t in pipe.sam_out]
+        desc = pipe.ovo.last_clip_embeds
+        trace.append({"n_points": out["n_points"], "n_instances": out["n_instances"], "cls": out.get("cls"), "sim": out.get("sim"),
+                      "dense_cls": out["dense_cls"], "dense_conf": out["dense_conf"], "desc": desc, "sam": sam})
+    torch.cuda.synchronize()                                     # pipelined: the only sync of the run
+    for r in trace:
+        for k in ("cls", "sim", "dense_cls", "dense_conf", "desc"):
+            r[k] = None if r[k] is None else r[k].cpu().numpy()
+        r["sam"] = [t.float().cpu().numpy() for t in r["sam"]]
     return trace, pipe
 
 
 def test_streams_do_not_change_results():
     """SAM2 encoder on its own stream + ViT tokens prefetched on a third: identical bits to the single-stream order."""
     ref, _ = _run(prefetch=False, side_stream=False)
-    got, pipe = _run(prefetch=True, side_stream=True)
+    _check(ref, *_run(prefetch=True, side_stream=True))
+    _check(ref, *_run(prefetch=True, side_stream=True, pipelined=True))     # no join at frame boundaries
+
+
+def _check(ref, got, pipe):
     assert pipe.ovo._vit_stream is not None, "the prefetch path did not run"
     assert any(r["desc"] is not None and r["desc"].shape[0] > 0 for r in ref), "fixture produced no descriptors"
     for a, b in zip(ref, got):

@@ -11,7 +11,11 @@ def run(m, n, k, iters=30):
     odt = {'bf16': (torch.bfloat16, 2), 'f32': (torch.float32, 0)}[os.environ.get('OUT', 'bf16')]
     out = torch.empty(m, n, dtype=odt[0], device=dev)
     g = L.Gemm(); g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, g.add, g.ld_add = a.data_ptr(), k, w.data_ptr(), k, None, out.data_ptr(), n, None, 0
-    g.M, g.N, g.K, g.in_dtype, g.out_dtype, g.act, g.alpha = m, n, k, 2, odt[1], 0, 1.0
+    g.M, g.N, g.K, g.in_dtype, g.out_dtype, g.act, g.alpha = m, n, k, 2, odt[1], int(os.environ.get('ACT', '0')), 1.0
+    if os.environ.get('BIAS'):
+        bias = torch.randn(n, device=dev); g.bias = bias.data_ptr()
+    if os.environ.get('ADD'):
+        add = torch.randn(m, n, device=dev); g.add, g.ld_add = add.data_ptr(), n
     for _ in range(3): L.check(lib.ovo_gemm(C.byref(g), L.stream()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
