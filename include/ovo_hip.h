@@ -238,6 +238,17 @@ int ovo_resize_normalize(const void *src, int src_dtype, int C, int H, int W, in
                          float *out, int oh, int ow, int antialias, float scale, const float *mean3_host,
                          const float *std3_host, ovo_stream_t stream);
 
+/* ---- a14: per-mask crops of the crop-mode descriptors (segment_utils.py:29-41 segmap2segimg, :43-94, :118-172) ----
+ * ovo_mask_boxes: masks u8 [n, H, W] -> boxes i32 [n, 4] = (x, y, w, h) with the reference's w = x_max - x_min,
+ *   h = y_max - y_min over INCLUSIVE edges (batched_mask_to_box + batched_box_xyxy_to_xywh), zeros for an empty mask.
+ * ovo_mask_crops: image CHW (3 channels, u8 = dtype 3 or f32 = 0, range 0..255) -> out f32 [n, 3 or 6, R, R]:
+ *   channels 0-2 the masked crop (zero background; zero-padded to a centred square when also_bbox = 0), channels 3-5
+ *   (also_bbox = 1) the box grown by `margin` pixels; each resized to R x R exactly as torchvision F.resize does for a
+ *   tensor (bilinear, antialias).  round_out = 1 rounds half-to-even like F.resize on a uint8 tensor. */
+int ovo_mask_boxes(const uint8_t *masks, int n, int H, int W, int32_t *boxes_xywh, ovo_stream_t stream);
+int ovo_mask_crops(const void *image, int img_dtype, int H, int W, const uint8_t *masks, const int32_t *boxes_xywh, int n,
+                   int also_bbox, int margin, int R, int round_out, float *out, ovo_stream_t stream);
+
 /* 2-D rotary embedding on q and k of a packed QKV buffer (perception_models Rope2D), in place.
  * qkv bf16 [B, T, 3, H, hd]; cos/sin f32 [T, hd]; pairs (2i, 2i+1) rotate together (interleaved form);
  * rows t < t0 (class token) are left alone. */

@@ -188,3 +188,49 @@ def masks_to_boxes(masks: np.ndarray) -> np.ndarray:
         if ys.size:
             out[i] = (xs.min(), ys.min(), xs.max(), ys.max())
     return out
+
+
+def mask_crops(masks: np.ndarray, image: np.ndarray, also_bbox: bool, margin: int = 50, out_l: int = 224) -> np.ndarray:
+    """segment_utils.py:29-41 segmap2segimg with its helpers (:88-94 xyxy->xywh over inclusive edges, :118-126
+    seg_img_from_image, :128-139 get_seg_img / get_bbox_img, :141-150 pad_img, :152-172 increase_bbox_by_margin).
+    masks bool [N,H,W], image [3,H,W] u8 or f32 (0..255) -> f32 [N, 3|6, out_l, out_l].
+    torchvision is not installed here: F.resize on a tensor is restated as what it dispatches to,
+    torch.nn.functional.interpolate(mode="bilinear", antialias=True, align_corners=False), computed in f32 and -- for a
+    uint8 image -- rounded (torch.round, half to even) like torchvision's _cast_squeeze_out.  Degenerate boxes (w or h = 0,
+    where the reference raises inside F.resize) give zeros."""
+    import torch
+    img = torch.from_numpy(np.ascontiguousarray(image))
+    is_u8 = img.dtype == torch.uint8
+
+    def resize(t: torch.Tensor) -> torch.Tensor:
+        if t.shape[-1] == 0 or t.shape[-2] == 0:
+            return torch.zeros((t.shape[0], out_l, out_l), dtype=torch.float32)
+        r = torch.nn.functional.interpolate(t[None].float(), size=(out_l, out_l), mode="bilinear", antialias=True, align_corners=False)[0]
+        return torch.round(r) if is_u8 else r
+
+    boxes = masks_to_boxes(masks)
+    out = []
+    for mk, (x1, y1, x2, y2) in zip(masks, boxes):
+        x, y, w, h = int(x1), int(y1), int(x2 - x1), int(y2 - y1)
+        m = torch.from_numpy(np.ascontiguousarray(mk[y:y + h, x:x + w]))
+        seg = torch.zeros((3, h, w), dtype=img.dtype)
+        seg[:, m] = img[:, y:y + h, x:x + w][:, m]
+        if also_bbox:
+            bx, by, bw, bh = x - margin, y - margin, w + 2 * margin, h + 2 * margin
+            if bx < 0:
+                bw, bx = bw + bx, 0
+            if by < 0:
+                bh, by = bh + by, 0
+            box = img[:, by:by + max(bh, 0), bx:bx + max(bw, 0)]
+            out.append(torch.cat([resize(seg), resize(box)], 0))
+        else:
+            side = max(w, h)
+            pad = torch.zeros((3, side, side), dtype=img.dtype)
+            if h > w:
+                pad[..., (h - w) // 2:(h - w) // 2 + w] = seg
+            else:
+                pad[:, (w - h) // 2:(w - h) // 2 + h, :] = seg
+            out.append(resize(pad))
+    if not out:
+        return np.zeros((0, 6 if also_bbox else 3, out_l, out_l), np.float32)
+    return torch.stack(out).numpy().astype(np.float32)

@@ -106,6 +106,8 @@ _SIGNATURES = {
     "ovo_fuse_views": (_I32, [_P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P]),
     "ovo_scatter_accum": (_I32, [_P, _I64, _P, _I32, _P, _I32, _P, _P, _P]),
     "ovo_similarity": (_I32, [_P, _I32, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P, _P]),
+    "ovo_mask_boxes": (_I32, [_P, _I32, _I32, _I32, _P, _P]),
+    "ovo_mask_crops": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "ovo_row_argmax": (_I32, [_P, _I64, _I32, _I32, _F32, _F32, _F32, _P, _P, _P]),
     "ovo_mask_intersections": (_I32, [_P, _I32, _I64, _P, _P]),
     "ovo_pack_masks": (_I32, [_P, _I32, _I64, _P, _I64, _P]),

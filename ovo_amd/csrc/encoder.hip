@@ -145,6 +145,102 @@ __global__ void __launch_bounds__(256) k_resize_norm(ResizeArgs a, float *__rest
     }
 }
 
+// ---- a14: per-mask crops for the crop-mode descriptors (segment_utils.py:29-41, 118-170) ----
+// k_mask_boxes: XYXY box of every mask (inclusive max edges) -> XYWH with the reference's w = x2 - x1, h = y2 - y1 (the last
+// column / row is NOT part of the crop: segment_utils.py:88-94 subtracts inclusive edges); empty mask -> 0,0,0,0.
+__global__ void __launch_bounds__(256) k_mask_boxes(const uint8_t *__restrict__ masks, int H, int W, int32_t *__restrict__ boxes) {
+    __shared__ int s[4];
+    if (threadIdx.x == 0) { s[0] = W; s[1] = H; s[2] = -1; s[3] = -1; }
+    __syncthreads();
+    const uint8_t *m = masks + (long long)blockIdx.x * H * W;
+    int x0 = W, y0 = H, x1 = -1, y1 = -1;
+    for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
+        if (m[i]) {
+            const int y = i / W, x = i - y * W;
+            x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1; y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
+        }
+    }
+    if (x1 >= 0) { atomicMin(&s[0], x0); atomicMin(&s[1], y0); atomicMax(&s[2], x1); atomicMax(&s[3], y1); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t *b = boxes + 4 * blockIdx.x;
+        if (s[2] < 0) { b[0] = b[1] = b[2] = b[3] = 0; }
+        else { b[0] = s[0]; b[1] = s[1]; b[2] = s[2] - s[0]; b[3] = s[3] - s[1]; }
+    }
+}
+
+// k_mask_crops: out[i, part] = antialiased-bilinear resize to R x R (torchvision F.resize on a tensor) of
+//   part 0: the masked crop (zero background) -- zero-padded to a centred square first when there is no bbox part ("vanilla")
+//   part 1: the box crop grown by `margin` px (clamped at 0 on the left / top, sliced at the image edge on the right / bottom)
+// One thread per output pixel, all 3 channels; the source "canvas" is virtual (never materialised).
+struct CropArgs {
+    const void *img; int img_u8, H, W;
+    const uint8_t *masks; const int32_t *boxes;
+    int n, also_bbox, margin, R, round_out;
+};
+__global__ void __launch_bounds__(256) k_mask_crops(CropArgs a, float *__restrict__ out) {
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int parts = a.also_bbox ? 2 : 1, i = blockIdx.z / parts, part = blockIdx.z % parts;
+    if (ox >= a.R || oy >= a.R) return;
+    const int32_t *b = a.boxes + 4 * i;
+    int bx = b[0], by = b[1], bw = b[2], bh = b[3];
+    int ch, cw, offy = 0, offx = 0;                      // canvas size, placement of the crop inside it
+    const uint8_t *mask = nullptr;
+    if (part == 0) {
+        mask = a.masks + (long long)i * a.H * a.W;
+        if (a.also_bbox) { ch = bh; cw = bw; }
+        else {                                           // pad_img (segment_utils.py:141-150)
+            ch = cw = bh > bw ? bh : bw;
+            if (bh > bw) offx = (bh - bw) / 2; else offy = (bw - bh) / 2;
+        }
+    } else {                                             // increase_bbox_by_margin + slicing (segment_utils.py:152-172, 136-139)
+        bx -= a.margin; by -= a.margin; bw += 2 * a.margin; bh += 2 * a.margin;
+        if (bx < 0) { bw += bx; bx = 0; }
+        if (by < 0) { bh += by; by = 0; }
+        if (bx + bw > a.W) bw = a.W - bx;
+        if (by + bh > a.H) bh = a.H - by;
+        ch = bh; cw = bw;
+    }
+    float *o = out + ((long long)(i * parts + part) * 3) * a.R * a.R + (long long)oy * a.R + ox;
+    const long long plane = (long long)a.R * a.R;
+    if (ch <= 0 || cw <= 0) { o[0] = 0.f; o[plane] = 0.f; o[2 * plane] = 0.f; return; }   // degenerate box (the reference raises)
+    const float sy = (float)ch / (float)a.R, sx = (float)cw / (float)a.R;
+    const float supy = sy >= 1.f ? sy : 1.f, supx = sx >= 1.f ? sx : 1.f;
+    const float ivy = sy >= 1.f ? 1.f / sy : 1.f, ivx = sx >= 1.f ? 1.f / sx : 1.f;
+    const float cy = sy * ((float)oy + 0.5f), cx = sx * ((float)ox + 0.5f);
+    int ymin = (int)(cy - supy + 0.5f); ymin = ymin < 0 ? 0 : ymin;
+    int ymax = (int)(cy + supy + 0.5f); ymax = ymax > ch ? ch : ymax;
+    int xmin = (int)(cx - supx + 0.5f); xmin = xmin < 0 ? 0 : xmin;
+    int xmax = (int)(cx + supx + 0.5f); xmax = xmax > cw ? cw : xmax;
+    float wy_tot = 0.f, wx_tot = 0.f;
+    for (int y = ymin; y < ymax; ++y) wy_tot += tri(((float)y - cy + 0.5f) * ivy);
+    for (int x = xmin; x < xmax; ++x) wx_tot += tri(((float)x - cx + 0.5f) * ivx);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int y = ymin; y < ymax; ++y) {
+        const float wy = tri(((float)y - cy + 0.5f) * ivy) / wy_tot;
+        const int yy = y - offy;
+        float row[3] = {0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < bh) {
+            for (int x = xmin; x < xmax; ++x) {
+                const int xx = x - offx;
+                if (xx < 0 || xx >= bw) continue;
+                const long long pix = (long long)(by + yy) * a.W + (bx + xx);
+                if (mask && !mask[pix]) continue;
+                const float wx = tri(((float)x - cx + 0.5f) * ivx) / wx_tot;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const long long idx = (long long)c * a.H * a.W + pix;
+                    row[c] += wx * (a.img_u8 ? (float)((const uint8_t *)a.img)[idx] : ((const float *)a.img)[idx]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] += wy * row[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c * plane] = a.round_out ? rintf(acc[c]) : acc[c];
+}
+
 // ---- rotary embedding on q, k of a packed [B, T, 3, H, hd] bf16 buffer ----
 __global__ void __launch_bounds__(256) k_rope_qk(uint32_t *__restrict__ qkv, int B, int T, int H, int hd, const float *__restrict__ cos_t,
                                                  const float *__restrict__ sin_t, int t0) {
@@ -309,6 +405,30 @@ int ovo_resize_normalize(const void *src, int src_dtype, int C, int H, int W, in
     for (int c = 0; c < 4; ++c) { a.mean[c] = mean3_host && c < C ? mean3_host[c] : 0.f; a.std[c] = std3_host && c < C ? std3_host[c] : 1.f; }
     dim3 grid((ow + 63) / 64, (oh + 3) / 4);
     k_resize_norm<<<grid, 256, 0, (hipStream_t)stream>>>(a, out);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_mask_boxes(const uint8_t *masks, int n, int H, int W, int32_t *boxes_xywh, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && H > 0 && W > 0, "bad shape");
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(masks && boxes_xywh, "null pointer");
+    k_mask_boxes<<<n, 256, 0, (hipStream_t)stream>>>(masks, H, W, boxes_xywh);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_mask_crops(const void *image, int img_dtype, int H, int W, const uint8_t *masks, const int32_t *boxes_xywh, int n,
+                   int also_bbox, int margin, int R, int round_out, float *out, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && H > 0 && W > 0 && R > 0 && margin >= 0, "bad shape");
+    OVO_REQUIRE(img_dtype == 0 || img_dtype == 3, "img_dtype: 0 = f32, 3 = u8");
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(image && masks && boxes_xywh && out, "null pointer");
+    CropArgs a;
+    a.img = image; a.img_u8 = img_dtype == 3; a.H = H; a.W = W; a.masks = masks; a.boxes = boxes_xywh; a.n = n;
+    a.also_bbox = also_bbox != 0; a.margin = margin; a.R = R; a.round_out = round_out != 0;
+    dim3 grid((R + 63) / 64, (R + 3) / 4, n * (a.also_bbox ? 2 : 1));
+    k_mask_crops<<<grid, 256, 0, (hipStream_t)stream>>>(a, out);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

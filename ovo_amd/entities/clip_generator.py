@@ -115,10 +115,10 @@ class CLIPGenerator:
         if self.embed_type == "TextRegion":
             img = image if image.dtype == torch.uint8 else image.float()
             return self.textregion.predict(img.contiguous(), binary_maps, scale=1.0 / 255.0)
-        from ..utils import crop_utils
-        img = image.float() if image.dtype != torch.float32 else image
+        from ..utils import segment_utils
         also_bbox = self.embed_type != "vanilla"
-        seg = crop_utils.segmap2segimg(binary_maps, img, also_bbox, out_l=self.mask_res) / 255.0
+        seg = segment_utils.segmap2segimg(binary_maps, image, also_bbox, out_l=self.mask_res) / 255.0
+        img = image.float() if image.dtype != torch.float32 else image
         norm = torch.nn.functional.normalize
         if not also_bbox:
             return norm(self.encode_image(seg[:, :3]), p=2, dim=-1)

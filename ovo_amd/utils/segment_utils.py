@@ -117,3 +117,54 @@ def batched_mask_to_box(masks: torch.Tensor) -> torch.Tensor:
     box = torch.stack([left, top, right, bottom], dim=-1)
     box = box * ~((right < left) | (bottom < top)).unsqueeze(-1)
     return box.reshape(*masks.shape[:-2], 4)
+
+
+def batched_box_xyxy_to_xywh(box_xyxy: torch.Tensor) -> torch.Tensor:
+    """Reference: segment_utils.py:88-94 (in place, like the reference): w = x2 - x1, h = y2 - y1 over INCLUSIVE edges."""
+    box_xyxy[:, 2] = box_xyxy[:, 2] - box_xyxy[:, 0]
+    box_xyxy[:, 3] = box_xyxy[:, 3] - box_xyxy[:, 1]
+    return box_xyxy
+
+
+def increase_bbox_by_margin(bbox, margin: int):
+    """Reference: segment_utils.py:152-172."""
+    x, y, w, h = (int(v) for v in bbox)
+    x, y, w, h = x - margin, y - margin, w + 2 * margin, h + 2 * margin
+    if x < 0:
+        w, x = w + x, 0
+    if y < 0:
+        h, y = h + y, 0
+    return x, y, w, h
+
+
+def mask_boxes_xywh(binary_map: torch.Tensor) -> torch.Tensor:
+    """batched_mask_to_box followed by batched_box_xyxy_to_xywh in ONE launch -> i32 [N, 4] on the GPU."""
+    m = binary_map if binary_map.dtype == torch.uint8 else binary_map.view(torch.uint8) if binary_map.dtype == torch.bool else binary_map.to(torch.uint8)
+    m = L.dev(m.contiguous(), torch.uint8, "binary_map")
+    n, h, w = m.shape
+    boxes = torch.empty((n, 4), dtype=torch.int32, device=m.device)
+    L.check(L.load().ovo_mask_boxes(L.ptr(m), n, h, w, L.ptr(boxes), L.stream()))
+    return boxes
+
+
+def segmap2segimg(binary_map: torch.Tensor, image: torch.Tensor, also_bbox: bool, bbox_margin: int = 50, out_l: int = 224) -> torch.Tensor:
+    """Reference: segment_utils.py:29-41 (+ :118-150).  binary_map bool [N, H, W], image [3, H, W] (u8 or float, 0..255)
+    -> f32 [N, 3 | 6, out_l, out_l]: the masked crop (zero background; zero-padded to a square when there is no bbox part)
+    and, with `also_bbox`, the box crop grown by `bbox_margin`, each resized like torchvision's F.resize (bilinear,
+    antialias).  A uint8 image gives rounded values, as F.resize does for uint8 tensors.  All masks in one launch."""
+    n = int(binary_map.shape[0])
+    parts = 6 if also_bbox else 3
+    img = L.dev(image.contiguous(), image.dtype if image.dtype == torch.uint8 else torch.float32, "image") \
+        if image.dtype in (torch.uint8, torch.float32) else L.dev(image.float().contiguous(), torch.float32, "image")
+    out = torch.empty((n, parts, out_l, out_l), dtype=torch.float32, device=img.device)
+    if n == 0:
+        return out
+    m = binary_map.view(torch.uint8) if binary_map.dtype == torch.bool else binary_map.to(torch.uint8)
+    m = L.dev(m.contiguous(), torch.uint8, "binary_map")
+    _, h, w = img.shape
+    if tuple(m.shape[1:]) != (h, w):
+        raise L.OvoHipError(f"mask size {tuple(m.shape[1:])} != image size {(h, w)}")
+    boxes = mask_boxes_xywh(m)
+    L.check(L.load().ovo_mask_crops(L.ptr(img), L.DTYPE_CODE[img.dtype], h, w, L.ptr(m), L.ptr(boxes), n, int(also_bbox), int(bbox_margin),
+                                    int(out_l), int(img.dtype == torch.uint8), L.ptr(out), L.stream()))
+    return out

@@ -168,3 +168,69 @@ def test_mask_intersections_full_res():
     masks = syn.make_masks(480, 640, grid=(6, 8), n_blobs=40, seed=2)
     inter = SU.mask_intersections(_t(masks)).cpu().numpy()
     assert np.array_equal(inter, OF.mask_intersections(masks))
+
+
+# ------------------------------------------------------------------ a14: per-mask crops + crop-mode descriptors
+def _crop_fixture(H=150, W=200):
+    from ovo_amd import synthetic as syn
+    masks = syn.make_masks(H, W, grid=(2, 3), n_blobs=4, seed=2)
+    extra = np.zeros((4, H, W), bool)
+    extra[0, 40:90, 70] = True            # one pixel wide -> w = 0 after the inclusive-edge subtraction (degenerate)
+    extra[1, 0:30, 0:45] = True           # touches the top-left corner (margin clamps at 0)
+    extra[2, H - 20:H, W - 60:W] = True   # touches the bottom-right corner (margin slices at the image edge)
+    # extra[3] stays empty -> box 0,0,0,0
+    masks = np.concatenate([masks, extra])
+    img = syn.render_rgb(H, W, 4).transpose(2, 0, 1).copy()
+    return masks, img
+
+
+@pytest.mark.parametrize("also_bbox", [False, True])
+@pytest.mark.parametrize("as_u8", [True, False])
+def test_mask_crops_vs_oracle(also_bbox, as_u8):
+    from oracle import features as OF
+    from ovo_amd.utils import segment_utils as SU
+    masks, img = _crop_fixture()
+    img = img if as_u8 else img.astype(np.float32) * 0.731
+    boxes = SU.mask_boxes_xywh(_t(masks)).cpu().numpy()
+    ref_boxes = OF.masks_to_boxes(masks)
+    ref_boxes[:, 2] -= ref_boxes[:, 0]; ref_boxes[:, 3] -= ref_boxes[:, 1]
+    assert np.array_equal(boxes, ref_boxes)                                       # integer boxes: bit-exact
+    got = SU.segmap2segimg(_t(masks), _t(img), also_bbox, bbox_margin=50, out_l=96).cpu().numpy()
+    ref = OF.mask_crops(masks, img, also_bbox, 50, 96)
+    assert got.shape == ref.shape == (masks.shape[0], 6 if also_bbox else 3, 96, 96)
+    d = np.abs(got - ref)
+    if as_u8:        # rounded outputs: equal except where the f32 sum lands within an ulp of .5
+        assert d.max() <= 1.0 and (d > 0).mean() < 2e-3
+    else:
+        assert d.max() < 2e-3                                                     # 0..255 scale, f32 accumulation order only
+    assert np.all(got[-1, :3] == 0) and np.all(got[-4, :3] == 0)                  # empty / degenerate masked crops -> zeros
+
+
+@pytest.mark.parametrize("mode", ["vanilla", "fixed_weights", "hovsg", "adaptive_weights", "concept_fusion"])
+def test_extract_clip_crop_modes_vs_oracle(mode):
+    """clip_generator.py:125-158 for the crop-based embed types: crops -> ViT pooled descriptors -> fusion."""
+    from oracle import features as OF, vit as OV
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state
+    from ovo_amd.entities.clip_generator import CLIPGenerator
+    spec = SPECS["tiny-clip"]
+    sd = random_state(spec, seed=6)
+    gen = CLIPGenerator({"embed_type": mode, "model_card": "tiny-clip", "mask_res": 80}, device=DEV, encoder=HipViT(spec, sd, device=DEV))
+    masks, img = _crop_fixture()
+    masks = masks[:-4]                                   # regular masks only (the reference raises on degenerate boxes)
+    got = gen.extract_clip(_t(img), _t(masks)).cpu().numpy()
+
+    def encode(x01):                                     # encode_image: preprocess to the model size, pooled + projected
+        b = torch.stack([OV.resize_normalize(torch.from_numpy(np.ascontiguousarray(im)), spec.image_size, spec.mean, spec.std, None, scale=1.0) for im in x01])
+        f = OV.vit_forward(sd, b, patch=spec.patch, heads=spec.heads, act=spec.act, rope=None, tokens=False).numpy()
+        return f / np.linalg.norm(f, axis=-1, keepdims=True)
+    crops = OF.mask_crops(masks, img, mode != "vanilla", 50, 80) / 255.0
+    if mode == "vanilla":
+        ref = encode(crops[:, :3])
+    else:
+        g = encode(img[None].astype(np.float32) / 255.0)
+        ref = OF.fuse_crop_descriptors(np.repeat(g, len(masks), 0), encode(crops[:, :3]), encode(crops[:, 3:]), mode, gen.w_masked, gen.w_global)
+    assert got.shape == ref.shape == (len(masks), spec.out_dim)
+    err = np.abs(got - ref).max()
+    print(f"{mode}: max |unit descriptor error| = {err:.2e}")
+    assert err < 1e-3 * max(1.0, (512 / spec.out_dim) ** 0.5 * 1.5)               # bf16 encoder vs fp32 oracle, as in test_gpu_encoder
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
