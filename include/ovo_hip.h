@@ -268,6 +268,15 @@ int ovo_feature_masks(const uint8_t *masks, int N, int H, int W, int gh, int gw,
 int ovo_stitch_tokens_t(const float *tokens, int tokens_per_crop, int t0, int d, int P, int nh, int nw, void *out,
                         int gpad, ovo_stream_t stream);
 
+/* ---- a18: remove_global_patch (textregion.py:31-50), off in OVO's configuration (clip_generator.py:46) -------
+ * The reference's patch_2_region_avg[t, n] = (1/|n|) sum_{t' in n} p_t . p_t' equals p_t . mean_{t' in n}(p_t'), so the
+ * T x T patch similarity is never formed:  ovo_unit_tokens -> unit tokens in both GEMM layouts (u_t bf16 [d, gpad],
+ * u bf16 [gpad, d]) from the stitched tokens x_t bf16 [d, gpad];  two ovo_gemm calls give r_t f32 [N, gpad];
+ * ovo_global_patch_filter clears, in weights bf16 [N, gpad] ({0,1}), every token column whose mean score inside its
+ * masks minus its mean score outside them is < th, and recounts cnt f32 [N]. */
+int ovo_unit_tokens(const void *x_t, int d, int G, int gpad, void *u_t, void *u, ovo_stream_t stream);
+int ovo_global_patch_filter(const float *r_t, void *weights, int N, int G, int gpad, float th, float *cnt, ovo_stream_t stream);
+
 /* rows of f32 [N, d] scaled by 1 / cnt[row] -> bf16 [N, d] (masked mean);  y = x / ||x||_2 per row (f32). */
 int ovo_scale_rows_bf16(const float *x, const float *cnt, int N, int d, void *y, ovo_stream_t stream);
 int ovo_l2_normalize_rows(const float *x, int64_t N, int d, float *y, ovo_stream_t stream);

@@ -234,3 +234,20 @@ def mask_crops(masks: np.ndarray, image: np.ndarray, also_bbox: bool, margin: in
     if not out:
         return np.zeros((0, 6 if also_bbox else 3, out_l, out_l), np.float32)
     return torch.stack(out).numpy().astype(np.float32)
+
+
+def remove_global_patch(x: np.ndarray, fmask: np.ndarray, th: float = 0.07) -> Tuple[np.ndarray, np.ndarray]:
+    """textregion.py:31-50, literally (with the [T, T] patch similarity).  x f32 [T, d] stitched tokens, fmask f32 [N, T]
+    -> (fmask with the "global" token columns cleared, the per-token difference score f32 [T])."""
+    import torch
+    xi = torch.from_numpy(np.asarray(x, np.float32))[None]
+    fm = torch.from_numpy(np.asarray(fmask, np.float32)).clone()
+    pf = (xi / xi.norm(dim=-1, keepdim=True))[0]
+    sim = pf @ pf.T
+    p2r = sim @ (fm > 0).float().T
+    avg = p2r / (fm > 0).sum(dim=-1)
+    belong = (avg * (fm > 0).float().T).sum(dim=-1) / ((fm > 0).sum(dim=0) + 1e-9)
+    outside = (avg * (fm == 0).float().T).sum(dim=-1) / ((fm == 0).sum(dim=0) + 1e-9)
+    diff = (belong - outside).float().numpy()
+    fm[:, torch.from_numpy(diff < th)] = 0
+    return fm.numpy(), diff

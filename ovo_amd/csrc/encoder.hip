@@ -8,6 +8,7 @@
 
 namespace {
 
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
 __device__ __forceinline__ uint16_t f2bf(float x) {
     const uint32_t u = __float_as_uint(x);
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
@@ -324,6 +325,56 @@ __global__ void __launch_bounds__(256) k_stitch_t(const float *__restrict__ toke
     }
 }
 
+// ---- a18: remove_global_patch (textregion.py:31-50) ----
+// k_unit_tokens: per token g the L2 norm over the d channels of x_t [d, gpad] (lanes run along g: coalesced), then the
+// unit token in BOTH layouts the two GEMMs of the score need: u_t [d, gpad] and u [gpad, d]; padding tokens are zero.
+__global__ void __launch_bounds__(256) k_unit_tokens(const uint16_t *__restrict__ x_t, int d, int G, int gpad, uint16_t *__restrict__ u_t,
+                                                     uint16_t *__restrict__ u) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= gpad) return;
+    float ss = 0.f;
+    if (g < G)
+        for (int c = 0; c < d; ++c) { const float v = bf2f(x_t[(long long)c * gpad + g]); ss = fmaf(v, v, ss); }
+    const float inv = g < G ? 1.0f / sqrtf(ss) : 0.f;
+    for (int c = 0; c < d; ++c) {
+        const uint16_t q = g < G ? f2bf(bf2f(x_t[(long long)c * gpad + g]) * inv) : (uint16_t)0;
+        u_t[(long long)c * gpad + g] = q;
+        u[(long long)g * d + c] = q;
+    }
+}
+
+// k_global_patch: r_t f32 [N, gpad] holds, per mask n and token g, cos(token g, mean unit token of mask n) -- the
+// reference's patch_2_region_avg without its T x T similarity matrix (sum_t' in n of p_g.p_t' = p_g . sum_t' p_t').
+// A token whose mean score over the masks it belongs to does not exceed its mean score over the others by `th` is a
+// "global" patch: its column is cleared in every mask.
+__global__ void __launch_bounds__(256) k_global_patch(const float *__restrict__ r_t, uint16_t *__restrict__ w, int N, int G, int gpad,
+                                                      float th) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    float belong = 0.f, outside = 0.f, nb = 0.f, no = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const bool in = w[(long long)n * gpad + g] != 0;
+        const float r = r_t[(long long)n * gpad + g];
+        belong += in ? r : r * 0.f;                    // r * 0 keeps a NaN score (empty mask: 0/0 in the reference) poisonous
+        outside += in ? r * 0.f : r;
+        nb += in ? 1.f : 0.f;
+        no += in ? 0.f : 1.f;
+    }
+    const float diff = belong / (nb + 1e-9f) - outside / (no + 1e-9f);
+    if (diff < th)
+        for (int n = 0; n < N; ++n) w[(long long)n * gpad + g] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_row_count(const uint16_t *__restrict__ w, int gpad, float *__restrict__ cnt) {
+    int local = 0;
+    for (int g = threadIdx.x; g < gpad; g += blockDim.x) local += w[(long long)blockIdx.x * gpad + g] != 0;
+    __shared__ int red[256];
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) cnt[blockIdx.x] = (float)red[0];
+}
+
 __global__ void __launch_bounds__(256) k_scale_rows(const float *__restrict__ x, const float *__restrict__ cnt, int N, int d,
                                                     uint16_t *__restrict__ y) {
     const long long total = (long long)N * d;
@@ -456,6 +507,23 @@ int ovo_stitch_tokens_t(const float *tokens, int tokens_per_crop, int t0, int d,
     OVO_REQUIRE(tokens_per_crop >= t0 + P * P && gpad >= P * P * nh * nw && gpad % 32 == 0, "bad token / grid shape");
     k_stitch_t<<<ovo_grid((long long)d * gpad, 256), 256, 0, (hipStream_t)stream>>>(tokens, tokens_per_crop, t0, d, P, nh, nw,
                                                                                    (uint16_t *)out, gpad);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_unit_tokens(const void *x_t, int d, int G, int gpad, void *u_t, void *u, ovo_stream_t stream) {
+    OVO_REQUIRE(x_t && u_t && u && d > 0 && G > 0 && gpad >= G, "bad argument");
+    k_unit_tokens<<<(gpad + 255) / 256, 256, 0, (hipStream_t)stream>>>((const uint16_t *)x_t, d, G, gpad, (uint16_t *)u_t, (uint16_t *)u);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_global_patch_filter(const float *r_t, void *weights, int N, int G, int gpad, float th, float *cnt, ovo_stream_t stream) {
+    OVO_REQUIRE(N >= 0 && G > 0 && gpad >= G, "bad shape");
+    if (N == 0) return OVO_OK;
+    OVO_REQUIRE(r_t && weights && cnt, "null pointer");
+    k_global_patch<<<(G + 255) / 256, 256, 0, (hipStream_t)stream>>>(r_t, (uint16_t *)weights, N, G, gpad, th);
+    k_row_count<<<N, 256, 0, (hipStream_t)stream>>>((const uint16_t *)weights, gpad, cnt);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

@@ -43,9 +43,8 @@ class PETextRegion(torch.nn.Module):
         super().__init__()
         if not model_card.startswith("PE"):
             raise NotImplementedError("Current TextRegion implementaion supports only PE models.")
-        if remove_global_patch:
-            raise NotImplementedError("remove_global_patch (textregion.py:31-50) is off in OVO's configuration "
-                                      "(clip_generator.py:46) and not built yet")
+        self.remove_global_patch = bool(remove_global_patch)
+        self.global_patch_threshold = float(global_patch_threshold)
         if upsample_times != 1 or mask_type != "soft":
             raise NotImplementedError("only upsample_times=1 / mask_type='soft' (the reference defaults)")
         self.vlm = model
@@ -126,6 +125,8 @@ class PETextRegion(torch.nn.Module):
         else:                                                     # single crop: x_input = tokens (no 0.5*global term)
             x_t.zero_()
             x_t[:, :p * p] = tok[0, t0:].t().to(torch.bfloat16)
+        if self.remove_global_patch and n > 0:
+            weights, cnt = self._remove_global_patch(x_t, weights, cnt, nh * nw * p * p if self.resize_method == "multi_resolution" else p * p)
         sums = _gemm(weights, x_t, None, torch.empty((n, d), dtype=torch.float32, device=tok.device))
         mean = torch.empty((n, d), dtype=torch.bfloat16, device=tok.device)
         L.check(lib.ovo_scale_rows_bf16(L.ptr(sums), L.ptr(cnt), n, d, L.ptr(mean), L.stream()))
@@ -134,6 +135,23 @@ class PETextRegion(torch.nn.Module):
             return out
         L.check(lib.ovo_l2_normalize_rows(L.ptr(out), n, self.out_dim, L.ptr(out), L.stream()))
         return out
+
+    def _remove_global_patch(self, x_t: torch.Tensor, weights: torch.Tensor, cnt: torch.Tensor, g: int):
+        """Reference: textregion.py:31-50.  Clears "global" token columns of the {0,1} weights and recounts.  The
+        reference's [T, T] patch similarity is folded away (include/ovo_hip.h, a18): two small MFMA GEMMs instead."""
+        lib = L.load()
+        d, gpad = x_t.shape
+        n = weights.shape[0]
+        u_t = torch.empty_like(x_t)
+        u = torch.empty((gpad, d), dtype=torch.bfloat16, device=x_t.device)
+        L.check(lib.ovo_unit_tokens(L.ptr(x_t), d, g, gpad, L.ptr(u_t), L.ptr(u), L.stream()))
+        sums = _gemm(weights, u_t, None, torch.empty((n, d), dtype=torch.float32, device=x_t.device))
+        mean = torch.empty((n, d), dtype=torch.bfloat16, device=x_t.device)
+        L.check(lib.ovo_scale_rows_bf16(L.ptr(sums), L.ptr(cnt), n, d, L.ptr(mean), L.stream()))
+        r_t = _gemm(mean, u, None, torch.empty((n, gpad), dtype=torch.float32, device=x_t.device))
+        weights, cnt = weights.clone(), torch.empty_like(cnt)     # get_features_mask's result stays usable by the caller
+        L.check(lib.ovo_global_patch_filter(L.ptr(r_t), L.ptr(weights), n, g, gpad, self.global_patch_threshold, L.ptr(cnt), L.stream()))
+        return weights, cnt
 
     def predict(self, image: torch.Tensor, region_masks: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
         """Reference: textregion.py:197-203.  image [3, H, W] in [0, 1] -> f32 [N, D] unit descriptors."""

@@ -239,3 +239,45 @@ def test_textregion_predict_vs_oracle(hw):
     print(f"textregion {hw}: max |unit descriptor error| = {err:.2e} ({int(empty.sum())} empty masks)")
     assert err < 3e-3 and out.shape == (masks.shape[0], spec.out_dim)
     np.testing.assert_allclose(np.linalg.norm(out[~empty], axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("th", [0.02, 0.07])
+def test_textregion_remove_global_patch_vs_oracle(th):
+    """a18 (textregion.py:31-50): the folded two-GEMM score must clear the same token columns as the literal T x T form."""
+    from oracle import features as OF, vit as OV
+    from ovo_amd import synthetic as syn
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state, rope_tables
+    from ovo_amd.entities.textregion import PETextRegion
+    spec = SPECS["tiny-pe"]
+    sd = random_state(spec, seed=4)
+    vit = HipViT(spec, sd, device=DEV)
+    tr = PETextRegion(vit, "PE-tiny-084", remove_global_patch=True, global_patch_threshold=th)
+    plain = PETextRegion(vit, "PE-tiny-084", remove_global_patch=False)
+    H, W = 170, 260
+    g = torch.Generator().manual_seed(8)
+    img = (torch.rand(3, H, W, generator=g) * 255).to(torch.uint8)
+    masks = syn.make_masks(H, W, grid=(2, 3), n_blobs=3, seed=6)
+    dm = torch.from_numpy(masks).to(DEV)
+    feats = tr.get_img_features(img.to(DEV), scale=1 / 255.0)
+    # the device's own stitched tokens (bf16) feed the oracle: the comparison isolates the filter, not the encoder
+    from ovo_amd import _lib as L
+    P, nh, nw, d = spec.grid, tr.crop_num_h, tr.crop_num_w, spec.width
+    G = P * P * nh * nw
+    gpad = (G + 31) // 32 * 32
+    x_t = torch.empty((d, gpad), dtype=torch.bfloat16, device=DEV)
+    L.check(L.load().ovo_stitch_tokens_t(L.ptr(feats), feats.shape[1], 1, d, P, nh, nw, L.ptr(x_t), gpad, L.stream()))
+    w0, c0 = tr.get_features_mask(dm)
+    w1, c1 = tr._remove_global_patch(x_t, w0, c0, G)
+    x = x_t.float().t()[:G].cpu().numpy()
+    fm0 = w0[:, :G].float().cpu().numpy()
+    fm_ref, diff = OF.remove_global_patch(x, fm0, th)
+    got = w1[:, :G].float().cpu().numpy()
+    sure = np.abs(diff - th) > 4e-3                   # bf16 unit tokens / means in the two GEMMs: ~1e-3 on a cosine
+    assert sure.mean() > 0.6 and (diff[sure] < th).any() and (diff[sure] >= th).any(), "fixture does not exercise both outcomes"
+    assert np.array_equal(got[:, sure], fm_ref[:, sure])
+    assert np.array_equal(c1.cpu().numpy(), got.sum(1)) and np.array_equal(w0[:, :G].float().cpu().numpy(), fm0)
+    # end to end: predict() with the filter == the plain pooling over the filtered weights
+    out = tr.predict(img.to(DEV), dm, scale=1 / 255.0)
+    plain._crops(H, W)                                   # sets the tiling state predict() would have set
+    ref = plain.pe_value_with_sam2_attn((w1, c1), feats)
+    assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(ref))
