@@ -53,9 +53,9 @@ def main():
     a = ap.parse_args()
     fetch_fix, write_fix, notes = 2.0, 1.0, {}
     if a.calib_fetch_dir:
-        f1, k1 = calib_factor(a.calib_fetch_dir, "FETCH_SIZE", r"k_similarity_mfma", (1 << 20) * 1024 * 4.0)
+        f1, k1 = calib_factor(a.calib_fetch_dir, "FETCH_SIZE", r"k_similarity_mfma", float(1 << 30))
         f2, k2 = calib_factor(a.calib_fetch_dir, "FETCH_SIZE", r"copy|Copy", float(1 << 30))
-        notes["fetch_calibration"] = {"ovo_similarity 4 GiB read": f1, "torch copy 1 GiB read": f2, "applied": fetch_fix}
+        notes["fetch_calibration"] = {"ovo_similarity 1 GiB read": f1, "torch copy 1 GiB read": f2, "applied": fetch_fix}
     if a.calib_write_dir:
         w1, _ = calib_factor(a.calib_write_dir, "WRITE_SIZE", r"fill|Fill", float(1 << 30))
         w2, _ = calib_factor(a.calib_write_dir, "WRITE_SIZE", r"copy|Copy", float(1 << 30))
