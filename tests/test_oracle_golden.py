@@ -133,3 +133,24 @@ def test_query_and_classify():
     cls, conf = OF.classify(d["sim_ensemble"], float(d["th"]))
     assert np.array_equal(cls, d["classes"])
     np.testing.assert_allclose(conf, d["conf"], atol=0, rtol=0)
+
+
+def test_sam2_decoder_vs_hf_golden():
+    """oracle/sam2_decoder.py (prompt encoder + two-way transformer + hyper-network heads) against HuggingFace's
+    Sam2PromptEncoder / Sam2MaskDecoder on the same random weights (tools/gen_hf_sam2_decoder.py)."""
+    import torch
+    from oracle import sam2_decoder as SD
+    d = golden("hf_sam2_decoder")
+    sd = SD.hf_sam2_decoder_to_sam2({k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")})
+    size = int(d["image_size"])
+    sparse = SD.embed_points(sd, torch.from_numpy(d["points"]), torch.from_numpy(d["labels"]), size)
+    np.testing.assert_allclose(sparse.numpy(), d["sparse"], atol=2e-6, rtol=0)
+    s = d["embed"].shape[-1]
+    ipe = SD.image_pe(sd, s).t().reshape(-1, s, s)
+    np.testing.assert_allclose(ipe.numpy(), d["image_pe"], atol=2e-6, rtol=0)
+    masks, iou, obj = SD.mask_decoder(sd, torch.from_numpy(d["embed"]), torch.from_numpy(d["feat_s1"]), torch.from_numpy(d["feat_s0"]),
+                                      sparse, heads=int(d["heads"]), multimask=True)
+    scale = np.abs(d["masks_multi"]).max()
+    assert np.abs(masks.numpy() - d["masks_multi"]).max() < 2e-5 * max(scale, 1.0)
+    np.testing.assert_allclose(iou.numpy(), d["iou_multi"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(obj.numpy(), d["obj_multi"], atol=1e-5, rtol=0)
