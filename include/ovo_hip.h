@@ -186,7 +186,7 @@ int ovo_mask_area(const uint8_t *masks, int64_t pixels, const int32_t *rows, int
 
 /* C[M,N] = act(alpha * A[M,K] . W[N,K]^T + bias[N]) + add[M,N]      (nn.Linear layout: W is [out, in])
  *   in_dtype : 1 = f16, 2 = bf16 (A and W);  out_dtype: 0 = f32, 1 = f16, 2 = bf16
- *   act      : 0 none, 1 GELU (erf), 2 QuickGELU x*sigmoid(1.702x)      (open_clip "-qg" cards)
+ *   act      : 0 none, 1 GELU (erf), 2 QuickGELU x*sigmoid(1.702x) (open_clip "-qg" cards), 3 ReLU, 4 sigmoid (SAM2 decoder)
  *   add      : optional f32 [M,N] (residual stream / position embedding); may alias C when out_dtype = 0
  *   K % 32 == 0, N % 4 == 0, lda/ldw multiples of 8 elements, 16-byte aligned bases. */
 typedef struct {
@@ -364,6 +364,28 @@ size_t ovo_hiera_workspace_bytes(const ovo_hiera_config_t *cfg, int B);
 /* images f32 [B, 3, S, S], already resized + normalised. */
 int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *w, const float *images, int B,
                       float *feat0, float *feat1, float *feat2, void *ws, size_t ws_bytes, ovo_stream_t stream);
+
+/* =============================================================================================
+ * f1: SAM2 mask decoder (the reference reaches it through sam2.automatic_mask_generator, segment_utils.py:291-308,
+ * mask_generator.py:113).  Its matrix products are ovo_gemm / ovo_attention calls; these are the passes between them.
+ * ============================================================================================= */
+
+/* One pass over R rows of C channels (C % 4 == 0, C <= 1024):  v = x[r] (+ base[r % base_rows]);  if gamma: v = LN(v);
+ * then any of  y f32[R,C] (may alias x),  y16 bf16[R,C],  ype16 bf16[R,C] = v + pe[r % pe_rows]  (NULL = skip).
+ * This is every LayerNorm / residual / "+ positional code" / cast of the two-way transformer. */
+int ovo_row_epilogue(const float *x, int64_t R, int C, const float *base, int64_t base_rows, const float *gamma, const float *beta,
+                     float eps, const float *pe, int64_t pe_rows, float *y, void *y16, void *ype16, ovo_stream_t stream);
+
+/* Upscaling stage 1: g bf16 [P*s*s, 4*C1] = embedding . W^T of ConvTranspose2d(C, C1, 2, stride 2) with GEMM column
+ * (dy*2 + dx)*C1 + c;  out bf16 [P, 2s, 2s, C1] = GELU(LayerNorm2d(pixel_shuffle(g) + bias + feat))), feat f32 [2s, 2s, C1]. */
+int ovo_sam_upscale_ln(const void *g, const float *bias, const float *feat, const float *gamma, const float *beta, float eps,
+                       int64_t P, int s, int C1, void *out, ovo_stream_t stream);
+
+/* Upscaling stage 2 fused with the hyper-network product: g bf16 [P*s2*s2, 4*C2] (same column order), feat f32 [2 s2, 2 s2, C2],
+ * hyper f32 [P, n_mask, C2]  ->  out f32 [P, n_mask - first, 2 s2, 2 s2],  out[p,i] = sum_c hyper[p, first+i, c] *
+ * GELU(pixel_shuffle(g) + bias + feat)[c]  (the 1 GB upscaled embedding of 256 prompts is never written). */
+int ovo_sam_upscale_masks(const void *g, const float *bias, const float *feat, const float *hyper, int n_mask, int first, int64_t P,
+                          int s2, int C2, float *out, ovo_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,8 @@ def mask_decoder(sd: Dict[str, torch.Tensor], image_embed: torch.Tensor, feat_s1
     n_mask = sd[MD + "mask_tokens.weight"].shape[0]
     tokens = torch.cat([out_tok[None].expand(p, -1, -1), sparse], dim=1)
     dense = sd[PE + "no_mask_embed.weight"].reshape(c, 1, 1)
+    if "no_mem_embed" in sd:                                     # SAM2ImagePredictor.set_image adds it to the coarsest feature [upstream-knowledge]
+        dense = dense + sd["no_mem_embed"].reshape(c, 1, 1)
     keys = (image_embed + dense).reshape(c, s * s).t()[None].expand(p, -1, -1)
     q, keys = two_way_transformer(sd, tokens, keys, image_pe(sd, s), heads)
     iou_tok, mask_tok = q[:, 1], q[:, 2:2 + n_mask]

@@ -92,6 +92,12 @@ __device__ __forceinline__ void act4(float *v, int act) {
     } else if (act == 2) {                                       // QuickGELU x * sigmoid(1.702 x)   (open_clip "-qg" cards)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+    } else if (act == 3) {                                       // ReLU (SAM2 decoder MLPs)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    } else if (act == 4) {                                       // sigmoid (SAM2 IoU head)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + __expf(-v[r]));
     }
 }
 

@@ -1,0 +1,209 @@
+// samdec.hip -- glue kernels of the SAM2 mask decoder.  The matrix products of the decoder run on
+// ovo_gemm / ovo_attention; this file holds what sits between them:
+//   * k_row_epilogue  : [+ broadcast base] -> [LayerNorm] -> f32 / bf16 / bf16(+ positional code) copies, one pass
+//   * k_upscale_ln    : ConvTranspose2d(2x2, stride 2) as GEMM -> pixel shuffle + bias + skip feature + LayerNorm2d + GELU
+//   * k_upscale_masks : second ConvTranspose2d + skip + GELU fused with the hyper-network product -> mask logits
+// All tensors are token-major (NHWC): the image embedding of the encoder is consumed as it is produced.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f2bf(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+    return make_uint2((uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16), (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16));
+}
+// GELU (erf form) with the polynomial erf of gemm.hip (|error| <= 8.6e-6 absolute)
+__device__ __forceinline__ float gelu_poly(float x) {
+    const float z = x * 0.70710678118654752f;
+    const float zc = fminf(fmaxf(z, -3.5f), 3.5f);
+    const float s = fmaf(zc * zc, 0.16326530612244897f, -1.0f);
+    float p = -3.398861796e-03f;
+    p = fmaf(p, s, 8.621919328e-03f); p = fmaf(p, s, -8.698635955e-03f); p = fmaf(p, s, 1.271555869e-02f);
+    p = fmaf(p, s, -2.870869786e-02f); p = fmaf(p, s, 4.709060027e-02f); p = fmaf(p, s, -6.528488840e-02f);
+    p = fmaf(p, s, 8.795614477e-02f); p = fmaf(p, s, -1.145324569e-01f); p = fmaf(p, s, 1.467849556e-01f);
+    p = fmaf(p, s, -2.007044758e-01f); p = fmaf(p, s, 4.038725490e-01f);
+    const float hx = 0.5f * x;
+    return fmaf(hx, p * zc, hx);
+}
+
+// ---- one wave per row of C <= 1024 channels (C % 4 == 0) ----
+struct RowArgs {
+    const float *x; const float *base; long long base_rows;
+    const float *gamma, *beta; float eps;
+    const float *pe; long long pe_rows;
+    float *y; uint16_t *y16; uint16_t *ype16;
+    long long R; int C;
+};
+__global__ void __launch_bounds__(256) k_row_epilogue(RowArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long waves = (long long)gridDim.x * 4;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < a.R; r += waves) {
+        float4 v[4];
+        const int nv = (a.C + 255) / 256;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < nv && c < a.C) {
+                v[i] = *(const float4 *)(a.x + r * a.C + c);
+                if (a.base) {
+                    const float4 b = *(const float4 *)(a.base + (r % a.base_rows) * a.C + c);
+                    v[i].x += b.x; v[i].y += b.y; v[i].z += b.z; v[i].w += b.w;
+                }
+                sum += v[i].x + v[i].y + v[i].z + v[i].w;
+            }
+        }
+        if (a.gamma) {
+            const float mean = wave_sum(sum) / (float)a.C;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (i < nv && c < a.C) {
+                    const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+                    sq += dx * dx + dy * dy + dz * dz + dw * dw;
+                }
+            }
+            const float rstd = rsqrtf(wave_sum(sq) / (float)a.C + a.eps);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (i < nv && c < a.C) {
+                    const float4 g = *(const float4 *)(a.gamma + c), b = *(const float4 *)(a.beta + c);
+                    v[i].x = (v[i].x - mean) * rstd * g.x + b.x; v[i].y = (v[i].y - mean) * rstd * g.y + b.y;
+                    v[i].z = (v[i].z - mean) * rstd * g.z + b.z; v[i].w = (v[i].w - mean) * rstd * g.w + b.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (i < nv && c < a.C) {
+                if (a.y) *(float4 *)(a.y + r * a.C + c) = v[i];
+                if (a.y16) *(uint2 *)(a.y16 + r * a.C + c) = pack4(v[i].x, v[i].y, v[i].z, v[i].w);
+                if (a.ype16) {
+                    const float4 p = *(const float4 *)(a.pe + (r % a.pe_rows) * a.C + c);
+                    *(uint2 *)(a.ype16 + r * a.C + c) = pack4(v[i].x + p.x, v[i].y + p.y, v[i].z + p.z, v[i].w + p.w);
+                }
+            }
+        }
+    }
+}
+
+// ---- upscale stage 1: g bf16 [P * s * s, 4 * C1] with column = (dy * 2 + dx) * C1 + c  ->  out bf16 [P, 2s, 2s, C1] ----
+// LPP lanes per output pixel, 4 channels per lane (C1 = 4 * LPP)
+template <int LPP>
+__global__ void __launch_bounds__(256) k_upscale_ln(const uint16_t *__restrict__ g, const float *__restrict__ bias, const float *__restrict__ feat,
+                                                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps, long long P, int s,
+                                                    uint16_t *__restrict__ out) {
+    constexpr int C1 = 4 * LPP, PPB = 256 / LPP;
+    const int sub = threadIdx.x % LPP;
+    const long long pix = (long long)blockIdx.x * PPB + threadIdx.x / LPP, side = 2 * s, total = P * side * side;
+    if (pix >= total) return;
+    const long long p = pix / (side * side);
+    const int rem = (int)(pix % (side * side)), y = rem / (int)side, x = rem % (int)side;
+    const long long row = p * s * s + (long long)(y >> 1) * s + (x >> 1);
+    const int col = (((y & 1) << 1) | (x & 1)) * C1 + sub * 4;
+    const uint2 raw = *(const uint2 *)(g + row * (4 * C1) + col);
+    const float4 b = *(const float4 *)(bias + sub * 4), f = *(const float4 *)(feat + (long long)rem * C1 + sub * 4);
+    float v0 = bf2f((uint16_t)(raw.x & 0xffff)) + b.x + f.x, v1 = bf2f((uint16_t)(raw.x >> 16)) + b.y + f.y;
+    float v2 = bf2f((uint16_t)(raw.y & 0xffff)) + b.z + f.z, v3 = bf2f((uint16_t)(raw.y >> 16)) + b.w + f.w;
+    float sum = v0 + v1 + v2 + v3;
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)C1;
+    const float d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean;
+    float sq = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = rsqrtf(sq / (float)C1 + eps);
+    const float4 gm = *(const float4 *)(gamma + sub * 4), bt = *(const float4 *)(beta + sub * 4);
+    *(uint2 *)(out + pix * C1 + sub * 4) = pack4(gelu_poly(d0 * rstd * gm.x + bt.x), gelu_poly(d1 * rstd * gm.y + bt.y),
+                                                 gelu_poly(d2 * rstd * gm.z + bt.z), gelu_poly(d3 * rstd * gm.w + bt.w));
+}
+
+// ---- upscale stage 2 + hyper-network product: g bf16 [P * s2 * s2, 4 * C2]  ->  masks f32 [P, n_out, 2 s2, 2 s2] ----
+// one thread per output pixel; the prompt's n_out x C2 hyper-network rows sit in LDS (blockIdx.y = prompt)
+__global__ void __launch_bounds__(256) k_upscale_masks(const uint16_t *__restrict__ g, const float *__restrict__ bias, const float *__restrict__ feat,
+                                                       const float *__restrict__ hyper, int n_mask, int first, int n_out, int s2, int C2,
+                                                       float *__restrict__ out) {
+    extern __shared__ float sh[];                                // [n_out][C2] hyper rows, then [C2] bias
+    const long long p = blockIdx.y;
+    for (int i = threadIdx.x; i < n_out * C2; i += blockDim.x) sh[i] = hyper[(p * n_mask + first) * C2 + i];
+    for (int i = threadIdx.x; i < C2; i += blockDim.x) sh[n_out * C2 + i] = bias[i];
+    __syncthreads();
+    const int side = 2 * s2;
+    const int rem = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rem >= side * side) return;
+    const int y = rem / side, x = rem % side;
+    const long long row = p * s2 * s2 + (long long)(y >> 1) * s2 + (x >> 1);
+    const uint16_t *src = g + row * (4 * C2) + (((y & 1) << 1) | (x & 1)) * C2;
+    const float *ft = feat + (long long)rem * C2;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C2; c += 4) {
+        const uint2 raw = *(const uint2 *)(src + c);
+        const float4 f = *(const float4 *)(ft + c);
+        const float *bs = sh + n_out * C2 + c;
+        const float v0 = gelu_poly(bf2f((uint16_t)(raw.x & 0xffff)) + bs[0] + f.x), v1 = gelu_poly(bf2f((uint16_t)(raw.x >> 16)) + bs[1] + f.y);
+        const float v2 = gelu_poly(bf2f((uint16_t)(raw.y & 0xffff)) + bs[2] + f.z), v3 = gelu_poly(bf2f((uint16_t)(raw.y >> 16)) + bs[3] + f.w);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n_out) {
+                const float *h = sh + i * C2 + c;
+                acc[i] = fmaf(h[0], v0, fmaf(h[1], v1, fmaf(h[2], v2, fmaf(h[3], v3, acc[i]))));
+            }
+    }
+    for (int i = 0; i < n_out; ++i) out[((p * n_out + i) * side + y) * side + x] = acc[i];
+}
+
+}  // namespace
+
+extern "C" int ovo_row_epilogue(const float *x, int64_t R, int C, const float *base, int64_t base_rows, const float *gamma,
+                                const float *beta, float eps, const float *pe, int64_t pe_rows, float *y, void *y16, void *ype16,
+                                ovo_stream_t stream) {
+    OVO_REQUIRE(R >= 0 && C > 0 && C % 4 == 0 && C <= 1024, "C must be a multiple of 4, <= 1024");
+    if (R == 0) return OVO_OK;
+    OVO_REQUIRE(x && (y || y16 || ype16), "null pointer");
+    OVO_REQUIRE((gamma == nullptr) == (beta == nullptr), "gamma and beta go together");
+    OVO_REQUIRE((!base || base_rows > 0) && (!ype16 || (pe && pe_rows > 0)), "broadcast sources need their row counts");
+    RowArgs a;
+    a.x = x; a.base = base; a.base_rows = base_rows; a.gamma = gamma; a.beta = beta; a.eps = eps; a.pe = pe; a.pe_rows = pe_rows;
+    a.y = y; a.y16 = (uint16_t *)y16; a.ype16 = (uint16_t *)ype16; a.R = R; a.C = C;
+    k_row_epilogue<<<ovo_grid(R, 4, 256 * 16), 256, 0, (hipStream_t)stream>>>(a);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+extern "C" int ovo_sam_upscale_ln(const void *g, const float *bias, const float *feat, const float *gamma, const float *beta, float eps,
+                                  int64_t P, int s, int C1, void *out, ovo_stream_t stream) {
+    OVO_REQUIRE(P >= 0 && s > 0, "bad shape");
+    OVO_REQUIRE(C1 == 16 || C1 == 32 || C1 == 64 || C1 == 128 || C1 == 256, "C1 must be 16, 32, 64, 128 or 256");
+    if (P == 0) return OVO_OK;
+    OVO_REQUIRE(g && bias && feat && gamma && beta && out, "null pointer");
+    const long long total = P * 4LL * s * s;
+    hipStream_t st = (hipStream_t)stream;
+#define GO(L) k_upscale_ln<L><<<(unsigned)((total + 256 / L - 1) / (256 / L)), 256, 0, st>>>((const uint16_t *)g, bias, feat, gamma, beta, eps, P, s, (uint16_t *)out)
+    if (C1 == 16) GO(4); else if (C1 == 32) GO(8); else if (C1 == 64) GO(16); else if (C1 == 128) GO(32); else GO(64);
+#undef GO
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+extern "C" int ovo_sam_upscale_masks(const void *g, const float *bias, const float *feat, const float *hyper, int n_mask, int first,
+                                     int64_t P, int s2, int C2, float *out, ovo_stream_t stream) {
+    OVO_REQUIRE(P >= 0 && P <= 65535 && s2 > 0 && C2 > 0 && C2 % 4 == 0 && C2 <= 256, "bad shape");
+    OVO_REQUIRE(n_mask > 0 && first >= 0 && first < n_mask && n_mask - first <= 4, "at most 4 mask tokens");
+    if (P == 0) return OVO_OK;
+    OVO_REQUIRE(g && bias && feat && hyper && out, "null pointer");
+    const int n_out = n_mask - first, side = 2 * s2;
+    dim3 grid((side * side + 255) / 256, (unsigned)P);
+    k_upscale_masks<<<grid, 256, (size_t)(n_out + 1) * C2 * sizeof(float), (hipStream_t)stream>>>((const uint16_t *)g, bias, feat, hyper, n_mask,
+                                                                                                  first, n_out, s2, C2, out);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
