@@ -387,6 +387,19 @@ int ovo_sam_upscale_ln(const void *g, const float *bias, const float *feat, cons
 int ovo_sam_upscale_masks(const void *g, const float *bias, const float *feat, const float *hyper, int n_mask, int first, int64_t P,
                           int s2, int C2, float *out, ovo_stream_t stream);
 
+/* Automatic-mask-generator filters on the low-resolution logits f32 [n, h, w], evaluated on their H x W bilinear
+ * upsampling (torch F.interpolate, align_corners = False) without materialising it:
+ * ovo_amg_mask_stats: stats i32 [n, 7] = {#(v > thr + offset), #(v > thr - offset), #(v > thr), x_min, y_min, x_max, y_max}
+ *   (stability score = stats[0] / stats[1]; the box is that of the binary mask v > thr; empty -> W, H, -1, -1).
+ * ovo_amg_binarize: out u8 [n_sel, H, W] = upsampled logits[sel[k]] > thr. */
+int ovo_amg_mask_stats(const float *logits, int n, int h, int w, int H, int W, float thr, float offset, int32_t *stats,
+                       ovo_stream_t stream);
+int ovo_amg_binarize(const float *logits, const int32_t *sel, int n_sel, int h, int w, int H, int W, float thr, uint8_t *out,
+                     ovo_stream_t stream);
+/* mask2segmap's painting (segment_utils.py:12-27) for masks already in descending-stability order:
+ * seg i32 [pixels] = index of the first mask u8 [n, pixels] covering the pixel, -1 if none. */
+int ovo_paint_segmap(const uint8_t *masks, int n, int64_t pixels, int32_t *seg, ovo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

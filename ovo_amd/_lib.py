@@ -132,6 +132,9 @@ _SIGNATURES = {
     "ovo_row_epilogue": (_I32, [_P, _I64, _I32, _P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _P]),
     "ovo_sam_upscale_ln": (_I32, [_P, _P, _P, _P, _P, _F32, _I64, _I32, _I32, _P, _P]),
     "ovo_sam_upscale_masks": (_I32, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _P, _P]),
+    "ovo_paint_segmap": (_I32, [_P, _I32, _I64, _P, _P]),
+    "ovo_amg_mask_stats": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _F32, _F32, _P, _P]),
+    "ovo_amg_binarize": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _F32, _P, _P]),
     "ovo_vit_workspace_bytes": (_SZ, [C.POINTER(VitConfig), _I32]),
     "ovo_vit_forward": (_I32, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _I32, _P, _P, _SZ, _P]),
     "ovo_hiera_workspace_bytes": (_SZ, [C.POINTER(HieraConfig), _I32]),

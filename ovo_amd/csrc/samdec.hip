@@ -161,7 +161,104 @@ __global__ void __launch_bounds__(256) k_upscale_masks(const uint16_t *__restric
     for (int i = 0; i < n_out; ++i) out[((p * n_out + i) * side + y) * side + x] = acc[i];
 }
 
+// ---- automatic mask generator: low-res logits -> full-resolution statistics / binary masks ----
+// value of the H x W bilinear upsampling (torch upsample_bilinear2d, align_corners = False) of one h x w logit map
+__device__ __forceinline__ float up_sample(const float *__restrict__ m, int h, int w, float sy, float sx, int Y, int X) {
+    float fy = sy * ((float)Y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+    float fx = sx * ((float)X + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    return (1.f - ly) * ((1.f - lx) * m[y0 * w + x0] + lx * m[y0 * w + x1]) + ly * ((1.f - lx) * m[y1 * w + x0] + lx * m[y1 * w + x1]);
+}
+
+__global__ void k_amg_init(int32_t *__restrict__ stats, int n, int H, int W) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t *s = stats + 7 * i;
+    s[0] = s[1] = s[2] = 0; s[3] = W; s[4] = H; s[5] = -1; s[6] = -1;
+}
+
+// stats[i] = {#(v > thr + off), #(v > thr - off), #(v > thr), x_min, y_min, x_max, y_max of (v > thr)} over the H x W upsampling
+__global__ void __launch_bounds__(256) k_amg_stats(const float *__restrict__ logits, int h, int w, int H, int W, float thr, float off,
+                                                   int32_t *__restrict__ stats) {
+    const float *m = logits + (long long)blockIdx.y * h * w;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    int hi = 0, lo = 0, ar = 0, x0 = W, y0 = H, x1 = -1, y1 = -1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+        const int Y = i / W, X = i - Y * W;
+        const float v = up_sample(m, h, w, sy, sx, Y, X);
+        hi += v > thr + off; lo += v > thr - off;
+        if (v > thr) { ++ar; x0 = X < x0 ? X : x0; x1 = X > x1 ? X : x1; y0 = Y < y0 ? Y : y0; y1 = Y > y1 ? Y : y1; }
+    }
+    __shared__ int sh[7];
+    if (threadIdx.x == 0) { sh[0] = sh[1] = sh[2] = 0; sh[3] = W; sh[4] = H; sh[5] = -1; sh[6] = -1; }
+    __syncthreads();
+    if (lo) { atomicAdd(&sh[0], hi); atomicAdd(&sh[1], lo); }
+    if (ar) { atomicAdd(&sh[2], ar); atomicMin(&sh[3], x0); atomicMin(&sh[4], y0); atomicMax(&sh[5], x1); atomicMax(&sh[6], y1); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t *s = stats + 7 * blockIdx.y;
+        if (sh[1]) { atomicAdd(&s[0], sh[0]); atomicAdd(&s[1], sh[1]); }
+        if (sh[2]) { atomicAdd(&s[2], sh[2]); atomicMin(&s[3], sh[3]); atomicMin(&s[4], sh[4]); atomicMax(&s[5], sh[5]); atomicMax(&s[6], sh[6]); }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_amg_binarize(const float *__restrict__ logits, const int32_t *__restrict__ sel, int h, int w, int H, int W,
+                                                      float thr, uint8_t *__restrict__ out) {
+    const float *m = logits + (long long)sel[blockIdx.y] * h * w;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    uint8_t *o = out + (long long)blockIdx.y * H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+        const int Y = i / W, X = i - Y * W;
+        o[i] = up_sample(m, h, w, sy, sx, Y, X) > thr;
+    }
+}
+
+// seg[p] = first mask (in the given order) that covers pixel p, -1 if none: mask2segmap's "most stable mask wins" painting
+__global__ void __launch_bounds__(256) k_paint_segmap(const uint8_t *__restrict__ masks, int n, long long pixels, int32_t *__restrict__ seg) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (long long)gridDim.x * blockDim.x) {
+        int id = -1;
+        for (int i = 0; i < n; ++i)
+            if (masks[i * pixels + p]) { id = i; break; }
+        seg[p] = id;
+    }
+}
+
 }  // namespace
+
+extern "C" int ovo_paint_segmap(const uint8_t *masks, int n, int64_t pixels, int32_t *seg, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && pixels > 0 && seg && (n == 0 || masks), "bad argument");
+    k_paint_segmap<<<ovo_grid(pixels, 256), 256, 0, (hipStream_t)stream>>>(masks, n, pixels, seg);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+extern "C" int ovo_amg_mask_stats(const float *logits, int n, int h, int w, int H, int W, float thr, float offset, int32_t *stats,
+                                  ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && n <= 65535 && h > 0 && w > 0 && H > 0 && W > 0, "bad shape");
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(logits && stats, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    k_amg_init<<<(n + 255) / 256, 256, 0, st>>>(stats, n, H, W);
+    int bx = (H * W + 256 * 16 - 1) / (256 * 16);
+    bx = bx < 1 ? 1 : bx;
+    k_amg_stats<<<dim3(bx, n), 256, 0, st>>>(logits, h, w, H, W, thr, offset, stats);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+extern "C" int ovo_amg_binarize(const float *logits, const int32_t *sel, int n_sel, int h, int w, int H, int W, float thr, uint8_t *out,
+                                ovo_stream_t stream) {
+    OVO_REQUIRE(n_sel >= 0 && n_sel <= 65535 && h > 0 && w > 0 && H > 0 && W > 0, "bad shape");
+    if (n_sel == 0) return OVO_OK;
+    OVO_REQUIRE(logits && sel && out, "null pointer");
+    int bx = (H * W + 256 * 8 - 1) / (256 * 8);
+    bx = bx < 1 ? 1 : bx;
+    k_amg_binarize<<<dim3(bx, n_sel), 256, 0, (hipStream_t)stream>>>(logits, sel, h, w, H, W, thr, out);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
 
 extern "C" int ovo_row_epilogue(const float *x, int64_t R, int C, const float *base, int64_t base_rows, const float *gamma,
                                 const float *beta, float eps, const float *pe, int64_t pe_rows, float *y, void *y16, void *ype16,

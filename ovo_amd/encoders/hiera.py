@@ -78,6 +78,8 @@ SPECS: Dict[str, HieraSpec] = {
     "hiera_b+": HieraSpec("hiera_b+", 112, 2, (2, 3, 16, 3), (12, 16, 20), (8, 4, 14, 7), (14, 14)),
     "hiera_l": HieraSpec("hiera_l", 144, 2, (2, 6, 36, 4), (23, 33, 43), (8, 4, 16, 8), (7, 7)),
     "hiera_test": HieraSpec("hiera_test", 32, 1, (1, 2, 3, 2), (4,), (8, 4, 6, 4), (5, 5), image_size=256, fpn_dim=64),
+    # small trunk with the real FPN width: pairs with the SAM2 mask decoder (sam_decoder.SPECS["sam2_small"]) in tests
+    "hiera_test256": HieraSpec("hiera_test256", 32, 1, (1, 2, 3, 2), (4,), (8, 4, 6, 4), (5, 5), image_size=256, fpn_dim=256),
 }
 
 

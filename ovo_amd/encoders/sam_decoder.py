@@ -41,6 +41,7 @@ class SamDecoderSpec:
 
 SPECS: Dict[str, SamDecoderSpec] = {
     "sam2": SamDecoderSpec("sam2"),
+    "sam2_small": SamDecoderSpec("sam2_small", mlp_dim=512, embed_size=16, image_size=256),      # real widths, 256^2 input
     "sam2_test": SamDecoderSpec("sam2_test", hidden=128, heads=4, mlp_dim=256, embed_size=16, image_size=256, iou_hidden=128),
 }
 

@@ -3,13 +3,12 @@
 Mirror of the reference's `ovo/entities/mask_generator.py:MaskGenerator` (same constructor, `get_masks`,
 `segment`, `precompute`, `.npy` cache names -- SURVEY.md §8b).
 
-Scope: the SAM2 *image encoder* (Hiera trunk + FPN neck, where the FLOPs are) runs
-on the GPU through `ovo_amd.encoders.hiera.HipHiera`.  The prompt encoder, mask decoder and the
-automatic-mask-generator post-processing are the next row (f1); until they exist the masks themselves come
-from the reference's own precomputed-mask seam (mask_generator.py:94-95,170-195: `sam.precomputed: True` +
-`.npy` files) or from an injected `mask_source(image, image_embeddings) -> list[dict]` producing SAM-style
-mask dicts (`segmentation`, `predicted_iou`, `stability_score`), which then go through the same NMS and
-seg-map painting as the reference (mask_generator.py:118-119).
+Scope (SURVEY.md §8 a10 + f1): the SAM2 image encoder (`ovo_amd.encoders.hiera.HipHiera`), the prompt encoder + mask
+decoder (`ovo_amd.encoders.sam_decoder.HipSamDecoder`) and the automatic mask generator
+(`ovo_amd.entities.sam_amg.HipSam2AutomaticMaskGenerator`) all run on the GPU; the masks go through the same NMS and
+seg-map painting as the reference (mask_generator.py:118-119) without leaving HBM.  Masks can still come from the
+reference's precomputed-mask seam (mask_generator.py:94-95,170-195: `sam.precomputed: True` + `.npy` files) or from an
+injected `mask_source(image, image_embeddings) -> list[dict]` of SAM-style mask dicts.
 """
 from __future__ import annotations
 
@@ -47,12 +46,25 @@ class MaskGenerator:
             self.load_mask_generator(config)
 
     def load_mask_generator(self, config: Dict[str, Any]) -> None:
-        """Reference: mask_generator.py:39-53 (loads SAM/SAM2 and warms it up).  Here: the Hiera image encoder."""
+        """Reference: mask_generator.py:39-53 + segment_utils.py:262-308 (loads SAM2 and builds its automatic mask
+        generator with points_per_side / pred_iou_thresh (sic: `nms_iou_th`) / stability_score_thresh from the config).
+        Here: Hiera image encoder + mask decoder + generator, all on the GPU (random-init unless `sam_ckpt_state` /
+        a state dict is supplied -- there are no checkpoints offline)."""
         from ..encoders.hiera import SPECS, HipHiera
+        from ..encoders.sam_decoder import SPECS as DSPECS, HipSamDecoder
+        from .sam_amg import HipSam2AutomaticMaskGenerator
         enc = config.get("sam_encoder", "hiera_l")
         if enc not in SPECS:
             raise NotImplementedError(f"sam_encoder {enc}: supported here: {sorted(SPECS)} (SAM1 ViT encoders are not built)")
-        self.image_encoder = HipHiera(SPECS[enc], None, device=self.device, seed=config.get("seed", 0))
+        state = config.get("sam_state")                           # optional sam2-style state dict (trunk.*, neck.*, sam_mask_decoder.*, ...)
+        if self.image_encoder is None:
+            self.image_encoder = HipHiera(SPECS[enc], state, device=self.device, seed=config.get("seed", 0))
+        dspec = DSPECS[config.get("sam_decoder", "sam2")]
+        decoder = HipSamDecoder(dspec, state, device=self.device, seed=config.get("seed", 0))
+        self.mask_generator = HipSam2AutomaticMaskGenerator(
+            self.image_encoder, decoder, points_per_side=config.get("points_per_side", 32),
+            pred_iou_thresh=config.get("nms_iou_th", 0.8), stability_score_thresh=config.get("stability_score_th", 0.95),
+            min_mask_region_area=config.get("min_mask_region_area", 0), use_m2m=config.get("use_m2m", False))
 
     def to(self, device: str) -> None:
         self.device = device
@@ -67,11 +79,13 @@ class MaskGenerator:
     def get_masks(self, image: np.ndarray, frame_id: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Reference: mask_generator.py:81-99 -> (seg_map i32[H,W], binary_maps bool[N,H,W]) on the device;
         two empty tensors when nothing was segmented."""
+        dev = "cuda" if self.device == "cpu" else self.device
         if self.precomputed:
             seg_map, binary_maps = self._load_masks(frame_id)
+        elif self.mask_source is None:                            # native generator: the masks never leave the GPU
+            return self.segment_device(image)
         else:
             seg_map, binary_maps = self.segment(image)
-        dev = "cuda" if self.device == "cpu" else self.device
         return torch.from_numpy(seg_map).to(dev), torch.from_numpy(binary_maps).to(dev)
 
     @torch.no_grad()
@@ -83,12 +97,28 @@ class MaskGenerator:
         return self.last_embeddings
 
     @torch.no_grad()
+    def segment_device(self, image) -> Tuple[torch.Tensor, torch.Tensor]:
+        """`segment` with every stage on the GPU: generator -> masks_update (NMS) -> mask2segmap."""
+        if self.mask_generator is None:
+            self.load_mask_generator(self.config)
+        r = self.mask_generator.generate_device(image)
+        self.last_embeddings = self.mask_generator.last_embeddings
+        masks = r["masks"]
+        dev = masks.device
+        if masks.shape[0] == 0:
+            return torch.empty(0, device=dev), torch.empty(0, device=dev)
+        keep = segment_utils.masks_update_device(masks, r["predicted_iou"], r["stability_score"], iou_thr=self.nms_iou_th,
+                                                 score_thr=self.nms_score_th, inner_thr=self.nms_inner_th)
+        kept = masks.index_select(0, keep.to(dev))
+        return segment_utils.mask2segmap_device(kept, r["stability_score"][keep.numpy()])
+
+    @torch.no_grad()
     def segment(self, image: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """Reference: mask_generator.py:102-120."""
-        emb = self.encode(image)
         if self.mask_source is None:
-            raise NotImplementedError("SAM2 prompt encoder / mask decoder / automatic mask generator are the next row "
-                                      "(SURVEY.md §8 f1): use sam.precomputed masks or inject mask_source")
+            seg_map, binary_maps = self.segment_device(image)
+            return seg_map.cpu().numpy(), binary_maps.cpu().numpy()
+        emb = self.encode(image)
         masks = self.mask_source(image, emb)
         if len(masks) == 0:
             return np.array([]), np.array([])

@@ -1,0 +1,118 @@
+"""SAM2 automatic mask generator on MI355X.
+
+The reference builds `sam2.automatic_mask_generator.SAM2AutomaticMaskGenerator(model, points_per_side, pred_iou_thresh,
+stability_score_thresh, min_mask_region_area, use_m2m)` (segment_utils.py:291-308) and calls `.generate(image)`
+(mask_generator.py:113).  That package is not vendored; this class restates its published single-crop pipeline
+(crop_n_layers = 0, multimask_output = True, min_mask_region_area = 0, use_m2m = False -- the reference's settings):
+
+    image encoder -> regular grid of foreground clicks -> mask decoder (3 masks + predicted IoU per click)
+    -> keep predicted IoU > pred_iou_thresh -> stability score  #(logit > +offset) / #(logit > -offset) >= thresh
+    -> binarise at 0 -> boxes -> box NMS (IoU > 0.7 suppressed, by predicted IoU) -> SAM-style records
+
+MI355X design: all clicks of the grid go through the decoder in one batch (`HipSamDecoder`); the filters run on the
+256 x 256 logits through their H x W bilinear upsampling evaluated on the fly (`ovo_amg_mask_stats`: one pass, 7 integers
+per candidate, one small D2H copy); only the masks that survive NMS are ever written at full resolution
+(`ovo_amg_binarize`).  The reference materialises 3 x points full-resolution logit maps per batch of 64 clicks.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+
+def box_nms(boxes: np.ndarray, scores: np.ndarray, iou_threshold: float) -> np.ndarray:
+    """torchvision.ops.nms restated (greedy, descending score, suppress IoU > threshold; areas (x2-x1)*(y2-y1)).
+    boxes f32 [n, 4] XYXY -> kept indices in descending-score order."""
+    order = np.argsort(-scores, kind="stable")
+    b = boxes[order].astype(np.float32)
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    alive = np.ones(len(order), bool)
+    keep = []
+    for i in range(len(order)):
+        if not alive[i]:
+            continue
+        keep.append(order[i])
+        w = np.clip(np.minimum(b[i, 2], b[i + 1:, 2]) - np.maximum(b[i, 0], b[i + 1:, 0]), 0, None)
+        h = np.clip(np.minimum(b[i, 3], b[i + 1:, 3]) - np.maximum(b[i, 1], b[i + 1:, 1]), 0, None)
+        inter = w * h
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iou = inter / (area[i] + area[i + 1:] - inter)
+        alive[i + 1:] &= ~(iou > np.float32(iou_threshold))
+    return np.asarray(keep, dtype=np.int64)
+
+
+class HipSam2AutomaticMaskGenerator:
+    def __init__(self, image_encoder, decoder, points_per_side: int = 32, pred_iou_thresh: float = 0.8,
+                 stability_score_thresh: float = 0.95, stability_score_offset: float = 1.0, mask_threshold: float = 0.0,
+                 box_nms_thresh: float = 0.7, min_mask_region_area: int = 0, use_m2m: bool = False, **unused):
+        if min_mask_region_area > 0 or use_m2m:
+            raise NotImplementedError("min_mask_region_area > 0 (cv2 connected components) and use_m2m are not built; "
+                                      "the reference runs SAM2 with 0 / False (segment_utils.py:300-303)")
+        self.encoder, self.decoder = image_encoder, decoder
+        self.points_per_side = points_per_side
+        self.pred_iou_thresh, self.stability_score_thresh = pred_iou_thresh, stability_score_thresh
+        self.stability_score_offset, self.mask_threshold, self.box_nms_thresh = stability_score_offset, mask_threshold, box_nms_thresh
+        self.grid01 = None
+        self.last_embeddings = None
+
+    def _set_grid(self):
+        if self.grid01 is None:
+            from ..encoders.sam_decoder import point_grid
+            self.grid01 = point_grid(self.points_per_side)
+            self.decoder.set_points(self.grid01 * self.decoder.spec.image_size)
+
+    @torch.no_grad()
+    def generate_device(self, image) -> Dict[str, Any]:
+        """image u8 [H, W, 3] (numpy or device tensor) -> dict(masks u8 [n, H, W] on the GPU, predicted_iou f32 [n],
+        stability_score f32 [n], boxes_xyxy i32 [n, 4], point_index i64 [n]), in descending predicted-IoU order."""
+        self._set_grid()
+        lib = L.load()
+        if isinstance(image, np.ndarray):
+            H, W = image.shape[:2]
+        else:
+            H, W = (image.shape[0], image.shape[1]) if image.shape[-1] == 3 else (image.shape[1], image.shape[2])
+            if image.shape[-1] == 3:
+                image = image.permute(2, 0, 1).contiguous()
+        emb = self.encoder.encode_frame(image)
+        self.last_embeddings = emb
+        f0, f1 = emb["high_res_feats"]
+        logits, iou = self.decoder.forward(emb["image_embed"][0], f1[0], f0[0], multimask=True)       # [P, 3, h, w], [P, 3]
+        self.last_logits, self.last_iou = logits, iou                # kept for inspection / parity tests
+        P, nm, h, w = logits.shape
+        n = P * nm
+        stats = torch.empty((n, 7), dtype=torch.int32, device=logits.device)
+        L.check(lib.ovo_amg_mask_stats(L.ptr(logits), n, h, w, H, W, float(self.mask_threshold), float(self.stability_score_offset),
+                                       L.ptr(stats), L.stream()))
+        iou_h = iou.reshape(-1).cpu().numpy()                       # the one sync of the generator
+        st = stats.cpu().numpy()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            stab = (st[:, 0].astype(np.float32) / st[:, 1].astype(np.float32)).astype(np.float32)
+        cand = np.nonzero((iou_h > np.float32(self.pred_iou_thresh)) & (stab >= np.float32(self.stability_score_thresh)))[0]
+        boxes = st[cand, 3:7].copy()
+        boxes[st[cand, 2] == 0] = 0                                 # empty mask -> [0, 0, 0, 0] like batched_mask_to_box
+        keep = box_nms(boxes.astype(np.float32), iou_h[cand], self.box_nms_thresh)
+        sel = cand[keep]
+        masks = torch.empty((len(sel), H, W), dtype=torch.uint8, device=logits.device)
+        if len(sel):
+            d_sel = torch.from_numpy(sel.astype(np.int32)).to(logits.device)
+            L.check(lib.ovo_amg_binarize(L.ptr(logits), L.ptr(d_sel), len(sel), h, w, H, W, float(self.mask_threshold), L.ptr(masks), L.stream()))
+        return {"masks": masks, "predicted_iou": iou_h[sel], "stability_score": stab[sel], "boxes_xyxy": boxes[keep],
+                "area": st[sel, 2].copy(), "point_index": sel // nm}
+
+    def generate(self, image) -> List[Dict[str, Any]]:
+        """SAM-style records like `SAM2AutomaticMaskGenerator.generate` (segmentation as a numpy bool array)."""
+        r = self.generate_device(image)
+        seg = r["masks"].cpu().numpy().astype(bool)
+        H, W = seg.shape[1:] if len(seg) else (0, 0)
+        pts = (self.grid01.numpy() * np.array([W, H])) if len(seg) else None
+        out = []
+        for i in range(len(seg)):
+            x0, y0, x1, y1 = (int(v) for v in r["boxes_xyxy"][i])
+            out.append({"segmentation": seg[i], "area": int(r["area"][i]), "bbox": [x0, y0, x1 - x0, y1 - y0],
+                        "predicted_iou": float(r["predicted_iou"][i]), "point_coords": [pts[r["point_index"][i]].tolist()],
+                        "stability_score": float(r["stability_score"][i]), "crop_box": [0, 0, W, H]})
+        return out

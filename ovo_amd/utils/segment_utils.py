@@ -90,6 +90,29 @@ def masks_update(*args, device="cuda", **kwargs) -> Tuple[List[Dict[str, Any]], 
     return out
 
 
+def masks_update_device(seg: torch.Tensor, predicted_iou, stability_score, **kwargs) -> torch.Tensor:
+    """`masks_update` (segment_utils.py:173-186) for masks that are already on the GPU: seg u8/bool [n, H, W] ->
+    kept indices in their ORIGINAL order (what `filter` produces), as an i64 CPU tensor."""
+    scores = torch.as_tensor(np.asarray(stability_score)) * torch.as_tensor(np.asarray(predicted_iou))
+    keep = mask_nms(seg, scores, **kwargs)
+    return torch.sort(keep.cpu().long()).values
+
+
+def mask2segmap_device(seg: torch.Tensor, stability_score) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`mask2segmap` (segment_utils.py:12-27, sort=True) on the GPU: masks ordered by descending stability (stable),
+    seg_map i32 [H, W] = first mask covering the pixel (-1 = none), binary_maps bool [N, H, W] in that order."""
+    n, h, w = seg.shape
+    order = np.argsort(-np.asarray(stability_score, np.float32), kind="stable")
+    m = seg if seg.dtype == torch.uint8 else seg.view(torch.uint8)
+    if (h * w) % 16 == 0 and m.is_contiguous():
+        ordered = L.gather_rows(m, order.tolist())
+    else:
+        ordered = m.index_select(0, torch.from_numpy(order).to(m.device))
+    seg_map = torch.empty((h, w), dtype=torch.int32, device=m.device)
+    L.check(L.load().ovo_paint_segmap(L.ptr(ordered), n, h * w, L.ptr(seg_map), L.stream()))
+    return seg_map, ordered.view(torch.bool)
+
+
 def mask2segmap(masks: List[Dict[str, Any]], image: np.ndarray, sort: bool = True) -> Tuple[np.ndarray, np.ndarray]:
     """Reference: segment_utils.py:12-27.  i32[H, W] seg map (-1 = none) + bool[N, H, W]; most stable mask wins."""
     if sort:
