@@ -387,6 +387,11 @@ int ovo_sam_upscale_ln(const void *g, const float *bias, const float *feat, cons
 int ovo_sam_upscale_masks(const void *g, const float *bias, const float *feat, const float *hyper, int n_mask, int first, int64_t P,
                           int s2, int C2, float *out, ovo_stream_t stream);
 
+/* image -> token cross attention of the two-way transformer (head_dim 16, T <= 16 token keys per prompt):
+ * q bf16 [P (stride q_batch_stride elements; 0 = shared), S, 16 H], k / v bf16 [P, T, 16 H] -> o bf16 [P, S, 16 H]. */
+int ovo_sam_i2t_attention(const void *q, int64_t q_batch_stride, const void *k, const void *v, void *o, int64_t P, int S, int T, int H,
+                          float scale, ovo_stream_t stream);
+
 /* Automatic-mask-generator filters on the low-resolution logits f32 [n, h, w], evaluated on their H x W bilinear
  * upsampling (torch F.interpolate, align_corners = False) without materialising it:
  * ovo_amg_mask_stats: stats i32 [n, 7] = {#(v > thr + offset), #(v > thr - offset), #(v > thr), x_min, y_min, x_max, y_max}

@@ -298,8 +298,12 @@ class HipSamDecoder:
             vt = self._gemm(q16, a + "v_proj", bf)
             qi = self._gemm(kpe16, a + "q_proj", bf)                                      # [S | P*S, ci]
             oi = torch.empty((P * S, ci), dtype=bf, device=dev)
-            self._attn((qi, 0), (kt, 0), (vt, 0), (oi, 0), P, H, S, T, hd_c, (0 if shared else S * ci, hd_c, ci), (T * ci, hd_c, ci),
-                       (T * ci, hd_c, ci), (S * ci, hd_c, ci))
+            if hd_c == 16 and T <= 16 and 256 % H == 0:           # S queries x 8 keys: the dedicated HBM-bound kernel
+                L.check(L.load().ovo_sam_i2t_attention(L.ptr(qi), 0 if shared else S * ci, L.ptr(kt), L.ptr(vt), L.ptr(oi), P, S, T, H,
+                                                       hd_c ** -0.5, L.stream()))
+            else:
+                self._attn((qi, 0), (kt, 0), (vt, 0), (oi, 0), P, H, S, T, hd_c, (0 if shared else S * ci, hd_c, ci), (T * ci, hd_c, ci),
+                           (T * ci, hd_c, ci), (S * ci, hd_c, ci))
             if shared:                                            # the prompts diverge here: materialise per-prompt keys
                 keys = self._gemm(oi, a + "out_proj", f32)
                 k16 = torch.empty((P * S, c), dtype=bf, device=dev)

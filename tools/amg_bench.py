@@ -1,0 +1,41 @@
+"""SAM2 automatic mask generator at the reference's settings (points_per_side 16 -> 256 clicks, 640x480 frame): time per frame
+of encoder / decoder / post-processing.  Diagnosis tool."""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import torch
+from ovo_amd import synthetic as syn
+from ovo_amd.encoders.hiera import SPECS as HS, HipHiera
+from ovo_amd.encoders.sam_decoder import SPECS as DS, HipSamDecoder
+from ovo_amd.entities.sam_amg import HipSam2AutomaticMaskGenerator
+dev = "cuda"
+pps = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+enc = HipHiera(HS[os.environ.get("ENC", "hiera_b+")], None, device=dev)
+dec = HipSamDecoder(DS["sam2"], None, device=dev)
+amg = HipSam2AutomaticMaskGenerator(enc, dec, points_per_side=pps, pred_iou_thresh=0.5, stability_score_thresh=0.5)
+img = torch.from_numpy(syn.render_rgb(480, 640, 1)).to(dev)
+def timed(name, fn, n=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n): out = fn()
+    torch.cuda.synchronize()
+    print(f"{name:30s} {1e3 * (time.perf_counter() - t0) / n:8.2f} ms")
+    return out
+emb = timed("encoder", lambda: enc.encode_frame(img.permute(2, 0, 1).contiguous()))
+amg._set_grid()
+f0, f1 = emb["high_res_feats"]
+timed(f"decoder ({pps * pps} clicks)", lambda: dec.forward(emb["image_embed"][0], f1[0], f0[0]))
+r = timed("generate_device (all)", lambda: amg.generate_device(img))
+print("kept", r["masks"].shape[0], "of", pps * pps * 3, "| peak memory GB", torch.cuda.max_memory_allocated() / 2**30)
+if os.environ.get("OVO_PROF_DUMP"):
+    import ctypes as C, collections
+    from ovo_amd import _lib as L
+    lib = L.load(); open(os.environ["OVO_PROF_DUMP"], "w").close()
+    L.check(lib.ovo_profile_start()); dec.forward(emb["image_embed"][0], f1[0], f0[0])
+    ms, work, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
+    L.check(lib.ovo_profile_stop(ms, work, n, 8))
+    agg = collections.OrderedDict()
+    for line in open(os.environ["OVO_PROF_DUMP"]):
+        k, a, b, c, w, t = line.split(); e = agg.setdefault((int(k), int(a), int(b), int(c)), [0, 0.0, 0.0]); e[0] += 1; e[1] += float(t); e[2] += float(w)
+    for (k, a, b, c), (cnt, t, w) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"kind {k} shape {(a, b, c)!s:26s} x{cnt:3d} {1e3 * t / cnt:9.1f} us  total {t:7.3f} ms  {w / t / 1e9:7.0f} TF")
+    print("gemm+attn ms:", sum(ms))
