@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--map-points", type=int, default=1_000_000)
     ap.add_argument("--texts", type=int, default=10)
     ap.add_argument("--no-dense", action="store_true", help="skip the dense per-point accumulate / query")
+    ap.add_argument("--sam-full", action="store_true", help="not the headline workload: also run SAM2's mask decoder on a 16x16 click grid and the "
+                    "automatic-mask-generator filters every frame (SURVEY.md f1); tracking still consumes the synthetic masks, because "
+                    "random-init SAM2 weights keep no mask")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
@@ -147,7 +150,7 @@ def main():
 
     total = args.warmup + args.steps + (0 if args.no_roofline else 2 * args.profile_steps)
     sam = None if args.sam == "none" else args.sam
-    pipe = FramePipeline(dev, vit_card=args.vit, sam_card=sam, n_map=args.map_points, n_text=args.texts, dense=not args.no_dense,
+    pipe = FramePipeline(dev, vit_card=args.vit, sam_card=sam, n_map=args.map_points, n_text=args.texts, dense=not args.no_dense, sam_full=args.sam_full,
                          extra_capacity=(total + 2) * 72_000, seed=0)
     frames = synthetic_frames(total, dev, seed=100 * rank)          # each rank streams its own frames (weak scaling)
     H, W = frames[0].rgb.shape[:2]
@@ -215,6 +218,7 @@ def main():
                                    f"{args.map_points}-point map + multi-view fusion + dense per-point fusion + {args.texts}-prompt "
                                    f"instance and dense-map query; every frame a keyframe; masks from the precomputed-mask seam (32/frame)",
                        "frames_per_step_per_gpu": 1, "map_points": args.map_points, "texts": args.texts, "masks_per_frame": int(frames[0].masks.shape[0]),
+                       "sam2": "image encoder + mask decoder (256 clicks) + automatic-mask-generator filters" if args.sam_full else "image encoder",
                        "parallelism": f"frame-sharded x{world}, per-step RCCL all-reduce of descriptor accumulators" if world > 1 else "single GPU",
                        "gflop_per_frame": {k: round(v / 1e9, 1) for k, v in fl.items()},
                        "points_end": pipe.last.get("n_points"), "instances_end": pipe.last.get("n_instances")},

@@ -58,6 +58,7 @@ class HipSam2AutomaticMaskGenerator:
         self.stability_score_offset, self.mask_threshold, self.box_nms_thresh = stability_score_offset, mask_threshold, box_nms_thresh
         self.grid01 = None
         self.last_embeddings = None
+        self._pinned = None
 
     def _set_grid(self):
         if self.grid01 is None:
@@ -66,9 +67,10 @@ class HipSam2AutomaticMaskGenerator:
             self.decoder.set_points(self.grid01 * self.decoder.spec.image_size)
 
     @torch.no_grad()
-    def generate_device(self, image) -> Dict[str, Any]:
-        """image u8 [H, W, 3] (numpy or device tensor) -> dict(masks u8 [n, H, W] on the GPU, predicted_iou f32 [n],
-        stability_score f32 [n], boxes_xyxy i32 [n, 4], point_index i64 [n]), in descending predicted-IoU order."""
+    def generate_launch(self, image) -> Dict[str, Any]:
+        """Enqueue encoder -> decoder -> candidate statistics on the current stream and start the (small) device->host copy of
+        the statistics into pinned memory.  Nothing waits; `generate_finish` does.  Lets the caller overlap the generator with
+        other streams' work (the ViT forward, back-projection) instead of parking the host in a sync."""
         self._set_grid()
         lib = L.load()
         if isinstance(image, np.ndarray):
@@ -87,8 +89,23 @@ class HipSam2AutomaticMaskGenerator:
         stats = torch.empty((n, 7), dtype=torch.int32, device=logits.device)
         L.check(lib.ovo_amg_mask_stats(L.ptr(logits), n, h, w, H, W, float(self.mask_threshold), float(self.stability_score_offset),
                                        L.ptr(stats), L.stream()))
-        iou_h = iou.reshape(-1).cpu().numpy()                       # the one sync of the generator
-        st = stats.cpu().numpy()
+        if self._pinned is None or self._pinned[0].shape[0] != n:
+            self._pinned = (torch.empty((n, 7), dtype=torch.int32).pin_memory(), torch.empty(n, dtype=torch.float32).pin_memory())
+        self._pinned[0].copy_(stats, non_blocking=True)
+        self._pinned[1].copy_(iou.reshape(-1), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return {"logits": logits, "iou": iou, "stats": stats, "done": done, "HW": (H, W), "stream": torch.cuda.current_stream()}
+
+    @torch.no_grad()
+    def generate_finish(self, h: Dict[str, Any]) -> Dict[str, Any]:
+        """Wait for the statistics, filter + box-NMS on the host (a few hundred candidates), binarise the survivors."""
+        lib = L.load()
+        h["done"].synchronize()                                      # the one sync of the generator
+        logits = h["logits"]
+        P, nm, lh, lw = logits.shape
+        H, W = h["HW"]
+        st, iou_h = self._pinned[0].numpy().copy(), self._pinned[1].numpy().copy()
         with np.errstate(divide="ignore", invalid="ignore"):
             stab = (st[:, 0].astype(np.float32) / st[:, 1].astype(np.float32)).astype(np.float32)
         cand = np.nonzero((iou_h > np.float32(self.pred_iou_thresh)) & (stab >= np.float32(self.stability_score_thresh)))[0]
@@ -96,12 +113,19 @@ class HipSam2AutomaticMaskGenerator:
         boxes[st[cand, 2] == 0] = 0                                 # empty mask -> [0, 0, 0, 0] like batched_mask_to_box
         keep = box_nms(boxes.astype(np.float32), iou_h[cand], self.box_nms_thresh)
         sel = cand[keep]
-        masks = torch.empty((len(sel), H, W), dtype=torch.uint8, device=logits.device)
-        if len(sel):
-            d_sel = torch.from_numpy(sel.astype(np.int32)).to(logits.device)
-            L.check(lib.ovo_amg_binarize(L.ptr(logits), L.ptr(d_sel), len(sel), h, w, H, W, float(self.mask_threshold), L.ptr(masks), L.stream()))
+        with torch.cuda.stream(h["stream"]):
+            masks = torch.empty((len(sel), H, W), dtype=torch.uint8, device=logits.device)
+            if len(sel):
+                d_sel = torch.from_numpy(sel.astype(np.int32)).to(logits.device, non_blocking=True)
+                L.check(lib.ovo_amg_binarize(L.ptr(logits), L.ptr(d_sel), len(sel), lh, lw, H, W, float(self.mask_threshold), L.ptr(masks),
+                                             L.stream()))
         return {"masks": masks, "predicted_iou": iou_h[sel], "stability_score": stab[sel], "boxes_xyxy": boxes[keep],
                 "area": st[sel, 2].copy(), "point_index": sel // nm}
+
+    def generate_device(self, image) -> Dict[str, Any]:
+        """image u8 [H, W, 3] (numpy or device tensor) -> dict(masks u8 [n, H, W] on the GPU, predicted_iou f32 [n],
+        stability_score f32 [n], boxes_xyxy i32 [n, 4], point_index i64 [n]), in descending predicted-IoU order."""
+        return self.generate_finish(self.generate_launch(image))
 
     def generate(self, image) -> List[Dict[str, Any]]:
         """SAM-style records like `SAM2AutomaticMaskGenerator.generate` (segmentation as a numpy bool array)."""

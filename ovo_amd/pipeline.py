@@ -76,7 +76,7 @@ def synthetic_frames(n: int, device, scale: float = 1.0, n_masks_grid=(4, 6), n_
 class FramePipeline:
     def __init__(self, device="cuda", vit_card: str = "PE-Core-L14-336", sam_card: Optional[str] = "hiera_b+",
                  n_map: int = 1_000_000, n_text: int = 10, dense: bool = True, scale: float = 1.0, extra_capacity: int = 4_000_000,
-                 seed: int = 0, depth_filter: bool = True, track_th: int = 100):
+                 seed: int = 0, depth_filter: bool = True, track_th: int = 100, sam_full: bool = False, points_per_side: int = 16):
         self.device = torch.device(device)
         self.scale = scale
         self.crop_edge = int(round(syn.SCANNET["crop_edge"] * scale))
@@ -96,6 +96,11 @@ class FramePipeline:
         self.ovo = OVO(cfg, None, "synthetic", K, device=str(self.device), clip_generator=self.clip, mask_generator=self.masks)
         self.sam = HipHiera(HIERA_SPECS[sam_card], None, self.device, seed) if sam_card else None
         self.sam_out = None
+        self.amg = None
+        if sam_card and sam_full:                                  # SAM2 end to end (f1): decoder + automatic mask generator after the encoder
+            from .encoders.sam_decoder import SPECS as DEC_SPECS, HipSamDecoder
+            from .entities.sam_amg import HipSam2AutomaticMaskGenerator
+            self.amg = HipSam2AutomaticMaskGenerator(self.sam, HipSamDecoder(DEC_SPECS["sam2"], None, self.device, seed), points_per_side=points_per_side)
         self.prefetch = not os.environ.get("OVO_NO_PREFETCH")
         self.join_each_step = bool(os.environ.get("OVO_JOIN_EACH_STEP"))
         self.sam_stream = torch.cuda.Stream(device=self.device) if (sam_card and not os.environ.get("OVO_SAM_SAME_STREAM")) else None
@@ -115,6 +120,7 @@ class FramePipeline:
     def step(self, f: Frame) -> Dict[str, object]:
         lib = L.load()
         self.masks.frames = {f.index: f}
+        amg_pending = None
         # The two encoders first: nothing of theirs depends on the map, and the map update below ends in a host sync (the
         # count of new points) behind which the host could not launch them.
         if self.sam is not None:                                   # SAM2 image encoder (masks come from the seam)
@@ -124,7 +130,10 @@ class FramePipeline:
             if f.ready is not None:                                # the frame's upload, if it is still in flight
                 side.wait_event(f.ready)
             with torch.cuda.stream(side):
-                self.sam_out = self.sam.forward(self.sam.preprocess(f.rgb.permute(2, 0, 1).contiguous()))
+                if self.amg is not None:                           # the whole generator: encoder + 256-click decoder + filters
+                    amg_pending = self.amg.generate_launch(f.rgb)
+                else:
+                    self.sam_out = self.sam.forward(self.sam.preprocess(f.rgb.permute(2, 0, 1).contiguous()))
         if self.prefetch:                                          # ViT tokens do not depend on the masks: start them now
             self.ovo.prefetch_image_features(f.rgb)
         fd = [f.index, f.rgb_lr, f.depth, f.c2w]
@@ -161,6 +170,8 @@ class FramePipeline:
         if self.dense:                                             # dense query: per-point mean descriptor x texts
             _, out["dense_cls"], out["dense_conf"] = clip_utils.similarity(self.acc[:n], self.texts, cnt=self.cnt[:n], want_sim=False,
                                                                            want_argmax=True)
+        if amg_pending is not None:                                # host filter + NMS + binarise: by now the statistics are long there
+            self.sam_out = self.amg.generate_finish(amg_pending)
         if self.join_each_step:                                    # strict frame boundaries (tests); the stream of frames is
             self.join()                                            # otherwise software-pipelined: tail(t) || encoders(t+1)
         self.last = out
