@@ -12,9 +12,11 @@ fusion, dense per-point fusion, instance query and dense-map query.  Every frame
 Inputs are synthetic (seeded) and resident in HBM before the timed region; weights are seeded random init of the
 named architectures (no checkpoints offline) -- throughput is weight independent.
 
-Rank 0 prints ONE JSON line: the driver contract fields plus `roofline` (dominant kernel = the 128x128-tile bf16
-MFMA GEMM, measured with hipEvents around every launch in a second, profiled pass) and `cpu_baseline` (the CPU
-oracle of the same path on one frame, N = 1 only).
+Rank 0 prints ONE JSON line: the driver contract fields plus `roofline` (dominant kernel = the bf16 MFMA GEMM
+instantiation with the most time, measured with hipEvents around every launch in a second, profiled pass -- as run on
+three concurrent streams, and again with the streams folded under `isolated`; `traffic` = HBM bytes per launch from the
+committed PMC reduction profiles/pmc_traffic.json) and `cpu_baseline` (the CPU oracle of the same path on one frame,
+N = 1 only).
 """
 from __future__ import annotations
 

@@ -103,7 +103,7 @@ class FramePipeline:
             self.amg = HipSam2AutomaticMaskGenerator(self.sam, HipSamDecoder(DEC_SPECS["sam2"], None, self.device, seed), points_per_side=points_per_side)
         self.prefetch = not os.environ.get("OVO_NO_PREFETCH")
         self.join_each_step = bool(os.environ.get("OVO_JOIN_EACH_STEP"))
-        self.sam_stream = torch.cuda.Stream(device=self.device) if (sam_card and not os.environ.get("OVO_SAM_SAME_STREAM")) else None
+        self.sam_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("OVO_SAM_PRIORITY", "0"))) if (sam_card and not os.environ.get("OVO_SAM_SAME_STREAM")) else None
         self.D = self.clip.clip_dim
         self.texts = torch.from_numpy(syn.unit_vectors(n_text, self.D, seed=seed + 7)).to(self.device)
         self.dense = dense
