@@ -405,6 +405,23 @@ int ovo_amg_binarize(const float *logits, const int32_t *sel, int n_sel, int h, 
  * seg i32 [pixels] = index of the first mask u8 [n, pixels] covering the pixel, -1 if none. */
 int ovo_paint_segmap(const uint8_t *masks, int n, int64_t pixels, int32_t *seg, ovo_stream_t stream);
 
+/* =============================================================================================
+ * f3: loop-closure semantic update (ovo.py:366-424 update_map, instance_utils.py:5-35 same_instance / fuse_instances).
+ * ============================================================================================= */
+
+/* One pass over the map: cnt i32 [n_slots] points per instance id, sums f64 [n_slots, 3] of their coordinates
+ * (centroid = sums / cnt: instance_utils' `obj_pcd.mean(axis=0)`; cnt > 0 replaces `points_ins_ids.unique()`).  Both are zeroed here. */
+int ovo_instance_moments(const float *xyz, const int32_t *ins, int64_t n, int n_slots, double *sums, int32_t *cnt, ovo_stream_t stream);
+
+/* instance_utils.py:20-27 without the KD-tree: for every candidate pair (a, b) (pairs i32 [n_pairs, 2], slots of the CSR
+ * grouping pts_by_instance f32 [*, 3] / offsets i64 [n_slots + 1]) near_count[pair] = number of points of a that have a point of
+ * b at distance < th  (=> p_dist = near_count / |a|).  max_points_a = largest |a| among the pairs (grid size). */
+int ovo_near_fraction(const float *pts_by_instance, const int64_t *offsets, const int32_t *pairs, int n_pairs, int64_t max_points_a,
+                      float th, int32_t *near_count, ovo_stream_t stream);
+
+/* ins[i] = table[ins[i]] for ids in [0, n_slots): all `points_ins_ids[points_ins_ids == id2] = id1` of the merges in one pass. */
+int ovo_remap_instances(int32_t *ins, int64_t n, const int32_t *table, int n_slots, ovo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,9 @@ _SIGNATURES = {
     "ovo_row_epilogue": (_I32, [_P, _I64, _I32, _P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _P]),
     "ovo_sam_upscale_ln": (_I32, [_P, _P, _P, _P, _P, _F32, _I64, _I32, _I32, _P, _P]),
     "ovo_sam_upscale_masks": (_I32, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _P, _P]),
+    "ovo_instance_moments": (_I32, [_P, _P, _I64, _I32, _P, _P, _P]),
+    "ovo_near_fraction": (_I32, [_P, _P, _P, _I32, _I64, _F32, _P, _P]),
+    "ovo_remap_instances": (_I32, [_P, _I64, _P, _I32, _P]),
     "ovo_sam_i2t_attention": (_I32, [_P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P]),
     "ovo_paint_segmap": (_I32, [_P, _I32, _I64, _P, _P]),
     "ovo_amg_mask_stats": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _F32, _F32, _P, _P]),

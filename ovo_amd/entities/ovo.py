@@ -361,8 +361,102 @@ class OVO:
             obj.update_clip(self.keyframes["ins_descriptors"], force_update=force_update)
 
     def update_map(self, map_data, kfs):
-        """Loop-closure semantic update (ovo.py:366-424): a 'next' row; needs ORB-SLAM3."""
-        raise NotImplementedError("OVO.update_map (loop closure) is not part of this build yet")
+        """Loop-closure semantic update.  Reference: ovo.py:366-424 with instance_utils.py:5-35.
+
+        Same steps and the same greedy merge order; what changed underneath: one pass over the map gives every instance's
+        point count and centroid (`ovo_instance_moments`, replacing `unique()` + a boolean slice per instance); the
+        pair predicate is static during the merge loop (it only reads centroids, point sets and descriptors taken BEFORE
+        any merge), so centroid distances and descriptor cosines are evaluated for all pairs at once, the nearest-neighbour
+        test (`(dists < th).mean()` over an Open3D KD-tree in the reference) runs for the surviving pairs in one launch
+        (`ovo_near_fraction`), and the per-merge relabelling of the map becomes one `ovo_remap_instances` pass."""
+        lib = L.load()
+        self.complete_semantic_info()
+        points_3d, _, points_ins_ids = map_data
+        for i, kf in enumerate(self.keyframes["frame_id"]):           # 0.1 keyframes the SLAM back end deleted
+            if kf not in kfs:
+                if kf in self.keyframes["ins_descriptors"]:
+                    self.keyframes["ins_descriptors"].pop(kf)
+                self.keyframes["frame_id"][i] = "Deleted"
+        if not self.objects:
+            return points_ins_ids
+        pts = L.dev(points_3d, torch.float32, "points_3d")
+        ins = L.dev(points_ins_ids.reshape(-1), torch.int32, "points_ins_ids")
+        dev, n = pts.device, pts.shape[0]
+        n_slots = max(self.objects) + 1
+        sums = torch.empty((n_slots, 3), dtype=torch.float64, device=dev)
+        cnt = torch.empty(n_slots, dtype=torch.int32, device=dev)
+        L.check(lib.ovo_instance_moments(L.ptr(pts), L.ptr(ins), n, n_slots, L.ptr(sums), L.ptr(cnt), L.stream()))
+        cnt_h, sums_h = cnt.cpu().numpy(), sums.cpu().numpy()
+        # 1. instances that lost all their points
+        objects_list = [o for i, o in self.objects.items() if cnt_h[i] > 0]
+        n_removed = len(self.objects) - len(objects_list)
+        ids = [o.id for o in objects_list]
+        N = len(ids)
+        # 2. pair predicate for all i < j (static during the merge loop)
+        same = np.zeros((N, N), bool)
+        if N > 1:
+            cen = (sums_h[ids] / cnt_h[ids, None]).astype(np.float32)
+            dist = np.sqrt(((cen[:, None, :] - cen[None, :, :]) ** 2).sum(-1, dtype=np.float32))
+            feats = self.bank.gather(ids)                              # [N, D], rows = clip_feature[0]
+            unit = torch.empty_like(feats)
+            L.check(lib.ovo_l2_normalize_rows(L.ptr(feats), N, feats.shape[1], L.ptr(unit), L.stream()))
+            from ..utils import clip_utils
+            cos = clip_utils.similarity(unit, unit)[0].cpu().numpy()
+            iu, ju = np.nonzero(np.triu(np.ones((N, N), bool), 1) & ~(dist > np.float32(self.th_centroid)) & ~(cos < np.float32(self.th_cossim)))
+            if len(iu):
+                # group the map by instance: CSR over instance ids (points with id -1 sort first and are skipped)
+                order = torch.argsort(ins, stable=True)
+                grouped = pts.index_select(0, order).contiguous()
+                off = np.zeros(n_slots + 1, np.int64)
+                off[1:] = np.cumsum(cnt_h)
+                off += int(n - cnt_h.sum())                            # skip unassigned (-1) and out-of-table ids
+                d_off = torch.from_numpy(off).to(dev)
+                slots = np.asarray(ids, np.int32)
+                pairs = torch.from_numpy(np.stack([slots[iu], slots[ju]], 1).astype(np.int32)).to(dev)
+                near = torch.empty(len(iu), dtype=torch.int32, device=dev)
+                for s in range(0, len(iu), 65535):                     # grid.y limit
+                    e = min(s + 65535, len(iu))
+                    L.check(lib.ovo_near_fraction(L.ptr(grouped), L.ptr(d_off), pairs[s:e].data_ptr(), e - s, int(cnt_h[slots[iu[s:e]]].max()),
+                                                  float(self.th_points), near[s:e].data_ptr(), L.stream()))
+                p_dist = near.cpu().numpy().astype(np.float64) / cnt_h[slots[iu]]
+                ok = (p_dist > 0.5) | ((cos[iu, ju] > np.float32(0.9)) & (p_dist > 0.2))
+                same[iu[ok], ju[ok]] = True
+        # greedy merge in the reference's order
+        objects: Dict[int, Instance3D] = {}
+        fused: Dict[int, int] = {}
+        for i, a in enumerate(objects_list):
+            if a.id in fused:
+                continue
+            for j in range(i + 1, N):
+                b = objects_list[j]
+                if b.id in fused or not same[i, j]:
+                    continue
+                a.add_points_ids(b.points_ids)                         # instance_utils.fuse_instances
+                for kf in b.kfs_ids:
+                    a.add_keyframes(kf)
+                for area, kf_id in b.top_kf:
+                    a.add_top_kf(kf_id, area)
+                fused[b.id] = a.id
+            objects[a.id] = a
+        print(f"Semantic Map update: removed {n_removed}, fused {len(fused)} instances")
+        if fused:
+            table = np.arange(n_slots, dtype=np.int32)
+            for b_id, a_id in fused.items():
+                table[b_id] = a_id
+            d_table = torch.from_numpy(table).to(dev)
+            L.check(lib.ovo_remap_instances(L.ptr(ins), n, L.ptr(d_table), n_slots, L.stream()))
+            if ins.data_ptr() != points_ins_ids.data_ptr():            # the caller's tensor was converted: hand the result back
+                points_ins_ids = ins.reshape(points_ins_ids.shape).to(points_ins_ids.dtype)
+        # 3. descriptors of merged instances move to the surviving id
+        for id2, id1 in fused.items():
+            for kf in self.objects[id2].kfs_ids:
+                view = self.keyframes["ins_descriptors"].get(kf)
+                if view is None or id2 not in view:
+                    continue
+                view[id1] = view.pop(id2)
+        self.objects = objects
+        self.update_objects_clip()                                     # 4.
+        return points_ins_ids
 
     # ------------------------------------------------------------------ query (ovo.py:473-527)
     @torch.no_grad()
