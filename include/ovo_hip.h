@@ -211,6 +211,7 @@ typedef struct {
     int64_t q_sb, q_sh, q_st, k_sb, k_sh, k_st, v_sb, v_sh, v_st, o_sb, o_sh, o_st;
     int32_t B, H, Tq, Tk, hd;
     float scale;
+    int32_t causal;                                   /* 1: key j is visible to query i only if j <= i (text towers); ABI v2 */
 } ovo_attention_t;
 int ovo_attention(const ovo_attention_t *a, ovo_stream_t stream);
 

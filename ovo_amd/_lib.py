@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libovo_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class OvoHipError(RuntimeError):
@@ -46,7 +46,7 @@ class Attention(C.Structure):
     """ovo_attention_t"""
     _fields_ = [("q", _P), ("k", _P), ("v", _P), ("o", _P)] + \
                [(n, _I64) for n in ("q_sb", "q_sh", "q_st", "k_sb", "k_sh", "k_st", "v_sb", "v_sh", "v_st", "o_sb", "o_sh", "o_st")] + \
-               [(n, C.c_int32) for n in ("B", "H", "Tq", "Tk", "hd")] + [("scale", _F32)]
+               [(n, C.c_int32) for n in ("B", "H", "Tq", "Tk", "hd")] + [("scale", _F32), ("causal", C.c_int32)]
 
 
 class VitConfig(C.Structure):

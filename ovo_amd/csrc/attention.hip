@@ -30,6 +30,7 @@ struct AttnArgs {
     long long o_sb, o_sh, o_st;
     int B, H, Tq, Tk, hd;
     float scale_log2e;
+    int causal;                   // keys after the query are masked (text towers)
 };
 
 // float -> bf16 through the compiler's conversion (v_cvt_pk_bf16_f32 on gfx950: one instruction per pair, RNE)
@@ -127,6 +128,13 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (k0 + kt * 16 + fq * 4 + r >= a.Tk) s[kt][r] = -3.0e38f;
+            }
+            if (a.causal) {                                         // key 0 is never masked, so no row is ever all -inf in its first tile
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + kt * 16 + fq * 4 + r > q_row[t]) s[kt][r] = -3.0e38f;
             }
             float mx = -3.0e38f;                                    // max of the RAW scores (scale > 0 commutes with max)
 #pragma unroll
@@ -235,6 +243,7 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     a.v_sb = p->v_sb; a.v_sh = p->v_sh; a.v_st = p->v_st; a.o_sb = p->o_sb; a.o_sh = p->o_sh; a.o_st = p->o_st;
     a.B = p->B; a.H = p->H; a.Tq = p->Tq; a.Tk = p->Tk; a.hd = p->hd;
     a.scale_log2e = p->scale * 1.4426950408889634f;
+    a.causal = p->causal;
     hipStream_t s = (hipStream_t)stream;
     // two q-tiles per wave once there are enough 128-query workgroups to fill the chip
     // (tools/attn_bench.py: 128-query workgroups win once there are >= 2 of them per CU; below that the 64-query form's

@@ -322,7 +322,7 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         TRY(gemm(k.h, kin, L.qkv_w, kin, L.qkv_b, k.qkv, 3 * dout, 2, nullptr, 0, g.rows, 3 * dout, kin, 0, stream));
         const long long n_win = (long long)B * g.nwh * g.nww;
         const int tk = g.wh * g.ww, tq = p.pool[i] ? tk / 4 : tk;
-        ovo_attention_t a;
+        ovo_attention_t a = {};
         a.k = k.qkv + dout; a.v = k.qkv + 2 * dout; a.o = k.att;
         a.k_sb = a.v_sb = (int64_t)tk * 3 * dout; a.k_sh = a.v_sh = hd; a.k_st = a.v_st = 3 * dout;
         if (p.pool[i]) {

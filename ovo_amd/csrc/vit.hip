@@ -91,7 +91,7 @@ int ovo_vit_forward(const ovo_vit_config_t *cfg, const ovo_vit_weights_t *w, con
         TRY(ovo_layernorm(k.x, D, M, D, L.ln1_g, L.ln1_b, c.ln_eps, k.h, D, 2, stream));
         TRY(gemm(k.h, D, L.qkv_w, D, L.qkv_b, k.qkv, 3 * D, 2, nullptr, 0, M, 3 * D, D, 0, stream));
         if (c.use_rope) TRY(ovo_rope_qk(k.qkv, B, T, c.heads, hd, w->rope_cos, w->rope_sin, c.n_prefix, stream));
-        ovo_attention_t a;
+        ovo_attention_t a = {};
         a.q = k.qkv; a.k = k.qkv + D; a.v = k.qkv + 2 * D; a.o = k.att;
         a.q_sb = a.k_sb = a.v_sb = (int64_t)T * 3 * D; a.q_sh = a.k_sh = a.v_sh = hd; a.q_st = a.k_st = a.v_st = 3 * D;
         a.o_sb = (int64_t)T * D; a.o_sh = hd; a.o_st = D;

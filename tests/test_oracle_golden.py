@@ -154,3 +154,16 @@ def test_sam2_decoder_vs_hf_golden():
     assert np.abs(masks.numpy() - d["masks_multi"]).max() < 2e-5 * max(scale, 1.0)
     np.testing.assert_allclose(iou.numpy(), d["iou_multi"], atol=2e-6, rtol=0)
     np.testing.assert_allclose(obj.numpy(), d["obj_multi"], atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
+def test_text_tower_vs_hf_golden(act):
+    """oracle/text.py (CLIP text transformer, causal mask, end-of-text pooling) against HuggingFace's
+    CLIPTextModelWithProjection on the same random weights (tools/gen_hf_text.py)."""
+    import torch
+    from oracle import text as OT
+    d = golden("hf_clip_text")
+    pre = f"{act}:w:"
+    sd = OT.hf_clip_text_to_openclip({k[len(pre):]: torch.from_numpy(d[k]) for k in d.files if k.startswith(pre)})
+    out = OT.text_forward(sd, torch.from_numpy(d[f"{act}:ids"]), heads=int(d["heads"]), act=act)
+    np.testing.assert_allclose(out.numpy(), d[f"{act}:out"], atol=3e-6, rtol=1e-5)
