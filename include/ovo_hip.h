@@ -163,6 +163,7 @@ int ovo_similarity(const void *F, int feat_dtype, int64_t n, int D, const float 
  * (same out_cls / out_conf meaning as ovo_similarity).  Q % 4 == 0. */
 int ovo_row_argmax(float *S, int64_t n, int Q, int siglip, float logit_scale, float logit_bias, float th,
                    int64_t *out_cls, float *out_conf, ovo_stream_t stream);
+/* (the fused form of this query, ovo_gemm_argmax / ovo_decode_best, is declared after ovo_gemm_t below) */
 
 /* ---- a11: mask NMS intersections (segment_utils.py:218-230) --------------------------------------
  * bits u64[n, words] bit-packed masks (little-endian bit order, zero padded); inter i32[n,n]. */
@@ -200,6 +201,12 @@ typedef struct {
     float alpha;
 } ovo_gemm_t;
 int ovo_gemm(const ovo_gemm_t *g, ovo_stream_t stream);
+/* The large-vocabulary query (BASELINE.json config 5) with the argmax FUSED into the GEMM epilogue: per row and wave one
+ * 64-bit atomicMax on (order-preserving bits of the score << 32 | ~column) into best u64[M] (ZERO on entry; columns >=
+ * n_valid -- vocabulary padding -- never win).  store_scores = 0 never writes the score matrix at all (g->C may be NULL).
+ * ovo_decode_best turns `best` into classes / confidences with the threshold semantics of ovo.py:487-491. */
+int ovo_gemm_argmax(const ovo_gemm_t *g, uint64_t *best, int store_scores, int n_valid, ovo_stream_t stream);
+int ovo_decode_best(const uint64_t *best, int64_t n, float th, int64_t *out_cls, float *out_conf, ovo_stream_t stream);
 
 /* O = softmax(Q K^T * scale) V per (batch, head); bf16 in/out, fp32 softmax and accumulation.
  * Element (b, h, t, d) of X lives at X + b*x_sb + h*x_sh + t*x_st + d (strides in ELEMENTS, d contiguous), so

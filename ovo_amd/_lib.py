@@ -115,6 +115,8 @@ _SIGNATURES = {
     "ovo_gather_rows": (_I32, [_P, _I64, _P, _I32, _P, _P]),
     "ovo_mask_area": (_I32, [_P, _I64, _P, _I32, _P, _P]),
     "ovo_gemm": (_I32, [C.POINTER(Gemm), _P]),
+    "ovo_gemm_argmax": (_I32, [C.POINTER(Gemm), _P, _I32, _I32, _P]),
+    "ovo_decode_best": (_I32, [_P, _I64, _F32, _P, _P, _P]),
     "ovo_attention": (_I32, [C.POINTER(Attention), _P]),
     "ovo_layernorm": (_I32, [_P, _I64, _I64, _I32, _P, _P, _F32, _P, _I64, _I32, _P]),
     "ovo_vit_embed": (_I32, [_P, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _F32, _P, _P]),

@@ -39,6 +39,8 @@ struct GemmArgs {
     float alpha;
     int nbn;
     int chunk, tiles;          // chunk > 0: XCD-chunked tile order (see launch())
+    unsigned long long *best;  // ovo_gemm_argmax: packed (score, column) running maximum per row, or NULL
+    int store, n_valid;        // with best: also store C?; columns >= n_valid (vocabulary padding) never win
 };
 
 template <typename VT> struct Mfma;
@@ -229,6 +231,8 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm0 + i * 16 + fr;
         if (m >= g.M) continue;
+        float row_best = -3.0e38f;                               // fused first-max argmax of this lane's columns (g.best)
+        int row_arg = 0x7fffffff;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn0 + j * 16 + fq * 4;
@@ -239,6 +243,12 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
             v[0] += bias_r[j].x; v[1] += bias_r[j].y; v[2] += bias_r[j].z; v[3] += bias_r[j].w;
             if (g.act) act4(v, g.act);
             if (g.add) { v[0] += add_r[i][j].x; v[1] += add_r[i][j].y; v[2] += add_r[i][j].z; v[3] += add_r[i][j].w; }
+            if (g.best) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < g.n_valid && v[r] > row_best) { row_best = v[r]; row_arg = n + r; }   // ascending columns: ties keep the first
+                if (!g.store) continue;
+            }
             if (g.out_dtype == 0) {
                 *(float4 *)((float *)g.C + (long long)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -246,6 +256,21 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
                 if (g.out_dtype == 2) { p.x = pack_bf16(v[0], v[1]); p.y = pack_bf16(v[2], v[3]); }
                 else { p.x = pack_f16(v[0], v[1]); p.y = pack_f16(v[2], v[3]); }
                 *(uint2 *)((uint16_t *)g.C + (long long)m * g.ldc + n) = p;
+            }
+        }
+        if (g.best) {
+            // the row's columns of this wave tile sit in the 4 lanes that share fr: two xor-shuffles, then ONE 64-bit atomicMax per
+            // row and wave on (order-preserving float bits << 32 | ~column): larger score wins, equal scores keep the smaller column
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ob = __shfl_xor(row_best, o, 64);
+                const int oa = __shfl_xor(row_arg, o, 64);
+                if (ob > row_best || (ob == row_best && oa < row_arg)) { row_best = ob; row_arg = oa; }
+            }
+            if (fq == 0 && row_arg != 0x7fffffff) {
+                uint32_t u = __float_as_uint(row_best);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                atomicMax(g.best + m, ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (uint32_t)row_arg));
             }
         }
     }
@@ -313,11 +338,11 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int ovo_gemm(const ovo_gemm_t *p, ovo_stream_t stream) {
+static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, int n_valid, ovo_stream_t stream) {
     OVO_REQUIRE(p, "null descriptor");
     OVO_REQUIRE(p->M >= 0 && p->N > 0 && p->K > 0, "bad shape");
     if (p->M == 0) return OVO_OK;
-    OVO_REQUIRE(p->A && p->W && p->C, "null pointer");
+    OVO_REQUIRE(p->A && p->W && (p->C || (best && !store)), "null pointer");
     OVO_REQUIRE(p->K % 32 == 0, "K must be a multiple of 32 (pad activations and weights with zeros)");
     OVO_REQUIRE(p->N % 4 == 0, "N must be a multiple of 4");
     OVO_REQUIRE(p->in_dtype == 1 || p->in_dtype == 2, "in_dtype: 1 = f16, 2 = bf16");
@@ -330,8 +355,44 @@ extern "C" int ovo_gemm(const ovo_gemm_t *p, ovo_stream_t stream) {
     g.A = (const char *)p->A; g.lda = p->lda; g.W = (const char *)p->W; g.ldw = p->ldw; g.bias = p->bias;
     g.C = p->C; g.ldc = p->ldc; g.add = p->add; g.ld_add = p->ld_add;
     g.M = p->M; g.N = p->N; g.K = p->K; g.out_dtype = p->out_dtype; g.act = p->act; g.alpha = p->alpha; g.nbn = 0;
+    g.best = best; g.store = store; g.n_valid = n_valid;
     const int rc = p->in_dtype == 2 ? dispatch<bf16x8>(g, (hipStream_t)stream) : dispatch<f16x8>(g, (hipStream_t)stream);
     if (rc != OVO_OK) return rc;
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+extern "C" int ovo_gemm(const ovo_gemm_t *p, ovo_stream_t stream) { return gemm_entry(p, nullptr, 1, 0, stream); }
+
+// C as ovo_gemm, plus a fused per-row first-max argmax over columns [0, n_valid): best u64 [M] must be ZERO on entry and holds, per
+// row, (order-preserving bits of the best value << 32) | (0xffffffff - column); store_scores = 0 skips the C stores altogether
+// (the 5 GB score matrix of a 1.25M x 1000 query is then never written).  Decode with ovo_decode_best.
+extern "C" int ovo_gemm_argmax(const ovo_gemm_t *p, uint64_t *best, int store_scores, int n_valid, ovo_stream_t stream) {
+    OVO_REQUIRE(best && n_valid > 0 && p && n_valid <= p->N, "best must be non-null, 0 < n_valid <= N");
+    return gemm_entry(p, (unsigned long long *)best, store_scores != 0, n_valid, stream);
+}
+
+namespace {
+__global__ void __launch_bounds__(256) k_decode_best(const unsigned long long *__restrict__ best, long long n, float th, long long *__restrict__ cls,
+                                                     float *__restrict__ conf) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long b = best[i];
+    uint32_t u = (uint32_t)(b >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float v = __uint_as_float(u);
+    long long c = (long long)(0xffffffffu - (uint32_t)(b & 0xffffffffu));
+    if (b == 0ull || v <= th) { v = 0.f; c = -1; }                // threshold semantics of ovo.py:487-491
+    cls[i] = c;
+    conf[i] = v;
+}
+}  // namespace
+
+extern "C" int ovo_decode_best(const uint64_t *best, int64_t n, float th, int64_t *out_cls, float *out_conf, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0, "bad shape");
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(best && out_cls && out_conf, "null pointer");
+    k_decode_best<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned long long *)best, n, th, (long long *)out_cls, out_conf);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

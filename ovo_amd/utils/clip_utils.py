@@ -34,7 +34,7 @@ def similarity(img_embed: torch.Tensor, txt_embeds: torch.Tensor, *, siglip: boo
     cls = torch.empty(n, dtype=torch.int64, device=feats.device) if want_argmax else None
     conf = torch.empty(n, dtype=torch.float32, device=feats.device) if want_argmax else None
     if q >= LARGE_VOCABULARY and feats.dtype != torch.float32 and cnt is None and d % 32 == 0 and n > 0:
-        return _similarity_large(feats, txt, siglip, logit_scale, logit_bias, th, cls, conf)
+        return _similarity_large(feats, txt, siglip, logit_scale, logit_bias, th, cls, conf, want_sim)
     sim = torch.empty((n, q), dtype=torch.float32, device=feats.device) if want_sim else None
     if cnt is not None:
         cnt = L.dev(cnt, torch.int32, "cnt")
@@ -47,28 +47,34 @@ def similarity(img_embed: torch.Tensor, txt_embeds: torch.Tensor, *, siglip: boo
 LARGE_VOCABULARY = 64     # from here on the f16/bf16 score matrix is an MFMA GEMM (BASELINE.json config 5: 1k texts)
 
 
-def _similarity_large(feats, txt, siglip, logit_scale, logit_bias, th, cls, conf):
-    """S = F . T^T on the MFMA GEMM (inputs in F's 16-bit dtype, fp32 accumulation, fp32 scores), then one row pass for
-    the SigLIP epilogue and the argmax.  The vocabulary is padded to a multiple of 4 with copies of its last text, which
-    can never win the first-max argmax; the padded columns are sliced away."""
+def _similarity_large(feats, txt, siglip, logit_scale, logit_bias, th, cls, conf, want_sim=True):
+    """S = F . T^T on the MFMA GEMM (inputs in F's 16-bit dtype, fp32 accumulation), SigLIP as the GEMM's own epilogue
+    (alpha = exp(scale), bias, sigmoid), and the argmax FUSED into that epilogue (`ovo_gemm_argmax`): the score matrix is
+    written only when the caller wants it -- 5 GB at 1.25 M points x 1000 texts.  The vocabulary is zero-padded to a
+    multiple of 4; padded columns never enter the argmax and are sliced away."""
+    import math
     lib = L.load()
     n, d = feats.shape
     q = txt.shape[0]
     qp = (q + 3) // 4 * 4
     if qp != q:
-        txt = torch.cat([txt, txt[-1:].expand(qp - q, d)]).contiguous()
+        txt = torch.cat([txt, torch.zeros((qp - q, d), dtype=txt.dtype, device=txt.device)]).contiguous()
     t16 = torch.empty((qp, d), dtype=feats.dtype, device=feats.device)
     L.check(lib.ovo_cast_f32(L.ptr(txt), qp * d, L.ptr(t16), _DTYPE_CODE[feats.dtype], L.stream()))
-    sim = torch.empty((n, qp), dtype=torch.float32, device=feats.device)
+    sim = torch.empty((n, qp), dtype=torch.float32, device=feats.device) if want_sim else None
+    bias = torch.full((qp,), float(logit_bias), dtype=torch.float32, device=feats.device) if siglip else None
     g = L.Gemm()
-    g.A, g.lda, g.W, g.ldw, g.bias = feats.data_ptr(), d, t16.data_ptr(), d, None
-    g.C, g.ldc, g.add, g.ld_add = sim.data_ptr(), qp, None, 0
+    g.A, g.lda, g.W, g.ldw, g.bias = feats.data_ptr(), d, t16.data_ptr(), d, L.ptr(bias)
+    g.C, g.ldc, g.add, g.ld_add = L.ptr(sim), qp, None, 0
     g.M, g.N, g.K = n, qp, d
-    g.in_dtype, g.out_dtype, g.act, g.alpha = _DTYPE_CODE[feats.dtype], 0, 0, 1.0
-    L.check(lib.ovo_gemm(L.C.byref(g), L.stream()))
-    L.check(lib.ovo_row_argmax(L.ptr(sim), n, qp, int(siglip), float(logit_scale), float(logit_bias), float(th), L.ptr(cls), L.ptr(conf),
-                               L.stream()))
-    return (sim if qp == q else sim[:, :q]), cls, conf
+    g.in_dtype, g.out_dtype, g.act, g.alpha = _DTYPE_CODE[feats.dtype], 0, (4 if siglip else 0), (math.exp(logit_scale) if siglip else 1.0)
+    if cls is not None:
+        best = torch.zeros(n, dtype=torch.int64, device=feats.device)         # u64 (score, ~column) keys
+        L.check(lib.ovo_gemm_argmax(L.C.byref(g), L.ptr(best), int(want_sim), q, L.stream()))
+        L.check(lib.ovo_decode_best(L.ptr(best), n, float(th), L.ptr(cls), L.ptr(conf), L.stream()))
+    else:
+        L.check(lib.ovo_gemm(L.C.byref(g), L.stream()))
+    return (sim if (sim is None or qp == q) else sim[:, :q]), cls, conf
 
 
 def clip_cosine_similarity(txt_embeds: torch.Tensor, img_embed: torch.Tensor) -> torch.Tensor:
