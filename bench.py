@@ -154,7 +154,7 @@ def main():
     sam = None if args.sam == "none" else args.sam
     pipe = FramePipeline(dev, vit_card=args.vit, sam_card=sam, n_map=args.map_points, n_text=args.texts, dense=not args.no_dense, sam_full=args.sam_full,
                          extra_capacity=(total + 2) * 72_000, seed=0)
-    frames = synthetic_frames(total, dev, seed=100 * rank)          # each rank streams its own frames (weak scaling)
+    frames = synthetic_frames(total, dev, seed=100 * rank + int(os.environ.get("OVO_BENCH_SEED", "0")))   # each rank streams its own frames (weak scaling)
     H, W = frames[0].rgb.shape[:2]
     map0 = pipe.slam.pcd.cpu().numpy().copy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 

@@ -114,7 +114,29 @@ class FramePipeline:
             self.cnt = torch.zeros(cap, dtype=torch.int32, device=self.device)
         self.inst_delta = torch.zeros((4096, self.D), dtype=torch.float32, device=self.device)
         self.inst_delta_cnt = torch.zeros(4096, dtype=torch.float32, device=self.device)
+        self.xchg = torch.zeros((128, 1 + self.D), dtype=torch.float32, device=self.device)     # per-step exchange rows: slot | descriptor
         self.last: Dict[str, object] = {}
+        if parallel.world_size() > 1:
+            # one exchange with nothing to send: every torch kernel variant of the fold is loaded here, not inside a timed
+            # step (a first use costs 100-150 ms on ROCm; with several ranks loading at once, seconds were measured)
+            self._exchange(torch.zeros((1, self.D), dtype=torch.float32, device=self.device), [0])
+            self.inst_delta.zero_(); self.inst_delta_cnt.zero_()
+            torch.cuda.synchronize()
+
+    def _exchange(self, desc: Optional[torch.Tensor], slots: List[int]) -> None:
+        """The one exchange step of the frame-sharded ranks: this keyframe's descriptor contributions as a FIXED-SIZE gather
+        of the touched rows (slot | descriptor), issued by EVERY rank on EVERY step -- a rank whose frame matched nothing
+        sends rows flagged -1, it never skips the collective.  Every rank folds everyone's rows into its instance table."""
+        self.xchg[:, 0] = -1.0
+        if desc is not None:
+            k = min(desc.shape[0], self.xchg.shape[0])
+            self.xchg[:k, 0] = torch.tensor(slots[:k], dtype=torch.float32).to(self.device, non_blocking=True)
+            self.xchg[:k, 1:] = desc[:k]
+        rows = parallel.allgather_rows(self.xchg)
+        valid = rows[:, 0] >= 0
+        idx = rows[:, 0].clamp(min=0).long()
+        self.inst_delta.index_add_(0, idx, rows[:, 1:] * valid[:, None])
+        self.inst_delta_cnt.index_add_(0, idx, valid.float())
 
     # ------------------------------------------------------------------ one keyframe
     def step(self, f: Frame) -> Dict[str, object]:
@@ -155,14 +177,7 @@ class FramePipeline:
         else:
             desc = None
         if parallel.world_size() > 1:
-            # The one exchange step: sum-reduce of this keyframe's descriptor contributions (fixed-size tables, issued by
-            # EVERY rank on EVERY step -- a rank whose frame matched nothing contributes zeros, never skips the collective).
-            self.inst_delta.zero_(); self.inst_delta_cnt.zero_()
-            if desc is not None:
-                slots = torch.tensor([self.ovo.bank.slot_of[i] % 4096 for i in self.ovo.last_clip_ins_ids], device=self.device)
-                self.inst_delta.index_add_(0, slots, desc)
-                self.inst_delta_cnt.index_add_(0, slots, torch.ones(slots.shape[0], device=self.device))
-            parallel.allreduce_sum_([self.inst_delta, self.inst_delta_cnt])
+            self._exchange(desc, [self.ovo.bank.slot_of[i] % 4096 for i in self.ovo.last_clip_ins_ids] if desc is not None else [])
         out: Dict[str, object] = {"n_points": n, "n_instances": len(self.ovo.objects)}
         if len(self.ovo.objects) > 0:                              # query: instances x texts, fused argmax
             table = self.ovo.get_objs_clips()

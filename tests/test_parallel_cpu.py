@@ -31,6 +31,13 @@ def _worker(rank, world, port, out):
     c = torch.full((1000,), rank + 1, dtype=torch.int32)
     calls = parallel.allreduce_dense_(acc, c, bucket_bytes=4096)
     t = parallel.max_over_ranks(10.0 + rank, "cpu")
+    # per-step exchange of the touched descriptor rows: fixed-size all-gather, rank-major
+    rows = torch.full((4, 3), float(rank))
+    rows[:, 0] = torch.tensor([rank, -1.0, rank + 10, -1.0])
+    gathered = parallel.allgather_rows(rows)
+    assert gathered.shape == (world * 4, 3)
+    for r2 in range(world):
+        assert torch.equal(gathered[4 * r2:4 * r2 + 4, 0], torch.tensor([r2, -1.0, r2 + 10, -1.0])) and (gathered[4 * r2:4 * r2 + 4, 1:] == r2).all()
     parallel.barrier()
     out[rank] = (mine, delta, cnt, acc, c, calls, t)
     dist.destroy_process_group()
