@@ -8,9 +8,12 @@
 //   * block = 256 threads = 4 waves in a 2x2 arrangement; block tile BM x BN in {64,128}^2, BK in {32,64};
 //     each wave owns (BM/2) x (BN/2) as 16x16 MFMA tiles (v_mfma_f32_16x16x32_{bf16,f16}).
 //   * global -> LDS with global_load_lds_dwordx4 (16 B per lane, no VGPR round trip) into a ring of 3-4 LDS stages:
-//     tiles t+1..t+2 stay in flight across the (raw) barrier behind a COUNTED s_waitcnt vmcnt while tile t is
-//     multiplied -- these GEMMs are small (1 workgroup per CU), so exposed load latency, not MFMA rate, was the bound
-//     (28 us -> see DESIGN.md for the measured effect).
+//     tiles t+1..t+NS-1 stay in flight across the (raw) barrier behind a COUNTED s_waitcnt vmcnt while tile t is
+//     multiplied -- these GEMMs are 1-3 workgroup rounds long, so exposed load latency and L2->LDS traffic per flop of a
+//     64-row tile, not MFMA issue, are the bound (tools/gemm_probe.hip; DESIGN.md section 3 has the measurements).
+//   * tile order is XCD-aware (chunked) when the activation panels outweigh the weights; epilogue operands (bias, residual)
+//     are fetched during the last k-tile; GELU runs on packed f32 with a polynomial erf; short-K launches ask only for the
+//     LDS stages they use; ovo_gemm_argmax fuses a per-row first-max argmax (64-bit atomicMax) into the epilogue.
 //   * the DMA writes LDS lane-linearly, so the bank-conflict swizzle (16-byte chunk index XOR a row
 //     function) is applied to the per-lane SOURCE address and again when fragments are read (ds_read_b128).
 //   * operands are swapped (a = W fragment, b = activation fragment): the accumulator holds C^T tiles, i.e.

@@ -45,6 +45,24 @@ def test_mask_decoder_vs_oracle(card, n_side):
     assert (iou.cpu() - ri).abs().max().item() < 2e-2
 
 
+def test_mask_decoder_batch_invariance():
+    """The generator decodes all clicks in one batch where the reference uses batches of 64: a click's masks must not depend
+    on which other clicks share its batch (full-size decoder, 64 clicks at once vs 4 x 16)."""
+    from ovo_amd.encoders.sam_decoder import SPECS, HipSamDecoder, point_grid
+    spec = SPECS["sam2"]
+    dec = HipSamDecoder(spec, None, device=DEV, seed=5)
+    emb, f1, f0 = (t.to(DEV) for t in _inputs(spec, seed=4))
+    pts = point_grid(8) * spec.image_size
+    dec.set_points(pts)
+    all_m, all_i = dec.forward(emb, f1, f0)
+    for b in range(4):
+        dec.set_points(pts[16 * b:16 * b + 16])
+        m, i = dec.forward(emb, f1, f0)
+        scale = all_m[16 * b:16 * b + 16].abs().max().item()
+        assert (m - all_m[16 * b:16 * b + 16]).abs().max().item() <= 1e-5 * scale      # same k-order per output element: equal up to fp32 noise
+        assert (i - all_i[16 * b:16 * b + 16]).abs().max().item() <= 1e-6
+
+
 def test_amg_filters_vs_oracle():
     """Stability / area / box statistics and binarisation on the on-the-fly bilinear upsampling == torch's interpolate."""
     from oracle import sam2_amg as OA
