@@ -30,6 +30,22 @@ __device__ __forceinline__ float gelu_poly(float x) {
     return fmaf(hx, p * zc, hx);
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {                // gelu_poly on two values: v_pk_fma_f32 / v_pk_mul_f32
+    const f32x2 z = x * 0.70710678118654752f;
+    const f32x2 zc = __builtin_elementwise_min(__builtin_elementwise_max(z, (f32x2)(-3.5f)), (f32x2)(3.5f));
+    const f32x2 s = __builtin_elementwise_fma(zc * zc, (f32x2)(0.16326530612244897f), (f32x2)(-1.0f));
+    f32x2 p = (f32x2)(-3.398861796e-03f);
+    p = __builtin_elementwise_fma(p, s, (f32x2)(8.621919328e-03f)); p = __builtin_elementwise_fma(p, s, (f32x2)(-8.698635955e-03f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(1.271555869e-02f)); p = __builtin_elementwise_fma(p, s, (f32x2)(-2.870869786e-02f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(4.709060027e-02f)); p = __builtin_elementwise_fma(p, s, (f32x2)(-6.528488840e-02f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(8.795614477e-02f)); p = __builtin_elementwise_fma(p, s, (f32x2)(-1.145324569e-01f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(1.467849556e-01f)); p = __builtin_elementwise_fma(p, s, (f32x2)(-2.007044758e-01f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(4.038725490e-01f));
+    const f32x2 hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, p * zc, hx);
+}
+
 // ---- one wave per row of C <= 1024 channels (C % 4 == 0) ----
 struct RowArgs {
     const float *x; const float *base; long long base_rows;
@@ -132,7 +148,7 @@ __global__ void __launch_bounds__(256) k_upscale_ln(const uint16_t *__restrict__
 __global__ void __launch_bounds__(256) k_upscale_masks(const uint16_t *__restrict__ g, const float *__restrict__ bias, const float *__restrict__ feat,
                                                        const float *__restrict__ hyper, int n_mask, int first, int n_out, int s2, int C2,
                                                        float *__restrict__ out) {
-    extern __shared__ float sh[];                                // [n_out][C2] hyper rows, then [C2] bias
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // [n_out][C2] hyper rows, then [C2] bias
     const long long p = blockIdx.y;
     for (int i = threadIdx.x; i < n_out * C2; i += blockDim.x) sh[i] = hyper[(p * n_mask + first) * C2 + i];
     for (int i = threadIdx.x; i < C2; i += blockDim.x) sh[n_out * C2 + i] = bias[i];
@@ -145,17 +161,20 @@ __global__ void __launch_bounds__(256) k_upscale_masks(const uint16_t *__restric
     const uint16_t *src = g + row * (4 * C2) + (((y & 1) << 1) | (x & 1)) * C2;
     const float *ft = feat + (long long)rem * C2;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < C2; c += 4) {
-        const uint2 raw = *(const uint2 *)(src + c);
-        const float4 f = *(const float4 *)(ft + c);
-        const float *bs = sh + n_out * C2 + c;
-        const float v0 = gelu_poly(bf2f((uint16_t)(raw.x & 0xffff)) + bs[0] + f.x), v1 = gelu_poly(bf2f((uint16_t)(raw.x >> 16)) + bs[1] + f.y);
-        const float v2 = gelu_poly(bf2f((uint16_t)(raw.y & 0xffff)) + bs[2] + f.z), v3 = gelu_poly(bf2f((uint16_t)(raw.y >> 16)) + bs[3] + f.w);
+    for (int c = 0; c < C2; c += 8) {                            // 16-byte loads, GELU on packed f32 (two values per VALU slot)
+        const uint4 raw = *(const uint4 *)(src + c);
+        const float4 fa = *(const float4 *)(ft + c), fb = *(const float4 *)(ft + c + 4);
+        const float4 ba = *(const float4 *)(sh + n_out * C2 + c), bb = *(const float4 *)(sh + n_out * C2 + c + 4);
+        const f32x2 v01 = gelu2(f32x2{__uint_as_float(raw.x << 16) + ba.x + fa.x, __uint_as_float(raw.x & 0xffff0000u) + ba.y + fa.y});
+        const f32x2 v23 = gelu2(f32x2{__uint_as_float(raw.y << 16) + ba.z + fa.z, __uint_as_float(raw.y & 0xffff0000u) + ba.w + fa.w});
+        const f32x2 v45 = gelu2(f32x2{__uint_as_float(raw.z << 16) + bb.x + fb.x, __uint_as_float(raw.z & 0xffff0000u) + bb.y + fb.y});
+        const f32x2 v67 = gelu2(f32x2{__uint_as_float(raw.w << 16) + bb.z + fb.z, __uint_as_float(raw.w & 0xffff0000u) + bb.w + fb.w});
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < n_out) {
-                const float *h = sh + i * C2 + c;
-                acc[i] = fmaf(h[0], v0, fmaf(h[1], v1, fmaf(h[2], v2, fmaf(h[3], v3, acc[i]))));
+                const float4 ha = *(const float4 *)(sh + i * C2 + c), hb = *(const float4 *)(sh + i * C2 + c + 4);
+                acc[i] = fmaf(ha.x, v01.x, fmaf(ha.y, v01.y, fmaf(ha.z, v23.x, fmaf(ha.w, v23.y, acc[i]))));
+                acc[i] = fmaf(hb.x, v45.x, fmaf(hb.y, v45.y, fmaf(hb.z, v67.x, fmaf(hb.w, v67.y, acc[i]))));
             }
     }
     for (int i = 0; i < n_out; ++i) out[((p * n_out + i) * side + y) * side + x] = acc[i];
@@ -167,7 +186,7 @@ __global__ void __launch_bounds__(256) k_upscale_masks(const uint16_t *__restric
 // 16 outputs.  HBM-bound: 256 B read + 256 B written per pixel.  Lanes run head-fastest, so a wave touches 8 whole pixels.
 __global__ void __launch_bounds__(256) k_i2t_attention(const uint16_t *__restrict__ q, long long q_sb, const uint16_t *__restrict__ k,
                                                        const uint16_t *__restrict__ v, uint16_t *__restrict__ o, int S, int T, int H, float scale) {
-    extern __shared__ float kv[];                                // [T][ci] keys, then [T][ci] values (ci = 16 H)
+    extern __shared__ __attribute__((aligned(16))) float kv[];   // [T][ci] keys, then [T][ci] values (ci = 16 H)
     const int ci = 16 * H;
     const long long p = blockIdx.y;
     for (int i = threadIdx.x; i < T * ci; i += blockDim.x) {
@@ -190,10 +209,13 @@ __global__ void __launch_bounds__(256) k_i2t_attention(const uint16_t *__restric
         for (int t = 0; t < 16; ++t) {
             sc[t] = -3.0e38f;
             if (t < T) {
-                const float *kt = kv + t * ci + head * 16;
-                float a = 0.f;
+                const float4 *kt = (const float4 *)(kv + t * ci + head * 16);       // 4 x ds_read_b128 (the kernel was LDS-issue bound
+                float a = 0.f;                                                       // on 16 scalar reads per key)
 #pragma unroll
-                for (int d = 0; d < 16; ++d) a = fmaf(x[d], kt[d], a);
+                for (int d = 0; d < 4; ++d) {
+                    const float4 kk = kt[d];
+                    a = fmaf(x[4 * d], kk.x, fmaf(x[4 * d + 1], kk.y, fmaf(x[4 * d + 2], kk.z, fmaf(x[4 * d + 3], kk.w, a))));
+                }
                 sc[t] = a;
                 mx = fmaxf(mx, a);
             }
@@ -208,10 +230,14 @@ __global__ void __launch_bounds__(256) k_i2t_attention(const uint16_t *__restric
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             if (t < T) {
-                const float *vt = kv + (T + t) * ci + head * 16;
+                const float4 *vt = (const float4 *)(kv + (T + t) * ci + head * 16);
                 const float pt = sc[t] * inv;
 #pragma unroll
-                for (int d = 0; d < 16; ++d) out[d] = fmaf(pt, vt[d], out[d]);
+                for (int d = 0; d < 4; ++d) {
+                    const float4 vv = vt[d];
+                    out[4 * d] = fmaf(pt, vv.x, out[4 * d]); out[4 * d + 1] = fmaf(pt, vv.y, out[4 * d + 1]);
+                    out[4 * d + 2] = fmaf(pt, vv.z, out[4 * d + 2]); out[4 * d + 3] = fmaf(pt, vv.w, out[4 * d + 3]);
+                }
             }
         }
         uint16_t *op = o + (p * S + s) * ci + head * 16;
@@ -240,15 +266,27 @@ __global__ void k_amg_init(int32_t *__restrict__ stats, int n, int H, int W) {
     s[0] = s[1] = s[2] = 0; s[3] = W; s[4] = H; s[5] = -1; s[6] = -1;
 }
 
+#define AMG_RB 16
 // stats[i] = {#(v > thr + off), #(v > thr - off), #(v > thr), x_min, y_min, x_max, y_max of (v > thr)} over the H x W upsampling
 __global__ void __launch_bounds__(256) k_amg_stats(const float *__restrict__ logits, int h, int w, int H, int W, float thr, float off,
                                                    int32_t *__restrict__ stats) {
+    // A block owns a band of AMG_RB output rows of one candidate and stages the few logit rows they interpolate in LDS: the
+    // 4 taps of a sample then come from LDS instead of 4 dependent global loads (0.95 -> see DESIGN.md; same arithmetic as
+    // up_sample / k_amg_binarize, so the statistics and the binary masks agree bit for bit).
+    extern __shared__ __attribute__((aligned(16))) float rows_s[];
     const float *m = logits + (long long)blockIdx.y * h * w;
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const int Y0 = blockIdx.x * AMG_RB, Y1 = min(H, Y0 + AMG_RB);
+    float f0 = sy * ((float)Y0 + 0.5f) - 0.5f; f0 = f0 < 0.f ? 0.f : f0;
+    float f1 = sy * ((float)(Y1 - 1) + 0.5f) - 0.5f; f1 = f1 < 0.f ? 0.f : f1;
+    const int r0 = (int)f0, r1 = min((int)f1 + 1, h - 1);
+    for (int i = threadIdx.x; i < (r1 - r0 + 1) * w; i += blockDim.x) rows_s[i] = m[r0 * w + i];
+    __syncthreads();
+    const float *ms = rows_s - r0 * w;                           // ms[y * w + x] == m[y * w + x] for the staged rows
     int hi = 0, lo = 0, ar = 0, x0 = W, y0 = H, x1 = -1, y1 = -1;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
-        const int Y = i / W, X = i - Y * W;
-        const float v = up_sample(m, h, w, sy, sx, Y, X);
+    for (int i = threadIdx.x; i < (Y1 - Y0) * W; i += blockDim.x) {
+        const int Y = Y0 + i / W, X = i % W;
+        const float v = up_sample(ms, h, w, sy, sx, Y, X);
         hi += v > thr + off; lo += v > thr - off;
         if (v > thr) { ++ar; x0 = X < x0 ? X : x0; x1 = X > x1 ? X : x1; y0 = Y < y0 ? Y : y0; y1 = Y > y1 ? Y : y1; }
     }
@@ -314,9 +352,10 @@ extern "C" int ovo_amg_mask_stats(const float *logits, int n, int h, int w, int 
     OVO_REQUIRE(logits && stats, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     k_amg_init<<<(n + 255) / 256, 256, 0, st>>>(stats, n, H, W);
-    int bx = (H * W + 256 * 16 - 1) / (256 * 16);
-    bx = bx < 1 ? 1 : bx;
-    k_amg_stats<<<dim3(bx, n), 256, 0, st>>>(logits, h, w, H, W, thr, offset, stats);
+    const int src_rows = (int)((float)AMG_RB * (float)h / (float)H) + 3;      // logit rows a band of AMG_RB output rows can touch
+    const size_t lds = (size_t)src_rows * w * sizeof(float);
+    OVO_REQUIRE(lds <= 64 * 1024, "logit rows of one output band exceed 64 KiB of LDS (down-sampling by a large factor is not supported)");
+    k_amg_stats<<<dim3((H + AMG_RB - 1) / AMG_RB, n), 256, lds, st>>>(logits, h, w, H, W, thr, offset, stats);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }
@@ -366,7 +405,7 @@ extern "C" int ovo_sam_upscale_ln(const void *g, const float *bias, const float 
 
 extern "C" int ovo_sam_upscale_masks(const void *g, const float *bias, const float *feat, const float *hyper, int n_mask, int first,
                                      int64_t P, int s2, int C2, float *out, ovo_stream_t stream) {
-    OVO_REQUIRE(P >= 0 && P <= 65535 && s2 > 0 && C2 > 0 && C2 % 4 == 0 && C2 <= 256, "bad shape");
+    OVO_REQUIRE(P >= 0 && P <= 65535 && s2 > 0 && C2 > 0 && C2 % 8 == 0 && C2 <= 256, "C2 must be a multiple of 8, <= 256");
     OVO_REQUIRE(n_mask > 0 && first >= 0 && first < n_mask && n_mask - first <= 4, "at most 4 mask tokens");
     if (P == 0) return OVO_OK;
     OVO_REQUIRE(g && bias && feat && hyper && out, "null pointer");

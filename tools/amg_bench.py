@@ -1,7 +1,7 @@
 """SAM2 automatic mask generator at the reference's settings (points_per_side 16 -> 256 clicks, 640x480 frame): time per frame
 of encoder / decoder / post-processing.  Diagnosis tool."""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ovo_amd import synthetic as syn
 from ovo_amd.encoders.hiera import SPECS as HS, HipHiera
