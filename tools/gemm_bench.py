@@ -15,7 +15,7 @@ def run(m, n, k, iters=30):
     if os.environ.get('BIAS'):
         bias = torch.randn(n, device=dev); g.bias = bias.data_ptr()
     if os.environ.get('ADD'):
-        add = torch.randn(m, n, device=dev); g.add, g.ld_add = add.data_ptr(), n
+        add = out if os.environ.get('INPLACE') else torch.randn(m, n, device=dev); g.add, g.ld_add = add.data_ptr(), n
     for _ in range(3): L.check(lib.ovo_gemm(C.byref(g), L.stream()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
