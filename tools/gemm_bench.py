@@ -6,11 +6,12 @@ from ovo_amd import _lib as L
 dev = torch.device("cuda", 0)
 lib = L.load()
 ROT = int(os.environ.get('ROTATE', '1'))   # > 1: cycle through that many weight buffers (cold weights, like a layer stack)
+PAD = int(os.environ.get('PAD', '0'))      # extra elements per row of A and W (row stride K + PAD): breaks power-of-two strides
 def run(m, n, k, iters=30):
-    a = torch.randn(m, k, device=dev).to(torch.bfloat16); ws = [(torch.randn(n, k, device=dev) * k ** -0.5).to(torch.bfloat16) for _ in range(ROT)]; w = ws[0]
+    a = torch.randn(m, k + PAD, device=dev).to(torch.bfloat16); ws = [(torch.randn(n, k + PAD, device=dev) * k ** -0.5).to(torch.bfloat16) for _ in range(ROT)]; w = ws[0]
     odt = {'bf16': (torch.bfloat16, 2), 'f32': (torch.float32, 0)}[os.environ.get('OUT', 'bf16')]
     out = torch.empty(m, n, dtype=odt[0], device=dev)
-    g = L.Gemm(); g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, g.add, g.ld_add = a.data_ptr(), k, w.data_ptr(), k, None, out.data_ptr(), n, None, 0
+    g = L.Gemm(); g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, g.add, g.ld_add = a.data_ptr(), k + PAD, w.data_ptr(), k + PAD, None, out.data_ptr(), n, None, 0
     g.M, g.N, g.K, g.in_dtype, g.out_dtype, g.act, g.alpha = m, n, k, 2, odt[1], int(os.environ.get('ACT', '0')), 1.0
     if os.environ.get('BIAS'):
         bias = torch.randn(n, device=dev); g.bias = bias.data_ptr()
