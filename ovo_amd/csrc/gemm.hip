@@ -5,8 +5,9 @@
 // [tokens, K], nn.Linear weights [out, K]), so A and W tiles are staged the same way.
 //
 // Structure (gfx950):
-//   * block = 256 threads = 4 waves in a 2x2 arrangement; block tile BM x BN in {64,128}^2, BK in {32,64};
-//     each wave owns (BM/2) x (BN/2) as 16x16 MFMA tiles (v_mfma_f32_16x16x32_{bf16,f16}).
+//   * block = NW waves as (NW/2) x 2: 4 waves for the 64x64 / 64x128 / 128x64 tiles (2 workgroups per CU), 8 waves for the
+//     128x128 tile (1 workgroup per CU); BK in {32,64}; each wave owns (BM/(NW/2)) x (BN/2) as 16x16 MFMA tiles
+//     (v_mfma_f32_16x16x32_{bf16,f16}).
 //   * global -> LDS with global_load_lds_dwordx4 (16 B per lane, no VGPR round trip) into a ring of 3-4 LDS stages:
 //     tiles t+1..t+NS-1 stay in flight across the (raw) barrier behind a COUNTED s_waitcnt vmcnt while tile t is
 //     multiplied -- these GEMMs are 1-3 workgroup rounds long, so exposed load latency and L2->LDS traffic per flop of a
@@ -117,12 +118,13 @@ __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
     return *(const uint32_t *)&h;
 }
 
-template <int BM, int BN, int BK, int NS, typename VT>
-__global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
+template <int BM, int BN, int BK, int NS, typename VT, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
+    constexpr int NT = 64 * NW;                       // threads: NW waves as (NW / 2) x 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CPR = BK / 8;                       // 16-byte chunks per tile row
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16, KS = BK / 32;
+    constexpr int WM = BM / (NW / 2), WN = BN / 2, TM = WM / 16, TN = WN / 16, KS = BK / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
     // Workgroups go round-robin over the 8 XCDs (XCD = blockIdx % 8), each with its own L2.  In chunked order XCD x walks
@@ -143,17 +145,17 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // per-lane source pointers of the DMA pieces (swizzled chunk of a clamped row), advanced by BK elements per tile
-    constexpr int AI = A_BYTES / 4096, BI = B_BYTES / 4096;
+    constexpr int AI = A_BYTES / (16 * NT), BI = B_BYTES / (16 * NT);
     const char *a_src[AI], *b_src[BI];
 #pragma unroll
     for (int it = 0; it < AI; ++it) {
-        const int id = it * 256 + tid, row = id / CPR, c = (id % CPR) ^ swz<BK>(row);
+        const int id = it * NT + tid, row = id / CPR, c = (id % CPR) ^ swz<BK>(row);
         int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
         a_src[it] = g.A + ((long long)gr * g.lda + c * 8) * 2;
     }
 #pragma unroll
     for (int it = 0; it < BI; ++it) {
-        const int id = it * 256 + tid, row = id / CPR, c = (id % CPR) ^ swz<BK>(row);
+        const int id = it * NT + tid, row = id / CPR, c = (id % CPR) ^ swz<BK>(row);
         int gr = n0 + row; gr = gr < g.N ? gr : g.N - 1;
         b_src[it] = g.W + ((long long)gr * g.ldw + c * 8) * 2;
     }
@@ -161,9 +163,9 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
         char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
         const long long koff = (long long)kt * BK * 2;
 #pragma unroll
-        for (int it = 0; it < AI; ++it) glds16(a_src[it] + koff, sa + (it * 256 + wave * 64) * 16);
+        for (int it = 0; it < AI; ++it) glds16(a_src[it] + koff, sa + (it * NT + wave * 64) * 16);
 #pragma unroll
-        for (int it = 0; it < BI; ++it) glds16(b_src[it] + koff, sb + (it * 256 + wave * 64) * 16);
+        for (int it = 0; it < BI; ++it) glds16(b_src[it] + koff, sb + (it * NT + wave * 64) * 16);
     };
     auto frag = [&](const char *tile, int row, int chunk) -> VT {
         return *(const VT *)(tile + (row * CPR + (chunk ^ swz<BK>(row))) * 16);
@@ -281,9 +283,8 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
 
 template <int BM, int BN> struct Stages { static constexpr int value = (BM == 128 && BN == 128) || (BM == 64 && BN == 64) ? 4 : 3; };
 
-template <int BM, int BN, int BK, typename VT>
+template <int BM, int BN, int BK, typename VT, int NW = 4, int NS = Stages<BM, BN>::value>
 int launch(const GemmArgs &g0, hipStream_t s) {
-    constexpr int NS = Stages<BM, BN>::value;
     GemmArgs g = g0;
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;
@@ -294,7 +295,7 @@ int launch(const GemmArgs &g0, hipStream_t s) {
     const size_t lds = (size_t)(nt < NS ? nt : NS) * (BM + BN) * BK * 2;
     static bool attr_done = false;              // per instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_gemm<BM, BN, BK, NS, VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        hipError_t e = hipFuncSetAttribute((const void *)k_gemm<BM, BN, BK, NS, VT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e != hipSuccess) { ovo_set_error("ovo_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
         attr_done = true;
     }
@@ -305,7 +306,7 @@ int launch(const GemmArgs &g0, hipStream_t s) {
     g.tiles = nbm * g.nbn;
     g.chunk = (g.M > g.N || g.nbn % 8 != 0) && !getenv("OVO_GEMM_NO_CHUNK") ? (g.tiles + 7) / 8 : 0;
     const int grid = g.chunk > 0 ? g.chunk * 8 : g.tiles;
-    k_gemm<BM, BN, BK, NS, VT><<<grid, 256, lds, s>>>(g);
+    k_gemm<BM, BN, BK, NS, VT, NW><<<grid, 64 * NW, lds, s>>>(g);
     if (prof) ovo_prof_end(s);
     return OVO_OK;
 }
@@ -315,10 +316,12 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
     const bool k64 = g.K % 64 == 0;
     auto blocks = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
     // Tile choice (tools/gemm_bench.py, MI355X): these GEMMs are a handful of workgroup "rounds" long, so round
-    // quantisation on 256 CUs decides.  128x128 (1 workgroup/CU, 128 KiB LDS ring) only pays for >= 4 full rounds of
-    // deep-K work; otherwise take the tile with the fewest rounds x area at 2 workgroups/CU, larger tile on ties.
+    // quantisation on 256 CUs decides.  128x128 runs as ONE 8-wave workgroup per CU (wave tile 32x64, 3-stage 96 KiB ring:
+    // the L2 traffic of a 128^2 tile with the wave count of two 64x128 workgroups -- 10-18% faster than any 4-wave tile on
+    // the M = 1M decoder / 1k-text query GEMMs, 844 TFLOP/s at 8192^3) and pays from >= 4 full rounds; otherwise take
+    // the 4-wave tile with the fewest rounds x area at 2 workgroups/CU, larger tile on ties.
     int bm = 64, bn = 64;
-    if (blocks(128, 128) >= 1024 && g.K >= 1024) { bm = 128; bn = 128; }
+    if (blocks(128, 128) >= 1024) { bm = 128; bn = 128; }
     else {
         const int cand[3][2] = {{64, 128}, {128, 64}, {64, 64}};
         long long best = -1;
@@ -332,9 +335,10 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
         int fm = 0, fn = 0;
         if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm == 64 || fm == 128) && (fn == 64 || fn == 128)) { bm = fm; bn = fn; }
     }
+    if (bm == 128 && bn == 128) return k64 ? launch<128, 128, 64, VT, 8, 3>(g, s) : launch<128, 128, 32, VT, 8, 3>(g, s);
 #define GO(BM, BN)                                                         \
     if (bm == BM && bn == BN) return k64 ? launch<BM, BN, 64, VT>(g, s) : launch<BM, BN, 32, VT>(g, s);
-    GO(128, 128) GO(64, 128) GO(128, 64) GO(64, 64)
+    GO(64, 128) GO(128, 64) GO(64, 64)
 #undef GO
     return OVO_E_UNSUPPORTED;
 }
