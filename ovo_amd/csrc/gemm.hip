@@ -336,6 +336,14 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
         if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm == 64 || fm == 128) && (fn == 64 || fn == 128)) { bm = fm; bn = fn; }
     }
     if (bm == 128 && bn == 128) return k64 ? launch<128, 128, 64, VT, 8, 3>(g, s) : launch<128, 128, 32, VT, 8, 3>(g, s);
+    // BK = 64: 8 waves per workgroup on every tile (two workgroups = 16 waves per CU): same LDS and L2 traffic as the 4-wave
+    // form, twice the loads in flight and MFMA/LDS phases of different waves overlapping -- QKV 16.7 -> 14.9 us, FC1 25.1 ->
+    // 21.7, (4096,1792,448) 18.6 -> 15.8 (tools/gemm_bench.py).  BK = 32 tiles are too small for 512 threads' 16-byte pieces.
+    if (k64 && !getenv("OVO_GEMM_W4")) {
+        if (bm == 128 && bn == 64) return launch<128, 64, 64, VT, 8, 3>(g, s);
+        if (bm == 64 && bn == 128) return launch<64, 128, 64, VT, 8, 3>(g, s);
+        if (bm == 64 && bn == 64) return launch<64, 64, 64, VT, 8, 4>(g, s);
+    }
 #define GO(BM, BN)                                                         \
     if (bm == BM && bn == BN) return k64 ? launch<BM, BN, 64, VT>(g, s) : launch<BM, BN, 32, VT>(g, s);
     GO(64, 128) GO(128, 64) GO(64, 64)
