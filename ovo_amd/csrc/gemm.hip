@@ -316,20 +316,21 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
     const bool k64 = g.K % 64 == 0;
     auto blocks = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
     // Tile choice (tools/gemm_bench.py, MI355X): these GEMMs are a handful of workgroup "rounds" long, so round
-    // quantisation on 256 CUs decides.  128x128 runs as ONE 8-wave workgroup per CU (wave tile 32x64, 3-stage 96 KiB ring:
-    // the L2 traffic of a 128^2 tile with the wave count of two 64x128 workgroups -- 10-18% faster than any 4-wave tile on
-    // the M = 1M decoder / 1k-text query GEMMs, 844 TFLOP/s at 8192^3) and pays from >= 4 full rounds; otherwise take
-    // the 4-wave tile with the fewest rounds x area at 2 workgroups/CU, larger tile on ties.
-    int bm = 64, bn = 64;
-    if (blocks(128, 128) >= 1024) { bm = 128; bn = 128; }
-    else {
-        const int cand[3][2] = {{64, 128}, {128, 64}, {64, 64}};
-        long long best = -1;
+    // quantisation on 256 CUs decides.  cost = rounds x tile area at the workgroups a CU holds (2 for the 64/128-mixed
+    // tiles, 1 for 128x128, whose round therefore counts half its area), x 1.4 for 64x64 (most L2 traffic per flop: it
+    // only wins when it saves a round).  128x64 is listed first: on ties it beat 64x128 by 4-10% in the sweep.  128x128 (one
+    // 8-wave workgroup per CU, 867 TFLOP/s at 8192^3, 10-18% ahead on the M = 1M decoder / 1k-text query GEMMs) enters
+    // from 8 full rounds and wins ties.
+    int bm = 128, bn = 64;
+    {
+        const int cand[3][2] = {{128, 64}, {64, 128}, {64, 64}};
+        double best = -1.0;
         for (int i = 0; i < 3; ++i) {
             const long long rounds = (blocks(cand[i][0], cand[i][1]) + 511) / 512;
-            const long long cost = rounds * cand[i][0] * cand[i][1];
+            const double cost = (double)rounds * cand[i][0] * cand[i][1] * (i == 2 ? 1.4 : 1.0);
             if (best < 0 || cost < best) { best = cost; bm = cand[i][0]; bn = cand[i][1]; }
         }
+        if (blocks(128, 128) >= 2048 && (double)((blocks(128, 128) + 255) / 256) * 8192.0 <= best) { bm = 128; bn = 128; }
     }
     if (const char *force = getenv("OVO_GEMM_TILE")) {           // tuning knob (tools/gemm_bench.py): "128x128", "64x128", ...
         int fm = 0, fn = 0;
