@@ -41,6 +41,29 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
     return *(const uint32_t *)&h;
 }
 
+// xor-16 / xor-32 butterflies on VALU (gfx950 v_permlane16_swap / v_permlane32_swap) instead of ds_bpermute round trips
+// through the LDS crossbar: with one wave per SIMD nothing hides a ~100-cycle shuffle, and the online softmax has four per tile.
+typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+__device__ __forceinline__ float max_xor16_32(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_xor16_32(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+#ifdef OVO_ATTN_TRACE
+__device__ unsigned long long g_attn_trace[256];
+#define ATTN_STAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 1 && threadIdx.x == 0 && (i) < 256) g_attn_trace[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
+
 template <int HD, int QT>
 __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
     constexpr int KT = 64;                 // keys per tile
@@ -48,8 +71,10 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
     constexpr int VB = HD / 16 + 1;        // V blocks per key group (+1 block of padding: bank spread)
     constexpr int CH = HD / 8;             // 16-byte chunks per head row
     constexpr int NLD = KT * CH / 256;     // 16-byte pieces per thread per tile (K and V each)
-    __shared__ __attribute__((aligned(16))) uint16_t smem[KT * KROW + (KT / 4) * VB * 64];
-    uint16_t *sK = smem, *sV = smem + KT * KROW;
+    constexpr int TILE_ELEMS = KT * KROW + (KT / 4) * VB * 64;
+    constexpr bool DB = 2 * TILE_ELEMS * 2 <= 64 * 1024;      // double-buffered K/V tiles (one barrier per tile) when they fit
+    __shared__ __attribute__((aligned(16))) uint16_t smem[(DB ? 2 : 1) * TILE_ELEMS];
+    uint16_t *sK = smem, *sV = smem + KT * KROW;             // current tile (re-pointed per tile when DB)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -84,15 +109,25 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
 
     // two register sets: tiles t+1 and t+2 are in flight while tile t is multiplied (async-stage split, depth 2)
     uint4 k0r[NLD], v0r[NLD], k1r[NLD], v1r[NLD];
+    // per-thread source offsets of the NLD pieces inside a tile (row, chunk); the tile base advances by a wave-uniform stride
+    long long k_off[NLD], v_off[NLD];
+    int f_row[NLD];
+    bool f_ok[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int id = it * 256 + tid, row = id / CH, c = id % CH;
+        f_row[it] = row; f_ok[it] = c * 8 < a.hd;
+        k_off[it] = (long long)row * a.k_st + c * 8; v_off[it] = (long long)row * a.v_st + c * 8;
+    }
     auto fetch = [&](uint4 (&kr)[NLD], uint4 (&vr)[NLD], int k0) {      // global -> registers, thread -> (key row, 16-byte chunk)
+        const uint16_t *kt = kp + (long long)k0 * a.k_st, *vt = vp + (long long)k0 * a.v_st;
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
-            const int id = it * 256 + tid, row = id / CH, c = id % CH;
             kr[it] = make_uint4(0, 0, 0, 0);
             vr[it] = make_uint4(0, 0, 0, 0);
-            if (k0 + row < a.Tk && c * 8 < a.hd) {
-                kr[it] = *(const uint4 *)(kp + (long long)(k0 + row) * a.k_st + c * 8);
-                vr[it] = *(const uint4 *)(vp + (long long)(k0 + row) * a.v_st + c * 8);
+            if (f_ok[it] && k0 + f_row[it] < a.Tk) {
+                kr[it] = *(const uint4 *)(kt + k_off[it]);
+                vr[it] = *(const uint4 *)(vt + v_off[it]);
             }
         }
     };
@@ -121,6 +156,7 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
                     s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[kt], 0, 0, 0);
                 }
             }
+            ATTN_STAMP(100 + 4 * (k0 / KT));
             // ---- online softmax for query fr; this lane holds keys kt*16 + fq*4 + r ----
             if (k0 + KT > a.Tk) {                                   // wave-uniform: only the last tile has keys to mask
 #pragma unroll
@@ -139,8 +175,7 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
             float mx = -3.0e38f;                                    // max of the RAW scores (scale > 0 commutes with max)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = max_xor16_32(mx);
             const float m_new = fmaxf(m_run[t], mx * a.scale_log2e);
             const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
             float ps = 0.f;
@@ -152,8 +187,7 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
                     s[kt][r] = p;
                     ps += p;
                 }
-            ps += __shfl_xor(ps, 16, 64);
-            ps += __shfl_xor(ps, 32, 64);
+            ps = sum_xor16_32(ps);
             l_run[t] = l_run[t] * alpha + ps;
             m_run[t] = m_new;
             if (__any(alpha != 1.0f)) {                             // the running max settles after a few tiles
@@ -162,6 +196,7 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
                     oacc[t][i][0] *= alpha; oacc[t][i][1] *= alpha; oacc[t][i][2] *= alpha; oacc[t][i][3] *= alpha;
                 }
             }
+            ATTN_STAMP(101 + 4 * (k0 / KT));
             // ---- P fragments (bf16): element e of fragment kk <-> key (kk*2 + e/4)*16 + fq*4 + e%4 ----
             bf16x8 pf[2];
 #pragma unroll
@@ -171,6 +206,7 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
                 for (int e = 0; e < 8; e += 2) tmp[e >> 1] = pack2(s[kk * 2 + (e >> 2)][e & 3], s[kk * 2 + (e >> 2)][(e & 3) + 1]);
                 pf[kk] = *(bf16x8 *)tmp;
             }
+            ATTN_STAMP(102 + 4 * (k0 / KT));
             // ---- O^T += V^T P^T ----
 #pragma unroll
             for (int dt = 0; dt < HD / 16; ++dt) {
@@ -191,21 +227,53 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
     };
 
     const int n_tiles = (a.Tk + KT - 1) / KT;
+    ATTN_STAMP(0);
     fetch(k0r, v0r, 0);
     if (n_tiles > 1) fetch(k1r, v1r, KT);
-    for (int t = 0; t < n_tiles; t += 2) {
-        __syncthreads();                                        // previous tile fully consumed
+    ATTN_STAMP(1);
+    if (DB) {
+        // two LDS buffers: tile t is multiplied out of buffer t & 1 while tile t+1 (fetched one iteration ago) is committed to
+        // the other one and tile t+2 is fetched into the registers tile t just left -- ONE barrier per tile.
         commit(k0r, v0r);
         __syncthreads();
-        if (t + 2 < n_tiles) fetch(k0r, v0r, (t + 2) * KT);
-        compute(t * KT);
-        if (t + 1 >= n_tiles) break;
-        __syncthreads();
-        commit(k1r, v1r);
-        __syncthreads();
-        if (t + 3 < n_tiles) fetch(k1r, v1r, (t + 3) * KT);
-        compute((t + 1) * KT);
+        for (int t = 0; t < n_tiles; t += 2) {
+            ATTN_STAMP(2 + 4 * t);
+            if (t + 2 < n_tiles) fetch(k0r, v0r, (t + 2) * KT);
+            sK = smem; sV = smem + KT * KROW;
+            ATTN_STAMP(4 + 4 * t);
+            compute(t * KT);
+            ATTN_STAMP(5 + 4 * t);
+            if (t + 1 >= n_tiles) break;
+            sK = smem + TILE_ELEMS; sV = sK + KT * KROW;
+            commit(k1r, v1r);
+            __syncthreads();
+            ATTN_STAMP(6 + 4 * t);
+            if (t + 3 < n_tiles) fetch(k1r, v1r, (t + 3) * KT);
+            ATTN_STAMP(8 + 4 * t);
+            compute((t + 1) * KT);
+            ATTN_STAMP(9 + 4 * t);
+            if (t + 2 < n_tiles) {
+                sK = smem; sV = smem + KT * KROW;
+                commit(k0r, v0r);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int t = 0; t < n_tiles; t += 2) {
+            __syncthreads();                                        // previous tile fully consumed
+            commit(k0r, v0r);
+            __syncthreads();
+            if (t + 2 < n_tiles) fetch(k0r, v0r, (t + 2) * KT);
+            compute(t * KT);
+            if (t + 1 >= n_tiles) break;
+            __syncthreads();
+            commit(k1r, v1r);
+            __syncthreads();
+            if (t + 3 < n_tiles) fetch(k1r, v1r, (t + 3) * KT);
+            compute((t + 1) * KT);
+        }
     }
+    ATTN_STAMP(250);
     // ---- store: lane holds O[q_row][dt*16 + fq*4 + r] ----
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
