@@ -187,7 +187,8 @@ int ovo_mask_area(const uint8_t *masks, int64_t pixels, const int32_t *rows, int
 
 /* C[M,N] = act(alpha * A[M,K] . W[N,K]^T + bias[N]) + add[M,N]      (nn.Linear layout: W is [out, in])
  *   in_dtype : 1 = f16, 2 = bf16 (A and W);  out_dtype: 0 = f32, 1 = f16, 2 = bf16
- *   act      : 0 none, 1 GELU (erf), 2 QuickGELU x*sigmoid(1.702x) (open_clip "-qg" cards), 3 ReLU, 4 sigmoid (SAM2 decoder)
+ *   act      : 0 none, 1 GELU (erf), 2 QuickGELU x*sigmoid(1.702x) (open_clip "-qg" cards), 3 ReLU, 4 sigmoid (SAM2 decoder),
+ *              5 tanh-GELU (SigLIP towers)
  *   add      : optional f32 [M,N] (residual stream / position embedding); may alias C when out_dtype = 0
  *   K % 32 == 0, N % 4 == 0, lda/ldw multiples of 8 elements, 16-byte aligned bases. */
 typedef struct {
@@ -299,11 +300,12 @@ int ovo_cast_f32(const float *x, int64_t n, void *y, int dtype, ovo_stream_t str
 typedef struct {
     int32_t image_size, patch, width, layers, heads, mlp_dim, out_dim;
     int32_t n_prefix;  /* 1 = class token, 0 = none                                             */
-    int32_t act;       /* 1 = GELU, 2 = QuickGELU                                               */
+    int32_t act;       /* 1 = GELU, 2 = QuickGELU, 5 = tanh-GELU (SigLIP)                       */
     int32_t pre_ln;    /* ln_pre present                                                        */
     int32_t use_rope;  /* 2-D rotary embedding on q, k (PE)                                     */
     int32_t pool;      /* 0: all tokens after ln_post -> f32 [B, T, width] (forward_features);  */
                        /* 1: ln_post(class token) @ proj -> f32 [B, out_dim] (encode_image)     */
+                       /* 2: SigLIP attention-pool head over ln_post(tokens) -> f32 [B, width]  */
     int32_t kpad;      /* 3*patch*patch rounded up to a multiple of 32                          */
     float ln_eps;
 } ovo_vit_config_t;
@@ -325,6 +327,13 @@ typedef struct {
     const void *proj_w;                               /* [out_dim, width] (= proj^T) when pool = 1                    */
     const float *rope_cos, *rope_sin;                 /* [n_prefix + P, head_dim] when use_rope                       */
     const ovo_vit_layer_t *layers;                    /* HOST array of cfg.layers entries                            */
+    /* pool = 2 (timm AttentionPoolLatent, SigLIP "map" pooling; open_clip TimmModel towers, clip_utils.py:53-75):    */
+    const void *map_q;                                /* bf16 [width] = latent . Wq^T + bq (input independent)       */
+    const void *map_kv_w; const float *map_kv_b;      /* [2*width, width] (k | v)                                    */
+    const void *map_proj_w; const float *map_proj_b;  /* [width, width]                                              */
+    const float *map_ln_g, *map_ln_b;
+    const void *map_fc1_w; const float *map_fc1_b;    /* [mlp_dim, width]                                            */
+    const void *map_fc2_w; const float *map_fc2_b;    /* [width, mlp_dim]                                            */
 } ovo_vit_weights_t;
 
 size_t ovo_vit_workspace_bytes(const ovo_vit_config_t *cfg, int B);

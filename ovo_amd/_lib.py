@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libovo_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class OvoHipError(RuntimeError):
@@ -64,7 +64,9 @@ class VitLayer(C.Structure):
 class VitWeights(C.Structure):
     """ovo_vit_weights_t"""
     _fields_ = [(n, _P) for n in ("patch_w", "patch_b", "prefix", "pos", "ln_pre_g", "ln_pre_b", "ln_post_g", "ln_post_b",
-                                   "proj_w", "rope_cos", "rope_sin")] + [("layers", C.POINTER(VitLayer))]
+                                   "proj_w", "rope_cos", "rope_sin")] + [("layers", C.POINTER(VitLayer))] + \
+        [(n, _P) for n in ("map_q", "map_kv_w", "map_kv_b", "map_proj_w", "map_proj_b", "map_ln_g", "map_ln_b",
+                           "map_fc1_w", "map_fc1_b", "map_fc2_w", "map_fc2_b")]
 
 
 class HieraConfig(C.Structure):

@@ -104,6 +104,12 @@ __device__ __forceinline__ void act4(float *v, int act) {
     } else if (act == 4) {                                       // sigmoid (SAM2 IoU head)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + __expf(-v[r]));
+    } else if (act == 5) {                                       // GELU, tanh form (SigLIP towers): x * sigmoid(2 sqrt(2/pi) (x + 0.044715 x^3))
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float u = 1.5957691216057308f * fmaf(0.044715f * v[r] * v[r], v[r], v[r]);
+            v[r] = v[r] / (1.0f + __expf(-u));
+        }
     }
 }
 

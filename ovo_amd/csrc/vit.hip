@@ -66,13 +66,15 @@ int ovo_vit_forward(const ovo_vit_config_t *cfg, const ovo_vit_weights_t *w, con
                     void *ws, size_t ws_bytes, ovo_stream_t stream) {
     OVO_REQUIRE(cfg && w && images && out && ws && B > 0, "null argument");
     const ovo_vit_config_t &c = *cfg;
-    OVO_REQUIRE(c.image_size % c.patch == 0 && c.width % c.heads == 0 && c.layers >= 0, "bad config");
+    OVO_REQUIRE(c.patch > 0 && c.image_size >= c.patch && c.width % c.heads == 0 && c.layers >= 0, "bad config");   // a trailing partial patch is dropped, as the stride-p conv does
     OVO_REQUIRE(c.width % 32 == 0 && c.mlp_dim % 32 == 0 && c.kpad % 32 == 0 && c.kpad >= 3 * c.patch * c.patch, "dims must be multiples of 32");
     OVO_REQUIRE(w->patch_w && w->layers && w->ln_post_g && w->ln_post_b, "missing weights");
     OVO_REQUIRE(c.n_prefix == 0 || w->prefix, "class embedding missing");
     OVO_REQUIRE(!c.pre_ln || (w->ln_pre_g && w->ln_pre_b), "ln_pre weights missing");
     OVO_REQUIRE(!c.use_rope || (w->rope_cos && w->rope_sin), "rope tables missing");
-    OVO_REQUIRE(c.pool == 0 || (c.pool == 1 && w->proj_w && c.n_prefix == 1 && c.out_dim % 4 == 0), "pool=1 needs a class token and proj");
+    OVO_REQUIRE(c.pool == 0 || c.pool == 2 || (c.pool == 1 && w->proj_w && c.n_prefix == 1 && c.out_dim % 4 == 0), "pool=1 needs a class token and proj");
+    OVO_REQUIRE(c.pool != 2 || (w->map_q && w->map_kv_w && w->map_kv_b && w->map_proj_w && w->map_proj_b && w->map_ln_g && w->map_ln_b &&
+                                w->map_fc1_w && w->map_fc1_b && w->map_fc2_w && w->map_fc2_b && c.out_dim == c.width), "pool=2 needs the map_* weights");
     const int G = c.image_size / c.patch, P = G * G, T = P + c.n_prefix, M = B * T, hd = c.width / c.heads;
     OVO_REQUIRE(hd % 8 == 0 && hd <= 128, "head_dim must be a multiple of 8, <= 128");
     Ws k = carve(c, B, ws);
@@ -105,6 +107,23 @@ int ovo_vit_forward(const ovo_vit_config_t *cfg, const ovo_vit_weights_t *w, con
 
     if (c.pool == 0) {
         TRY(ovo_layernorm(k.x, D, M, D, w->ln_post_g, w->ln_post_b, c.ln_eps, out, D, 0, stream));
+    } else if (c.pool == 2) {
+        // SigLIP "map" head: one learned query per image attends over ln_post(tokens); y = att @ Wo; out = y + mlp(LN(y)).
+        // The query projection does not depend on the input and arrives precomputed (map_q).
+        float *y = k.patch;                                               // [B, D] (the patch buffer is free by now)
+        TRY(ovo_layernorm(k.x, D, M, D, w->ln_post_g, w->ln_post_b, c.ln_eps, k.h, D, 2, stream));
+        TRY(gemm(k.h, D, w->map_kv_w, D, w->map_kv_b, k.qkv, 2 * D, 2, nullptr, 0, M, 2 * D, D, 0, stream));
+        ovo_attention_t a = {};
+        a.q = w->map_q; a.k = k.qkv; a.v = k.qkv + D; a.o = k.att;
+        a.q_sb = 0; a.q_sh = hd; a.q_st = D;
+        a.k_sb = a.v_sb = (int64_t)T * 2 * D; a.k_sh = a.v_sh = hd; a.k_st = a.v_st = 2 * D;
+        a.o_sb = D; a.o_sh = hd; a.o_st = D;
+        a.B = B; a.H = c.heads; a.Tq = 1; a.Tk = T; a.hd = hd; a.scale = scale;
+        TRY(ovo_attention(&a, stream));
+        TRY(gemm(k.att, D, w->map_proj_w, D, w->map_proj_b, y, D, 0, nullptr, 0, B, D, D, 0, stream));
+        TRY(ovo_layernorm(y, D, B, D, w->map_ln_g, w->map_ln_b, c.ln_eps, k.h, D, 2, stream));
+        TRY(gemm(k.h, D, w->map_fc1_w, D, w->map_fc1_b, k.u, c.mlp_dim, 2, nullptr, 0, B, c.mlp_dim, D, c.act, stream));
+        TRY(gemm(k.u, c.mlp_dim, w->map_fc2_w, c.mlp_dim, w->map_fc2_b, out, D, 0, y, D, B, D, c.mlp_dim, 0, stream));
     } else {
         // ln_post on the class token of each image (row stride T*D), then @ proj
         TRY(ovo_layernorm(k.x, (int64_t)T * D, B, D, w->ln_post_g, w->ln_post_b, c.ln_eps, k.h, D, 2, stream));

@@ -32,7 +32,7 @@ class ViTSpec:
     heads: int
     mlp_dim: int
     out_dim: int
-    act: str = "gelu"                 # "gelu" | "quick_gelu" (DFN "-qg" cards, clip_utils.py:57-60)
+    act: str = "gelu"                 # "gelu" | "quick_gelu" (DFN "-qg" cards, clip_utils.py:57-60) | "gelu_tanh" (SigLIP)
     pre_ln: bool = True
     use_rope: bool = False            # perception_models Rope2D
     cls_token: bool = True
@@ -40,6 +40,8 @@ class ViTSpec:
     mean: Tuple[float, float, float] = CLIP_MEAN
     std: Tuple[float, float, float] = CLIP_STD
     attn_pool_heads: int = 0          # > 0: PE attention-pool head (only W_v / W_o / proj are used by TextRegion)
+    map_pool: bool = False            # SigLIP: timm AttentionPoolLatent head instead of class token + proj
+    patch_bias: bool = False          # conv1 has a bias (timm / SigLIP patch embedding)
 
     @property
     def grid(self) -> int:
@@ -52,6 +54,11 @@ class ViTSpec:
     @property
     def kpad(self) -> int:
         return (3 * self.patch * self.patch + 31) // 32 * 32
+
+    @property
+    def mlp_pad(self) -> int:
+        """Hidden width the kernels run with: zero rows / columns up to a multiple of 32 (SigLIP so400m has 4304)."""
+        return (self.mlp_dim + 31) // 32 * 32
 
     def flops_per_image(self) -> float:
         """Dense FLOPs of one forward (SURVEY.md §8d formula: 24 N d^2 L + 4 N^2 d L + patch embed)."""
@@ -68,7 +75,19 @@ SPECS: Dict[str, ViTSpec] = {
     "ViT-H-14-qg": ViTSpec("ViT-H-14-qg", 224, 14, 1280, 32, 16, 5120, 1024, act="quick_gelu"),
     "PE-Core-L14-336": ViTSpec("PE-Core-L14-336", 336, 14, 1024, 24, 16, 4096, 1024, use_rope=True,
                                mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), attn_pool_heads=8),
+    "ViT-H-14-378qg": ViTSpec("ViT-H-14-378qg", 378, 14, 1280, 32, 16, 5120, 1024, act="quick_gelu"),
+    # SigLIP so400m towers (open_clip "ViT-SO400M-14-SigLIP[-384]", clip_utils.py:62-75): no class token, no ln_pre,
+    # tanh-GELU, LayerNorm eps 1e-6, attention-pool head, no output projection
+    "SigLIP": ViTSpec("SigLIP", 224, 14, 1152, 27, 16, 4304, 1152, act="gelu_tanh", pre_ln=False, cls_token=False, ln_eps=1e-6,
+                      mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), map_pool=True, patch_bias=True),
+    "SigLIP-384": ViTSpec("SigLIP-384", 384, 14, 1152, 27, 16, 4304, 1152, act="gelu_tanh", pre_ln=False, cls_token=False,
+                          ln_eps=1e-6, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), map_pool=True, patch_bias=True),   # 27x27 patches: the
+                                                                                     # stride-14 conv ignores the last 6 rows / columns
+    "SigLIP2-384": ViTSpec("SigLIP2-384", 384, 16, 1152, 27, 16, 4304, 1152, act="gelu_tanh", pre_ln=False, cls_token=False,
+                           ln_eps=1e-6, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), map_pool=True, patch_bias=True),
     # reduced shapes for tests
+    "tiny-siglip": ViTSpec("tiny-siglip", 56, 14, 128, 2, 4, 432, 128, act="gelu_tanh", pre_ln=False, cls_token=False, ln_eps=1e-6,
+                           mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), map_pool=True, patch_bias=True),
     "tiny-clip": ViTSpec("tiny-clip", 64, 16, 128, 2, 4, 512, 64, act="quick_gelu"),
     "tiny-pe": ViTSpec("tiny-pe", 84, 14, 128, 2, 4, 512, 128, use_rope=True, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5),
                        attn_pool_heads=4),
@@ -83,7 +102,11 @@ def random_state(spec: ViTSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
     def rn(*shape, std=0.02):
         return torch.randn(*shape, generator=g) * std
     sd = {"conv1.weight": rn(d, 3, spec.patch, spec.patch, std=0.05), "positional_embedding": rn(t, d),
-          "ln_post.weight": 1 + rn(d, std=0.05), "ln_post.bias": rn(d, std=0.05), "proj": rn(d, spec.out_dim, std=d ** -0.5)}
+          "ln_post.weight": 1 + rn(d, std=0.05), "ln_post.bias": rn(d, std=0.05)}
+    if not spec.map_pool:
+        sd["proj"] = rn(d, spec.out_dim, std=d ** -0.5)
+    if spec.patch_bias:
+        sd["conv1.bias"] = rn(d)
     if spec.cls_token:
         sd["class_embedding"] = rn(d)
     if spec.pre_ln:
@@ -101,6 +124,15 @@ def random_state(spec: ViTSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
         sd["attn_pool.attn.in_proj_weight"], sd["attn_pool.attn.in_proj_bias"] = rn(3 * d, d, std=d ** -0.5), rn(3 * d)
         sd["attn_pool.attn.out_proj.weight"], sd["attn_pool.attn.out_proj.bias"] = rn(d, d, std=d ** -0.5), rn(d)
         sd["attn_pool.layernorm.weight"], sd["attn_pool.layernorm.bias"] = 1 + rn(d, std=0.05), rn(d, std=0.05)
+    if spec.map_pool:
+        m = spec.mlp_dim
+        sd["attn_pool.latent"] = rn(1, 1, d, std=d ** -0.5)
+        sd["attn_pool.q.weight"], sd["attn_pool.q.bias"] = rn(d, d, std=d ** -0.5), rn(d)
+        sd["attn_pool.kv.weight"], sd["attn_pool.kv.bias"] = rn(2 * d, d, std=d ** -0.5), rn(2 * d)
+        sd["attn_pool.proj.weight"], sd["attn_pool.proj.bias"] = rn(d, d, std=d ** -0.5), rn(d)
+        sd["attn_pool.norm.weight"], sd["attn_pool.norm.bias"] = 1 + rn(d, std=0.05), rn(d, std=0.05)
+        sd["attn_pool.mlp.fc1.weight"], sd["attn_pool.mlp.fc1.bias"] = rn(m, d, std=d ** -0.5), rn(m)
+        sd["attn_pool.mlp.fc2.weight"], sd["attn_pool.mlp.fc2.bias"] = rn(d, m, std=m ** -0.5), rn(d)
     return sd
 
 
@@ -143,6 +175,14 @@ class HipViT:
             self._keep.append(x)
             return L.ptr(x)
 
+        extra = spec.mlp_pad - spec.mlp_dim               # zero hidden units: act(0) = 0 and their fc2 columns are 0
+
+        def pad_rows(t):
+            return t if not extra else torch.cat([t.float(), t.new_zeros((extra,) + tuple(t.shape[1:]), dtype=torch.float32)])
+
+        def pad_cols(t):
+            return t if not extra else torch.cat([t.float(), t.new_zeros((t.shape[0], extra), dtype=torch.float32)], dim=1)
+
         conv = sd["conv1.weight"].reshape(d, -1).float()
         pw = torch.zeros(d, spec.kpad)
         pw[:, :conv.shape[1]] = conv
@@ -162,8 +202,8 @@ class HipViT:
             ly.qkv_w, ly.qkv_b = mat(sd[p + "attn.in_proj_weight"]), vec(sd[p + "attn.in_proj_bias"])
             ly.out_w, ly.out_b = mat(ow), vec(ob)
             ly.ln2_g, ly.ln2_b = vec(sd[p + "ln_2.weight"]), vec(sd[p + "ln_2.bias"])
-            ly.fc1_w, ly.fc1_b = mat(sd[p + "mlp.c_fc.weight"]), vec(sd[p + "mlp.c_fc.bias"])
-            ly.fc2_w, ly.fc2_b = mat(fw), vec(fb)
+            ly.fc1_w, ly.fc1_b = mat(pad_rows(sd[p + "mlp.c_fc.weight"])), vec(pad_rows(sd[p + "mlp.c_fc.bias"]))
+            ly.fc2_w, ly.fc2_b = mat(pad_cols(fw)), vec(fb)
         w = L.VitWeights()
         w.patch_w = mat(pw)
         w.patch_b = vec(sd["conv1.bias"]) if "conv1.bias" in sd else None
@@ -172,7 +212,17 @@ class HipViT:
         if spec.pre_ln:
             w.ln_pre_g, w.ln_pre_b = vec(sd["ln_pre.weight"]), vec(sd["ln_pre.bias"])
         w.ln_post_g, w.ln_post_b = vec(sd["ln_post.weight"]), vec(sd["ln_post.bias"])
-        w.proj_w = mat(sd["proj"].float().t())
+        if "proj" in sd:
+            w.proj_w = mat(sd["proj"].float().t())
+        if spec.map_pool:
+            a = "attn_pool."
+            q = torch.nn.functional.linear(sd[a + "latent"].float().reshape(1, d), sd[a + "q.weight"].float(), sd[a + "q.bias"].float())
+            w.map_q = mat(q.reshape(d))
+            w.map_kv_w, w.map_kv_b = mat(sd[a + "kv.weight"]), vec(sd[a + "kv.bias"])
+            w.map_proj_w, w.map_proj_b = mat(sd[a + "proj.weight"]), vec(sd[a + "proj.bias"])
+            w.map_ln_g, w.map_ln_b = vec(sd[a + "norm.weight"]), vec(sd[a + "norm.bias"])
+            w.map_fc1_w, w.map_fc1_b = mat(pad_rows(sd[a + "mlp.fc1.weight"])), vec(pad_rows(sd[a + "mlp.fc1.bias"]))
+            w.map_fc2_w, w.map_fc2_b = mat(pad_cols(sd[a + "mlp.fc2.weight"].float())), vec(sd[a + "mlp.fc2.bias"])
         if spec.use_rope:
             cos, sin = rope_tables(spec)
             w.rope_cos, w.rope_sin = vec(cos), vec(sin)
@@ -180,7 +230,7 @@ class HipViT:
         self._weights = w
         self._cfg = {}
         self._ws: Optional[torch.Tensor] = None
-        self.proj = sd["proj"].detach().to(self.device, torch.float32)
+        self.proj = sd["proj"].detach().to(self.device, torch.float32) if "proj" in sd else None
         self.pool_weights = None
         if spec.attn_pool_heads:
             self.pool_weights = {k[len("attn_pool."):]: v.detach().float() for k, v in sd.items() if k.startswith("attn_pool.")}
@@ -189,8 +239,8 @@ class HipViT:
         c = self._cfg.get(pool)
         if c is None:
             s = self.spec
-            c = L.VitConfig(s.image_size, s.patch, s.width, s.layers, s.heads, s.mlp_dim, s.out_dim, int(s.cls_token),
-                            2 if s.act == "quick_gelu" else 1, int(s.pre_ln), int(s.use_rope), pool, s.kpad, s.ln_eps)
+            c = L.VitConfig(s.image_size, s.patch, s.width, s.layers, s.heads, s.mlp_pad, s.out_dim, int(s.cls_token),
+                            {"gelu": 1, "quick_gelu": 2, "gelu_tanh": 5}[s.act], int(s.pre_ln), int(s.use_rope), pool, s.kpad, s.ln_eps)
             self._cfg[pool] = c
         return c
 
@@ -224,13 +274,14 @@ class HipViT:
     # ---------------------------------------------------------------- forward
     def forward(self, images: torch.Tensor, tokens: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """images f32 [B, 3, S, S] (preprocessed).  tokens=False -> f32 [B, out_dim] = ln_post(cls) @ proj
-        (open_clip encode_image); tokens=True -> f32 [B, T, width] after ln_post (PE forward_features(norm=True))."""
+        (open_clip encode_image; the attention-pool head for SigLIP towers); tokens=True -> f32 [B, T, width] after
+        ln_post (PE forward_features(norm=True))."""
         s = self.spec
         x = L.dev(images, torch.float32, "images")
         b = x.shape[0]
         if tuple(x.shape[1:]) != (3, s.image_size, s.image_size):
             raise L.OvoHipError(f"expected [B, 3, {s.image_size}, {s.image_size}], got {tuple(x.shape)}")
-        cfg = self._config(0 if tokens else 1)
+        cfg = self._config(0 if tokens else (2 if s.map_pool else 1))
         ws, need = self._workspace(cfg, b)
         if out is None:
             shape = (b, s.tokens, s.width) if tokens else (b, s.out_dim)

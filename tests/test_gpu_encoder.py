@@ -52,7 +52,8 @@ def test_gemm_epilogues_and_padding():
     w = (torch.randn(n, k, generator=g) * 0.1).to(DEV, torch.bfloat16)
     bias, add = torch.randn(n, generator=g).to(DEV), torch.randn(m, n, generator=g).to(DEV)
     z = a.float() @ w.float().T
-    for act, fn in ((1, torch.nn.functional.gelu), (2, lambda x: x * torch.sigmoid(1.702 * x))):
+    for act, fn in ((1, torch.nn.functional.gelu), (2, lambda x: x * torch.sigmoid(1.702 * x)),
+                    (5, lambda x: torch.nn.functional.gelu(x, approximate="tanh"))):
         torch.testing.assert_close(_gemm(a, w, bias, act=act), fn(z + bias), atol=3e-4, rtol=3e-4)
     torch.testing.assert_close(_gemm(a, w, bias, add=add, alpha=0.5), 0.5 * z + bias + add, atol=3e-4, rtol=3e-4)
     x = add.clone()                                          # in-place residual: C aliases add
@@ -202,6 +203,50 @@ def test_vit_forward_vs_oracle_full_size(card, batch):
     print(f"{card}: max |unit feature error| = {err:.2e}, min cosine = {cos:.6f}")
     # bound scales with the element magnitude 1/sqrt(out_dim): 1e-3 at out_dim >= 512 (the BASELINE models)
     assert err < 1e-3 * max(1.0, (512 / spec.out_dim) ** 0.5 * 1.5) and cos > 0.9999
+
+
+def test_siglip_forward_vs_hf_golden():
+    """SigLIP tower (no class token, tanh-GELU, attention-pool head) vs HuggingFace SiglipVisionModel (fp32) on the golden
+    weights / input: width 64, hidden 176 (zero padded to 192 on the device), 2 layers, 16 tokens."""
+    from oracle import vit as OV
+    from ovo_amd.encoders.vit import HipViT, ViTSpec
+    d = golden("hf_siglip_vit")
+    sd = OV.hf_siglip_to_openclip({k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")})
+    spec = ViTSpec("hf-siglip-golden", 56, int(d["patch"]), 64, 2, int(d["heads"]), 176, 64, act="gelu_tanh", pre_ln=False,
+                   cls_token=False, ln_eps=1e-6, mean=(0.5,) * 3, std=(0.5,) * 3, map_pool=True, patch_bias=True)
+    vit = HipViT(spec, sd, device=DEV)
+    x = torch.from_numpy(d["x"]).to(DEV)
+    tok = vit.forward(x, tokens=True).cpu().numpy()
+    np.testing.assert_allclose(tok, d["tokens"], atol=5e-2, rtol=5e-2)
+    emb = vit.forward(x).cpu().numpy()
+    np.testing.assert_allclose(emb, d["pooled"], atol=3e-2, rtol=3e-2)
+    cos = (emb * d["pooled"]).sum(1) / np.linalg.norm(emb, axis=1) / np.linalg.norm(d["pooled"], axis=1)
+    assert cos.min() > 0.9995
+
+
+@pytest.mark.parametrize("card,batch,layers", [("tiny-siglip", 3, None), ("SigLIP", 2, 3), ("SigLIP-384", 1, 1), ("SigLIP2-384", 1, 1)])
+def test_siglip_forward_vs_oracle(card, batch, layers):
+    """SigLIP so400m shapes (width 1152, head_dim 72, hidden 4304 -> 4320 padded, 256 / 729 / 576 tokens) vs the fp32 oracle;
+    `layers` trims the depth so the CPU side finishes in seconds (every block is the same code)."""
+    import dataclasses
+    from oracle import vit as OV
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state
+    spec = SPECS[card]
+    if layers:
+        spec = dataclasses.replace(spec, layers=layers)
+    sd = random_state(spec, seed=13)
+    vit = HipViT(spec, sd, device=DEV)
+    x = torch.randn(batch, 3, spec.image_size, spec.image_size, generator=torch.Generator().manual_seed(3))
+    tok = OV.vit_forward(sd, x, patch=spec.patch, heads=spec.heads, act=spec.act, pre_ln=False, cls_token=False, eps=spec.ln_eps, tokens=True)
+    assert tok.shape[1] == spec.tokens
+    ref = OV.map_pool(sd, tok, spec.heads, act=spec.act, eps=spec.ln_eps)
+    out = vit.forward(x.to(DEV)).cpu()
+    nr, no = torch.nn.functional.normalize(ref, dim=-1), torch.nn.functional.normalize(out, dim=-1)
+    err, cos = (nr - no).abs().max().item(), (nr * no).sum(-1).min().item()
+    print(f"{card}: max |unit feature error| = {err:.2e}, min cosine = {cos:.6f}")
+    assert err < 1e-3 * max(1.0, (512 / spec.out_dim) ** 0.5 * 1.5) and cos > 0.9999
+    got_tok = vit.forward(x.to(DEV), tokens=True).cpu()
+    torch.testing.assert_close(got_tok, tok, atol=5e-2, rtol=5e-2)
 
 
 @pytest.mark.parametrize("hw", [(100, 150), (170, 260)])

@@ -206,22 +206,29 @@ def test_mask_crops_vs_oracle(also_bbox, as_u8):
     assert np.all(got[-1, :3] == 0) and np.all(got[-4, :3] == 0)                  # empty / degenerate masked crops -> zeros
 
 
-@pytest.mark.parametrize("mode", ["vanilla", "fixed_weights", "hovsg", "adaptive_weights", "concept_fusion"])
-def test_extract_clip_crop_modes_vs_oracle(mode):
-    """clip_generator.py:125-158 for the crop-based embed types: crops -> ViT pooled descriptors -> fusion."""
+@pytest.mark.parametrize("mode,card", [("vanilla", "tiny-clip"), ("fixed_weights", "tiny-clip"), ("hovsg", "tiny-clip"),
+                                       ("adaptive_weights", "tiny-clip"), ("concept_fusion", "tiny-clip"),
+                                       ("vanilla", "tiny-siglip"), ("hovsg", "tiny-siglip")])
+def test_extract_clip_crop_modes_vs_oracle(mode, card):
+    """clip_generator.py:125-158 for the crop-based embed types: crops -> ViT pooled descriptors -> fusion; with a CLIP tower
+    (class token + proj) and a SigLIP one (attention-pool head; the reference's default model_card is SigLIP-384)."""
     from oracle import features as OF, vit as OV
     from ovo_amd.encoders.vit import SPECS, HipViT, random_state
     from ovo_amd.entities.clip_generator import CLIPGenerator
-    spec = SPECS["tiny-clip"]
+    spec = SPECS[card]
     sd = random_state(spec, seed=6)
-    gen = CLIPGenerator({"embed_type": mode, "model_card": "tiny-clip", "mask_res": 80}, device=DEV, encoder=HipViT(spec, sd, device=DEV))
+    gen = CLIPGenerator({"embed_type": mode, "model_card": card, "mask_res": 80}, device=DEV, encoder=HipViT(spec, sd, device=DEV))
     masks, img = _crop_fixture()
     masks = masks[:-4]                                   # regular masks only (the reference raises on degenerate boxes)
     got = gen.extract_clip(_t(img), _t(masks)).cpu().numpy()
 
     def encode(x01):                                     # encode_image: preprocess to the model size, pooled + projected
         b = torch.stack([OV.resize_normalize(torch.from_numpy(np.ascontiguousarray(im)), spec.image_size, spec.mean, spec.std, None, scale=1.0) for im in x01])
-        f = OV.vit_forward(sd, b, patch=spec.patch, heads=spec.heads, act=spec.act, rope=None, tokens=False).numpy()
+        if spec.map_pool:
+            t = OV.vit_forward(sd, b, patch=spec.patch, heads=spec.heads, act=spec.act, pre_ln=False, cls_token=False, eps=spec.ln_eps, tokens=True)
+            f = OV.map_pool(sd, t, spec.heads, act=spec.act, eps=spec.ln_eps).numpy()
+        else:
+            f = OV.vit_forward(sd, b, patch=spec.patch, heads=spec.heads, act=spec.act, rope=None, tokens=False).numpy()
         return f / np.linalg.norm(f, axis=-1, keepdims=True)
     crops = OF.mask_crops(masks, img, mode != "vanilla", 50, 80) / 255.0
     if mode == "vanilla":

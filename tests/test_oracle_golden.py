@@ -167,3 +167,17 @@ def test_text_tower_vs_hf_golden(act):
     sd = OT.hf_clip_text_to_openclip({k[len(pre):]: torch.from_numpy(d[k]) for k in d.files if k.startswith(pre)})
     out = OT.text_forward(sd, torch.from_numpy(d[f"{act}:ids"]), heads=int(d["heads"]), act=act)
     np.testing.assert_allclose(out.numpy(), d[f"{act}:out"], atol=3e-6, rtol=1e-5)
+
+
+def test_siglip_tower_vs_hf_golden():
+    """oracle/vit.py on the SigLIP variant (no class token, no pre-LN, tanh-GELU, attention-pooling head) against
+    HuggingFace's SiglipVisionModel on the same random weights (tools/gen_hf_siglip.py)."""
+    import torch
+    from oracle import vit as OV
+    d = golden("hf_siglip_vit")
+    sd = OV.hf_siglip_to_openclip({k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")})
+    x = torch.from_numpy(d["x"])
+    tok = OV.vit_forward(sd, x, patch=int(d["patch"]), heads=int(d["heads"]), act="gelu_tanh", pre_ln=False, cls_token=False, eps=1e-6, tokens=True)
+    np.testing.assert_allclose(tok.numpy(), d["tokens"], atol=2e-5, rtol=1e-5)
+    pooled = OV.map_pool(sd, tok, heads=int(d["heads"]))
+    np.testing.assert_allclose(pooled.numpy(), d["pooled"], atol=2e-5, rtol=1e-5)
