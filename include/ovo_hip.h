@@ -387,7 +387,7 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
  * mask_generator.py:113).  Its matrix products are ovo_gemm / ovo_attention calls; these are the passes between them.
  * ============================================================================================= */
 
-/* One pass over R rows of C channels (C % 4 == 0, C <= 1024):  v = x[r] (+ base[r % base_rows]);  if gamma: v = LN(v);
+/* One pass over R rows of C channels (C % 4 == 0, C <= 2048):  v = x[r] (+ base[r % base_rows]);  if gamma: v = LN(v);
  * then any of  y f32[R,C] (may alias x),  y16 bf16[R,C],  ype16 bf16[R,C] = v + pe[r % pe_rows]  (NULL = skip).
  * This is every LayerNorm / residual / "+ positional code" / cast of the two-way transformer. */
 int ovo_row_epilogue(const float *x, int64_t R, int C, const float *base, int64_t base_rows, const float *gamma, const float *beta,

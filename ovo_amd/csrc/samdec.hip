@@ -54,15 +54,16 @@ struct RowArgs {
     float *y; uint16_t *y16; uint16_t *ype16;
     long long R; int C;
 };
+template <int NV>
 __global__ void __launch_bounds__(256) k_row_epilogue(RowArgs a) {
     const int lane = threadIdx.x & 63;
     const long long waves = (long long)gridDim.x * 4;
     for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < a.R; r += waves) {
-        float4 v[4];
+        float4 v[NV];
         const int nv = (a.C + 255) / 256;
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < nv && c < a.C) {
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256) k_row_epilogue(RowArgs a) {
             const float mean = wave_sum(sum) / (float)a.C;
             float sq = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 const int c = (i * 64 + lane) * 4;
                 if (i < nv && c < a.C) {
                     const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256) k_row_epilogue(RowArgs a) {
             }
             const float rstd = rsqrtf(wave_sum(sq) / (float)a.C + a.eps);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 const int c = (i * 64 + lane) * 4;
                 if (i < nv && c < a.C) {
                     const float4 g = *(const float4 *)(a.gamma + c), b = *(const float4 *)(a.beta + c);
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256) k_row_epilogue(RowArgs a) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
             if (i < nv && c < a.C) {
                 if (a.y) *(float4 *)(a.y + r * a.C + c) = v[i];
@@ -375,7 +376,7 @@ extern "C" int ovo_amg_binarize(const float *logits, const int32_t *sel, int n_s
 extern "C" int ovo_row_epilogue(const float *x, int64_t R, int C, const float *base, int64_t base_rows, const float *gamma,
                                 const float *beta, float eps, const float *pe, int64_t pe_rows, float *y, void *y16, void *ype16,
                                 ovo_stream_t stream) {
-    OVO_REQUIRE(R >= 0 && C > 0 && C % 4 == 0 && C <= 1024, "C must be a multiple of 4, <= 1024");
+    OVO_REQUIRE(R >= 0 && C > 0 && C % 4 == 0 && C <= 2048, "C must be a multiple of 4, <= 2048");
     if (R == 0) return OVO_OK;
     OVO_REQUIRE(x && (y || y16 || ype16), "null pointer");
     OVO_REQUIRE((gamma == nullptr) == (beta == nullptr), "gamma and beta go together");
@@ -383,7 +384,8 @@ extern "C" int ovo_row_epilogue(const float *x, int64_t R, int C, const float *b
     RowArgs a;
     a.x = x; a.base = base; a.base_rows = base_rows; a.gamma = gamma; a.beta = beta; a.eps = eps; a.pe = pe; a.pe_rows = pe_rows;
     a.y = y; a.y16 = (uint16_t *)y16; a.ype16 = (uint16_t *)ype16; a.R = R; a.C = C;
-    k_row_epilogue<<<ovo_grid(R, 4, 256 * 16), 256, 0, (hipStream_t)stream>>>(a);
+    if (C <= 1024) k_row_epilogue<4><<<ovo_grid(R, 4, 256 * 16), 256, 0, (hipStream_t)stream>>>(a);
+    else k_row_epilogue<8><<<ovo_grid(R, 4, 256 * 16), 256, 0, (hipStream_t)stream>>>(a);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

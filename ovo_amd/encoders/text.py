@@ -27,7 +27,16 @@ class TextSpec:
     layers: int
     heads: int
     out_dim: int
-    act: str = "gelu"             # "quick_gelu" for the OpenAI / "-quickgelu" open_clip cards
+    act: str = "gelu"             # "quick_gelu" for the OpenAI / "-quickgelu" open_clip cards; "gelu_tanh" for SigLIP
+    mlp_dim: int = 0              # 0 = 4 * width
+    causal: bool = True           # SigLIP: text_cfg.no_causal_mask
+    pool: str = "argmax"          # "argmax" = features of the end-of-text (highest id) token; "last" = last position (SigLIP)
+    proj_bias: bool = False       # SigLIP: the projection is a Linear with bias
+    ln_eps: float = 1e-5
+
+    @property
+    def hidden(self) -> int:
+        return self.mlp_dim or 4 * self.width
 
 
 # open_clip model configs (text side) of the cards in clip_utils.py:65-75; PE-Core-L14-336: perception_models' text config
@@ -36,13 +45,18 @@ SPECS: Dict[str, TextSpec] = {
     "ViT-L-14-qg": TextSpec("ViT-L-14-qg", 49408, 77, 768, 12, 12, 768, "quick_gelu"),
     "ViT-H-14": TextSpec("ViT-H-14", 49408, 77, 1024, 24, 16, 1024),
     "PE-Core-L14-336": TextSpec("PE-Core-L14-336", 49408, 32, 1024, 24, 16, 1024),
+    # SigLIP so400m text towers (open_clip ViT-SO400M-14-SigLIP[-384] text_cfg; SigLIP2: 256k Gemma vocabulary)
+    "SigLIP": TextSpec("SigLIP", 32000, 16, 1152, 27, 16, 1152, "gelu_tanh", 4304, False, "last", True, 1e-6),
+    "SigLIP-384": TextSpec("SigLIP-384", 32000, 64, 1152, 27, 16, 1152, "gelu_tanh", 4304, False, "last", True, 1e-6),
+    "SigLIP2-384": TextSpec("SigLIP2-384", 256000, 64, 1152, 27, 16, 1152, "gelu_tanh", 4304, False, "last", True, 1e-6),
+    "tiny-siglip-text": TextSpec("tiny-siglip-text", 100, 16, 128, 2, 4, 128, "gelu_tanh", 432, False, "last", True, 1e-6),
     "tiny-text": TextSpec("tiny-text", 100, 16, 64, 3, 4, 32, "quick_gelu"),
 }
 
 
 def random_state(spec: TextSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
     g = torch.Generator().manual_seed(seed)
-    w = spec.width
+    w, m = spec.width, spec.hidden
     sd = {"token_embedding.weight": torch.randn(spec.vocab, w, generator=g) * 0.02,
           "positional_embedding": torch.randn(spec.context, w, generator=g) * 0.01,
           "ln_final.weight": 1.0 + 0.1 * torch.randn(w, generator=g), "ln_final.bias": 0.1 * torch.randn(w, generator=g),
@@ -55,10 +69,12 @@ def random_state(spec: TextSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
         sd[p + "attn.in_proj_bias"] = torch.randn(3 * w, generator=g) * 0.02
         sd[p + "attn.out_proj.weight"] = torch.randn(w, w, generator=g) * w ** -0.5
         sd[p + "attn.out_proj.bias"] = torch.randn(w, generator=g) * 0.02
-        sd[p + "mlp.c_fc.weight"] = torch.randn(4 * w, w, generator=g) * w ** -0.5
-        sd[p + "mlp.c_fc.bias"] = torch.randn(4 * w, generator=g) * 0.02
-        sd[p + "mlp.c_proj.weight"] = torch.randn(w, 4 * w, generator=g) * (4 * w) ** -0.5
+        sd[p + "mlp.c_fc.weight"] = torch.randn(m, w, generator=g) * w ** -0.5
+        sd[p + "mlp.c_fc.bias"] = torch.randn(m, generator=g) * 0.02
+        sd[p + "mlp.c_proj.weight"] = torch.randn(w, m, generator=g) * m ** -0.5
         sd[p + "mlp.c_proj.bias"] = torch.randn(w, generator=g) * 0.02
+    if spec.proj_bias:
+        sd["text_projection.weight"], sd["text_projection.bias"] = sd.pop("text_projection").t().contiguous(), torch.randn(spec.out_dim, generator=g) * 0.02
     return sd
 
 
@@ -73,16 +89,27 @@ class HipTextEncoder:
         dev = self.device
         self.tok = sd["token_embedding.weight"].to(dev, f32).contiguous()
         self.pos = sd["positional_embedding"].to(dev, f32).contiguous()
-        self.w: Dict[str, torch.Tensor] = {"ln_final.g": sd["ln_final.weight"].to(dev, f32), "ln_final.b": sd["ln_final.bias"].to(dev, f32),
-                                           "proj.w": sd["text_projection"].t().to(dev, bf).contiguous()}
+        self.w: Dict[str, torch.Tensor] = {"ln_final.g": sd["ln_final.weight"].to(dev, f32), "ln_final.b": sd["ln_final.bias"].to(dev, f32)}
+        if "text_projection.weight" in sd:                              # nn.Linear form (SigLIP, proj_bias)
+            self.w["proj.w"] = sd["text_projection.weight"].to(dev, bf).contiguous()
+            if "text_projection.bias" in sd:
+                self.w["proj.b"] = sd["text_projection.bias"].to(dev, f32).contiguous()
+        else:
+            self.w["proj.w"] = sd["text_projection"].t().to(dev, bf).contiguous()
+        pad = (-spec.hidden) % 32                                        # zero hidden units up to a multiple of 32 (so400m: 4304 -> 4320)
         self.layers = 0
         while f"transformer.resblocks.{self.layers}.ln_1.weight" in sd:
             p = f"transformer.resblocks.{self.layers}."
             for n in ("ln_1", "ln_2"):
                 self.w[p + n + ".g"], self.w[p + n + ".b"] = sd[p + n + ".weight"].to(dev, f32), sd[p + n + ".bias"].to(dev, f32)
             for n, src in (("qkv", "attn.in_proj_"), ("out", "attn.out_proj."), ("fc1", "mlp.c_fc."), ("fc2", "mlp.c_proj.")):
-                self.w[p + n + ".w"] = sd[p + src + "weight"].to(dev, bf).contiguous()
-                self.w[p + n + ".b"] = sd[p + src + "bias"].to(dev, f32).contiguous()
+                wt, bs = sd[p + src + "weight"].float(), sd[p + src + "bias"].float()
+                if pad and n == "fc1":
+                    wt, bs = torch.cat([wt, wt.new_zeros(pad, wt.shape[1])]), torch.cat([bs, bs.new_zeros(pad)])
+                if pad and n == "fc2":
+                    wt = torch.cat([wt, wt.new_zeros(wt.shape[0], pad)], dim=1)
+                self.w[p + n + ".w"] = wt.to(dev, bf).contiguous()
+                self.w[p + n + ".b"] = bs.to(dev, f32).contiguous()
             self.layers += 1
 
     def _gemm(self, a, wname, out_dtype, act=0, add=None, out=None, bias=True):
@@ -114,11 +141,11 @@ class HipTextEncoder:
         x = L.gather_rows(self.tok, tokens.reshape(-1).tolist())                       # [R, w] f32 token embeddings
         h16 = torch.empty((R, w), dtype=bf, device=self.device)
         att = torch.empty((R, w), dtype=bf, device=self.device)
-        act = 2 if spec.act == "quick_gelu" else 1
+        act = {"gelu": 1, "quick_gelu": 2, "gelu_tanh": 5}[spec.act]
 
         def rows(norm, base=None, base_rows=0, y=None, y16=None):
             g_, b_ = (self.w[norm + ".g"], self.w[norm + ".b"]) if norm else (None, None)
-            L.check(lib.ovo_row_epilogue(L.ptr(x), R, w, L.ptr(base), base_rows, L.ptr(g_), L.ptr(b_), 1e-5, None, 0, L.ptr(y), L.ptr(y16), None,
+            L.check(lib.ovo_row_epilogue(L.ptr(x), R, w, L.ptr(base), base_rows, L.ptr(g_), L.ptr(b_), spec.ln_eps, None, 0, L.ptr(y), L.ptr(y16), None,
                                          L.stream()))
         rows(None, base=self.pos, base_rows=t, y=x)                                    # + positional embedding (rows repeat per text)
         for i in range(self.layers):
@@ -131,7 +158,7 @@ class HipTextEncoder:
             a.q_sh = a.k_sh = a.v_sh = hd
             a.q_st = a.k_st = a.v_st = 3 * w
             a.o_sb, a.o_sh, a.o_st = t * w, hd, w
-            a.B, a.H, a.Tq, a.Tk, a.hd, a.scale, a.causal = b, H, t, t, hd, hd ** -0.5, 1
+            a.B, a.H, a.Tq, a.Tk, a.hd, a.scale, a.causal = b, H, t, t, hd, hd ** -0.5, int(spec.causal)
             L.check(lib.ovo_attention(C.byref(a), L.stream()))
             self._gemm(att, p + "out", f32, add=x, out=x)
             rows(p + "ln_2", y16=h16)
@@ -139,9 +166,12 @@ class HipTextEncoder:
             self._gemm(hidden, p + "fc2", f32, add=x, out=x)
         final = torch.empty((R, w), dtype=bf, device=self.device)
         rows("ln_final", y16=final)
-        eot = (torch.arange(b, device=self.device) * t + tokens.argmax(dim=-1)).tolist()   # end-of-text = highest id (open_clip)
+        if spec.pool == "last":
+            eot = [r * t + t - 1 for r in range(b)]
+        else:
+            eot = (torch.arange(b, device=self.device) * t + tokens.argmax(dim=-1)).tolist()   # end-of-text = highest id (open_clip)
         pooled = L.gather_rows(final, eot)
-        return self._gemm(pooled, "proj", f32, bias=False)
+        return self._gemm(pooled, "proj", f32, bias="proj.b" in self.w)
 
     def __call__(self, texts: List[str]) -> torch.Tensor:
         """The `text_encoder` callable `CLIPGenerator` expects: list of strings -> [n, out_dim]."""

@@ -30,6 +30,41 @@ def test_text_tower_hf_weights(act):
     assert out.shape == ref.shape and err < 1e-3 * (512 / 32) ** 0.5 * 1.5     # 1e-3 at D >= 512, scaled to this 32-d projection (as in test_gpu_encoder)
 
 
+def test_siglip_text_tower_hf_weights():
+    """HuggingFace SiglipTextModel golden weights through the HIP tower (bidirectional attention, last-position pooling, tanh-GELU,
+    hidden 176 zero-padded to 192, projection bias)."""
+    from oracle import text as OT
+    from ovo_amd.encoders.text import HipTextEncoder, TextSpec
+    d = golden("hf_siglip_text")
+    sd = OT.hf_siglip_text_to_openclip({k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")})
+    spec = TextSpec("golden", 100, 16, 64, 3, int(d["heads"]), 64, "gelu_tanh", 176, False, "last", True, 1e-6)
+    out = HipTextEncoder(spec, sd, device=DEV).encode_tokens(torch.from_numpy(d["ids"])).cpu().numpy()
+    err = np.abs(_unit(out) - _unit(d["out"])).max()
+    print(f"max |unit embedding error| vs HuggingFace = {err:.2e}")
+    assert out.shape == d["out"].shape and err < 1e-3 * (512 / 64) ** 0.5 * 1.5
+
+
+@pytest.mark.parametrize("card,batch,layers", [("tiny-siglip-text", 5, None), ("SigLIP-384", 3, 2)])
+def test_siglip_text_tower_vs_oracle(card, batch, layers):
+    """so400m text shape: width 1152 (row kernels with 8 vectors per lane), head_dim 72, hidden 4304 -> 4320, 64 positions."""
+    import dataclasses
+    from oracle import text as OT
+    from ovo_amd.encoders.text import SPECS, HipTextEncoder, random_state
+    spec = SPECS[card]
+    if layers:
+        spec = dataclasses.replace(spec, layers=layers, vocab=500)
+    sd = random_state(spec, seed=4)
+    ids = torch.randint(2, spec.vocab, (batch, spec.context), generator=torch.Generator().manual_seed(batch))
+    for r in range(batch):
+        ids[r, 3 + 5 * r:] = 1                                # padded to the context length, as SigLIP's tokenizer does
+    out = HipTextEncoder(spec, sd, device=DEV).encode_tokens(ids).cpu().numpy()
+    ref = OT.text_forward(sd, ids, heads=spec.heads, act=spec.act, eps=spec.ln_eps, causal=False, pool="last").numpy()
+    err = np.abs(_unit(out) - _unit(ref)).max()
+    cos = (_unit(out) * _unit(ref)).sum(-1).min()
+    print(f"{card}: max |unit embedding error| = {err:.2e}, min cosine = {cos:.6f}")
+    assert err < 1e-3 * max(1.0, (512 / spec.out_dim) ** 0.5 * 1.5) and cos > 0.9999
+
+
 @pytest.mark.parametrize("card,batch,t", [("tiny-text", 7, 16), ("tiny-text", 3, 9), ("ViT-B-16-qg", 4, 77)])
 def test_text_tower_vs_oracle(card, batch, t):
     from oracle import text as OT

@@ -181,3 +181,14 @@ def test_siglip_tower_vs_hf_golden():
     np.testing.assert_allclose(tok.numpy(), d["tokens"], atol=2e-5, rtol=1e-5)
     pooled = OV.map_pool(sd, tok, heads=int(d["heads"]))
     np.testing.assert_allclose(pooled.numpy(), d["pooled"], atol=2e-5, rtol=1e-5)
+
+
+def test_siglip_text_tower_vs_hf_golden():
+    """oracle/text.py in SigLIP mode (no causal mask, last-position pooling, tanh-GELU, projection with bias) against
+    HuggingFace's SiglipTextModel on the same random weights (tools/gen_hf_siglip_text.py)."""
+    import torch
+    from oracle import text as OT
+    d = golden("hf_siglip_text")
+    sd = OT.hf_siglip_text_to_openclip({k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")})
+    out = OT.text_forward(sd, torch.from_numpy(d["ids"]), heads=int(d["heads"]), act="gelu_tanh", eps=1e-6, causal=False, pool="last")
+    np.testing.assert_allclose(out.numpy(), d["out"], atol=3e-6, rtol=1e-5)
