@@ -50,6 +50,7 @@ SPECS: Dict[str, TextSpec] = {
     "SigLIP-384": TextSpec("SigLIP-384", 32000, 64, 1152, 27, 16, 1152, "gelu_tanh", 4304, False, "last", True, 1e-6),
     "SigLIP2-384": TextSpec("SigLIP2-384", 256000, 64, 1152, 27, 16, 1152, "gelu_tanh", 4304, False, "last", True, 1e-6),
     "tiny-siglip-text": TextSpec("tiny-siglip-text", 100, 16, 128, 2, 4, 128, "gelu_tanh", 432, False, "last", True, 1e-6),
+    "tiny-clip": TextSpec("tiny-clip", 714, 16, 64, 2, 4, 64, "quick_gelu"),       # pairs with the tiny-clip image tower (200-merge test vocabulary)
     "tiny-text": TextSpec("tiny-text", 100, 16, 64, 3, 4, 32, "quick_gelu"),
 }
 

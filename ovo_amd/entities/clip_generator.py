@@ -70,6 +70,19 @@ class CLIPGenerator:
                                            remove_global_patch=config.get("remove_global_patch", False),
                                            project_and_normalize=config.get("project_and_normalize", True))
             self.clip_dim = self.textregion.out_dim
+        if text_encoder is None and config.get("vocab_path"):
+            # the real text side (clip_generator.py:161-173): tokenizer file + text tower of the same card
+            from ..encoders.text import SPECS as TEXT_SPECS, HipTextEncoder
+            from ..encoders.tokenizer import get_tokenizer
+            tcard = card if card in TEXT_SPECS else {"ViT-H-14-qg": "ViT-H-14", "ViT-H-14-378qg": "ViT-H-14"}.get(card, card)
+            if tcard not in TEXT_SPECS:
+                raise NotImplementedError(f"no text tower for model card {self.model_card}: supported here: {sorted(TEXT_SPECS)}")
+            tstate = None
+            tpath = config.get("text_weights_path") or config.get("weights_path")
+            if tpath and os.path.exists(tpath):
+                tstate = {k: v for k, v in torch.load(tpath, map_location="cpu").items() if not k.startswith("visual.")}
+            text_encoder = HipTextEncoder(TEXT_SPECS[tcard], tstate, device=device, seed=config.get("seed", 0),
+                                          tokenizer=get_tokenizer(self.model_card, config["vocab_path"]))
         self._encode_text = text_encoder or hash_text_encoder(self.clip_dim)
         self.tokenizer = None
         if self.model_card.startswith("SigLIP"):

@@ -111,3 +111,32 @@ def test_text_encoder_plugs_into_clip_generator():
     assert e.shape == (3, spec.out_dim) and torch.allclose(e.norm(dim=-1), torch.ones(3, device=e.device), atol=1e-5)
     with pytest.raises(Exception):
         HipTextEncoder(spec, None, device=DEV)(["no tokenizer"])
+
+
+def test_clip_generator_builds_its_text_side_from_a_vocabulary_file(tmp_path):
+    """config["vocab_path"] -> tokenizer + text tower of the card; `get_embed_txt_similarity` (clip_generator.py:176-199) end to end."""
+    from oracle import text as OT
+    from test_tokenizer import CORPUS, _train_bpe
+    from ovo_amd.encoders.text import SPECS, random_state
+    from ovo_amd.encoders.vit import SPECS as VS, HipViT
+    from ovo_amd.entities.clip_generator import CLIPGenerator
+    merges = _train_bpe(CORPUS, 200)
+    vocab = tmp_path / "bpe_simple_vocab.txt"
+    vocab.write_text("#version: 0.2\n" + "\n".join(" ".join(m) for m in merges) + "\n", encoding="utf-8")
+    gen = CLIPGenerator({"embed_type": "vanilla", "model_card": "tiny-clip", "vocab_path": str(vocab), "seed": 5}, device=DEV,
+                        encoder=HipViT(VS["tiny-clip"], None, device=DEV))
+    phrases = ["a photo of a chair", "the table in a room", "shower curtain"]
+    e = gen.get_txt_embedding(phrases).cpu().numpy()
+    spec = SPECS["tiny-clip"]
+    ids = gen._encode_text.tokenizer(phrases)
+    assert ids.shape == (3, spec.context) and int(ids.max()) == spec.vocab - 1
+    ref = OT.text_forward(random_state(spec, 5), ids, heads=spec.heads, act=spec.act).numpy()
+    assert np.abs(e - _unit(ref)).max() < 1e-3 * (512 / spec.out_dim) ** 0.5 * 1.5
+    desc = torch.nn.functional.normalize(torch.randn(7, spec.out_dim, generator=torch.Generator().manual_seed(1)), dim=-1).to(DEV)
+    sim = gen.get_embed_txt_similarity(desc, ["chair", "table"], templates=["a photo of a {}", "there is a {} in the scene"])
+    t = np.stack([_unit(_unit(OT.text_forward(random_state(spec, 5), gen._encode_text.tokenizer([f"a photo of a {q}", f"there is a {q} in the scene"]),
+                                              heads=spec.heads, act=spec.act).numpy()).mean(0)) for q in ("chair", "table")])
+    want = desc.cpu().numpy() @ t.T
+    got = sim.cpu().numpy()
+    got = got if got.shape == want.shape else got.T
+    np.testing.assert_allclose(got, want, atol=5e-3)
