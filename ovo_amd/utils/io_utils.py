@@ -90,3 +90,34 @@ def save_dict_to_yaml(dictionary: Dict[str, Any], file_name: str, *, directory: 
     directory.mkdir(parents=True, exist_ok=True)
     with open(directory / file_name, "w") as f:
         yaml.dump(dictionary, f)
+
+
+# ---- layered YAML configuration (io_utils.py:13-61; merged in run_eval.py:66-84) -------------------------------
+def update_recursive(dict1: Dict[str, Any], dict2: Dict[str, Any]) -> None:
+    """Reference: io_utils.py:42-61.  In-place deep merge of dict2 into dict1: nested dicts merge key by key, anything
+    else overwrites.  Like the reference, a key of dict2 that dict1 lacks is created as an empty dict first, so merging a
+    dict into a scalar raises (AttributeError / TypeError) instead of silently replacing it."""
+    for key, value in dict2.items():
+        if key not in dict1:
+            dict1[key] = {}
+        if isinstance(value, dict):
+            update_recursive(dict1[key], value)
+        else:
+            dict1[key] = value
+
+
+def load_config(path: str, default_path: str = None, inherit: bool = True) -> Dict[str, Any]:
+    """Reference: io_utils.py:13-40.  The file at `path`, laid over its `inherit_from` chain (each link itself laid over
+    `default_path`) or, without `inherit_from`, over `default_path`."""
+    import yaml
+    with open(path, "r") as f:
+        special = yaml.full_load(f)
+    base: Dict[str, Any] = {}
+    parent = special.get("inherit_from")
+    if parent is not None and inherit:
+        base = load_config(parent, default_path)
+    elif default_path is not None:
+        with open(default_path, "r") as f:
+            base = yaml.full_load(f)
+    update_recursive(base, special)
+    return base

@@ -56,6 +56,37 @@ def main(reference="/root/reference"):
         IO.write_labels(os.path.join(d, "labels.txt"), labels)
         arrays["labels_text"] = np.asarray(open(os.path.join(d, "labels.txt")).read())
         assert np.array_equal(IO.read_labels(os.path.join(d, "labels.txt")), labels)
+    # layered YAML configuration (io_utils.py:13-61) and the logger's text files (logger.py:85-96), by the reference's own code
+    yamls = {"base.yaml": "semantic:\n  segment_every: 10\n  sam:\n    points_per_side: 16\n    nms_iou_th: 0.8\n  clip:\n    embed_type: learned\n    k_top_views: 10\ndata:\n  input_path: /data\n",
+             "slam.yaml": "inherit_from: {d}/base.yaml\nslam:\n  module: vanilla\nsemantic:\n  sam:\n    points_per_side: 32\n  clip:\n    embed_type: TextRegion\n",
+             "scene.yaml": "inherit_from: {d}/slam.yaml\ndata:\n  scene_name: scene0011_00\n  frame_limit: -1\nsemantic:\n  track_th: 100\ncam:\n  H: 480\n  W: 640\n",
+             "default.yaml": "vis:\n  stream: false\nsemantic:\n  segment_every: 5\n  log: true\n",
+             "plain.yaml": "semantic:\n  segment_every: 2\n"}
+    gen_golden._stub("wandb")
+    from ovo.entities.logger import Logger
+    with tempfile.TemporaryDirectory() as d:
+        for name, text in yamls.items():
+            open(os.path.join(d, name), "w").write(text.replace("{d}", d))
+        merged = {"chain": IO.load_config(os.path.join(d, "scene.yaml")),
+                  "chain_default": IO.load_config(os.path.join(d, "scene.yaml"), os.path.join(d, "default.yaml")),
+                  "no_inherit": IO.load_config(os.path.join(d, "scene.yaml"), os.path.join(d, "default.yaml"), inherit=False),
+                  "plain_default": IO.load_config(os.path.join(d, "plain.yaml"), os.path.join(d, "default.yaml"))}
+        arrays["cfg_names"] = np.asarray(sorted(yamls))
+        arrays["cfg_texts"] = np.asarray([yamls[k] for k in sorted(yamls)])
+        arrays["cfg_merged_json"] = np.asarray(json.dumps(merged, sort_keys=True).replace(d, "{d}"))
+        lg = Logger(os.path.join(d, "run"))
+        for i in range(4):
+            lg.log_ovo_stats({"frame_id": 10 * i, "t_sam": 0.125 * (i + 1), "t_obj": 1e-3 * i, "n_obj": [i, 2 * i], "n_matches": 3 * i,
+                              "t_up": 0.5, "t_clip": 1.0 / (i + 3)})
+            lg.log_fps(30.0 / (i + 1))
+            lg.log_spf(0.01 * i)
+            lg.stats["ram"].append(1.5 + i)
+            lg.stats["vram"].append(0.25 * i)
+        lg.stats["max_vram"], lg.stats["max_ram"] = [0.75], [float(np.asarray(lg.stats["ram"]).max())]
+        lg.write_stats()
+        logs = {n: open(os.path.join(d, "run", "logger", n)).read() for n in sorted(os.listdir(os.path.join(d, "run", "logger"))) if n.endswith(".log")}
+        arrays["log_names"], arrays["log_texts"] = np.asarray(list(logs)), np.asarray(list(logs.values()))
+        arrays["log_dirs"] = np.asarray(sorted(n for n in os.listdir(os.path.join(d, "run", "logger")) if not n.endswith(".log")))
     out = os.path.join(ROOT, "tests", "golden", "io_formats.npz")
     np.savez_compressed(out, **arrays)
     print("wrote", out, os.path.getsize(out) // 1024, "KiB;", len(files), "files from write_instances")
