@@ -327,17 +327,27 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
     // only wins when it saves a round).  128x64 is listed first: on ties it beat 64x128 by 4-10% in the sweep.  128x128 (one
     // 8-wave workgroup per CU, 867 TFLOP/s at 8192^3, 10-18% ahead on the M = 1M decoder / 1k-text query GEMMs) enters
     // from 8 full rounds and wins ties.
+    // The 8-wave 128x64 kernel needs 65 VGPRs, so a CU takes three of its workgroups once the ring is two stages deep (48 KB)
+    // instead of three (72 KB): 768 resident workgroups instead of 512, each a little slower.  Taken when that saves
+    // rounds: FC1 (1154, 4096, 1024) = 640 workgroups 24.0 -> 21.0 us, (1154, 8192, 1024) 37.2 -> 33.1; QKV (480 workgroups)
+    // and the Hiera stage-3 GEMMs (800-900) are better off with the deeper ring (tools/gemm_bench.py).
+    const long long b12864 = blocks(128, 64);
+    const double r512 = (double)((b12864 + 511) / 512), r768 = 1.5 * (double)((b12864 + 767) / 768);
+    const bool ns2_ok = k64 && !getenv("OVO_GEMM_W4") && !getenv("OVO_GEMM_NO_NS2");
+    bool ns2 = false;
     int bm = 128, bn = 64;
     {
         const int cand[3][2] = {{128, 64}, {64, 128}, {64, 64}};
         double best = -1.0;
         for (int i = 0; i < 3; ++i) {
-            const long long rounds = (blocks(cand[i][0], cand[i][1]) + 511) / 512;
-            const double cost = (double)rounds * cand[i][0] * cand[i][1] * (i == 2 ? 1.4 : 1.0);
+            double rounds = (double)((blocks(cand[i][0], cand[i][1]) + 511) / 512);
+            if (i == 0 && ns2_ok && r768 <= r512) rounds = r768;
+            const double cost = rounds * cand[i][0] * cand[i][1] * (i == 2 ? 1.4 : 1.0);
             if (best < 0 || cost < best) { best = cost; bm = cand[i][0]; bn = cand[i][1]; }
         }
         if (blocks(128, 128) >= 2048 && (double)((blocks(128, 128) + 255) / 256) * 8192.0 <= best) { bm = 128; bn = 128; }
     }
+    ns2 = ns2_ok && bm == 128 && bn == 64 && r768 <= r512;
     if (const char *force = getenv("OVO_GEMM_TILE")) {           // tuning knob (tools/gemm_bench.py): "128x128", "64x128", ...
         int fm = 0, fn = 0;
         if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm == 64 || fm == 128) && (fn == 64 || fn == 128)) { bm = fm; bn = fn; }
@@ -347,6 +357,7 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
     // form, twice the loads in flight and MFMA/LDS phases of different waves overlapping -- QKV 16.7 -> 14.9 us, FC1 25.1 ->
     // 21.7, (4096,1792,448) 18.6 -> 15.8 (tools/gemm_bench.py).  BK = 32 tiles are too small for 512 threads' 16-byte pieces.
     if (k64 && !getenv("OVO_GEMM_W4")) {
+        if (bm == 128 && bn == 64 && ns2) return launch<128, 64, 64, VT, 8, 2>(g, s);
         if (bm == 128 && bn == 64) return launch<128, 64, 64, VT, 8, 3>(g, s);
         if (bm == 64 && bn == 128) return launch<64, 128, 64, VT, 8, 3>(g, s);
         if (bm == 64 && bn == 64) return launch<64, 64, 64, VT, 8, 4>(g, s);
