@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -230,6 +231,9 @@ class HipViT:
         self._weights = w
         self._cfg = {}
         self._ws: Optional[torch.Tensor] = None
+        self.split_streams = bool(os.environ.get("OVO_VIT_SPLIT"))     # two half-batch chains on two streams (_forward_split)
+        self._side = None
+        self._ws2 = None
         self.proj = sd["proj"].detach().to(self.device, torch.float32) if "proj" in sd else None
         self.pool_weights = None
         if spec.attn_pool_heads:
@@ -282,11 +286,35 @@ class HipViT:
         if tuple(x.shape[1:]) != (3, s.image_size, s.image_size):
             raise L.OvoHipError(f"expected [B, 3, {s.image_size}, {s.image_size}], got {tuple(x.shape)}")
         cfg = self._config(0 if tokens else (2 if s.map_pool else 1))
-        ws, need = self._workspace(cfg, b)
         if out is None:
             shape = (b, s.tokens, s.width) if tokens else (b, s.out_dim)
             out = torch.empty(shape, dtype=torch.float32, device=x.device)
-        L.check(L.load().ovo_vit_forward(C.byref(cfg), C.byref(self._weights), L.ptr(x), b, L.ptr(out), L.ptr(ws), need, L.stream()))
+        lib = L.load()
+        if self.split_streams and b >= 2:
+            return self._forward_split(lib, cfg, x, out)
+        ws, need = self._workspace(cfg, b)
+        L.check(lib.ovo_vit_forward(C.byref(cfg), C.byref(self._weights), L.ptr(x), b, L.ptr(out), L.ptr(ws), need, L.stream()))
+        return out
+
+    def _forward_split(self, lib, cfg, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """The batch as two independent layer chains on two HIP streams (the caller's and a side stream), each with its own
+        workspace: a chain is a strict sequence of ~200 small launches, so two of them interleave their LayerNorm / RoPE /
+        attention phases with each other's GEMMs."""
+        b = x.shape[0]
+        h0 = (b + 1) // 2
+        main = torch.cuda.current_stream(x.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=x.device)
+        need0 = lib.ovo_vit_workspace_bytes(C.byref(cfg), h0)
+        need1 = lib.ovo_vit_workspace_bytes(C.byref(cfg), b - h0)
+        if self._ws2 is None or self._ws2[0].numel() < need0 or self._ws2[1].numel() < need1:
+            self._ws2 = (torch.empty(need0, dtype=torch.uint8, device=x.device), torch.empty(max(need1, 1), dtype=torch.uint8, device=x.device))
+        self._side.wait_stream(main)                          # inputs (and the previous readers of `out`) are ordered on `main`
+        L.check(lib.ovo_vit_forward(C.byref(cfg), C.byref(self._weights), L.ptr(x[:h0]), h0, L.ptr(out[:h0]), L.ptr(self._ws2[0]), need0, L.stream()))
+        with torch.cuda.stream(self._side):
+            L.check(lib.ovo_vit_forward(C.byref(cfg), C.byref(self._weights), L.ptr(x[h0:]), b - h0, L.ptr(out[h0:]), L.ptr(self._ws2[1]), need1,
+                                        L.stream()))
+        main.wait_stream(self._side)
         return out
 
     encode_image = forward
