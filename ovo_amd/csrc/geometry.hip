@@ -225,14 +225,18 @@ __global__ void __launch_bounds__(256) k_track_project(const float *__restrict__
         }
         wave_hist_add(hist, cell, vote);
     }
-    // per-wave reduction of the two counters, one atomic per wave
+    // the two counters: wave reduction, then across the workgroup's waves through LDS -> one atomic pair per workgroup
+    // (every wave of the grid adding to the same two addresses serialises in the L2 atomic unit: 16k same-address atomics)
     for (int o = 32; o > 0; o >>= 1) {
         n_in += __shfl_xor(n_in, o, 64);
         n_match += __shfl_xor(n_match, o, 64);
     }
-    if (lane == 0) {
-        if (n_in) atomicAdd(counters, (unsigned long long)n_in);
-        if (n_match) atomicAdd(counters + 1, (unsigned long long)n_match);
+    __shared__ long long s_cnt[2][4];
+    if (lane == 0) { s_cnt[0][threadIdx.x >> 6] = n_in; s_cnt[1][threadIdx.x >> 6] = n_match; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const long long t = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+        if (t) atomicAdd(counters + threadIdx.x, (unsigned long long)t);
     }
 }
 
