@@ -202,6 +202,14 @@ typedef struct {
     float alpha;
 } ovo_gemm_t;
 int ovo_gemm(const ovo_gemm_t *g, ovo_stream_t stream);
+/* ovo_gemm with PE's rotary embedding (ovo_rope_qk below; perception_models Rope2D, textregion.py:141-142) fused into the
+ * epilogue: columns [0, cols) of row m are rotated pairwise with cos/sin f32 [T, hd] at (m % T, column % hd), rows with
+ * m % T < t0 (class token) untouched.  For the packed QKV projection: cols = 2 * width (q and k), hd = head_dim. */
+typedef struct {
+    const float *cos, *sin;
+    int32_t T, hd, cols, t0;
+} ovo_rope_t;
+int ovo_gemm_rope(const ovo_gemm_t *g, const ovo_rope_t *rope, ovo_stream_t stream);
 /* The large-vocabulary query (BASELINE.json config 5) with the argmax FUSED into the GEMM epilogue: per row and wave one
  * 64-bit atomicMax on (order-preserving bits of the score << 32 | ~column) into best u64[M] (ZERO on entry; columns >=
  * n_valid -- vocabulary padding -- never win).  store_scores = 0 never writes the score matrix at all (g->C may be NULL).

@@ -45,6 +45,8 @@ struct GemmArgs {
     int chunk, tiles;          // chunk > 0: XCD-chunked tile order (see launch())
     unsigned long long *best;  // ovo_gemm_argmax: packed (score, column) running maximum per row, or NULL
     int store, n_valid;        // with best: also store C?; columns >= n_valid (vocabulary padding) never win
+    const float *rope_cos, *rope_sin;   // ovo_gemm_rope: rotary embedding of columns [0, rope_cols) in the epilogue, or NULL
+    int rope_T, rope_hd, rope_cols, rope_t0;
 };
 
 template <typename VT> struct Mfma;
@@ -253,6 +255,17 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
             v[0] += bias_r[j].x; v[1] += bias_r[j].y; v[2] += bias_r[j].z; v[3] += bias_r[j].w;
             if (g.act) act4(v, g.act);
+            if (g.rope_cos && n < g.rope_cols) {
+                // rotary embedding of the (2i, 2i+1) pairs this lane holds: row = token m % T, column within the head n % hd
+                const int t = m % g.rope_T;
+                if (t >= g.rope_t0) {
+                    const long long at = (long long)t * g.rope_hd + n % g.rope_hd;
+                    const float4 c = *(const float4 *)(g.rope_cos + at), sn = *(const float4 *)(g.rope_sin + at);
+                    const float y0 = v[0] * c.x - v[1] * sn.x, y1 = v[1] * c.y + v[0] * sn.y;
+                    const float y2 = v[2] * c.z - v[3] * sn.z, y3 = v[3] * c.w + v[2] * sn.w;
+                    v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
+                }
+            }
             if (g.add) { v[0] += add_r[i][j].x; v[1] += add_r[i][j].y; v[2] += add_r[i][j].z; v[3] += add_r[i][j].w; }
             if (g.best) {
 #pragma unroll
@@ -371,7 +384,7 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
 
 }  // namespace
 
-static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, int n_valid, ovo_stream_t stream) {
+static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, int n_valid, ovo_stream_t stream, const ovo_rope_t *rope = nullptr) {
     OVO_REQUIRE(p, "null descriptor");
     OVO_REQUIRE(p->M >= 0 && p->N > 0 && p->K > 0, "bad shape");
     if (p->M == 0) return OVO_OK;
@@ -389,6 +402,12 @@ static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, 
     g.C = p->C; g.ldc = p->ldc; g.add = p->add; g.ld_add = p->ld_add;
     g.M = p->M; g.N = p->N; g.K = p->K; g.out_dtype = p->out_dtype; g.act = p->act; g.alpha = p->alpha; g.nbn = 0;
     g.best = best; g.store = store; g.n_valid = n_valid;
+    g.rope_cos = g.rope_sin = nullptr; g.rope_T = 1; g.rope_hd = 4; g.rope_cols = 0; g.rope_t0 = 0;
+    if (rope) {
+        OVO_REQUIRE(rope->cos && rope->sin && rope->T > 0 && rope->hd > 0 && rope->hd % 4 == 0 && rope->cols % rope->hd == 0 && rope->cols <= p->N &&
+                    rope->t0 >= 0 && (((uintptr_t)rope->cos | (uintptr_t)rope->sin) & 15) == 0, "bad rope descriptor");
+        g.rope_cos = rope->cos; g.rope_sin = rope->sin; g.rope_T = rope->T; g.rope_hd = rope->hd; g.rope_cols = rope->cols; g.rope_t0 = rope->t0;
+    }
     const int rc = p->in_dtype == 2 ? dispatch<bf16x8>(g, (hipStream_t)stream) : dispatch<f16x8>(g, (hipStream_t)stream);
     if (rc != OVO_OK) return rc;
     OVO_CHECK_LAUNCH();
@@ -396,6 +415,13 @@ static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, 
 }
 
 extern "C" int ovo_gemm(const ovo_gemm_t *p, ovo_stream_t stream) { return gemm_entry(p, nullptr, 1, 0, stream); }
+
+// ovo_gemm with the rotary embedding of PE's attention (ovo_rope_qk) applied to the f32 accumulators of columns [0, cols) before
+// the store: the QKV projection writes rotated q, k directly (one rounding instead of two, one launch less per block).
+extern "C" int ovo_gemm_rope(const ovo_gemm_t *p, const ovo_rope_t *rope, ovo_stream_t stream) {
+    OVO_REQUIRE(rope, "null rope descriptor");
+    return gemm_entry(p, nullptr, 1, 0, stream, rope);
+}
 
 // C as ovo_gemm, plus a fused per-row first-max argmax over columns [0, n_valid): best u64 [M] must be ZERO on entry and holds, per
 // row, (order-preserving bits of the best value << 32) | (0xffffffff - column); store_scores = 0 skips the C stores altogether

@@ -1,9 +1,9 @@
 // vit.hip -- ViT forward driver: the whole layer loop of an open_clip / PE vision transformer in one C call.
 //
 // Launch sequence per block (residual stream x kept in fp32, GEMM operands bf16, fp32 accumulation):
-//   LN1 -> QKV GEMM(+bias) -> [RoPE] -> fused attention -> out-proj GEMM(+bias, += x)
+//   LN1 -> QKV GEMM(+bias, RoPE of q and k in the epilogue) -> fused attention -> out-proj GEMM(+bias, += x)
 //   LN2 -> FC1 GEMM(+bias, GELU) -> FC2 GEMM(+bias, += x)
-// 7 (8 with RoPE) launches per block, no host synchronisation, nothing allocated: the caller captures the
+// 7 launches per block, no host synchronisation, nothing allocated: the caller captures the
 // call in a hipGraph (torch.cuda.graph) to remove launch latency.
 #include "common.h"
 
@@ -91,8 +91,15 @@ int ovo_vit_forward(const ovo_vit_config_t *cfg, const ovo_vit_weights_t *w, con
     for (int l = 0; l < c.layers; ++l) {
         const ovo_vit_layer_t &L = w->layers[l];
         TRY(ovo_layernorm(k.x, D, M, D, L.ln1_g, L.ln1_b, c.ln_eps, k.h, D, 2, stream));
-        TRY(gemm(k.h, D, L.qkv_w, D, L.qkv_b, k.qkv, 3 * D, 2, nullptr, 0, M, 3 * D, D, 0, stream));
-        if (c.use_rope) TRY(ovo_rope_qk(k.qkv, B, T, c.heads, hd, w->rope_cos, w->rope_sin, c.n_prefix, stream));
+        if (c.use_rope) {                                                // q, k rotated in the projection's epilogue
+            ovo_gemm_t g;
+            g.A = k.h; g.lda = D; g.W = L.qkv_w; g.ldw = D; g.bias = L.qkv_b; g.C = k.qkv; g.ldc = 3 * D; g.add = nullptr; g.ld_add = 0;
+            g.M = M; g.N = 3 * D; g.K = D; g.in_dtype = 2; g.out_dtype = 2; g.act = 0; g.alpha = 1.0f;
+            const ovo_rope_t r = {w->rope_cos, w->rope_sin, T, hd, 2 * D, c.n_prefix};
+            TRY(ovo_gemm_rope(&g, &r, stream));
+        } else {
+            TRY(gemm(k.h, D, L.qkv_w, D, L.qkv_b, k.qkv, 3 * D, 2, nullptr, 0, M, 3 * D, D, 0, stream));
+        }
         ovo_attention_t a = {};
         a.q = k.qkv; a.k = k.qkv + D; a.v = k.qkv + 2 * D; a.o = k.att;
         a.q_sb = a.k_sb = a.v_sb = (int64_t)T * 3 * D; a.q_sh = a.k_sh = a.v_sh = hd; a.q_st = a.k_st = a.v_st = 3 * D;

@@ -68,6 +68,41 @@ def test_gemm_epilogues_and_padding():
     assert torch.equal(ob, _gemm(a, w, bias).to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("b,t,heads,hd", [(2, 37, 4, 32), (2, 577, 16, 64), (3, 50, 4, 72)])
+def test_gemm_rope_epilogue_vs_rope_kernel_and_torch(b, t, heads, hd):
+    """ovo_gemm_rope: the packed QKV projection with q, k rotated in the epilogue == ovo_gemm followed by the stand-alone
+    rotation (up to the one bf16 rounding it saves) == the fp32 formula; v and the class-token rows are not rotated."""
+    from ovo_amd import _lib as L
+    g0 = torch.Generator().manual_seed(7)
+    d = heads * hd
+    m = b * t
+    a = torch.randn(m, d, generator=g0).to(DEV, torch.bfloat16)
+    w = (torch.randn(3 * d, d, generator=g0) * d ** -0.5).to(DEV, torch.bfloat16)
+    bias = torch.randn(3 * d, generator=g0).to(DEV)
+    ang = torch.rand(t, hd // 2, generator=g0) * 6.28
+    ang[0] = 0.3                                              # a non-identity row for the class token: must stay unrotated (t0 = 1)
+    ang = ang.repeat_interleave(2, dim=1)
+    cos, sin = ang.cos().contiguous().to(DEV), ang.sin().contiguous().to(DEV)
+    out = torch.empty(m, 3 * d, dtype=torch.bfloat16, device=DEV)
+    gg = L.Gemm()
+    gg.A, gg.lda, gg.W, gg.ldw, gg.bias, gg.C, gg.ldc = a.data_ptr(), d, w.data_ptr(), d, bias.data_ptr(), out.data_ptr(), 3 * d
+    gg.M, gg.N, gg.K, gg.in_dtype, gg.out_dtype, gg.act, gg.alpha = m, 3 * d, d, 2, 2, 0, 1.0
+    rp = L.Rope(cos.data_ptr(), sin.data_ptr(), t, hd, 2 * d, 1)
+    L.check(L.load().ovo_gemm_rope(C.byref(gg), C.byref(rp), L.stream()))
+    z = (a.float() @ w.float().T + bias).reshape(b, t, 3, heads, hd)
+    x0, x1 = z[..., 0::2], z[..., 1::2]
+    c, s = cos.reshape(1, t, 1, 1, hd), sin.reshape(1, t, 1, 1, hd)
+    rot = torch.stack([x0 * c[..., 0::2] - x1 * s[..., 0::2], x1 * c[..., 1::2] + x0 * s[..., 1::2]], dim=-1).flatten(-2)
+    ref = z.clone()
+    ref[:, 1:, :2] = rot[:, 1:, :2]
+    torch.testing.assert_close(out.float().reshape(b, t, 3, heads, hd), ref, atol=2e-2, rtol=1.6e-2)     # one bf16 rounding of O(1) values
+    two = _gemm(a, w, bias, out_dtype=torch.bfloat16)
+    L.check(L.load().ovo_rope_qk(two.data_ptr(), b, t, heads, hd, cos.data_ptr(), sin.data_ptr(), 1, L.stream()))
+    torch.testing.assert_close(out.float(), two.float(), atol=4e-2, rtol=3.2e-2)                          # two roundings vs one
+    assert torch.equal(out.reshape(b, t, 3, d)[:, :, 2], two.reshape(b, t, 3, d)[:, :, 2])                # v: untouched
+    assert torch.equal(out.reshape(b, t, 3 * d)[:, 0], two.reshape(b, t, 3 * d)[:, 0])                    # class token: untouched
+
+
 @pytest.mark.parametrize("B,H,Tq,Tk,hd", [(2, 16, 577, 577, 64), (1, 4, 197, 197, 64), (64, 2, 16, 64, 56), (3, 1, 49, 196, 96),
                                           (2, 2, 1, 1, 8), (1, 2, 130, 70, 72), (1, 1, 4096, 4096, 56), (2, 8, 257, 257, 128)])
 def test_attention_vs_torch(B, H, Tq, Tk, hd):
