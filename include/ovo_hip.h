@@ -210,6 +210,14 @@ typedef struct {
     int32_t T, hd, cols, t0;
 } ovo_rope_t;
 int ovo_gemm_rope(const ovo_gemm_t *g, const ovo_rope_t *rope, ovo_stream_t stream);
+/* ovo_gemm for Hiera's attention output projection (sam2 `window_unpartition` + residual, inside the encoder the reference
+ * reaches at mask_generator.py:113): product row m is a token in WINDOW-major order -- windows of wh x ww tiling a B x H x W
+ * token grid padded up to whole windows, M = B * ceil(H/wh) * ceil(W/ww) * wh * ww -- while C and add are addressed by the
+ * token's SPATIAL row (b*H + y)*W + x; padding rows are dropped.  add may alias C (in-place residual). */
+typedef struct {
+    int32_t B, H, W, wh, ww;
+} ovo_window_t;
+int ovo_gemm_unwindow(const ovo_gemm_t *g, const ovo_window_t *win, ovo_stream_t stream);
 /* The large-vocabulary query (BASELINE.json config 5) with the argmax FUSED into the GEMM epilogue: per row and wave one
  * 64-bit atomicMax on (order-preserving bits of the score << 32 | ~column) into best u64[M] (ZERO on entry; columns >=
  * n_valid -- vocabulary padding -- never win).  store_scores = 0 never writes the score matrix at all (g->C may be NULL).

@@ -47,6 +47,11 @@ class Rope(C.Structure):
     _fields_ = [("cos", _P), ("sin", _P), ("T", C.c_int32), ("hd", C.c_int32), ("cols", C.c_int32), ("t0", C.c_int32)]
 
 
+class Window(C.Structure):
+    """ovo_window_t"""
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "wh", "ww")]
+
+
 class Attention(C.Structure):
     """ovo_attention_t"""
     _fields_ = [("q", _P), ("k", _P), ("v", _P), ("o", _P)] + \
@@ -124,6 +129,7 @@ _SIGNATURES = {
     "ovo_gemm": (_I32, [C.POINTER(Gemm), _P]),
     "ovo_gemm_argmax": (_I32, [C.POINTER(Gemm), _P, _I32, _I32, _P]),
     "ovo_gemm_rope": (_I32, [C.POINTER(Gemm), C.POINTER(Rope), _P]),
+    "ovo_gemm_unwindow": (_I32, [C.POINTER(Gemm), C.POINTER(Window), _P]),
     "ovo_decode_best": (_I32, [_P, _I64, _F32, _P, _P, _P]),
     "ovo_attention": (_I32, [C.POINTER(Attention), _P]),
     "ovo_layernorm": (_I32, [_P, _I64, _I64, _I32, _P, _P, _F32, _P, _I64, _I32, _P]),

@@ -47,7 +47,20 @@ struct GemmArgs {
     int store, n_valid;        // with best: also store C?; columns >= n_valid (vocabulary padding) never win
     const float *rope_cos, *rope_sin;   // ovo_gemm_rope: rotary embedding of columns [0, rope_cols) in the epilogue, or NULL
     int rope_T, rope_hd, rope_cols, rope_t0;
+    int win_per, win_ww, win_wh, win_nww, win_nwin, win_H, win_W;   // ovo_gemm_unwindow: win_per > 0 remaps C / add rows (see row_dest)
 };
+
+// ovo_gemm_unwindow: product row m is a token in window-major order (windows of wh x ww tiling an H x W grid that is padded up to
+// whole windows); its C / add row is the token's spatial index (b*H + y)*W + x, or -1 for a padding position (row dropped).
+__device__ __forceinline__ long long row_dest(const GemmArgs &g, int m) {
+    if (g.win_per <= 0) return m;
+    const int win = m / g.win_per, p = m - win * g.win_per;
+    const int iy = p / g.win_ww, ix = p - iy * g.win_ww;
+    const int b = win / g.win_nwin, wr = win - b * g.win_nwin;
+    const int wy = wr / g.win_nww, wx = wr - wy * g.win_nww;
+    const int y = wy * g.win_wh + iy, x = wx * g.win_ww + ix;
+    return (y < g.win_H && x < g.win_W) ? ((long long)b * g.win_H + y) * g.win_W + x : -1;
+}
 
 template <typename VT> struct Mfma;
 template <> struct Mfma<bf16x8> {
@@ -197,6 +210,12 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
     // Epilogue operands (bias, residual) are fetched into registers during the LAST k-tile: issued after the main loop they
     // sat on the serial tail of every workgroup (2-4 us of a 15-25 us GEMM).
     float4 bias_r[TN], add_r[TM][TN];
+    long long md[TM];                               // destination row of C / add for each of this lane's rows (-1: none)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm0 + i * 16 + fr;
+        md[i] = m < g.M ? row_dest(g, m) : -1;
+    }
     auto fetch_epilogue = [&]() {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -210,7 +229,7 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n = n0 + wn0 + j * 16 + fq * 4;
-                    if (m < g.M && n < g.N) add_r[i][j] = *(const float4 *)(g.add + (long long)m * g.ld_add + n);
+                    if (md[i] >= 0 && n < g.N) add_r[i][j] = *(const float4 *)(g.add + md[i] * g.ld_add + n);
                 }
             }
         }
@@ -243,7 +262,7 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm0 + i * 16 + fr;
-        if (m >= g.M) continue;
+        if (m >= g.M || md[i] < 0) continue;
         float row_best = -3.0e38f;                               // fused first-max argmax of this lane's columns (g.best)
         int row_arg = 0x7fffffff;
 #pragma unroll
@@ -274,12 +293,12 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
                 if (!g.store) continue;
             }
             if (g.out_dtype == 0) {
-                *(float4 *)((float *)g.C + (long long)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4 *)((float *)g.C + md[i] * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 uint2 p;
                 if (g.out_dtype == 2) { p.x = pack_bf16(v[0], v[1]); p.y = pack_bf16(v[2], v[3]); }
                 else { p.x = pack_f16(v[0], v[1]); p.y = pack_f16(v[2], v[3]); }
-                *(uint2 *)((uint16_t *)g.C + (long long)m * g.ldc + n) = p;
+                *(uint2 *)((uint16_t *)g.C + md[i] * g.ldc + n) = p;
             }
         }
         if (g.best) {
@@ -384,7 +403,8 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
 
 }  // namespace
 
-static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, int n_valid, ovo_stream_t stream, const ovo_rope_t *rope = nullptr) {
+static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, int n_valid, ovo_stream_t stream, const ovo_rope_t *rope = nullptr,
+                      const ovo_window_t *win = nullptr) {
     OVO_REQUIRE(p, "null descriptor");
     OVO_REQUIRE(p->M >= 0 && p->N > 0 && p->K > 0, "bad shape");
     if (p->M == 0) return OVO_OK;
@@ -403,6 +423,13 @@ static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, 
     g.M = p->M; g.N = p->N; g.K = p->K; g.out_dtype = p->out_dtype; g.act = p->act; g.alpha = p->alpha; g.nbn = 0;
     g.best = best; g.store = store; g.n_valid = n_valid;
     g.rope_cos = g.rope_sin = nullptr; g.rope_T = 1; g.rope_hd = 4; g.rope_cols = 0; g.rope_t0 = 0;
+    g.win_per = 0; g.win_ww = g.win_wh = g.win_nww = g.win_nwin = 1; g.win_H = g.win_W = 0;
+    if (win) {
+        OVO_REQUIRE(win->B > 0 && win->H > 0 && win->W > 0 && win->wh > 0 && win->ww > 0, "bad window descriptor");
+        const int nwh = (win->H + win->wh - 1) / win->wh, nww = (win->W + win->ww - 1) / win->ww;
+        OVO_REQUIRE((long long)win->B * nwh * nww * win->wh * win->ww == p->M, "M must be B x windows x window size (padding rows included)");
+        g.win_per = win->wh * win->ww; g.win_ww = win->ww; g.win_wh = win->wh; g.win_nww = nww; g.win_nwin = nwh * nww; g.win_H = win->H; g.win_W = win->W;
+    }
     if (rope) {
         OVO_REQUIRE(rope->cos && rope->sin && rope->T > 0 && rope->hd > 0 && rope->hd % 4 == 0 && rope->cols % rope->hd == 0 && rope->cols <= p->N &&
                     rope->t0 >= 0 && (((uintptr_t)rope->cos | (uintptr_t)rope->sin) & 15) == 0, "bad rope descriptor");
@@ -421,6 +448,13 @@ extern "C" int ovo_gemm(const ovo_gemm_t *p, ovo_stream_t stream) { return gemm_
 extern "C" int ovo_gemm_rope(const ovo_gemm_t *p, const ovo_rope_t *rope, ovo_stream_t stream) {
     OVO_REQUIRE(rope, "null rope descriptor");
     return gemm_entry(p, nullptr, 1, 0, stream, rope);
+}
+
+// ovo_gemm whose C / add rows are addressed in spatial order while the product rows arrive in window order (Hiera's attention
+// output projection): the un-windowing + residual add pass of the block happens in the epilogue.
+extern "C" int ovo_gemm_unwindow(const ovo_gemm_t *p, const ovo_window_t *win, ovo_stream_t stream) {
+    OVO_REQUIRE(win, "null window descriptor");
+    return gemm_entry(p, nullptr, 1, 0, stream, nullptr, win);
 }
 
 // C as ovo_gemm, plus a fused per-row first-max argmax over columns [0, n_valid): best u64 [M] must be ZERO on entry and holds, per

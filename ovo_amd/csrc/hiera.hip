@@ -6,7 +6,7 @@
 //   k_qpool       2x2 max-pool of q inside each window     (stage-change blocks only)
 //   ovo_attention per-window (or global) fused attention, windows folded into the batch dimension
 //   ovo_gemm      output projection -> fp32 rows in window order
-//   k_unwindow_add  window order -> spatial order, + residual (the pooled projected skip at stage changes)
+//   (epilogue of that GEMM, ovo_gemm_unwindow)  window order -> spatial order, + residual (the pooled projected skip at stage changes)
 //   k_ln_window(identity) -> FC1 GEMM(+GELU) -> FC2 GEMM(+bias, += x)
 // All GEMM operands have K padded to a multiple of 32 with zeros (dims 112 / 144 of hiera_b+ / hiera_l).
 #include "common.h"
@@ -114,23 +114,6 @@ __global__ void __launch_bounds__(256) k_qpool(const uint16_t *__restrict__ qkv,
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) m = fmaxf(m, bf2f(base[((long long)(2 * oy + dy) * ww + (2 * ox + dx)) * 3 * C]));
         qp[i] = f2bf(m);
-    }
-}
-
-// out[b, y, x, :] = (res ? res[b, y, x, :] : 0) + rows[row_of(b, y, x), :]      (window order -> spatial)
-__global__ void __launch_bounds__(256) k_unwindow_add(const float *__restrict__ rows, Grid g, int C, const float *__restrict__ res,
-                                                      float *__restrict__ out) {
-    const int c4 = C >> 2;
-    const long long total = (long long)g.B * g.H * g.W * c4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4);
-        long long t = i / c4;
-        const int x = (int)(t % g.W); t /= g.W;
-        const int y = (int)(t % g.H);
-        const int b = (int)(t / g.H);
-        float4 v = ((const float4 *)(rows + row_of(g, b, y, x) * C))[c];
-        if (res) { const float4 r = ((const float4 *)res)[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-        ((float4 *)out)[i] = v;
     }
 }
 
@@ -335,12 +318,18 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         a.o_sb = (int64_t)tq * kout; a.o_sh = hd; a.o_st = kout;
         a.B = (int)n_win; a.H = p.heads[i]; a.Tq = tq; a.Tk = tk; a.hd = hd; a.scale = 1.0f / sqrtf((float)hd);
         TRY(ovo_attention(&a, stream));
-        TRY(gemm(k.att, kout, L.out_w, kout, L.out_b, k.tmp, dout, 0, nullptr, 0, n_win * tq, dout, kout, 0, stream));
-        // window order (pooled window size) -> spatial, + residual
+        // output projection; its epilogue also takes the rows from window order (pooled window size) back to spatial order and
+        // adds the residual (ovo_gemm_unwindow; k_unwindow_add was a pass of its own).  In place: same-dim blocks add onto x; at a
+        // stage change the old x is dead (only LN1 read it) and the pooled skip lives in `spare`, so the smaller new stream is
+        // written over the old buffer.
         const Grid go = make_grid(B, Ho, Ho, p.ws[i] > 0 ? (p.pool[i] ? p.ws[i] / 2 : p.ws[i]) : 0);
-        // in place: same-dim blocks add onto x; at a stage change the old x is dead (only LN1 read it) and the
-        // pooled skip lives in `spare`, so the smaller new stream is written over the old buffer
-        k_unwindow_add<<<ovo_grid(tok_out * (dout / 4), 256), 256, 0, hs>>>(k.tmp, go, dout, residual, x);
+        {
+            ovo_gemm_t og;
+            og.A = k.att; og.lda = kout; og.W = L.out_w; og.ldw = kout; og.bias = L.out_b; og.C = x; og.ldc = dout; og.add = residual; og.ld_add = dout;
+            og.M = (int)(n_win * tq); og.N = dout; og.K = kout; og.in_dtype = 2; og.out_dtype = 0; og.act = 0; og.alpha = 1.0f;
+            const ovo_window_t ow = {go.B, go.H, go.W, go.wh, go.ww};
+            TRY(ovo_gemm_unwindow(&og, &ow, stream));
+        }
         // MLP
         const Grid gi = make_grid(B, Ho, Ho, 0);
         launch_ln_window(x, gi, dout, kout, L.ln2_g, L.ln2_b, c.ln_eps, k.h, hs);

@@ -68,6 +68,34 @@ def test_gemm_epilogues_and_padding():
     assert torch.equal(ob, _gemm(a, w, bias).to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("B,H,W,wh,ww,n,k", [(2, 64, 64, 14, 14, 448, 448), (1, 20, 12, 8, 8, 96, 64), (3, 16, 16, 16, 16, 64, 128), (2, 9, 13, 4, 7, 32, 32)])
+def test_gemm_unwindow_epilogue_vs_torch(B, H, W, wh, ww, n, k):
+    """ovo_gemm_unwindow: rows of the product in window order (padding rows included) land on their spatial rows with the
+    residual added -- Hiera's `window_unpartition` + skip connection -- also in place (C aliases add)."""
+    from ovo_amd import _lib as L
+    g0 = torch.Generator().manual_seed(11)
+    nwh, nww = -(-H // wh), -(-W // ww)
+    m = B * nwh * nww * wh * ww
+    a = torch.randn(m, k, generator=g0).to(DEV, torch.bfloat16)
+    w = (torch.randn(n, k, generator=g0) * k ** -0.5).to(DEV, torch.bfloat16)
+    bias = torch.randn(n, generator=g0).to(DEV)
+    res = torch.randn(B * H * W, n, generator=g0).to(DEV)
+    z = (a.float() @ w.float().T + bias).reshape(B, nwh, nww, wh, ww, n).permute(0, 1, 3, 2, 4, 5).reshape(B, nwh * wh, nww * ww, n)
+    ref = res + z[:, :H, :W].reshape(B * H * W, n)
+    for inplace in (False, True):
+        add = res.clone()
+        out = add if inplace else torch.full((B * H * W, n), float("nan"), device=DEV)
+        gg = L.Gemm()
+        gg.A, gg.lda, gg.W, gg.ldw, gg.bias, gg.C, gg.ldc, gg.add, gg.ld_add = a.data_ptr(), k, w.data_ptr(), k, bias.data_ptr(), out.data_ptr(), n, add.data_ptr(), n
+        gg.M, gg.N, gg.K, gg.in_dtype, gg.out_dtype, gg.act, gg.alpha = m, n, k, 2, 0, 0, 1.0
+        win = L.Window(B, H, W, wh, ww)
+        L.check(L.load().ovo_gemm_unwindow(C.byref(gg), C.byref(win), L.stream()))
+        torch.testing.assert_close(out, ref, atol=3e-4, rtol=3e-4)
+    gg.M = m - 1                                                 # M must be the padded window count
+    with pytest.raises(L.OvoHipError):
+        L.check(L.load().ovo_gemm_unwindow(C.byref(gg), C.byref(win), L.stream()))
+
+
 @pytest.mark.parametrize("b,t,heads,hd", [(2, 37, 4, 32), (2, 577, 16, 64), (3, 50, 4, 72)])
 def test_gemm_rope_epilogue_vs_rope_kernel_and_torch(b, t, heads, hd):
     """ovo_gemm_rope: the packed QKV projection with q, k rotated in the epilogue == ovo_gemm followed by the stand-alone
