@@ -246,7 +246,7 @@ def test_vit_forward_vs_hf_golden():
     torch.testing.assert_close(tok, ref, atol=5e-2, rtol=5e-2)
 
 
-@pytest.mark.parametrize("card,batch", [("tiny-pe", 3), ("ViT-B-16-qg", 2), ("PE-Core-L14-336", 2)])
+@pytest.mark.parametrize("card,batch", [("tiny-pe", 3), ("ViT-B-16-qg", 2), ("ViT-L-14-qg", 1), ("PE-Core-L14-336", 2)])
 def test_vit_forward_vs_oracle_full_size(card, batch):
     """Unit-normalised descriptor error vs the fp32 oracle: north_star bound 1e-3 (features) on ViT-B/16 and PE-L/14-336."""
     from oracle import vit as OV
@@ -287,7 +287,7 @@ def test_siglip_forward_vs_hf_golden():
     assert cos.min() > 0.9995
 
 
-@pytest.mark.parametrize("card,batch,layers", [("tiny-siglip", 3, None), ("SigLIP", 2, 3), ("SigLIP-384", 1, 1), ("SigLIP2-384", 1, 1)])
+@pytest.mark.parametrize("card,batch,layers", [("tiny-siglip", 3, None), ("SigLIP", 2, 3), ("SigLIP", 1, None), ("SigLIP-384", 1, 1), ("SigLIP2-384", 1, 1)])
 def test_siglip_forward_vs_oracle(card, batch, layers):
     """SigLIP so400m shapes (width 1152, head_dim 72, hidden 4304 -> 4320 padded, 256 / 729 / 576 tokens) vs the fp32 oracle;
     `layers` trims the depth so the CPU side finishes in seconds (every block is the same code)."""
