@@ -280,6 +280,7 @@ int launch_mfma(const void *F, int64_t n, int D, const float *T, int Q, const in
     const int64_t groups = (n + 15) / 16;
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    if (const char *e = getenv("OVO_SIM_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }
     int64_t grid = 256 * per_cu;
     if (grid * 4 > groups) grid = (groups + 3) / 4;
     k_similarity_mfma<DT><<<(int)(grid < 1 ? 1 : grid), 256, lds, s>>>(F, n, D, T, Q, cnt, siglip, se, bias, th, out_sim, cls, conf);
