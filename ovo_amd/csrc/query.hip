@@ -209,8 +209,20 @@ __global__ void __launch_bounds__(256) k_similarity_mfma(const void *__restrict_
 #pragma unroll 4
             for (int k0 = 0; k0 < D32; k0 += 32) {
                 float f[8];
-                load8<DT>(F, base + k0 + g * 8, f);
-                const float4 t0 = *(const float4 *)(tq + k0 + g * 8), t1 = *(const float4 *)(tq + k0 + g * 8 + 4);
+                float4 t0, t1;
+                if (DT == 0) {
+                    // f32 rows: the two 16-byte loads of a lane are 64 B apart, so ONE load instruction covers a contiguous
+                    // 64-byte half of each row's 128-byte line (4 lanes x 16 B) instead of four 16-byte pieces 32 B apart; the
+                    // k index of an MFMA is free as long as both operands agree on it
+                    load4<DT>(F, base + k0 + g * 4, f);
+                    load4<DT>(F, base + k0 + 16 + g * 4, f + 4);
+                    t0 = *(const float4 *)(tq + k0 + g * 4);
+                    t1 = *(const float4 *)(tq + k0 + 16 + g * 4);
+                } else {
+                    load8<DT>(F, base + k0 + g * 8, f);
+                    t0 = *(const float4 *)(tq + k0 + g * 8);
+                    t1 = *(const float4 *)(tq + k0 + g * 8 + 4);
+                }
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.x, f[0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.y, f[1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.z, f[2], acc, 0, 0, 0);
