@@ -31,6 +31,7 @@ struct AttnArgs {
     int B, H, Tq, Tk, hd;
     float scale_log2e;
     int causal;                   // keys after the query are masked (text towers)
+    int chunk, q_tiles;           // chunk > 0: 1-D grid in XCD-chunked order (see k_attention)
 };
 
 // float -> bf16 through the compiler's conversion (v_cvt_pk_bf16_f32 on gfx950: one instruction per pair, RNE)
@@ -78,7 +79,18 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int bh = blockIdx.y, b = bh / a.H, h = bh % a.H;
+    // Workgroups go round-robin over the 8 XCDs (XCD = linear id % 8), each with its own L2: XCD x takes the contiguous work
+    // range [x * chunk, (x + 1) * chunk) in (batch*head major, q-tile minor) order, so the q-tiles that share one head's K / V
+    // are co-resident on ONE L2 and K / V leave the fabric once instead of once per XCD.
+    int qtile = blockIdx.x;
+    int bh = blockIdx.y;
+    if (a.chunk > 0) {
+        const int work = (blockIdx.x & 7) * a.chunk + (blockIdx.x >> 3);
+        if (work >= a.q_tiles * a.B * a.H) return;
+        bh = work / a.q_tiles;
+        qtile = work - bh * a.q_tiles;
+    }
+    const int b = bh / a.H, h = bh % a.H;
     const uint16_t *qp = a.q + b * a.q_sb + h * a.q_sh;
     const uint16_t *kp = a.k + b * a.k_sb + h * a.k_sh;
     const uint16_t *vp = a.v + b * a.v_sb + h * a.v_sh;
@@ -88,7 +100,7 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
     bf16x8 qf[QT][HD / 32];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        q_row[t] = (blockIdx.x * 4 + wave) * (16 * QT) + t * 16 + fr;
+        q_row[t] = (qtile * 4 + wave) * (16 * QT) + t * 16 + fr;
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) {
             uint4 raw = make_uint4(0, 0, 0, 0);
@@ -319,6 +331,12 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     const bool wide = p->Tq >= 512 && (long long)((p->Tq + 127) / 128) * p->B * p->H >= 512 && !getenv("OVO_ATTN_NARROW");
     const int qpb = wide ? 128 : 64;
     dim3 grid((p->Tq + qpb - 1) / qpb, p->B * p->H);
+    a.q_tiles = (int)grid.x; a.chunk = 0;
+    if (grid.x > 1 && !getenv("OVO_ATTN_NO_CHUNK")) {             // several q-tiles share a head's K / V: keep them on one XCD's L2
+        const long long total = (long long)grid.x * grid.y;
+        a.chunk = (int)((total + 7) / 8);
+        grid = dim3((unsigned)(a.chunk * 8), 1);
+    }
     const bool prof = ovo_prof_enabled();
     if (prof) { ovo_prof_begin(1, 4.0 * p->B * p->H * (double)p->Tq * p->Tk * p->hd, s); ovo_prof_shape(p->B * p->H, p->Tq, p->Tk); }
     struct Done { bool on; hipStream_t s; ~Done() { if (on) ovo_prof_end(s); } } done{prof, s};
