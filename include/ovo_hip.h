@@ -376,19 +376,19 @@ typedef struct {
 
 typedef struct {
     const float *ln1_g, *ln1_b;
-    const void *qkv_w; const float *qkv_b;   /* [3*dim_out, pad32(dim)]      */
-    const void *out_w; const float *out_b;   /* [dim_out, pad32(dim_out)]    */
+    const void *qkv_w; const float *qkv_b;   /* [3*dim_out, pad64(dim)]      */
+    const void *out_w; const float *out_b;   /* [dim_out, pad64(dim_out)]    */
     const float *ln2_g, *ln2_b;
-    const void *fc1_w; const float *fc1_b;   /* [4*dim_out, pad32(dim_out)]  */
+    const void *fc1_w; const float *fc1_b;   /* [4*dim_out, pad64(dim_out)]  */
     const void *fc2_w; const float *fc2_b;   /* [dim_out, 4*dim_out]         */
-    const void *res_w; const float *res_b;   /* [dim_out, pad32(dim)] at stage changes, else NULL */
+    const void *res_w; const float *res_b;   /* [dim_out, pad64(dim)] at stage changes, else NULL */
 } ovo_hiera_block_t;
 
 typedef struct {
-    const void *patch_w; const float *patch_b;   /* [dims[0], 160] (3*7*7 = 147 padded), [dims[0]] */
+    const void *patch_w; const float *patch_b;   /* [dims[0], 192] (3*7*7 = 147 padded; pad64 = round up to a multiple of 64), [dims[0]] */
     const float *pos;                            /* [(S/4)^2, dims[0]] precomputed position embedding */
     const ovo_hiera_block_t *blocks;             /* HOST array, sum(blocks) entries */
-    const void *neck_w[4]; const float *neck_b[4]; /* level i (fine -> coarse): [fpn_dim, pad32(dims[i])] */
+    const void *neck_w[4]; const float *neck_b[4]; /* level i (fine -> coarse): [fpn_dim, pad64(dims[i])] */
     const void *s0_w; const float *s0_b;         /* [32, fpn_dim] */
     const void *s1_w; const float *s1_b;         /* [64, fpn_dim] */
 } ovo_hiera_weights_t;

@@ -129,7 +129,7 @@ def position_embedding(spec: HieraSpec, sd: Dict[str, torch.Tensor]) -> torch.Te
 
 def _pad_k(w: torch.Tensor) -> torch.Tensor:
     k = w.shape[1]
-    kp = (k + 31) // 32 * 32
+    kp = (k + 63) // 64 * 64                       # the rule of hiera.hip (padk)
     if kp == k:
         return w
     out = torch.zeros(w.shape[0], kp, dtype=w.dtype)
@@ -168,7 +168,7 @@ class HipHiera:
                 b.res_w, b.res_b = mat(sd[p + "proj.weight"]), vec(sd[p + "proj.bias"])
         w = L.HieraWeights()
         conv = sd["trunk.patch_embed.proj.weight"].float().reshape(spec.embed_dim, -1)
-        pw = torch.zeros(spec.embed_dim, 160)
+        pw = torch.zeros(spec.embed_dim, 192)
         pw[:, :147] = conv
         w.patch_w, w.patch_b = mat(pw), vec(sd["trunk.patch_embed.proj.bias"])
         w.pos = vec(position_embedding(spec, sd))
