@@ -48,12 +48,15 @@ def parse():
     ap.add_argument("--map-points", type=int, default=1_000_000)
     ap.add_argument("--texts", type=int, default=10)
     ap.add_argument("--no-dense", action="store_true", help="skip the dense per-point accumulate / query")
+    ap.add_argument("--encoder-batch", type=int, default=int(os.environ.get("OVO_ENCODER_BATCH", "4")),
+                    help="keyframes whose SAM2 / ViT forwards run as ONE batched forward each (encoder look-ahead; 1 = per frame). "
+                         "The reference defers a keyframe's descriptors by kf_queue_delay = 10 keyframes (ovo.yaml:53), so results do not change")
     ap.add_argument("--sam-full", action="store_true", help="not the headline workload: also run SAM2's mask decoder on a 16x16 click grid and the "
                     "automatic-mask-generator filters every frame (SURVEY.md f1); tracking still consumes the synthetic masks, because "
                     "random-init SAM2 weights keep no mask")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--profile-steps", type=int, default=8)
     return ap.parse_args()
 
 
@@ -108,7 +111,7 @@ def pmc_traffic(tile: str):
     bm, bn = tile.split(",")
     with open(path) as fh:
         kernels = json.load(fh)["kernels"]
-    hits = [v for k, v in kernels.items() if f"k_gemmILi{bm}ELi{bn}ELi64E" in k and "DF16b" in k]
+    hits = [v for k, v in kernels.items() if (f"k_gemmILi{bm}ELi{bn}ELi64E" in k or f"k_gemm8pILi{bm}ELi{bn}E" in k) and "DF16b" in k]
     n = sum(v["launches"] for v in hits)
     return round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n) if n else None
 
@@ -117,15 +120,18 @@ def profile_pass(pipe, it, steps, lib):
     """hipEvent pairs around every GEMM / attention / track_project launch of `steps` frames (on the launching streams)."""
     from ovo_amd import _lib as L
     L.check(lib.ovo_profile_start())
+    it.region(steps)
     for _ in range(steps):
-        pipe.step(next(it))
+        f, upcoming = next(it)
+        pipe.step(f, upcoming)
     ms, work, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
     L.check(lib.ovo_profile_stop(ms, work, n, 8))
-    tiles = {4: "128,128", 5: "128,64", 6: "64,128", 7: "64,64"}
+    tiles = {3: "256,256", 0: "256,128", 4: "128,128", 5: "128,64", 6: "64,128", 7: "64,64"}     # 256-row tiles: the ping-pong kernel (gemm8p.hip)
     dom = max(tiles, key=lambda k: ms[k])                      # the GEMM instantiation with the most time = dominant kernel
     tf = work[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
     gemm_ms, gemm_work = sum(ms[k] for k in tiles), sum(work[k] for k in tiles)
-    return {"bound": "mfma", "kernel": f"k_gemm<{tiles[dom]},64,bf16> (ovo_amd/csrc/gemm.hip)", "achieved": round(tf, 1),
+    name = f"k_gemm8p<{tiles[dom]},64,bf16> (ovo_amd/csrc/gemm8p.hip)" if dom in (0, 3) else f"k_gemm<{tiles[dom]},64,bf16> (ovo_amd/csrc/gemm.hip)"
+    return {"bound": "mfma", "kernel": name, "achieved": round(tf, 1),
             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
             "traffic": pmc_traffic(tiles[dom]),
             "launches_per_frame": n[dom] / steps, "avg_launch_us": round(1e3 * ms[dom] / max(n[dom], 1), 2),
@@ -153,27 +159,48 @@ def main():
     total = args.warmup + args.steps + (0 if args.no_roofline else 2 * args.profile_steps)
     sam = None if args.sam == "none" else args.sam
     pipe = FramePipeline(dev, vit_card=args.vit, sam_card=sam, n_map=args.map_points, n_text=args.texts, dense=not args.no_dense, sam_full=args.sam_full,
-                         extra_capacity=(total + 2) * 72_000, seed=0)
+                         extra_capacity=(total + 2) * 72_000, seed=0, encoder_batch=args.encoder_batch)
     frames = synthetic_frames(total, dev, seed=100 * rank + int(os.environ.get("OVO_BENCH_SEED", "0")))   # each rank streams its own frames (weak scaling)
     H, W = frames[0].rgb.shape[:2]
     map0 = pipe.slam.pcd.cpu().numpy().copy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
-    it = iter(frames)
-    for _ in range(args.warmup):
-        pipe.step(next(it))
+    class Feed:
+        """Frames in order; a step also sees the frames that follow it INSIDE the same region (warm-up / timed / profiled), so the
+        encoder look-ahead never does work of a timed frame outside the timed region, nor work of later frames inside it."""
+        def __init__(self, frames):
+            self.frames, self.pos, self.end = frames, 0, 0
+
+        def region(self, n):
+            self.end = self.pos + n
+
+        def __next__(self):
+            f = self.frames[self.pos]
+            self.pos += 1
+            return f, self.frames[self.pos:self.end]
+
+    it = Feed(frames)
+
+    def run(n):
+        it.region(n)
+        for _ in range(n):
+            f, upcoming = next(it)
+            pipe.step(f, upcoming)
+
+    run(args.warmup)
     torch.cuda.synchronize()
     parallel.barrier()
     t0 = time.perf_counter()
     if os.environ.get("OVO_BENCH_PER_STEP"):                       # diagnosis only: sync + stamp every step
         stamps = []
+        it.region(args.steps)
         for _ in range(args.steps):
-            pipe.step(next(it))
+            f, upcoming = next(it)
+            pipe.step(f, upcoming)
             torch.cuda.synchronize()
             stamps.append(time.perf_counter())
         print("per-step ms:", [round(1e3 * (b - a), 2) for a, b in zip([t0] + stamps, stamps)], file=sys.stderr)
     else:
-        for _ in range(args.steps):
-            pipe.step(next(it))
+        run(args.steps)
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
@@ -188,10 +215,16 @@ def main():
     roof = None
     if not args.no_roofline and args.profile_steps > 0:
         roof = profile_pass(pipe, it, args.profile_steps, lib)                 # as timed: three concurrent HIP streams
-        streams = (pipe.sam_stream, pipe.prefetch)
-        pipe.sam_stream, pipe.prefetch = None, False                           # one stream: every kernel has the chip to itself
-        iso = profile_pass(pipe, it, args.profile_steps, lib)
-        pipe.sam_stream, pipe.prefetch = streams
+        torch.cuda.synchronize()
+        if args.encoder_batch > 1:
+            pipe.serial = True                                                 # one stream: every kernel has the chip to itself
+            iso = profile_pass(pipe, it, args.profile_steps, lib)
+            pipe.serial = False
+        else:
+            streams = (pipe.sam_stream, pipe.prefetch)
+            pipe.sam_stream, pipe.prefetch = None, False
+            iso = profile_pass(pipe, it, args.profile_steps, lib)
+            pipe.sam_stream, pipe.prefetch = streams
         roof["isolated"] = {k: iso[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "gemm_all_ms_per_frame", "gemm_all_tflops",
                                                 "attention_ms_per_frame", "attention_tflops", "track_project_gbs")}
         roof["isolated"]["note"] = "same kernels, second profiled pass with the SAM2 / ViT-prefetch streams folded into one"

@@ -147,6 +147,12 @@ int ovo_fuse_views(const float *store, int D, const int32_t *csr_off, const int3
  *   acc[i,:] += desc[mask_row[m],:]; cnt[i] += 1.      acc f32[n,D], cnt i32[n], desc f32[*,D]. */
 int ovo_scatter_accum(const int16_t *point_seg, int64_t n, const int32_t *mask_row, int n_masks,
                       const float *desc, int D, float *acc, int32_t *cnt, ovo_stream_t stream);
+/* The same pass, also emitting WHICH points it changed: touched i32[>= n] receives their indices (in any order), n_touched i32[1]
+ * (zeroed by the caller) their number.  Only those points can change class in the dense query of this keyframe
+ * (ovo.py:473-492 semantics per point): feed the list to ovo_similarity_rows instead of re-querying the whole map. */
+int ovo_scatter_accum_touched(const int16_t *point_seg, int64_t n, const int32_t *mask_row, int n_masks,
+                              const float *desc, int D, float *acc, int32_t *cnt, int32_t *touched, int32_t *n_touched,
+                              ovo_stream_t stream);
 
 /* ---- a21 + a22: similarity query (clip_utils.py:10-19, ovo.py:487-491) ---------------------------
  * S[i,q] = row_scale(i) * sum_k F[i,k] T[q,k];  siglip: S = sigmoid(S * exp(logit_scale) + logit_bias).
@@ -158,6 +164,13 @@ int ovo_scatter_accum(const int16_t *point_seg, int64_t n, const int32_t *mask_r
 int ovo_similarity(const void *F, int feat_dtype, int64_t n, int D, const float *T, int Q, const int32_t *cnt,
                    int siglip, float logit_scale, float logit_bias, float th, float *out_sim,
                    int64_t *out_cls, float *out_conf, ovo_stream_t stream);
+/* ovo_similarity over the rows named in rows[0 .. *n_rows) only (*n_rows <= max_rows is read on the device: no host sync).
+ * out_cls / out_conf are indexed by the row id itself -- a class / confidence map that stays resident across keyframes and is
+ * patched in place; per row the arithmetic is ovo_similarity's, so the patched map equals a full re-query bit for bit.
+ * Needs D % 16 == 0 (the MFMA form). */
+int ovo_similarity_rows(const void *F, int feat_dtype, const int32_t *rows, const int32_t *n_rows, int64_t max_rows, int D,
+                        const float *T, int Q, const int32_t *cnt, int siglip, float logit_scale, float logit_bias, float th,
+                        int64_t *out_cls, float *out_conf, ovo_stream_t stream);
 /* Large vocabularies (BASELINE.json config 5, 1k texts x fp16 map): S f32[n,Q] = ovo_gemm(F, T) in f16/bf16 with fp32
  * accumulation, then this pass: optional SigLIP epilogue in place, first-max argmax / confidence / threshold per row
  * (same out_cls / out_conf meaning as ovo_similarity).  Q % 4 == 0. */

@@ -218,12 +218,14 @@ class SemanticTracker:
         return np.stack([o.feature for o in self.objects.values()]).astype(np.float32)
 
 
-def merge_instances(xyz: np.ndarray, ins: np.ndarray, ids, feats, th_centroid: float = 1.5, th_cossim: float = 0.81, th_points: float = 0.1):
+def merge_instances(xyz: np.ndarray, ins: np.ndarray, ids, feats, th_centroid: float = 1.5, th_cossim: float = 0.81, th_points: float = 0.1,
+                    same=None):
     """ovo.py:381-407 (update_map steps 1-2) with instance_utils.py:5-35, literally: instances without map points are
     dropped, then every ordered pair is tested (centroid distance, descriptor cosine, fraction of points of the first
     whose nearest neighbour in the second is closer than th_points) and merged greedily in dictionary order.
     Open3D's `compute_point_cloud_distance` (a KD-tree nearest-neighbour query in double precision) is restated with
-    scipy's cKDTree -- Open3D is not installed here (parity unpinned for that call).
+    scipy's cKDTree -- Open3D is not installed here; the rest is pinned by tests/golden/loopclose.npz (the reference's own
+    update_map run with that same stand-in, and with `same_instance` replaced by a table: `same(id1, id2)` here).
     ids: instance ids in `objects` order; feats: {id: f32[D]}.  -> (kept ids, {merged id: surviving id}, updated ins)."""
     import torch
     from scipy.spatial import cKDTree
@@ -233,7 +235,7 @@ def merge_instances(xyz: np.ndarray, ins: np.ndarray, ids, feats, th_centroid: f
     pcds = {i: xyz[ins == i] for i in objects_list}
     cents = {i: torch.from_numpy(pcds[i]).mean(axis=0) for i in objects_list}
 
-    def same(i1, i2):
+    def geometric(i1, i2):
         if ((cents[i1] - cents[i2]) ** 2).sum().sqrt() > th_centroid:
             return False
         cos = torch.nn.functional.cosine_similarity(torch.from_numpy(feats[i1]), torch.from_numpy(feats[i2]), dim=0)
@@ -242,6 +244,7 @@ def merge_instances(xyz: np.ndarray, ins: np.ndarray, ids, feats, th_centroid: f
         d, _ = cKDTree(pcds[i2].astype(np.float64)).query(pcds[i1].astype(np.float64))
         p = (d < th_points).astype(float).mean()
         return bool(p > 0.5 or (cos > 0.9 and p > 0.2))
+    same = same or geometric
     kept, fused = [], {}
     for a, i1 in enumerate(objects_list):
         if i1 in fused:

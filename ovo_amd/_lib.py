@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libovo_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class OvoHipError(RuntimeError):
@@ -118,6 +118,8 @@ _SIGNATURES = {
     "ovo_fuse_views": (_I32, [_P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P]),
     "ovo_scatter_accum": (_I32, [_P, _I64, _P, _I32, _P, _I32, _P, _P, _P]),
     "ovo_similarity": (_I32, [_P, _I32, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P, _P]),
+    "ovo_similarity_rows": (_I32, [_P, _I32, _P, _P, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P]),
+    "ovo_scatter_accum_touched": (_I32, [_P, _I64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P]),
     "ovo_mask_boxes": (_I32, [_P, _I32, _I32, _I32, _P, _P]),
     "ovo_mask_crops": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "ovo_row_argmax": (_I32, [_P, _I64, _I32, _I32, _F32, _F32, _F32, _P, _P, _P]),

@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(256) k_fuse_views(const float *__restrict__ st
 __global__ void __launch_bounds__(256) k_scatter_accum(const int16_t *__restrict__ point_seg, int64_t n,
                                                        const int32_t *__restrict__ mask_row, int n_masks,
                                                        const float *__restrict__ desc, int D, float *__restrict__ acc,
-                                                       int32_t *__restrict__ cnt) {
+                                                       int32_t *__restrict__ cnt, int32_t *__restrict__ touched = nullptr,
+                                                       int32_t *__restrict__ n_touched = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int D4 = D >> 2;
@@ -81,6 +82,12 @@ __global__ void __launch_bounds__(256) k_scatter_accum(const int16_t *__restrict
             if (s >= 0 && s < n_masks) row = mask_row[s];
         }
         unsigned long long hits = __ballot(row >= 0);
+        if (touched && hits) {                                     // compacted list of the points this keyframe changed: one atomic per chunk
+            int at = 0;
+            if (lane == 0) at = atomicAdd(n_touched, __popcll(hits));
+            at = __shfl(at, 0, 64);
+            if (row >= 0) touched[at + __popcll(hits & ((1ull << lane) - 1ull))] = (int32_t)i;
+        }
         while (hits) {
             const int src = __ffsll((long long)hits) - 1;
             hits &= hits - 1;
@@ -110,6 +117,20 @@ int ovo_fuse_views(const float *store, int D, const int32_t *csr_off, const int3
     if (n_updates == 0) return OVO_OK;
     OVO_REQUIRE(store && csr_off && csr_rows && table && table_rows, "null pointer");
     k_fuse_views<<<n_updates, 256, 0, (hipStream_t)stream>>>(store, D, csr_off, csr_rows, mode, table, table_rows, out_view);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+// ovo_scatter_accum that also emits WHICH points it changed: touched i32[>= n] receives their indices (any order), n_touched i32[1]
+// (zeroed by the caller) their number -- the row list of ovo_similarity_rows, so that only those points are re-queried.
+int ovo_scatter_accum_touched(const int16_t *point_seg, int64_t n, const int32_t *mask_row, int n_masks, const float *desc,
+                              int D, float *acc, int32_t *cnt, int32_t *touched, int32_t *n_touched, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && n < (1ll << 31) && D > 0 && n_masks > 0, "bad argument");
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(point_seg && mask_row && desc && acc && cnt && touched && n_touched, "null pointer");
+    OVO_REQUIRE((((uintptr_t)desc | (uintptr_t)acc) & 15) == 0 && D % 4 == 0, "acc/desc must be 16-byte aligned, D % 4 == 0");
+    k_scatter_accum<<<ovo_grid((n + 63) / 64 * 64, 256), 256, 0, (hipStream_t)stream>>>(point_seg, n, mask_row, n_masks,
+                                                                                       desc, D, acc, cnt, touched, n_touched);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

@@ -19,125 +19,16 @@
 //     function) is applied to the per-lane SOURCE address and again when fragments are read (ds_read_b128).
 //   * operands are swapped (a = W fragment, b = activation fragment): the accumulator holds C^T tiles, i.e.
 //     each lane owns 4 consecutive output columns of one output row -> 8/16-byte epilogue stores.
-#include <hip/hip_bf16.h>
-#include <hip/hip_fp16.h>
-
 #include <stdlib.h>
 
-#include "common.h"
+#include <type_traits>
+
+#include "gemm_common.h"
+
+using namespace ovo_gemm_detail;
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-struct GemmArgs {
-    const char *A; long long lda;
-    const char *W; long long ldw;
-    const float *bias;
-    void *C; long long ldc;
-    const float *add; long long ld_add;
-    int M, N, K;
-    int out_dtype, act;
-    float alpha;
-    int nbn;
-    int chunk, tiles;          // chunk > 0: XCD-chunked tile order (see launch())
-    unsigned long long *best;  // ovo_gemm_argmax: packed (score, column) running maximum per row, or NULL
-    int store, n_valid;        // with best: also store C?; columns >= n_valid (vocabulary padding) never win
-    const float *rope_cos, *rope_sin;   // ovo_gemm_rope: rotary embedding of columns [0, rope_cols) in the epilogue, or NULL
-    int rope_T, rope_hd, rope_cols, rope_t0;
-    int win_per, win_ww, win_wh, win_nww, win_nwin, win_H, win_W;   // ovo_gemm_unwindow: win_per > 0 remaps C / add rows (see row_dest)
-};
-
-// ovo_gemm_unwindow: product row m is a token in window-major order (windows of wh x ww tiling an H x W grid that is padded up to
-// whole windows); its C / add row is the token's spatial index (b*H + y)*W + x, or -1 for a padding position (row dropped).
-__device__ __forceinline__ long long row_dest(const GemmArgs &g, int m) {
-    if (g.win_per <= 0) return m;
-    const int win = m / g.win_per, p = m - win * g.win_per;
-    const int iy = p / g.win_ww, ix = p - iy * g.win_ww;
-    const int b = win / g.win_nwin, wr = win - b * g.win_nwin;
-    const int wy = wr / g.win_nww, wx = wr - wy * g.win_nww;
-    const int y = wy * g.win_wh + iy, x = wx * g.win_ww + ix;
-    return (y < g.win_H && x < g.win_W) ? ((long long)b * g.win_H + y) * g.win_W + x : -1;
-}
-
-template <typename VT> struct Mfma;
-template <> struct Mfma<bf16x8> {
-    __device__ static f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct Mfma<f16x8> {
-    __device__ static f32x4 run(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-};
-
-template <int BK> __device__ __forceinline__ int swz(int row) {
-    return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
-}
-
-__device__ __forceinline__ void glds16(const void *src, void *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
-
-// GELU(x) = x/2 (1 + erf(x/sqrt2)) on PACKED f32 (v_pk_fma_f32: two values per VALU slot) with a polynomial erf and no
-// transcendental op:  erf(z) ~ zc * P(s),  zc = clamp(z, +-3.5),  s = 2 zc^2 / 3.5^2 - 1,  P of degree 11 (Chebyshev-node
-// weighted least squares, tools/ history in DESIGN.md).  |erf error| <= 1.9e-6, |GELU error| <= 8.6e-6 absolute for every
-// x -- far below the bf16 rounding of the stored activation.  The library erff is ~50 branchy instructions and an
-// exp/rcp form still pays two quarter-rate transcendentals per value; the GELU sits on the serial tail of every FC1
-// tile (the epilogue does not overlap MFMA work), where it cost up to a quarter of the GEMM.
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
-    const f32x2 z = x * 0.70710678118654752f;
-    const f32x2 zc = __builtin_elementwise_min(__builtin_elementwise_max(z, (f32x2)(-3.5f)), (f32x2)(3.5f));
-    const f32x2 s = __builtin_elementwise_fma(zc * zc, (f32x2)(0.16326530612244897f), (f32x2)(-1.0f));
-    f32x2 p = (f32x2)(-3.398861796e-03f);
-    p = __builtin_elementwise_fma(p, s, (f32x2)(8.621919328e-03f));
-    p = __builtin_elementwise_fma(p, s, (f32x2)(-8.698635955e-03f));
-    p = __builtin_elementwise_fma(p, s, (f32x2)(1.271555869e-02f));
-    p = __builtin_elementwise_fma(p, s, (f32x2)(-2.870869786e-02f));
-    p = __builtin_elementwise_fma(p, s, (f32x2)(4.709060027e-02f));
-    p = __builtin_elementwise_fma(p, s, (f32x2)(-6.528488840e-02f));
-    p = __builtin_elementwise_fma(p, s, (f32x2)(8.795614477e-02f));
-    p = __builtin_elementwise_fma(p, s, (f32x2)(-1.145324569e-01f));
-    p = __builtin_elementwise_fma(p, s, (f32x2)(1.467849556e-01f));
-    p = __builtin_elementwise_fma(p, s, (f32x2)(-2.007044758e-01f));
-    p = __builtin_elementwise_fma(p, s, (f32x2)(4.038725490e-01f));
-    const f32x2 hx = x * 0.5f;
-    return __builtin_elementwise_fma(hx, p * zc, hx);
-}
-
-__device__ __forceinline__ void act4(float *v, int act) {
-    if (act == 1) {
-        const f32x2 a = gelu2(f32x2{v[0], v[1]}), b = gelu2(f32x2{v[2], v[3]});
-        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
-    } else if (act == 2) {                                       // QuickGELU x * sigmoid(1.702 x)   (open_clip "-qg" cards)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
-    } else if (act == 3) {                                       // ReLU (SAM2 decoder MLPs)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-    } else if (act == 4) {                                       // sigmoid (SAM2 IoU head)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + __expf(-v[r]));
-    } else if (act == 5) {                                       // GELU, tanh form (SigLIP towers): x * sigmoid(2 sqrt(2/pi) (x + 0.044715 x^3))
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float u = 1.5957691216057308f * fmaf(0.044715f * v[r] * v[r], v[r], v[r]);
-            v[r] = v[r] / (1.0f + __expf(-u));
-        }
-    }
-}
-
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
-    const uint32_t ra = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;         // round-to-nearest-even (finite values)
-    const uint32_t rb = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
-    return ra | (rb << 16);
-}
-__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
-    const __half2 h = __floats2half2_rn(a, b);
-    return *(const uint32_t *)&h;
-}
 
 template <int BM, int BN, int BK, int NS, typename VT, int NW = 4>
 __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
@@ -380,9 +271,28 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
         if (blocks(128, 128) >= 2048 && (double)((blocks(128, 128) + 255) / 256) * 8192.0 <= best) { bm = 128; bn = 128; }
     }
     ns2 = ns2_ok && bm == 128 && bn == 64 && r768 <= r512;
-    if (const char *force = getenv("OVO_GEMM_TILE")) {           // tuning knob (tools/gemm_bench.py): "128x128", "64x128", ...
+    // The 256-row ping-pong kernels (gemm8p.hip) for the batched forwards.  One workgroup per CU, so their cost is
+    //   rounds x (fixed + K-tiles x per-tile), fixed ~8-9 us (prologue from HBM, epilogue, nothing overlaps them), per 64-deep K-tile
+    //   1.5 us (256x256) / 0.62 us (256x128), floored by the HBM time of the operands and the output;
+    // the ring kernels above run ~650 TFLOP/s + 4 us at these sizes (tools/gemm_bench.py on MI355X, profiles/r02*_gemm_sweep.txt).
+    if (k64 && g.M >= 2048 && g.N >= 256 && !getenv("OVO_GEMM_TILE") && !getenv("OVO_GEMM_NO_8P")) {
+        const double flop = 2.0 * g.M * (double)g.N * g.K, kt = g.K / 64;
+        const double bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (double)g.M * g.N * (g.out_dtype == 0 ? 4.0 : 2.0) * (g.add ? 2.0 : 1.0);
+        const double t_mem = bytes / 4.0e6;                                            // us at 4 TB/s
+        const double t_ring = flop / 650.0e6 + 4.0;
+        const double r256 = (double)((blocks(256, 256) + 255) / 256), r128 = (double)((blocks(256, 128) + 255) / 256);
+        double t256 = r256 * (8.0 + 1.5 * kt), t128 = r128 * (9.0 + 0.62 * kt);
+        t256 = t256 > t_mem ? t256 : t_mem; t128 = t128 > t_mem ? t128 : t_mem;
+        const double t8 = t256 < t128 ? t256 : t128;
+        if (t8 < 0.93 * (t_ring > t_mem ? t_ring : t_mem)) {
+            const int rc = gemm8p_launch(g, t256 < t128 ? 256 : 128, std::is_same<VT, bf16x8>::value ? 2 : 1, s);
+            if (rc != OVO_E_UNSUPPORTED) return rc;
+        }
+    }
+    if (const char *force = getenv("OVO_GEMM_TILE")) {           // tuning knob (tools/gemm_bench.py): "128x128", "64x128", "256x256", ...
         int fm = 0, fn = 0;
         if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm == 64 || fm == 128) && (fn == 64 || fn == 128)) { bm = fm; bn = fn; }
+        if (fm == 256 && (fn == 256 || fn == 128) && k64) return gemm8p_launch(g, fn, std::is_same<VT, bf16x8>::value ? 2 : 1, s);
     }
     if (bm == 128 && bn == 128) return k64 ? launch<128, 128, 64, VT, 8, 3>(g, s) : launch<128, 128, 32, VT, 8, 3>(g, s);
     // BK = 64: 8 waves per workgroup on every tile (two workgroups = 16 waves per CU): same LDS and L2 traffic as the 4-wave
@@ -423,7 +333,7 @@ static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, 
     g.M = p->M; g.N = p->N; g.K = p->K; g.out_dtype = p->out_dtype; g.act = p->act; g.alpha = p->alpha; g.nbn = 0;
     g.best = best; g.store = store; g.n_valid = n_valid;
     g.rope_cos = g.rope_sin = nullptr; g.rope_T = 1; g.rope_hd = 4; g.rope_cols = 0; g.rope_t0 = 0;
-    g.win_per = 0; g.win_ww = g.win_wh = g.win_nww = g.win_nwin = 1; g.win_H = g.win_W = 0;
+    g.dbg = 0; g.stamps = nullptr; g.win_per = 0; g.win_ww = g.win_wh = g.win_nww = g.win_nwin = 1; g.win_H = g.win_W = 0;
     if (win) {
         OVO_REQUIRE(win->B > 0 && win->H > 0 && win->W > 0 && win->wh > 0 && win->ww > 0, "bad window descriptor");
         const int nwh = (win->H + win->wh - 1) / win->wh, nww = (win->W + win->ww - 1) / win->ww;

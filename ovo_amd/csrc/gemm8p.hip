@@ -1,0 +1,354 @@
+// gemm8p.hip -- the large-tile MFMA GEMM of the batched encoder forwards: C[M,N] = act(alpha * A[M,K] . W[N,K]^T + bias) (+ add).
+//
+// Same contract and epilogue as k_gemm (gemm.hip); different main loop, built for M >= ~2000 rows (several keyframes' crops per
+// forward) where the 128-row ring kernel sits on the LDS port (32x32 wave tiles: one LDS byte per 4 flop):
+//
+//   * 256 x BN x 64 tiles (BN = 256: 8 waves as 2 x 4, wave tile 128 x 64;  BN = 128: 4 x 2, wave tile 64 x 64), one workgroup per CU,
+//     128 / 96 KB of LDS = two K-tile buffers, each split in four HALF-tiles: Ah0 / Ah1 hold sub-tile 0 / 1 (upper / lower half of the
+//     rows) of EVERY wave's A rows, Bh0 / Bh1 likewise for the W rows.  A K-tile is consumed in four phases, one C quadrant each:
+//         q0: read A.sub0 + B.sub0 -> acc[0][0]     q1: read B.sub1 -> acc[0][1]     q2: read A.sub1 -> acc[1][1]     q3: -> acc[1][0]
+//     so a half-tile is dead two phases after it was read and is restaged (LDS-DMA, global_load_lds_dwordx4) for K-tile t+2 while K-tile t
+//     is still being multiplied: q0 stages Bh1(t+1), q1 Ah1(t+1), q2 Ah0(t+2), q3 Bh0(t+2); every stage is read >= 5 phases later.
+//   * the two wave groups {0..3} / {4..7} (one wave of each per SIMD) run ONE BARRIER APART: a phase is
+//         [ds_read fragments | issue DMA | counted vmcnt] s_barrier [MFMA quadrant] s_barrier
+//     and while one group multiplies, the other reads its next fragments -- the matrix pipe of a SIMD alternates between its two waves
+//     and never waits for LDS (ping-pong).  Counted s_waitcnt vmcnt leaves the four newest stages in flight across the barriers.
+//   * fragments: v_mfma_f32_16x16x32_{bf16,f16}, operands swapped as in k_gemm (a = W fragment, b = activation fragment: a lane owns 4
+//     consecutive output columns); 128-byte LDS rows with the 16-byte-chunk XOR swizzle applied to the DMA source address and to the
+//     ds_read_b128 address.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "gemm_common.h"
+
+using namespace ovo_gemm_detail;
+
+namespace {
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {             // f(integral_constant<I>) ... f(integral_constant<N-1>): indices stay compile-time constants
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+#define OVO_FENCE() asm volatile("" ::: "memory")
+#define OVO_BARRIER()                      \
+    do {                                   \
+        __builtin_amdgcn_sched_barrier(0); \
+        __builtin_amdgcn_s_barrier();      \
+        OVO_FENCE();                       \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+#define OVO_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int BM, int BN, int WARPS_M, typename VT, bool STAGED>
+__global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
+#if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (its parse of lambdas that call LDS-DMA builtins drops the stub silently)
+    constexpr int WARPS_N = 8 / WARPS_M;
+    constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;            // wave tile
+    constexpr int HM = WTM / 2, HN = WTN / 2;                        // one sub-tile ("half") of the wave tile
+    constexpr int TMH = HM / 16, TNH = HN / 16;                      // 16x16 MFMA tiles per sub-tile
+    constexpr int A_HALF = (BM / 2) * 128, B_HALF = (BN / 2) * 128;  // bytes of a half-tile: rows x 64 two-byte elements
+    constexpr int BUF = 2 * A_HALF + 2 * B_HALF;
+    constexpr int NA = A_HALF / (512 * 16), NB = B_HALF / (512 * 16);   // DMA pieces (1 KB = 8 rows per wave instruction) per thread
+    static_assert(NA >= 1 && NB >= 1 && TMH >= 1 && TNH >= 1, "tile too small for 512 threads");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR
+    const int wr = wave / WARPS_N, wc = wave % WARPS_N, group = wave >> 2;
+    int tile = blockIdx.x;
+    if (g.chunk > 0) {                                   // XCD-chunked tile order (see k_gemm)
+        tile = (blockIdx.x & 7) * g.chunk + (blockIdx.x >> 3);
+        if (tile >= g.tiles) return;
+    }
+    const int m0 = (tile / g.nbn) * BM, n0 = (tile % g.nbn) * BN;
+    const int fr = lane & 15, fq = lane >> 4;
+    if (g.dbg & 1) return;
+    auto stamp = [&](int k) { if (g.stamps && tid == 0) g.stamps[(long long)tile * 4 + k] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
+
+    // ---- DMA sources: half h, piece (it * 8 + wave) = local rows [8 * piece, +8), lane -> (row, swizzled 16-byte chunk).
+    // 32-bit byte offsets from the (wave-uniform) operand base: the launch checks that both operands span < 4 GB.
+    uint32_t a_off[2][NA], b_off[2][NB];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+            const int r = (it * 8 + wave) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+            int gr = m0 + (r / HM) * WTM + h * HM + (r % HM);
+            gr = gr < g.M ? gr : g.M - 1;
+            a_off[h][it] = (uint32_t)(((long long)gr * g.lda + c * 8) * 2);
+        }
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int r = (it * 8 + wave) * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+            int gr = n0 + (r / HN) * WTN + h * HN + (r % HN);
+            gr = gr < g.N ? gr : g.N - 1;
+            b_off[h][it] = (uint32_t)(((long long)gr * g.ldw + c * 8) * 2);
+        }
+    }
+    // buffer_load_dwordx4 ... lds: resource = operand base (SGPRs), voffset = the lane's byte offset, soffset = the K-tile's byte offset.
+    // A stage for a K-tile past the end goes through a zero-length resource: nothing is fetched (zeros land in a buffer nobody reads any
+    // more), but the instruction still counts in vmcnt -- the loop body and its counted waits are the same for every K-tile.
+    const int a_bytes = (int)((long long)g.M * g.lda * 2), b_bytes = (int)((long long)g.N * g.ldw * 2);
+    auto stage_a = [&](int buf, int h, int kt, bool valid = true) {
+        char *dst = smem + buf * BUF + h * A_HALF + wave * 1024;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)g.A, 0, valid ? a_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < NA; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst + it * 8192), 16, a_off[h][it], kt * 128, 0, 0);
+    };
+    auto stage_b = [&](int buf, int h, int kt, bool valid = true) {
+        char *dst = smem + buf * BUF + 2 * A_HALF + h * B_HALF + wave * 1024;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)g.W, 0, valid ? b_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < NB; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst + it * 8192), 16, b_off[h][it], kt * 128, 0, 0);
+    };
+
+    // ---- fragment addresses: local row = (wave's first row in the half) + 16 i + fr, chunk (4 ks + fq) ^ swizzle(row)
+    const int sw = (fr >> 1) & 7;
+    const int off_a = (wr * HM + fr) * 128 + ((fq ^ sw) << 4);      // ks = 0; ks = 1 is the same address with bit 6 flipped
+    const int off_b = (wc * HN + fr) * 128 + ((fq ^ sw) << 4);
+
+    f32x4 acc[2 * TMH][2 * TNH];
+#pragma unroll
+    for (int i = 0; i < 2 * TMH; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * TNH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    VT xa[TMH][2], wb0[TNH][2], wb1[TNH][2];
+
+    auto load_a = [&](const char *cur, int h) {
+#pragma unroll
+        for (int i = 0; i < TMH; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xa[i][ks] = *(const VT *)(cur + h * A_HALF + ((off_a ^ (ks << 6)) + i * 2048));
+    };
+    auto load_b = [&](const char *cur, int h, VT (&wb)[TNH][2]) {
+#pragma unroll
+        for (int j = 0; j < TNH; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wb[j][ks] = *(const VT *)(cur + 2 * A_HALF + h * B_HALF + ((off_b ^ (ks << 6)) + j * 2048));
+    };
+    auto quadrant = [&](int ih, int jh, VT (&wb)[TNH][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TMH; ++i)
+#pragma unroll
+                for (int j = 0; j < TNH; ++j)
+                    acc[ih * TMH + i][jh * TNH + j] = Mfma<VT>::run(wb[j][ks], xa[i][ks], acc[ih * TMH + i][jh * TNH + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int nt = g.K / 64;
+
+    // ---- prologue: the six stages of "phases -6 .. -1": Ah0(0) Bh0(0) Bh1(0) Ah1(0) Ah0(1) Bh0(1)
+    stage_a(0, 0, 0);
+    stage_b(0, 0, 0);
+    stage_b(0, 1, 0);
+    stage_a(0, 1, 0);
+    stage_a(1, 0, 1, nt > 1);
+    stage_b(1, 0, 1, nt > 1);
+    OVO_VMCNT(2 * NA + 2 * NB);                           // Ah0(0), Bh0(0) landed (this wave's pieces)
+    OVO_BARRIER();
+    stamp(1);
+    if (g.dbg & 2) { OVO_VMCNT(0); return; }
+    if (group == 1) OVO_BARRIER();                        // group 1 runs one barrier behind group 0 from here on
+
+    // One K-tile = four phases.  The counted wait of a phase leaves exactly the stages of the last four phases in flight
+    // (2 NA + 2 NB pieces), i.e. the stage issued four phases ago -- first read in the NEXT phase -- has landed.
+    auto body = [&](auto PAR, int t) {
+        constexpr int b = decltype(PAR)::value;
+        const bool v1 = t + 1 < nt, v2 = t + 2 < nt;
+        const char *cur = smem + b * BUF;
+        // q0: A.sub0 x B.sub0
+        load_a(cur, 0);
+        load_b(cur, 0, wb0);
+        stage_b(b ^ 1, 1, t + 1, v1);
+        OVO_VMCNT(2 * NA + 2 * NB);
+        OVO_BARRIER();
+        quadrant(0, 0, wb0);
+        OVO_BARRIER();
+        // q1: A.sub0 x B.sub1
+        load_b(cur, 1, wb1);
+        stage_a(b ^ 1, 1, t + 1, v1);
+        OVO_VMCNT(2 * NA + 2 * NB);
+        OVO_BARRIER();
+        quadrant(0, 1, wb1);
+        OVO_BARRIER();
+        // q2: A.sub1 x B.sub1
+        load_a(cur, 1);
+        stage_a(b, 0, t + 2, v2);
+        OVO_VMCNT(2 * NA + 2 * NB);
+        OVO_BARRIER();
+        quadrant(1, 1, wb1);
+        OVO_BARRIER();
+        // q3: A.sub1 x B.sub0 (fragments kept from q0)
+        stage_b(b, 0, t + 2, v2);
+        OVO_VMCNT(2 * NA + 2 * NB);
+        OVO_BARRIER();
+        quadrant(1, 0, wb0);
+        if (v1 || group == 0) OVO_BARRIER();              // group 1 skips its very last barrier: both groups execute 8 nt + 1
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {                          // two K-tiles per trip (static buffer parity)
+        body(I0{}, t);
+        body(I1{}, t + 1);
+    }
+    if (t < nt) body(I0{}, t);
+    OVO_VMCNT(0);
+    stamp(2);
+    if (g.dbg & 4) { if (acc[0][0][0] == 12345.678f) *(float *)g.C = 1.f; return; }
+
+    if constexpr (STAGED) {
+        // ---- epilogue through LDS.  Stored straight from the accumulators a wave instruction writes 16 rows x 32-64 bytes; with 16-32
+        // such groups per lane the store ISSUE (one request per row segment) cost more than the K-loop of a K = 1024 tile.  Instead each
+        // wave transposes its tile through a private LDS slab (two passes of HM rows, rows padded by 16 bytes against bank conflicts)
+        // and then reads rows back so that every store / residual load instruction covers whole 128-256-byte row segments.
+        OVO_BARRIER();                                    // every wave's LDS-DMA has landed and every fragment read is done: LDS is free
+        constexpr int ROWB = WTN * 4 + 16;
+        char *slab = smem + wave * (HM * ROWB);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int i = 0; i < TMH; ++i)
+#pragma unroll
+                for (int j = 0; j < 2 * TNH; ++j)
+                    *(f32x4 *)(slab + (i * 16 + fr) * ROWB + (j * 16 + fq * 4) * 4) = acc[pass * TMH + i][j];
+            OVO_FENCE();
+            const int mw = m0 + wr * WTM + pass * HM, nw = n0 + wc * WTN;
+            if (g.out_dtype == 0) {                       // f32 rows: 16 lanes x 16 bytes per row, 4 rows per instruction
+                constexpr int LPR = WTN / 4, RPI = 64 / LPR;
+                const int c = (lane % LPR) * 4, n = nw + c;
+                const float4 bias = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+                for (int it = 0; it < HM / RPI; ++it) {
+                    const int r = it * RPI + lane / LPR, m = mw + r;
+                    const f32x4 a = *(const f32x4 *)(slab + r * ROWB + c * 4);
+                    const long long md = (m < g.M && n < g.N) ? row_dest(g, m) : -1;
+                    if (md < 0) continue;
+                    const float4 addv = g.add ? *(const float4 *)(g.add + md * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float v[4] = {a[0], a[1], a[2], a[3]};
+                    math4(g, m, n, v, bias, addv);
+                    *(float4 *)((float *)g.C + md * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {                                      // 2-byte rows: 8 lanes x 16 bytes per row, 8 rows per instruction
+                constexpr int LPR = WTN / 8, RPI = 64 / LPR;
+                const int c = (lane % LPR) * 8, n = nw + c;
+                const bool in0 = n < g.N, in1 = n + 4 < g.N;
+                const float4 bias0 = (g.bias && in0) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 bias1 = (g.bias && in1) ? *(const float4 *)(g.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+                for (int it = 0; it < HM / RPI; ++it) {
+                    const int r = it * RPI + lane / LPR, m = mw + r;
+                    const f32x4 a0 = *(const f32x4 *)(slab + r * ROWB + c * 4), a1 = *(const f32x4 *)(slab + r * ROWB + c * 4 + 16);
+                    const long long md = (m < g.M && in0) ? row_dest(g, m) : -1;
+                    if (md < 0) continue;
+                    float4 add0 = make_float4(0.f, 0.f, 0.f, 0.f), add1 = add0;
+                    if (g.add) {
+                        add0 = *(const float4 *)(g.add + md * g.ld_add + n);
+                        if (in1) add1 = *(const float4 *)(g.add + md * g.ld_add + n + 4);
+                    }
+                    float v0[4] = {a0[0], a0[1], a0[2], a0[3]}, v1[4] = {a1[0], a1[1], a1[2], a1[3]};
+                    math4(g, m, n, v0, bias0, add0);
+                    math4(g, m, n + 4, v1, bias1, add1);
+                    uint4 p;
+                    if (g.out_dtype == 2) { p.x = pack_bf16(v0[0], v0[1]); p.y = pack_bf16(v0[2], v0[3]); p.z = pack_bf16(v1[0], v1[1]); p.w = pack_bf16(v1[2], v1[3]); }
+                    else { p.x = pack_f16(v0[0], v0[1]); p.y = pack_f16(v0[2], v0[3]); p.z = pack_f16(v1[0], v1[1]); p.w = pack_f16(v1[2], v1[3]); }
+                    uint16_t *dst = (uint16_t *)g.C + md * g.ldc + n;
+                    if (in1 && ((uintptr_t)dst & 15) == 0) *(uint4 *)dst = p;
+                    else {
+                        *(uint2 *)dst = make_uint2(p.x, p.y);
+                        if (in1) *(uint2 *)(dst + 4) = make_uint2(p.z, p.w);
+                    }
+                }
+            }
+            OVO_FENCE();                                  // the slab is rewritten by the next pass: its reads above come first (same wave)
+        }
+    } else {
+        // ---- epilogue straight from the accumulators (the fused-argmax form needs a row's columns in neighbouring lanes):
+        // acc[i][j][r] = C[m = m0 + wr WTM + 16 i + fr][n = n0 + wc WTN + 16 j + 4 fq + r]
+        float4 bias_r[2 * TNH];
+#pragma unroll
+        for (int j = 0; j < 2 * TNH; ++j) {
+            const int n = n0 + wc * WTN + j * 16 + fq * 4;
+            bias_r[j] = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        static_for<0, 2 * TMH>([&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            const int m = m0 + wr * WTM + i * 16 + fr;
+            const long long md = m < g.M ? row_dest(g, m) : -1;
+            if (md >= 0) {
+                float4 add_r[2 * TNH];
+#pragma unroll
+                for (int j = 0; j < 2 * TNH; ++j) {
+                    const int n = n0 + wc * WTN + j * 16 + fq * 4;
+                    add_r[j] = (g.add && n < g.N) ? *(const float4 *)(g.add + md * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                float row_best = -3.0e38f;
+                int row_arg = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < 2 * TNH; ++j) {
+                    const int n = n0 + wc * WTN + j * 16 + fq * 4;
+                    if (n < g.N) finish4(g, m, md, n, acc[i][j], bias_r[j], add_r[j], row_best, row_arg);
+                }
+                if (g.best) finish_best(g, m, fq, row_best, row_arg);
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(3);
+#endif
+}
+
+template <int BM, int BN, int WARPS_M, typename VT, bool STAGED>
+int launch8p_(const GemmArgs &g0, hipStream_t s) {
+    GemmArgs g = g0;
+    g.dbg = getenv("OVO_8P_DEBUG") ? atoi(getenv("OVO_8P_DEBUG")) : 0;
+    g.stamps = getenv("OVO_8P_STAMPS") ? (unsigned long long *)strtoull(getenv("OVO_8P_STAMPS"), nullptr, 0) : nullptr;
+    g.nbn = (g.N + BN - 1) / BN;
+    const int nbm = (g.M + BM - 1) / BM;
+    constexpr size_t ring = 2 * (size_t)(BM + BN) * 128;                                  // two K-tile buffers
+    constexpr size_t slabs = 8 * (size_t)(BM / WARPS_M / 2) * ((BN / (8 / WARPS_M)) * 4 + 16);     // epilogue: 8 x HM rows x (4 WTN + 16) bytes
+    constexpr size_t lds = STAGED && slabs > ring ? slabs : ring;
+    static bool attr_done = false;              // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_gemm8p<BM, BN, WARPS_M, VT, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { ovo_set_error("ovo_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
+        attr_done = true;
+    }
+    const bool prof = ovo_prof_enabled();
+    if (prof) { ovo_prof_begin(BN == 256 ? 3 : 0, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); }     // kinds 3 / 0: 256x256 / 256x128
+    g.tiles = nbm * g.nbn;
+    g.chunk = (g.M > g.N || g.nbn % 8 != 0) && !getenv("OVO_GEMM_NO_CHUNK") ? (g.tiles + 7) / 8 : 0;
+    const int grid = g.chunk > 0 ? g.chunk * 8 : g.tiles;
+    k_gemm8p<BM, BN, WARPS_M, VT, STAGED><<<grid, 512, lds, s>>>(g);
+    if (prof) ovo_prof_end(s);
+    return OVO_OK;
+}
+
+template <int BM, int BN, int WARPS_M, typename VT>
+int launch8p(const GemmArgs &g, hipStream_t s) {
+    return g.best ? launch8p_<BM, BN, WARPS_M, VT, false>(g, s) : launch8p_<BM, BN, WARPS_M, VT, true>(g, s);
+}
+
+}  // namespace
+
+namespace ovo_gemm_detail {
+
+int gemm8p_launch(const GemmArgs &g, int bn, int in_dtype, hipStream_t s) {
+    if (g.K % 64 != 0 || g.K < 64) return OVO_E_UNSUPPORTED;
+    if ((long long)g.M * g.lda * 2 >= (1ll << 32) || (long long)g.N * g.ldw * 2 >= (1ll << 32)) return OVO_E_UNSUPPORTED;   // 32-bit DMA offsets
+    if (bn == 256) return in_dtype == 2 ? launch8p<256, 256, 2, bf16x8>(g, s) : launch8p<256, 256, 2, f16x8>(g, s);
+    if (bn == 128) return in_dtype == 2 ? launch8p<256, 128, 4, bf16x8>(g, s) : launch8p<256, 128, 4, f16x8>(g, s);
+    return OVO_E_UNSUPPORTED;
+}
+
+}  // namespace ovo_gemm_detail

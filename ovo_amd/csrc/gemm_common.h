@@ -1,0 +1,186 @@
+// gemm_common.h -- operand descriptor, MFMA wrappers and epilogue helpers shared by the MFMA GEMM kernels
+// (gemm.hip: LDS-DMA ring kernels; gemm8p.hip: the 256-row ping-pong kernel).
+#pragma once
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace ovo_gemm_detail {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct GemmArgs {
+    const char *A; long long lda;
+    const char *W; long long ldw;
+    const float *bias;
+    void *C; long long ldc;
+    const float *add; long long ld_add;
+    int M, N, K;
+    int out_dtype, act;
+    float alpha;
+    int nbn;
+    int chunk, tiles;          // chunk > 0: XCD-chunked tile order (see launch())
+    unsigned long long *best;  // ovo_gemm_argmax: packed (score, column) running maximum per row, or NULL
+    int store, n_valid;        // with best: also store C?; columns >= n_valid (vocabulary padding) never win
+    const float *rope_cos, *rope_sin;   // ovo_gemm_rope: rotary embedding of columns [0, rope_cols) in the epilogue, or NULL
+    int rope_T, rope_hd, rope_cols, rope_t0;
+    int win_per, win_ww, win_wh, win_nww, win_nwin, win_H, win_W;   // ovo_gemm_unwindow: win_per > 0 remaps C / add rows (see row_dest)
+    int dbg;                   // tools/ only (OVO_8P_DEBUG): 1 = leave before anything, 2 = leave after the prologue, 4 = no epilogue
+    unsigned long long *stamps;   // tools/ only (OVO_8P_STAMPS = address of u64[tiles][4]): s_memrealtime at start / K-loop / epilogue / end
+};
+
+// ovo_gemm_unwindow: product row m is a token in window-major order (windows of wh x ww tiling an H x W grid that is padded up to
+// whole windows); its C / add row is the token's spatial index (b*H + y)*W + x, or -1 for a padding position (row dropped).
+__device__ __forceinline__ long long row_dest(const GemmArgs &g, int m) {
+    if (g.win_per <= 0) return m;
+    const int win = m / g.win_per, p = m - win * g.win_per;
+    const int iy = p / g.win_ww, ix = p - iy * g.win_ww;
+    const int b = win / g.win_nwin, wr = win - b * g.win_nwin;
+    const int wy = wr / g.win_nww, wx = wr - wy * g.win_nww;
+    const int y = wy * g.win_wh + iy, x = wx * g.win_ww + ix;
+    return (y < g.win_H && x < g.win_W) ? ((long long)b * g.win_H + y) * g.win_W + x : -1;
+}
+
+template <typename VT> struct Mfma;
+template <> struct Mfma<bf16x8> {
+    __device__ static f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma<f16x8> {
+    __device__ static f32x4 run(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+template <int BK> __device__ __forceinline__ int swz(int row) {
+    return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+}
+
+__device__ __forceinline__ void glds16(const void *src, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// GELU(x) = x/2 (1 + erf(x/sqrt2)) on PACKED f32 (v_pk_fma_f32: two values per VALU slot) with a polynomial erf and no
+// transcendental op:  erf(z) ~ zc * P(s),  zc = clamp(z, +-3.5),  s = 2 zc^2 / 3.5^2 - 1,  P of degree 11 (Chebyshev-node
+// weighted least squares, tools/ history in DESIGN.md).  |erf error| <= 1.9e-6, |GELU error| <= 8.6e-6 absolute for every
+// x -- far below the bf16 rounding of the stored activation.  The library erff is ~50 branchy instructions and an
+// exp/rcp form still pays two quarter-rate transcendentals per value; the GELU sits on the serial tail of every FC1
+// tile (the epilogue does not overlap MFMA work), where it cost up to a quarter of the GEMM.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+    const f32x2 z = x * 0.70710678118654752f;
+    const f32x2 zc = __builtin_elementwise_min(__builtin_elementwise_max(z, (f32x2)(-3.5f)), (f32x2)(3.5f));
+    const f32x2 s = __builtin_elementwise_fma(zc * zc, (f32x2)(0.16326530612244897f), (f32x2)(-1.0f));
+    f32x2 p = (f32x2)(-3.398861796e-03f);
+    p = __builtin_elementwise_fma(p, s, (f32x2)(8.621919328e-03f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(-8.698635955e-03f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(1.271555869e-02f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(-2.870869786e-02f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(4.709060027e-02f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(-6.528488840e-02f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(8.795614477e-02f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(-1.145324569e-01f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(1.467849556e-01f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(-2.007044758e-01f));
+    p = __builtin_elementwise_fma(p, s, (f32x2)(4.038725490e-01f));
+    const f32x2 hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, p * zc, hx);
+}
+
+__device__ __forceinline__ void act4(float *v, int act) {
+    if (act == 1) {
+        const f32x2 a = gelu2(f32x2{v[0], v[1]}), b = gelu2(f32x2{v[2], v[3]});
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    } else if (act == 2) {                                       // QuickGELU x * sigmoid(1.702 x)   (open_clip "-qg" cards)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+    } else if (act == 3) {                                       // ReLU (SAM2 decoder MLPs)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    } else if (act == 4) {                                       // sigmoid (SAM2 IoU head)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + __expf(-v[r]));
+    } else if (act == 5) {                                       // GELU, tanh form (SigLIP towers): x * sigmoid(2 sqrt(2/pi) (x + 0.044715 x^3))
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float u = 1.5957691216057308f * fmaf(0.044715f * v[r] * v[r], v[r], v[r]);
+            v[r] = v[r] / (1.0f + __expf(-u));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+    const uint32_t ra = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;         // round-to-nearest-even (finite values)
+    const uint32_t rb = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
+    return ra | (rb << 16);
+}
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+    const __half2 h = __floats2half2_rn(a, b);
+    return *(const uint32_t *)&h;
+}
+
+// One 4-column group of the epilogue (shared by the kernels): v = act(alpha * acc + bias) -> rotary embedding -> + residual ->
+// running first-max argmax and/or the store of 4 consecutive columns of C row `mdst` (8 / 16 bytes).
+// The arithmetic of one 4-column group of the epilogue: v = act(alpha * acc + bias) -> rotary embedding -> + residual.
+__device__ __forceinline__ void math4(const GemmArgs &g, int m, int n, float (&v)[4], float4 bias, float4 addv) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
+    v[0] += bias.x; v[1] += bias.y; v[2] += bias.z; v[3] += bias.w;
+    if (g.act) act4(v, g.act);
+    if (g.rope_cos && n < g.rope_cols) {
+        // rotary embedding of the (2i, 2i+1) pairs this lane holds: row = token m % T, column within the head n % hd
+        const int t = m % g.rope_T;
+        if (t >= g.rope_t0) {
+            const long long at = (long long)t * g.rope_hd + n % g.rope_hd;
+            const float4 c = *(const float4 *)(g.rope_cos + at), sn = *(const float4 *)(g.rope_sin + at);
+            const float y0 = v[0] * c.x - v[1] * sn.x, y1 = v[1] * c.y + v[0] * sn.y;
+            const float y2 = v[2] * c.z - v[3] * sn.z, y3 = v[3] * c.w + v[2] * sn.w;
+            v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
+        }
+    }
+    if (g.add) { v[0] += addv.x; v[1] += addv.y; v[2] += addv.z; v[3] += addv.w; }
+}
+
+// One 4-column group of the epilogue straight from the accumulators (a lane owns 4 consecutive columns of one row): math4, then the
+// running first-max argmax and/or the 8 / 16-byte store into C row `mdst`.
+__device__ __forceinline__ void finish4(const GemmArgs &g, int m, long long mdst, int n, f32x4 a, float4 bias, float4 addv,
+                                        float &row_best, int &row_arg) {
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    math4(g, m, n, v, bias, addv);
+    if (g.best) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < g.n_valid && v[r] > row_best) { row_best = v[r]; row_arg = n + r; }   // ascending columns: ties keep the first
+        if (!g.store) return;
+    }
+    if (g.out_dtype == 0) {
+        *(float4 *)((float *)g.C + mdst * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        uint2 p;
+        if (g.out_dtype == 2) { p.x = pack_bf16(v[0], v[1]); p.y = pack_bf16(v[2], v[3]); }
+        else { p.x = pack_f16(v[0], v[1]); p.y = pack_f16(v[2], v[3]); }
+        *(uint2 *)((uint16_t *)g.C + mdst * g.ldc + n) = p;
+    }
+}
+
+// per-row close of the fused argmax: the row's columns of a wave tile sit in the 4 lanes that share lane & 15
+__device__ __forceinline__ void finish_best(const GemmArgs &g, int m, int fq, float row_best, int row_arg) {
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float ob = __shfl_xor(row_best, o, 64);
+        const int oa = __shfl_xor(row_arg, o, 64);
+        if (ob > row_best || (ob == row_best && oa < row_arg)) { row_best = ob; row_arg = oa; }
+    }
+    if (fq == 0 && row_arg != 0x7fffffff) {
+        uint32_t u = __float_as_uint(row_best);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        atomicMax(g.best + m, ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (uint32_t)row_arg));
+    }
+}
+
+// launch of the 256-row ping-pong kernels (gemm8p.hip); bn in {128, 256}; returns OVO_E_UNSUPPORTED when the shape does not fit
+int gemm8p_launch(const GemmArgs &g, int bn, int in_dtype, hipStream_t s);
+
+}  // namespace ovo_gemm_detail

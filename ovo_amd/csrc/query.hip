@@ -185,11 +185,15 @@ template <int DT>
 __global__ void __launch_bounds__(256) k_similarity_mfma(const void *__restrict__ F, int64_t n, int D, const float *__restrict__ T, int Q,
                                                          const int32_t *__restrict__ cnt, int siglip, float scale_exp, float bias,
                                                          float th, float *__restrict__ out_sim, long long *__restrict__ out_cls,
-                                                         float *__restrict__ out_conf) {
+                                                         float *__restrict__ out_conf, const int32_t *__restrict__ row_list = nullptr,
+                                                         const int32_t *__restrict__ n_list = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float sT[];                      // [min(Q, 16)][D]
     const int lane = threadIdx.x & 63, rr = lane & 15, g = lane >> 4;
     const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // ovo_similarity_rows: only the rows named in row_list[0 .. *n_list) are evaluated (count read on the device: no host sync);
+    // outputs stay indexed by the row itself, so a resident class / confidence map is patched in place
+    if (row_list) { const int64_t m = *n_list; n = m < n ? m : n; }
     const int64_t groups = (n + 15) / 16;
     const int D32 = D & ~31;
 
@@ -204,6 +208,7 @@ __global__ void __launch_bounds__(256) k_similarity_mfma(const void *__restrict_
             int64_t row = grp * 16 + rr;
             const bool live = row < n;
             if (!live) row = n - 1;
+            if (row_list) row = row_list[row];
             const int64_t base = row * D;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
@@ -364,6 +369,40 @@ extern "C" int ovo_row_argmax(float *S, int64_t n, int Q, int siglip, float logi
     int64_t grid = (n + 3) / 4;
     if (grid > 256 * 16) grid = 256 * 16;
     k_row_argmax<<<(int)grid, 256, 0, (hipStream_t)stream>>>(S, n, Q, siglip, expf(logit_scale), logit_bias, th, (long long *)out_cls, out_conf);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+// The touched-rows form of the dense query: S is evaluated only for rows[0 .. *n_rows) (a device-side count, e.g. the list
+// ovo_scatter_accum_touched emits) and out_cls / out_conf -- indexed by the row id, resident across keyframes -- are patched in place.
+// A row's arithmetic is the one ovo_similarity performs, so the patched map is bit-identical to a full re-query.
+extern "C" int ovo_similarity_rows(const void *F, int feat_dtype, const int32_t *rows, const int32_t *n_rows, int64_t max_rows, int D,
+                                   const float *T, int Q, const int32_t *cnt, int siglip, float logit_scale, float logit_bias, float th,
+                                   int64_t *out_cls, float *out_conf, ovo_stream_t stream) {
+    OVO_REQUIRE(max_rows >= 0 && D > 0 && Q > 0, "bad shape");
+    OVO_REQUIRE(feat_dtype >= 0 && feat_dtype <= 2, "feat_dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+    if (max_rows == 0) return OVO_OK;
+    OVO_REQUIRE(F && T && rows && n_rows && out_cls && out_conf, "null pointer");
+    OVO_REQUIRE(((uintptr_t)F & 15) == 0 && D % 16 == 0 && (size_t)16 * D * sizeof(float) <= 160 * 1024, "needs D % 16 == 0, D <= 2560 and 16-byte aligned rows");
+    hipStream_t s = (hipStream_t)stream;
+    const float se = expf(logit_scale);
+    const size_t lds = (size_t)(Q < 16 ? Q : 16) * D * sizeof(float);
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    int64_t grid = 256 * per_cu;
+    const int64_t groups = (max_rows + 15) / 16;
+    if (grid * 4 > groups) grid = (groups + 3) / 4;
+    if (grid < 1) grid = 1;
+#define OVO_ROWS_GO(DT)                                                                                                                      \
+    do {                                                                                                                                     \
+        if (lds > 64 * 1024) OVO_HIP(hipFuncSetAttribute((const void *)k_similarity_mfma<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        k_similarity_mfma<DT><<<(int)grid, 256, lds, s>>>(F, max_rows, D, T, Q, cnt, siglip, se, logit_bias, th, nullptr, (long long *)out_cls, \
+                                                          out_conf, rows, n_rows);                                                           \
+    } while (0)
+    if (feat_dtype == 0) OVO_ROWS_GO(0);
+    else if (feat_dtype == 1) OVO_ROWS_GO(1);
+    else OVO_ROWS_GO(2);
+#undef OVO_ROWS_GO
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

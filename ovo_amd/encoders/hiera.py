@@ -55,7 +55,7 @@ class HieraSpec:
                 ws = self.window_spec[s - 1] if first else self.window_spec[s]
                 if idx in self.global_blocks:
                     ws = 0
-                nw = 1 if ws == 0 else -(-h // ws) ** 2
+                nw = 1 if ws == 0 else (-(-h // ws)) ** 2        # windows, padding ones included
                 tk = h * h if ws == 0 else ws * ws
                 rows = nw * tk
                 tq = tk // 4 if first else tk

@@ -59,6 +59,32 @@ class KeyframeView:
         self._rows[ins_id] = self._bank.append(value.reshape(1, -1))[0]
 
 
+class _LazyMedoids(dict):
+    """slot -> clip_feature_kf.  The medoid fusions pick a view ON THE DEVICE; the index is only needed when a checkpoint is exported
+    (Instance3D.clip_feature_kf), so `fuse` parks (tensor, position) here and the device->host copy happens on the first read --
+    not once per keyframe on the frame's critical path."""
+
+    def _resolve(self, v):
+        if isinstance(v, tuple):
+            t, k = v
+            cache = getattr(t, "_ovo_host", None)
+            if cache is None:
+                cache = t.tolist()                      # one copy per fusion launch, shared by every slot it updated
+                t._ovo_host = cache
+            return int(cache[k])
+        return v
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        r = self._resolve(v)
+        if r is not v:
+            dict.__setitem__(self, key, r)
+        return r
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
 class DescriptorBank:
     def __init__(self, dim: int, device, rows: int = 4096, slots: int = 1024):
         self.dim, self.device = int(dim), device
@@ -67,7 +93,7 @@ class DescriptorBank:
         self.n_rows = 0
         self.slot_of: Dict[int, int] = {}
         self.views_of: Dict[int, int] = {}       # slot -> number of views used by the last fusion
-        self.medoid_of: Dict[int, Optional[int]] = {}
+        self.medoid_of: "_LazyMedoids" = _LazyMedoids()    # slot -> clip_feature_kf (position of the picked view), resolved on read
 
     # ---------------------------------------------------------------- storage
     def append(self, feats: torch.Tensor) -> List[int]:
@@ -131,14 +157,13 @@ class DescriptorBank:
         out_view = torch.empty(n, dtype=torch.int32, device=self.device) if m else None
         L.check(L.load().ovo_fuse_views(L.ptr(self.store), self.dim, L.ptr(csr_off), L.ptr(csr_rows), n, m,
                                         L.ptr(self.table), L.ptr(t_rows), L.ptr(out_view), L.stream()))
-        picked = out_view.tolist() if m else [None] * n
-        result = {}
+        result = _LazyMedoids()
         for k, (ins_id, r) in enumerate(updates):
             s = slots[k]
             self.views_of[s] = len(r)
-            kf = 0 if len(r) == 1 else (None if m == 0 else int(picked[k]))
-            self.medoid_of[s] = kf
-            result[ins_id] = kf
+            kf = 0 if len(r) == 1 else (None if m == 0 else (out_view, k))     # medoid position: resolved lazily (no sync here)
+            dict.__setitem__(self.medoid_of, s, kf)
+            dict.__setitem__(result, ins_id, kf)
         return result
 
     def gather(self, ins_ids: Iterable[int]) -> torch.Tensor:

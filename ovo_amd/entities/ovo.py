@@ -52,6 +52,7 @@ class OVO:
     _vit_stream = None      # side stream + pending result of prefetch_image_features()
     _prefetched = None
     _tokens_free = None     # recorded on the main stream after the pooling that last read the ViT workspace
+    _batch_slots = None     # prefetch_image_features_batch: two token buffers (double-buffered batches)
 
     def __init__(self, config: Dict[str, Any], logger=None, scene_name: Optional[str] = None,
                  cam_intrinsics: Optional[torch.Tensor] = None, eval: bool = False, device="cuda",
@@ -86,6 +87,7 @@ class OVO:
         self.bank = DescriptorBank(self.clip_generator.clip_dim, device)
         self.keyframes = {"ins_descriptors": dict(), "frame_id": list(), "ins_maps": list()}
         self.keyframes_queue = deque([])
+        self._prefetched_batch: Dict[int, tuple] = {}
         self.objects: Dict[int, Instance3D] = dict()
         self._time_cache: List[float] = []
         self.next_ins_id = 0
@@ -293,7 +295,7 @@ class OVO:
                                       print_output=True)
         self._time_cache = []
 
-    def prefetch_image_features(self, image) -> bool:
+    def prefetch_image_features(self, image, image_ready=None) -> bool:
         """MI355X extension (no counterpart in the reference): start the mask-independent half of `_extract_clip` -- the
         TextRegion crops' ViT forward (textregion.py:141-142 via :197-199) -- for `image` NOW, on a side HIP stream, so that
         it overlaps the tracking stage (whose host decisions wait on a device->host copy) and the SAM2 encoder.  The
@@ -311,6 +313,8 @@ class OVO:
             self._vit_stream.wait_event(self._tokens_free)
         else:
             self._vit_stream.wait_stream(torch.cuda.current_stream())
+        if image_ready is not None:                               # the image's upload / producer, if it runs on another stream
+            self._vit_stream.wait_event(image_ready)
         with torch.cuda.stream(self._vit_stream):
             img = image.permute(2, 0, 1).contiguous()
             feats = tr.get_img_features(img, scale=1.0 / 255.0)
@@ -319,9 +323,67 @@ class OVO:
         self._prefetched = (image, img, feats, done)
         return True
 
+    def prefetch_image_features_batch(self, images, ready=(), stream=None) -> bool:
+        """`prefetch_image_features` for SEVERAL keyframes' images in ONE ViT forward (MI355X extension).  The reference defers a
+        keyframe's descriptors by `kf_queue_delay` keyframes (ovo.yaml:53, ovo.py:326-332), so nothing needs the tokens of one image
+        before the next images exist; encoding B images' TextRegion crops together makes the encoder GEMMs B times taller (M = B x 2 x 577
+        for PE-L/14-336 on 640x480), which is what fills 256 CUs.  Every `_extract_clip(image, ...)` of one of
+        these image objects then only pools its slice.  Token buffers are double-buffered per batch: the forward of batch k+2 waits for the
+        last pooling of batch k, batch k+1 is encoded while batch k is consumed."""
+        tr = getattr(self.clip_generator, "textregion", None)
+        images = list(images)
+        if tr is None or not images or not all(isinstance(i, torch.Tensor) and i.is_cuda for i in images):
+            return False
+        dev = images[0].device
+        if self._vit_stream is None:
+            self._vit_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("OVO_VIT_PRIORITY", "0")))
+        if self._batch_slots is None:
+            self._batch_slots = [dict(batch=None, tokens=None, free=None, left=0) for _ in range(2)]
+            self._batch_next = 0
+        slot = self._batch_slots[self._batch_next]
+        self._batch_next ^= 1
+        if slot["left"] > 0:
+            raise L.OvoHipError("prefetch_image_features_batch: the batch before the previous one still has unconsumed images")
+        _, h, w = images[0].permute(2, 0, 1).shape
+        crops = tr._crops(h, w)
+        nc, spec = len(crops), tr.vlm.spec
+        n = len(images) * nc
+        if slot["batch"] is None or slot["batch"].shape[0] < n:
+            slot["batch"] = torch.empty((n, 3, spec.image_size, spec.image_size), dtype=torch.float32, device=dev)
+            slot["tokens"] = torch.empty((n, spec.tokens, spec.width), dtype=torch.float32, device=dev)
+        side = stream if stream is not None else self._vit_stream   # `stream`: measurement runs that fold the streams
+        if slot["free"] is not None:
+            side.wait_event(slot["free"])                         # the last pooling that read this slot's tokens
+        for ev in ready:                                          # the images' uploads, when they are still in flight (resident images:
+            side.wait_event(ev)                                   # nothing to wait for -- and no wait on the caller's stream, whose queue
+        with torch.cuda.stream(side):                             # holds the previous keyframes' tails this forward should overlap)
+            for k, image in enumerate(images):
+                tr.vlm.preprocess(image.permute(2, 0, 1).contiguous(), crops, scale=1.0 / 255.0, out=slot["batch"][k * nc:(k + 1) * nc])
+            tr.vlm.forward(slot["batch"][:n], tokens=True, out=slot["tokens"][:n])
+            done = torch.cuda.Event()
+            done.record(side)
+        slot["left"] = len(images)
+        for k, image in enumerate(images):
+            self._prefetched_batch[id(image)] = (image, slot["tokens"][k * nc:(k + 1) * nc], done, slot)
+        return True
+
     @_timed("t_clip")
     def _extract_clip(self, image: np.ndarray, binary_maps: torch.Tensor) -> torch.Tensor:
         """Reference: ovo.py:427-437 -- but the descriptors stay on the GPU."""
+        hit = self._prefetched_batch.pop(id(image), None)
+        if hit is not None and hit[0] is image:                  # tokens from a batched look-ahead forward
+            _, feats, done, slot = hit
+            torch.cuda.current_stream().wait_event(done)
+            tr = self.clip_generator.textregion
+            _, h, w = image.permute(2, 0, 1).shape
+            tr._crops(h, w)                                      # the tiling state of THIS image
+            out = tr.pe_value_with_sam2_attn(tr.get_features_mask(binary_maps), feats) if binary_maps.shape[0] > 0 else \
+                torch.empty((0, tr.out_dim), dtype=torch.float32, device=feats.device)
+            slot["left"] -= 1
+            if slot["left"] == 0:                                # last reader of this slot's tokens
+                slot["free"] = torch.cuda.Event()
+                slot["free"].record()
+            return out
         pre, self._prefetched = self._prefetched, None
         if pre is not None:
             torch.cuda.current_stream().wait_event(pre[3])       # also on the ordinary path: it reuses the same workspace
@@ -331,12 +393,17 @@ class OVO:
                 self._tokens_free = torch.cuda.Event()
                 self._tokens_free.record()
                 return out
-            self._tokens_free = None
         if isinstance(image, torch.Tensor):                      # already resident: HWC u8 -> CHW
             img = image.to(self.bank.device).permute(2, 0, 1).contiguous()
         else:
             img = torch.from_numpy(np.ascontiguousarray(image.transpose((2, 0, 1)))).to(self.bank.device, non_blocking=True)
-        return self.clip_generator.extract_clip(img, binary_maps, self.config.get("return_all_clips", False))
+        out = self.clip_generator.extract_clip(img, binary_maps, self.config.get("return_all_clips", False))
+        if self._vit_stream is not None:
+            # the ordinary path ran the encoder on THIS stream in the shared workspace: a later prefetch must wait for it, not for a
+            # stale event of an earlier keyframe (and it may read `image` only after its producers on this stream)
+            self._tokens_free = torch.cuda.Event()
+            self._tokens_free.record()
+        return out
 
     @_timed("t_up")
     def _update_matched_objects_clip(self, clip_embeds: torch.Tensor, matched_ins_ids: List[int], kf_id: int) -> None:
@@ -360,8 +427,10 @@ class OVO:
         for obj in self.objects.values():
             obj.update_clip(self.keyframes["ins_descriptors"], force_update=force_update)
 
-    def update_map(self, map_data, kfs):
+    def update_map(self, map_data, kfs, same_instance=None):
         """Loop-closure semantic update.  Reference: ovo.py:366-424 with instance_utils.py:5-35.
+        `same_instance(id1, id2) -> bool` (optional, not in the reference's signature) replaces the geometric pair predicate of
+        instance_utils.py:5-24 -- the seam the golden fixture `loopclose.npz` (case "table") pins the control flow through.
 
         Same steps and the same greedy merge order; what changed underneath: one pass over the map gives every instance's
         point count and centroid (`ovo_instance_moments`, replacing `unique()` + a boolean slice per instance); the
@@ -394,22 +463,34 @@ class OVO:
         N = len(ids)
         # 2. pair predicate for all i < j (static during the merge loop)
         same = np.zeros((N, N), bool)
-        if N > 1:
-            cen = (sums_h[ids] / cnt_h[ids, None]).astype(np.float32)
+        if N > 1 and same_instance is not None:
+            for i in range(N):
+                for j in range(i + 1, N):
+                    same[i, j] = bool(same_instance(ids[i], ids[j]))
+        elif N > 1:
+            self._adopt_loose_features()                               # checkpoint-restored descriptors move into the table first
+            has = np.asarray([self.bank.has_feature(i) for i in ids])  # the reference reads clip_feature only for pairs that pass the
+            cen = (sums_h[ids] / cnt_h[ids, None]).astype(np.float32)  # centroid test; an instance without one can never merge here
             dist = np.sqrt(((cen[:, None, :] - cen[None, :, :]) ** 2).sum(-1, dtype=np.float32))
-            feats = self.bank.gather(ids)                              # [N, D], rows = clip_feature[0]
-            unit = torch.empty_like(feats)
-            L.check(lib.ovo_l2_normalize_rows(L.ptr(feats), N, feats.shape[1], L.ptr(unit), L.stream()))
-            from ..utils import clip_utils
-            cos = clip_utils.similarity(unit, unit)[0].cpu().numpy()
-            iu, ju = np.nonzero(np.triu(np.ones((N, N), bool), 1) & ~(dist > np.float32(self.th_centroid)) & ~(cos < np.float32(self.th_cossim)))
+            with_f = [i for i, h in zip(ids, has) if h]
+            cos = np.zeros((N, N), np.float32)
+            if len(with_f) > 1:
+                feats = self.bank.gather(with_f)                       # rows = clip_feature[0]
+                unit = torch.empty_like(feats)
+                L.check(lib.ovo_l2_normalize_rows(L.ptr(feats), len(with_f), feats.shape[1], L.ptr(unit), L.stream()))
+                from ..utils import clip_utils
+                sel = np.nonzero(has)[0]
+                cos[np.ix_(sel, sel)] = clip_utils.similarity(unit, unit)[0].cpu().numpy()
+            both = has[:, None] & has[None, :]
+            iu, ju = np.nonzero(np.triu(np.ones((N, N), bool), 1) & both & ~(dist > np.float32(self.th_centroid)) & ~(cos < np.float32(self.th_cossim)))
             if len(iu):
-                # group the map by instance: CSR over instance ids (points with id -1 sort first and are skipped)
+                # group the map by instance: CSR over instance ids.  A stable sort puts the unassigned points (id -1) first -- their
+                # number is the offset of instance 0 -- and ids beyond the table last, where no row of the CSR reaches them
                 order = torch.argsort(ins, stable=True)
                 grouped = pts.index_select(0, order).contiguous()
                 off = np.zeros(n_slots + 1, np.int64)
                 off[1:] = np.cumsum(cnt_h)
-                off += int(n - cnt_h.sum())                            # skip unassigned (-1) and out-of-table ids
+                off += int((ins < 0).sum().item())
                 d_off = torch.from_numpy(off).to(dev)
                 slots = np.asarray(ids, np.int32)
                 pairs = torch.from_numpy(np.stack([slots[iu], slots[ju]], 1).astype(np.int32)).to(dev)
@@ -444,9 +525,7 @@ class OVO:
             for b_id, a_id in fused.items():
                 table[b_id] = a_id
             d_table = torch.from_numpy(table).to(dev)
-            L.check(lib.ovo_remap_instances(L.ptr(ins), n, L.ptr(d_table), n_slots, L.stream()))
-            if ins.data_ptr() != points_ins_ids.data_ptr():            # the caller's tensor was converted: hand the result back
-                points_ins_ids = ins.reshape(points_ins_ids.shape).to(points_ins_ids.dtype)
+            L.check(lib.ovo_remap_instances(L.ptr(ins), n, L.ptr(d_table), n_slots, L.stream()))      # `ins` views the caller's tensor: in place
         # 3. descriptors of merged instances move to the surviving id
         for id2, id1 in fused.items():
             for kf in self.objects[id2].kfs_ids:
@@ -462,6 +541,11 @@ class OVO:
     @torch.no_grad()
     def get_objs_clips(self) -> torch.Tensor:
         """f32[N_instances, D] on the GPU, rows in `self.objects` order."""
+        self._adopt_loose_features()
+        return self.bank.gather(self.objects.keys())
+
+    def _adopt_loose_features(self) -> None:
+        """Descriptors that live outside the resident table (restored from a checkpoint, or never fused) move into it."""
         loose = [o for o in self.objects.values() if o._own_feature is not None or not self.bank.has_feature(o.id)]
         for obj in loose:
             if obj._own_feature is not None:                   # restored from a checkpoint: adopt into the table
@@ -472,7 +556,6 @@ class OVO:
             else:                                              # "this should never happen" (ovo.py:523)
                 obj._bank, obj.to_update = self.bank, True
                 obj.update_clip(self.keyframes["ins_descriptors"])
-        return self.bank.gather(self.objects.keys())
 
     @torch.no_grad()
     def query(self, queries: List[str], templates=['{}'], ensemble: bool = False) -> torch.Tensor:

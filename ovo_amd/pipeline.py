@@ -76,7 +76,8 @@ def synthetic_frames(n: int, device, scale: float = 1.0, n_masks_grid=(4, 6), n_
 class FramePipeline:
     def __init__(self, device="cuda", vit_card: str = "PE-Core-L14-336", sam_card: Optional[str] = "hiera_b+",
                  n_map: int = 1_000_000, n_text: int = 10, dense: bool = True, scale: float = 1.0, extra_capacity: int = 4_000_000,
-                 seed: int = 0, depth_filter: bool = True, track_th: int = 100, sam_full: bool = False, points_per_side: int = 16):
+                 seed: int = 0, depth_filter: bool = True, track_th: int = 100, sam_full: bool = False, points_per_side: int = 16,
+                 encoder_batch: int = 1):
         self.device = torch.device(device)
         self.scale = scale
         self.crop_edge = int(round(syn.SCANNET["crop_edge"] * scale))
@@ -101,6 +102,14 @@ class FramePipeline:
             from .encoders.sam_decoder import SPECS as DEC_SPECS, HipSamDecoder
             from .entities.sam_amg import HipSam2AutomaticMaskGenerator
             self.amg = HipSam2AutomaticMaskGenerator(self.sam, HipSamDecoder(DEC_SPECS["sam2"], None, self.device, seed), points_per_side=points_per_side)
+        # encoder look-ahead: the two encoders of `encoder_batch` consecutive keyframes run as ONE batched forward each (step() is
+        # handed the upcoming frames).  Nothing of the encoders depends on the map, and the reference itself computes a keyframe's
+        # descriptors kf_queue_delay = 10 keyframes late (ovo.yaml:53), so this changes no result -- only the GEMM height.
+        self.encoder_batch = max(1, int(encoder_batch)) if not sam_full else 1
+        self._encoded: Dict[int, bool] = {}
+        self.serial = False                                        # measurement only: both encoders on the caller's stream
+        self._group_first: Dict[int, int] = {}
+        self._sam_in = None
         self.prefetch = not os.environ.get("OVO_NO_PREFETCH")
         self.join_each_step = bool(os.environ.get("OVO_JOIN_EACH_STEP"))
         self.sam_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("OVO_SAM_PRIORITY", "0"))) if (sam_card and not os.environ.get("OVO_SAM_SAME_STREAM")) else None
@@ -139,10 +148,44 @@ class FramePipeline:
         self.inst_delta_cnt.index_add_(0, idx, valid.float())
 
     # ------------------------------------------------------------------ one keyframe
-    def step(self, f: Frame) -> Dict[str, object]:
+    def _launch_encoders(self, group: List[Frame]) -> None:
+        """SAM2 image encoder and ViT forward of a group of keyframes, each as one batched forward on its side stream."""
+        if self.sam is not None:
+            side = torch.cuda.current_stream() if self.serial else (self.sam_stream or torch.cuda.current_stream())
+            for g in group:
+                if g.ready is not None:                            # the frame's upload, if it is still in flight
+                    side.wait_event(g.ready)
+            with torch.cuda.stream(side):
+                s = self.sam.spec.image_size
+                if self._sam_in is None or self._sam_in.shape[0] < len(group):
+                    self._sam_in = torch.empty((len(group), 3, s, s), dtype=torch.float32, device=self.device)
+                for k, g in enumerate(group):
+                    self.sam.preprocess(g.rgb.permute(2, 0, 1).contiguous(), out=self._sam_in[k:k + 1])
+                self.sam_out = self.sam.forward(self._sam_in[:len(group)])
+        if self.prefetch:
+            self.ovo.prefetch_image_features_batch([g.rgb for g in group], [g.ready for g in group if g.ready is not None],
+                                                   stream=torch.cuda.current_stream() if self.serial else None)
+        for g in group:
+            self._encoded[g.index] = True
+        self._group_first[group[0].index] = len(group)
+
+    def step(self, f: Frame, upcoming: Optional[List[Frame]] = None) -> Dict[str, object]:
+        """One keyframe.  `upcoming`: the frames that follow (only read when encoder_batch > 1: the next encoder_batch - 1 of them
+        are encoded together with `f` when `f` has not been encoded yet)."""
         lib = L.load()
         self.masks.frames = {f.index: f}
         amg_pending = None
+        if self.encoder_batch > 1:
+            upcoming = list(upcoming or [])
+            if f.index not in self._encoded:
+                self._launch_encoders([f] + upcoming[:self.encoder_batch - 1])
+            n_group = self._group_first.pop(f.index, 0)
+            if n_group:                                            # first frame of its group: the NEXT group's encoders start now, so
+                nxt = [g for g in upcoming[n_group - 1:n_group - 1 + self.encoder_batch] if g.index not in self._encoded]   # that they
+                if nxt:                                            # run beside this group's tracking / pooling / fusion / queries
+                    self._launch_encoders(nxt)
+            self._encoded.pop(f.index, None)
+            return self._step_main(f, lib, amg_pending)
         # The two encoders first: nothing of theirs depends on the map, and the map update below ends in a host sync (the
         # count of new points) behind which the host could not launch them.
         if self.sam is not None:                                   # SAM2 image encoder (masks come from the seam)
@@ -157,7 +200,10 @@ class FramePipeline:
                 else:
                     self.sam_out = self.sam.forward(self.sam.preprocess(f.rgb.permute(2, 0, 1).contiguous()))
         if self.prefetch:                                          # ViT tokens do not depend on the masks: start them now
-            self.ovo.prefetch_image_features(f.rgb)
+            self.ovo.prefetch_image_features(f.rgb, f.ready)
+        return self._step_main(f, lib, amg_pending)
+
+    def _step_main(self, f: Frame, lib, amg_pending) -> Dict[str, object]:
         fd = [f.index, f.rgb_lr, f.depth, f.c2w]
         self.slam.track_camera(fd)
         c2w = self.slam._c2w_host[f.index]                         # host copy: no D2H for the frustum set-up
@@ -195,7 +241,7 @@ class FramePipeline:
     def join(self) -> None:
         """Make the main stream wait for the SAM2 and ViT streams (everything of the frames stepped so far)."""
         for side in (self.sam_stream, self.ovo._vit_stream):
-            if side is not None:
+            if side is not None and side != torch.cuda.current_stream():
                 torch.cuda.current_stream().wait_stream(side)
 
     def merge_dense(self) -> int:

@@ -68,6 +68,36 @@ def test_gemm_epilogues_and_padding():
     assert torch.equal(ob, _gemm(a, w, bias).to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("tile", ["256x256", "256x128"])
+@pytest.mark.parametrize("m,n,k,dtype", [(4616, 3072, 1024, torch.bfloat16), (1154, 1024, 448, torch.bfloat16), (300, 260, 64, torch.bfloat16),
+                                         (2308, 1344, 192, torch.float16), (700, 132, 1792, torch.bfloat16), (257, 516, 128, torch.bfloat16)])
+def test_gemm_pingpong_kernel_vs_ring_kernel_and_torch(monkeypatch, tile, m, n, k, dtype):
+    """The 256-row ping-pong kernel (gemm8p.hip, forced through OVO_GEMM_TILE) against the fp32 product of the same rounded operands
+    and against the 128-row ring kernel: every output element is accumulated over k in the same order (32-wide MFMA steps in
+    ascending k), so the two kernels agree BIT FOR BIT -- ragged M / N edges, one to 28 K-tiles, residual and bf16 stores included."""
+    g = torch.Generator(device="cpu").manual_seed(m + 3 * n + 7 * k)
+    a = torch.randn(m, k + 64, generator=g).to(DEV, dtype)[:, :k]             # lda > K
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(DEV, dtype)
+    bias, add = torch.randn(n, generator=g).to(DEV), torch.randn(m, n, generator=g).to(DEV)
+    monkeypatch.delenv("OVO_GEMM_TILE", raising=False)
+    ring = _gemm(a, w, bias, add=add, act=1)
+    ring_b = _gemm(a, w, bias, out_dtype=torch.bfloat16)
+    monkeypatch.setenv("OVO_GEMM_TILE", tile)
+    out = _gemm(a, w, bias, add=add, act=1)
+    out_b = _gemm(a, w, bias, out_dtype=torch.bfloat16)
+    ref = torch.nn.functional.gelu(a.float() @ w.float().T + bias) + add
+    torch.testing.assert_close(out, ref, atol=3e-4, rtol=3e-4)
+    assert torch.equal(out, ring) and torch.equal(out_b, ring_b)
+    x = add.clone()                                                          # in-place residual: C aliases add
+    from ovo_amd import _lib as L
+    gg = L.Gemm()
+    gg.A, gg.lda, gg.W, gg.ldw, gg.bias = a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr()
+    gg.C, gg.ldc, gg.add, gg.ld_add = x.data_ptr(), n, x.data_ptr(), n
+    gg.M, gg.N, gg.K, gg.in_dtype, gg.out_dtype, gg.act, gg.alpha = m, n, k, L.DTYPE_CODE[dtype], 0, 0, 1.0
+    L.check(L.load().ovo_gemm(C.byref(gg), L.stream()))
+    torch.testing.assert_close(x, add + a.float() @ w.float().T + bias, atol=3e-4, rtol=3e-4)
+
+
 @pytest.mark.parametrize("B,H,W,wh,ww,n,k", [(2, 64, 64, 14, 14, 448, 448), (1, 20, 12, 8, 8, 96, 64), (3, 16, 16, 16, 16, 64, 128), (2, 9, 13, 4, 7, 32, 32)])
 def test_gemm_unwindow_epilogue_vs_torch(B, H, W, wh, ww, n, k):
     """ovo_gemm_unwindow: rows of the product in window order (padding rows included) land on their spatial rows with the
@@ -389,3 +419,59 @@ def test_textregion_remove_global_patch_vs_oracle(th):
     plain._crops(H, W)                                   # sets the tiling state predict() would have set
     ref = plain.pe_value_with_sam2_attn((w1, c1), feats)
     assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(ref))
+
+
+def test_vit_flops_accounting_matches_the_launched_work():
+    """`ViTSpec.flops_per_image()` against the GEMM + attention work the forward really launches (see the Hiera twin)."""
+    from ovo_amd import _lib as L
+    from ovo_amd.encoders.vit import SPECS, HipViT
+    spec = SPECS["ViT-B-16-qg"]
+    enc = HipViT(spec, None, DEV, seed=1)
+    x = torch.zeros(2, 3, spec.image_size, spec.image_size, device=DEV)
+    enc.forward(x, tokens=True)
+    lib = L.load()
+    L.check(lib.ovo_profile_start())
+    enc.forward(x, tokens=True)
+    ms, work, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
+    L.check(lib.ovo_profile_stop(ms, work, n, 8))
+    launched = work[1] + sum(work[k] for k in (3, 4, 5, 6, 7))
+    model = 2 * spec.flops_per_image()
+    assert abs(launched - model) / model < 0.03, (launched, model)
+
+
+@pytest.mark.parametrize("tag,hw", [("c", (100, 150)), ("d", (170, 260))])
+def test_textregion_remove_global_patch_vs_reference_golden(tag, hw):
+    """a18 against the reference itself: tests/golden/textregion.npz cases c / d were produced by the reference's PETextRegion with
+    remove_global_patch=True (textregion.py:31-50, threshold 0.07) on a fake PE tower.  The product path (folded two-GEMM score on
+    bf16 unit tokens) must clear exactly the same token columns and pool the same descriptors."""
+    import types
+    from ovo_amd.entities.textregion import PETextRegion
+    d = golden("textregion")
+    D, patch, crop = d["proj"].shape[0], int(d["patch"]), int(d["crop"])
+
+    class FakeTower:                                       # what PETextRegion reads of a HipViT
+        spec = types.SimpleNamespace(patch=patch, image_size=crop, width=D, cls_token=True)
+        device = torch.device(DEV)
+        proj = torch.from_numpy(d["proj"]).to(DEV)
+        pool_weights = {"attn.in_proj_weight": torch.from_numpy(d["in_proj_weight"]), "attn.in_proj_bias": torch.from_numpy(d["in_proj_bias"]),
+                        "attn.out_proj.weight": torch.from_numpy(d["out_proj_weight"]), "attn.out_proj.bias": torch.from_numpy(d["out_proj_bias"])}
+    tr = PETextRegion(FakeTower(), "PE-fake-%03d" % crop, remove_global_patch=True, global_patch_threshold=float(d[f"{tag}_th"]))
+    tr._crops(*hw)
+    gh, gw, nh, nw = d[f"{tag}_grid"].tolist()
+    assert (tr.points_per_h, tr.points_per_w, tr.crop_num_h, tr.crop_num_w) == (gh, gw, nh, nw)
+    masks = torch.from_numpy(unpack(d[f"{tag}_masks"], int(d[f"{tag}_mask_w"]))).to(DEV)
+    w0, c0 = tr.get_features_mask(masks)
+    G = gh * gw
+    assert np.array_equal(w0[:, :G].float().cpu().numpy(), (d[f"{tag}_feature_masks"] > 0).astype(np.float32))
+    tokens = torch.from_numpy(d[f"{tag}_tokens"]).to(DEV)
+    # the filter alone: same columns cleared as the reference's kept masks
+    from ovo_amd import _lib as L
+    gpad = w0.shape[1]
+    x_t = torch.empty((D, gpad), dtype=torch.bfloat16, device=DEV)
+    L.check(L.load().ovo_stitch_tokens_t(L.ptr(tokens), tokens.shape[1], 1, D, crop // patch, nh, nw, L.ptr(x_t), gpad, L.stream()))
+    w1, c1 = tr._remove_global_patch(x_t, w0, c0, G)
+    assert np.array_equal(w1[:, :G].float().cpu().numpy(), (d[f"{tag}_kept_masks"] > 0).astype(np.float32))
+    out = tr.pe_value_with_sam2_attn((w0, c0), tokens).cpu().numpy()
+    err = np.abs(out - d[f"{tag}_out"]).max()
+    print(f"textregion {tag} (remove_global_patch): max |unit descriptor error| vs the reference = {err:.2e}")
+    assert err < 3e-3

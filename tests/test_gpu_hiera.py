@@ -62,3 +62,25 @@ def test_hiera_preprocess_matches_torch():
     got = HipHiera.preprocess(enc, img.to(DEV))[0].cpu()
     ref = OV.resize_normalize(img, 1024, IMAGENET_MEAN, IMAGENET_STD, None, scale=1 / 255.0, antialias=True)
     torch.testing.assert_close(got, ref, atol=3e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("card", ["hiera_b+", "hiera_t"])
+def test_flops_accounting_matches_the_launched_work(card):
+    """`HieraSpec.flops_per_image()` (bench.py's gflop_per_frame / frame_frac) against the sum of 2MNK / 4BHTqTk.hd over the GEMM and
+    attention launches of one real forward (the library's hipEvent profiler records the shape of every launch)."""
+    import ctypes as C
+    from ovo_amd import _lib as L
+    from ovo_amd.encoders.hiera import SPECS, HipHiera
+    spec = SPECS[card]
+    enc = HipHiera(spec, None, device=DEV, seed=1)
+    x = torch.zeros(1, 3, spec.image_size, spec.image_size, device=DEV)
+    enc.forward(x)
+    lib = L.load()
+    L.check(lib.ovo_profile_start())
+    enc.forward(x)
+    ms, work, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
+    L.check(lib.ovo_profile_stop(ms, work, n, 8))
+    launched = work[1] + sum(work[k] for k in (3, 4, 5, 6, 7))
+    model = spec.flops_per_image()
+    print(f"{card}: launched {launched / 1e9:.1f} GFLOP, flops_per_image {model / 1e9:.1f} GFLOP")
+    assert abs(launched - model) / model < 0.03

@@ -94,3 +94,48 @@ def test_update_map_deleted_keyframes_and_noop():
     out = ovo.update_map((pts, None, ins), kfs=[0, 20])
     assert ovo.keyframes["frame_id"] == [0, "Deleted", 20] and 10 not in ovo.keyframes["ins_descriptors"]
     assert list(ovo.objects) == [0] and torch.equal(out, ins)
+
+
+@pytest.mark.parametrize("tag", ["kd", "table"])
+def test_update_map_vs_reference_golden(tag):
+    """OVO.update_map against what the reference's own update_map / fuse_instances produced on the same scene
+    (tests/golden/loopclose.npz, tools/gen_golden.py:gen_loopclose): relabelled map, surviving instances in order, their keyframe
+    lists, top-k heaps and re-fused descriptors, the re-keyed per-keyframe descriptor tables, the frame-id list.  `kd`: the geometric
+    predicate runs on the GPU (ovo_near_fraction vs the reference's same_instance over an exact nearest-neighbour stand-in for Open3D);
+    `table`: the predicate is a lookup table on both sides (control flow only), with two keyframes deleted."""
+    from conftest import golden
+    from ovo_amd.entities.descriptor_bank import KeyframeView
+    from ovo_amd.entities.instance3d import Instance3D
+    from ovo_amd.entities.ovo import OVO
+    d = golden("loopclose")
+    feats = d["feats"]
+    cfg = {"match_distance_th": 0.05, "track_th": 40, "clip": {"k_top_views": int(d["n_top_kf"]), "fusion": "avg_pooling"}, "sam": {"precomputed": True}}
+    ovo = OVO(cfg, None, "scene", torch.eye(3).to(DEV), device=DEV, clip_generator=_NoClip(), mask_generator=object())
+    ovo.th_centroid, ovo.th_cossim, ovo.th_points = (float(v) for v in d["th"])
+    ovo.keyframes["frame_id"] = d["frame_ids"].tolist()
+    for kf in range(16):
+        i = kf % 8
+        row = ovo.bank.append(torch.from_numpy(feats[i] * (1.0 if kf < 8 else 0.5))[None].to(DEV))[0]
+        ovo.keyframes["ins_descriptors"][kf] = KeyframeView(ovo.bank, {i: row})
+    for i in range(8):
+        o = Instance3D(i, kf_id=i, points_ids=[], mask_area=100 + i, bank=ovo.bank)
+        o.update([], i + 8, 50 + i)
+        ovo.objects[i] = o
+    ovo.update_objects_clip(force_update=True)
+    before = np.stack([ovo.objects[i].clip_feature.cpu().numpy().reshape(-1) for i in range(8)])
+    np.testing.assert_allclose(before, d[f"{tag}_before"], atol=1e-6)
+    pairs = {tuple(p) for p in d["table_pairs"].tolist()}
+    same = (lambda a, b: (a, b) in pairs) if tag == "table" else None
+    ins = torch.from_numpy(d["ins"].copy()).to(DEV)
+    out = ovo.update_map((torch.from_numpy(d["xyz"]).to(DEV), None, ins), kfs=d[f"{tag}_kfs"].tolist(), same_instance=same)
+    assert np.array_equal(out.cpu().numpy(), d[f"{tag}_out_ins"])
+    kept = d[f"{tag}_kept"].tolist()
+    assert list(ovo.objects) == kept
+    assert [str(f) for f in ovo.keyframes["frame_id"]] == d[f"{tag}_frame_id"].tolist()
+    keys = sorted((kf, i) for kf, view in ovo.keyframes["ins_descriptors"].items() for i in view)
+    assert keys == [tuple(r) for r in d[f"{tag}_desc_keys"].tolist()]
+    for i in kept:
+        o = ovo.objects[i]
+        assert o.kfs_ids == d[f"{tag}_obj{i}_kfs"].tolist()
+        assert sorted(o.top_kf) == [tuple(r) for r in d[f"{tag}_obj{i}_topkf"].tolist()]
+        np.testing.assert_allclose(o.clip_feature.cpu().numpy().reshape(-1), d[f"{tag}_obj{i}_clip"], atol=1e-6)

@@ -109,6 +109,44 @@ def test_textregion_pooling(tag):
     np.testing.assert_allclose(out, d[f"{tag}_out"], atol=2e-6, rtol=0)   # masked-mean identity
 
 
+@pytest.mark.parametrize("tag", ["c", "d"])
+def test_textregion_remove_global_patch(tag):
+    """textregion.py:31-50 run by the reference itself (remove_global_patch=True, threshold 0.07): the filtered feature masks and the
+    descriptors pooled from them pin the oracle's restatement (row a18)."""
+    d = golden("textregion")
+    gh, gw, nh, nw = d[f"{tag}_grid"].tolist()
+    P = int(d["crop"]) // int(d["patch"])
+    masks = unpack(d[f"{tag}_masks"], int(d[f"{tag}_mask_w"]))
+    fm = OF.feature_masks(masks, gh, gw)
+    np.testing.assert_allclose(fm, d[f"{tag}_feature_masks"], atol=1e-6, rtol=0)
+    x = OF.stitch_tokens(d[f"{tag}_tokens"][:, 1:], P, gh, gw, nh, nw)
+    np.testing.assert_allclose(x, d[f"{tag}_x_input"][0], atol=1e-6, rtol=0)
+    kept, diff = OF.remove_global_patch(x, fm, float(d[f"{tag}_th"]))
+    assert np.array_equal(kept, d[f"{tag}_kept_masks"])
+    assert ((kept > 0).any(0) != (fm > 0).any(0)).sum() > 0                    # the filter really removed columns
+    D = x.shape[1]
+    w, b = d["in_proj_weight"], d["in_proj_bias"]
+    out = OF.region_pool(x, kept, w[2 * D:], b[2 * D:], d["out_proj_weight"], d["out_proj_bias"], d["proj"])
+    np.testing.assert_allclose(out, d[f"{tag}_out"], atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("tag", ["kd", "table"])
+def test_loop_closure_merge(tag):
+    """ovo.py:381-407 + instance_utils.py:5-35 run by the reference (tools/gen_golden.py: gen_loopclose): surviving instances in
+    order, the merge map and the relabelled per-point ids.  `kd`: the reference's own same_instance with an exact nearest-neighbour
+    stand-in for Open3D; `table`: same_instance replaced by a lookup table (control flow only)."""
+    d = golden("loopclose")
+    ids = list(range(8))
+    feats = {i: d[f"{tag}_before"][i] for i in ids}
+    th = d["th"].tolist()
+    pairs = {tuple(p) for p in d["table_pairs"].tolist()}
+    same = (lambda a, b: (a, b) in pairs) if tag == "table" else None
+    kept, fused, out = OS.merge_instances(d["xyz"], d["ins"], ids, feats, th[0], th[1], th[2], same=same)
+    assert kept == d[f"{tag}_kept"].tolist()
+    assert np.array_equal(out, d[f"{tag}_out_ins"])
+    assert sorted(set(ids) - set(kept) - {7}) == sorted(fused)                  # 7 lost its points, the others were merged
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_mask_nms_and_segmap(tag):
     d = golden(f"segment_{tag}")

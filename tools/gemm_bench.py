@@ -7,7 +7,7 @@ dev = torch.device("cuda", 0)
 lib = L.load()
 ROT = int(os.environ.get('ROTATE', '1'))   # > 1: cycle through that many weight buffers (cold weights, like a layer stack)
 PAD = int(os.environ.get('PAD', '0'))      # extra elements per row of A and W (row stride K + PAD): breaks power-of-two strides
-def run(m, n, k, iters=30):
+def run(m, n, k, iters=int(os.environ.get('ITERS', '100'))):
     a = torch.randn(m, k + PAD, device=dev).to(torch.bfloat16); ws = [(torch.randn(n, k + PAD, device=dev) * k ** -0.5).to(torch.bfloat16) for _ in range(ROT)]; w = ws[0]
     odt = {'bf16': (torch.bfloat16, 2), 'f32': (torch.float32, 0)}[os.environ.get('OUT', 'bf16')]
     out = torch.empty(m, n, dtype=odt[0], device=dev)
@@ -17,7 +17,7 @@ def run(m, n, k, iters=30):
         bias = torch.randn(n, device=dev); g.bias = bias.data_ptr()
     if os.environ.get('ADD'):
         add = out if os.environ.get('INPLACE') else torch.randn(m, n, device=dev); g.add, g.ld_add = add.data_ptr(), n
-    for _ in range(3): L.check(lib.ovo_gemm(C.byref(g), L.stream()))
+    for _ in range(10): L.check(lib.ovo_gemm(C.byref(g), L.stream()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     for i in range(iters):
@@ -30,12 +30,19 @@ shapes = [(1154, 3072, 1024), (1154, 1024, 1024), (1154, 4096, 1024), (1154, 102
           (65536, 336, 128), (65536, 448, 128), (65536, 112, 448), (16384, 672, 224), (4096, 1344, 448), (4096, 1792, 448), (4096, 448, 1792)]
 if os.environ.get('SHAPES'): shapes = [tuple(int(v) for v in t.split(',')) for t in os.environ['SHAPES'].split(';')]
 tiles = os.environ.get("TILES", "auto,128x128,64x128,128x64,64x64").split(",")
+ROUNDS = int(os.environ.get("ROUNDS", "3"))     # interleaved rounds per shape; the MEDIAN is reported (clock / power state drifts between runs)
 print("%-22s" % "M,N,K" + "".join("%22s" % t for t in tiles))
 for s in shapes:
+    res = {t: [] for t in tiles}
+    for _ in range(ROUNDS):
+        for t in tiles:
+            os.environ.pop("OVO_GEMM_NO_8P", None)
+            if t == "auto": os.environ.pop("OVO_GEMM_TILE", None)
+            elif t == "ring": os.environ.pop("OVO_GEMM_TILE", None); os.environ["OVO_GEMM_NO_8P"] = "1"     # the 128-row ring kernels' own choice
+            else: os.environ["OVO_GEMM_TILE"] = t
+            res[t].append(run(*s)[0])
     row = "%-22s" % str(s)
     for t in tiles:
-        if t == "auto": os.environ.pop("OVO_GEMM_TILE", None)
-        else: os.environ["OVO_GEMM_TILE"] = t
-        us, tf = run(*s)
-        row += "%12.1fus %6.0fTF" % (us, tf)
+        us = sorted(res[t])[len(res[t]) // 2]
+        row += "%12.1fus %6.0fTF" % (us, 2.0 * s[0] * s[1] * s[2] / us / 1e6)
     print(row)

@@ -271,6 +271,51 @@ def gen_textregion(out, TR):
                        f"{tag}_mask_w": np.int64(W), f"{tag}_feature_masks": fm, f"{tag}_x_input": xin,
                        f"{tag}_out": outv, f"{tag}_grid": np.asarray([tr.points_per_h, tr.points_per_w, nh, nw]),
                        f"{tag}_batch": np.asarray(vlm.visual.seen_shape)})
+    # remove_global_patch=True (textregion.py:31-50, the reference's default): tokens with a shared "global" component on some
+    # patches so that the filter really removes columns; the seed is chosen so that no difference score sits within 0.01 (36
+    # columns) / 0.004 (216 columns) of the threshold (the HIP path evaluates it on bf16 unit tokens)
+    for tag, (H, W), want in (("c", (100, 150), 0.01), ("d", (170, 260), 0.004)):
+        tr = TR.PETextRegion(vlm, "PE-fake-%03d" % crop, pre, remove_global_patch=True, global_patch_threshold=0.07, device="cpu", dtype="fp32")
+        nh, nw = max(H // crop, 1), max(W // crop, 1)
+        for seed in range(1, 3000):
+            g = torch.Generator().manual_seed(seed)
+            img = torch.rand(3, H, W, generator=g)
+            masks = torch.from_numpy(syn.make_masks(H, W, grid=(2, 3), n_blobs=3, seed=61 + seed))
+            # tokens with structure: every mask has its own direction (patches inside it carry it), ~30 % "global" patches share one
+            # direction instead -- the difference score is then bimodal and the filter removes the global ones
+            ph, pw = P * nh, P * nw
+            cover = (torch.nn.functional.interpolate(masks[None].float(), [ph, pw], mode="bilinear")[0] > 0).reshape(-1, ph * pw).float()
+            dirs = torch.randn(masks.shape[0], D, generator=g)
+            glob = torch.rand(ph * pw, generator=g) < 0.3
+            shared = torch.randn(D, generator=g)
+            grid_tok = torch.randn(ph * pw, D, generator=g) + (~glob)[:, None] * 1.5 * (cover.T @ dirs) + glob[:, None] * 4.0 * shared
+            tok = torch.randn(1 + nh * nw, 1 + P * P, D, generator=g)
+            tok[0] *= 0.2                                                       # the whole-image crop: a small term of the stitch
+            tiles = grid_tok.reshape(nh, P, nw, P, D).permute(0, 2, 1, 3, 4).reshape(nh * nw, P * P, D)
+            tok[1:, 1:] = tiles
+            vlm.visual.tokens = tok
+            with torch.no_grad():
+                feats = tr.get_img_features(img)
+                keep = (tr.get_features_mask(masks) > 0).any(1)               # a mask smaller than a patch pools nothing: leave it out
+                masks = masks[keep]
+                fm = tr.get_features_mask(masks)
+                xin = TR.resize_features(feats[:, 1:], crop, patch, tr.points_per_h, tr.points_per_w, tr.crop_num_h, tr.crop_num_w)
+                kept = TR.remove_global_patch(xin, fm.clone(), 0.07)
+                outv = tr.pe_value_with_sam2_attn(fm.clone(), feats)
+                # the score the filter thresholds, recomputed only to check the margin of this fixture
+                pf = (xin / xin.norm(dim=-1, keepdim=True))[0]
+                p2r = (pf @ pf.T) @ (fm > 0).float().T / (fm > 0).sum(dim=-1)
+                diff = (p2r * (fm > 0).float().T).sum(-1) / ((fm > 0).sum(0) + 1e-9) - (p2r * (fm == 0).float().T).sum(-1) / ((fm == 0).sum(0) + 1e-9)
+            margin = (diff - 0.07).abs().min().item()
+            removed = int(((fm > 0).any(0) & ~(kept > 0).any(0)).sum())
+            if margin > want and removed > 0 and (kept > 0).any(1).all() and torch.isfinite(outv).all():
+                break
+        else:
+            raise RuntimeError("no seed gives a fixture with a clear threshold margin")
+        print(f"  textregion {tag}: seed {seed}, {masks.shape[0]} masks, {removed} of {fm.shape[1]} columns removed, threshold margin {margin:.4f}")
+        arrays.update({f"{tag}_tokens": tok, f"{tag}_masks": np.packbits(masks.numpy(), axis=-1), f"{tag}_mask_w": np.int64(W),
+                       f"{tag}_feature_masks": fm, f"{tag}_kept_masks": kept, f"{tag}_x_input": xin, f"{tag}_out": outv,
+                       f"{tag}_grid": np.asarray([tr.points_per_h, tr.points_per_w, nh, nw]), f"{tag}_th": np.float32(0.07)})
     ap = vlm.visual.attn_pool
     arrays.update(in_proj_weight=ap.attn.in_proj_weight, in_proj_bias=ap.attn.in_proj_bias,
                   out_proj_weight=ap.attn.out_proj.weight, out_proj_bias=ap.attn.out_proj.bias,
@@ -344,6 +389,93 @@ def gen_query(out, OVOcls, CG, I3D):
          capture_keys=np.asarray(sorted(cap.keys())))
 
 
+def loopclose_scene(seed=0):
+    """8 instances: (0,1) duplicates -> merge by p_dist > 0.5; (2,3) similar descriptors, partly overlapping -> merge by the
+    cos > 0.9 & p_dist > 0.2 clause; 4 close to 0 with another descriptor; 5 descriptor of 0 but no close points; 6 far away;
+    7 has lost all its points."""
+    rng = np.random.default_rng(seed)
+
+    def blob(centre, n, size=0.3):
+        return (np.asarray(centre, np.float32) + rng.uniform(-size, size, (n, 3))).astype(np.float32)
+    base = rng.standard_normal((8, 32)).astype(np.float32)
+    feats = np.stack([base[i] / np.linalg.norm(base[i]) for i in range(8)])
+    feats[1] = feats[0] + 0.15 * feats[1]
+    feats[3] = feats[2] + 0.05 * feats[3]
+    feats[5] = feats[0] + 0.02 * feats[5]
+    a = blob((0, 0, 0), 3000)
+    parts = {0: a, 1: a[:2500] + rng.normal(0, 0.01, (2500, 3)).astype(np.float32),
+             2: blob((3, 0, 0), 2000), 3: np.concatenate([blob((3.1, 0, 0), 700), blob((3.9, 0.5, 0), 1300, 0.2)]),
+             4: blob((0.1, 0.1, 0), 1500), 5: blob((0.0, 1.2, 0.0), 1800, 0.25), 6: blob((9, 9, 2), 1000)}
+    xyz = np.concatenate([parts[i] for i in parts] + [blob((5, 5, 5), 500)])
+    ins = np.concatenate([np.full(len(parts[i]), i, np.int32) for i in parts] + [np.full(500, -1, np.int32)])
+    perm = rng.permutation(len(xyz))
+    return xyz[perm], ins[perm], feats
+
+
+def gen_loopclose(out, OVOcls, I3D, IU):
+    """OVO.update_map (ovo.py:366-424) + instance_utils.fuse_instances (:26-35) run by the reference itself on a scene that
+    exercises both merge clauses, every rejection, an instance without points and a deleted keyframe.  Open3D is absent here:
+    case `kd` injects a stand-in whose `compute_point_cloud_distance` is an exact nearest-neighbour query (scipy cKDTree, float64
+    -- what Open3D computes), so same_instance (:5-24) itself runs; case `table` replaces same_instance by a lookup table of
+    pairs, which pins the control flow alone (greedy order, re-keyed descriptors, heaps, relabelling)."""
+    from collections import deque
+    from scipy.spatial import cKDTree
+    import open3d as o3d
+
+    class _PC:
+        points = None
+
+        def compute_point_cloud_distance(self, other):
+            return cKDTree(np.asarray(other.points, np.float64)).query(np.asarray(self.points, np.float64))[0]
+    o3d.geometry = types.SimpleNamespace(PointCloud=_PC)
+    o3d.utility = types.SimpleNamespace(Vector3dVector=lambda a: np.asarray(a, np.float64))
+    IU.o3d = o3d
+    real_same = IU.same_instance
+    xyz, ins, feats = loopclose_scene()
+    arrays = {"xyz": xyz, "ins": ins, "feats": feats, "n_top_kf": np.int64(10), "frame_ids": np.arange(0, 160, 10),
+              "th": np.asarray([1.5, 0.81, 0.1], np.float32)}
+    table_pairs = [(0, 1), (0, 5), (2, 3), (4, 6)]                # includes pairs the geometric test rejects
+    for tag, kfs in (("kd", list(range(0, 160, 10))), ("table", [k for k in range(0, 160, 10) if k not in (30, 120)])):
+        I3D.n_top_kf = 10
+        I3D.set_fusion("avg_pooling")
+        ovo = OVOcls.__new__(OVOcls)
+        ovo.config, ovo.device = {"log": False}, "cpu"
+        ovo.th_centroid, ovo.th_cossim, ovo.th_points = 1.5, 0.81, 0.1
+        ovo.keyframes_queue = deque([])
+        ovo.keyframes = {"ins_descriptors": {}, "frame_id": list(range(0, 160, 10)), "ins_maps": []}
+        ovo.objects = {}
+        # every instance was seen in keyframes id and id + 8 (descriptor: its feature, and the feature scaled by 0.5)
+        for kf in range(16):
+            i = kf % 8
+            ovo.keyframes["ins_descriptors"][kf] = {i: torch.from_numpy(feats[i] * (1.0 if kf < 8 else 0.5))}
+        for i in range(8):
+            o = I3D(i, kf_id=i, points_ids=[], mask_area=100 + i)
+            o.update([], i + 8, 50 + i)
+            ovo.objects[i] = o
+        ovo.update_objects_clip(force_update=True)
+        before = np.stack([ovo.objects[i].clip_feature.numpy().reshape(-1) for i in range(8)])
+        if tag == "table":
+            IU.same_instance = lambda a, b, *rest: (a.id, b.id) in table_pairs
+            # frame ids 30 and 120 are deleted; note the reference keys ins_descriptors by kf_id but tests `kf in ins_descriptors`
+            # with the FRAME id (ovo.py:376-378): only a frame id that is also a kf_id key is dropped -- none here
+        else:
+            IU.same_instance = real_same
+        out_ins = ovo.update_map((torch.from_numpy(xyz), None, torch.from_numpy(ins.copy())), kfs)
+        kept = list(ovo.objects.keys())
+        arrays.update({f"{tag}_kfs": np.asarray(kfs), f"{tag}_before": before, f"{tag}_out_ins": out_ins, f"{tag}_kept": np.asarray(kept),
+                       f"{tag}_frame_id": np.asarray([str(f) for f in ovo.keyframes["frame_id"]]),
+                       f"{tag}_desc_keys": np.asarray(sorted((kf, i) for kf, d in ovo.keyframes["ins_descriptors"].items() for i in d)).reshape(-1, 2)})
+        for i in kept:
+            o = ovo.objects[i]
+            arrays[f"{tag}_obj{i}_kfs"] = np.asarray(o.kfs_ids)
+            arrays[f"{tag}_obj{i}_topkf"] = np.asarray(sorted(o.top_kf)).reshape(-1, 2)
+            arrays[f"{tag}_obj{i}_clip"] = o.clip_feature.numpy().reshape(-1)
+        print(f"  loopclose {tag}: kept {kept}")
+    IU.same_instance = real_same
+    arrays["table_pairs"] = np.asarray(table_pairs)
+    save(out, "loopclose", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -372,6 +504,8 @@ def main():
     gen_textregion(args.out, TR)
     gen_segment(args.out, SU)
     gen_query(args.out, OVOcls, CG, I3Dmod.Instance3D)
+    from ovo.utils import instance_utils as IU
+    gen_loopclose(args.out, OVOcls, I3Dmod.Instance3D, IU)
 
 
 if __name__ == "__main__":
