@@ -5,18 +5,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A step = one 640x480 RGB-D keyframe through the whole path on each rank (ovo_amd/pipeline.py): back-projection,
-SAM2 image encoder, cull/project/match/vote/assign against the point map, ViT tokens + region pooling, multi-view
-fusion, dense per-point fusion, instance query and dense-map query.  Every frame is a semantic keyframe
+A step = one ROUND of N keyframes (N = number of GPUs; one 640x480 RGB-D keyframe per GPU) through the whole path
+(ovo_amd/pipeline.py): back-projection, SAM2 image encoder, cull/project/match/vote/assign against the point map, ViT tokens + region
+pooling, multi-view fusion, dense per-point fusion, instance query and dense-map query.  Every frame is a semantic keyframe
 (map_every = segment_every = 1); the reference's own `fps` divides by segment_every = 10 (ovomapping.py:218).
-Inputs are synthetic (seeded) and resident in HBM before the timed region; weights are seeded random init of the
-named architectures (no checkpoints offline) -- throughput is weight independent.
+Inputs are synthetic (seeded) and resident in HBM before the timed region; weights are seeded random init of the named
+architectures (no checkpoints offline) -- throughput is weight independent.  With several GPUs every rank holds the whole frame
+stream (the order-dependent integer passes run replicated), rank k owns keyframe k of a round for the encoders, and the round's one
+exchange (all-gather of the owners' descriptors over RCCL) sits INSIDE the step.
 
-Rank 0 prints ONE JSON line: the driver contract fields plus `roofline` (dominant kernel = the bf16 MFMA GEMM
-instantiation with the most time, measured with hipEvents around every launch in a second, profiled pass -- as run on
-three concurrent streams, and again with the streams folded under `isolated`; `traffic` = HBM bytes per launch from the
-committed PMC reduction profiles/pmc_traffic.json) and `cpu_baseline` (the CPU oracle of the same path on one frame,
-N = 1 only).
+Rank 0 prints ONE JSON line: the driver contract fields plus
+  roofline      dominant kernel = the bf16 MFMA GEMM instantiation with the most time, hipEvents around every launch in a second,
+                profiled pass -- as run on three concurrent streams, and with the streams folded under `isolated`; `traffic` = HBM
+                bytes per launch from the committed PMC reduction profiles/pmc_traffic.json; `frame_frac` = the whole frame's
+                flops / step time / peak; `measured_peaks` = stream copy and 8192^3 GEMM measured in this job
+  cpu_baseline  the CPU oracle of the same path: 1 warm-up + median of 3 frames, N = 1 only
+  parity        GPU vs oracle on one frame of this workload: max |descriptor error|, per-point instance-id mismatches
+  per_step_ms / sustained   step cadence statistics of the timed steps and a >= 2 s continuation of the same stream
 """
 from __future__ import annotations
 
@@ -49,7 +54,7 @@ def parse():
     ap.add_argument("--texts", type=int, default=10)
     ap.add_argument("--no-dense", action="store_true", help="skip the dense per-point accumulate / query")
     ap.add_argument("--encoder-batch", type=int, default=int(os.environ.get("OVO_ENCODER_BATCH", "4")),
-                    help="keyframes whose SAM2 / ViT forwards run as ONE batched forward each (encoder look-ahead; 1 = per frame). "
+                    help="keyframes (per GPU) whose SAM2 / ViT forwards run as ONE batched forward each (encoder look-ahead; 1 = per frame). "
                          "The reference defers a keyframe's descriptors by kf_queue_delay = 10 keyframes (ovo.yaml:53), so results do not change")
     ap.add_argument("--sam-full", action="store_true", help="not the headline workload: also run SAM2's mask decoder on a 16x16 click grid and the "
                     "automatic-mask-generator filters every frame (SURVEY.md f1); tracking still consumes the synthetic masks, because "
@@ -57,15 +62,16 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=8)
+    ap.add_argument("--sustain-seconds", type=float, default=2.0, help="after the timed steps: keep stepping the same stream for this long (0 = off)")
     return ap.parse_args()
 
 
-def cpu_baseline(pipe_args, frame_np, map_xyz, texts):
-    """The CPU oracle (a port of the reference's algorithm, oracle/) on ONE frame of the same workload."""
-    from oracle import features as OF, geometry as OG, hiera as OH, semantic as OS, vit as OV
+def cpu_frame(pipe_args, frame_np, map_xyz, texts):
+    """The CPU oracle (a port of the reference's algorithm, oracle/) on ONE frame of the same workload.
+    -> (seconds, descriptors f32[n, D], the masks they were pooled from, updated per-point instance ids, the oracle's point map)."""
+    from oracle import features as OF, hiera as OH, semantic as OS, vit as OV
     from ovo_amd import synthetic as syn
     from ovo_amd.encoders import hiera as EH, vit as EV
-    torch.set_num_threads(min(32, os.cpu_count() or 1))      # more threads only add OpenMP spin on these small ops
     spec = EV.SPECS[pipe_args.vit]
     sd = EV.random_state(spec, 0)
     rope = EV.rope_tables(spec) if spec.use_rope else None
@@ -73,7 +79,7 @@ def cpu_baseline(pipe_args, frame_np, map_xyz, texts):
     rgb, rgb_lr, depth, c2w, seg, masks = frame_np
     t0 = time.time()
     pm = OS.PointMap(K)
-    pm.xyz, pm.next_id = map_xyz, map_xyz.shape[0]
+    pm.xyz, pm.next_id = map_xyz.copy(), map_xyz.shape[0]
     pm.ids = np.arange(pm.next_id, dtype=np.int32)[:, None]
     pm.ins = np.full(pm.next_id, -1, np.int32)
     pm.rgb = np.zeros((pm.next_id, 3), np.uint8)
@@ -94,12 +100,64 @@ def cpu_baseline(pipe_args, frame_np, map_xyz, texts):
     tok = OV.vit_forward(sd, batch, patch=spec.patch, heads=spec.heads, act=spec.act, rope=rope, tokens=True)
     P = spec.grid
     xs = OF.stitch_tokens(tok[:, 1:].numpy(), P, P * nh, P * nw, nh, nw)
-    fm = OF.feature_masks(fused if len(fused) else masks, P * nh, P * nw)
+    used = fused if len(fused) else masks
+    fm = OF.feature_masks(used, P * nh, P * nw)
     d = spec.width
     desc = OF.region_pool(xs, fm, sd["attn_pool.attn.in_proj_weight"][2 * d:], sd["attn_pool.attn.in_proj_bias"][2 * d:],
                           sd["attn_pool.attn.out_proj.weight"], sd["attn_pool.attn.out_proj.bias"], sd["proj"])
     OF.classify(OF.similarity(np.nan_to_num(desc), texts))
-    return 1.0 / (time.time() - t0), torch.get_num_threads()
+    return time.time() - t0, desc, used, upd, pm
+
+
+def cpu_baseline(args, frames_np, map_xyz, texts):
+    """1 warm-up frame + the median of 3 timed frames on the host cores."""
+    threads = min(32, os.cpu_count() or 1)              # more threads only add OpenMP spin on these small ops
+    torch.set_num_threads(threads)
+    times, last = [], None
+    for i, f in enumerate(frames_np[:4]):
+        last = cpu_frame(args, f, map_xyz, texts)
+        if i > 0:
+            times.append(last[0])
+    times.sort()
+    return 1.0 / times[len(times) // 2], threads, times, last
+
+
+def parity_block(pipe, frame, map_xyz, oracle_out):
+    """GPU vs oracle on ONE frame of this workload (BASELINE.md section 2 "Reported"): TextRegion descriptors of the same masks
+    (max |unit-descriptor error|, north_star bound 1e-3) and the per-point instance ids after back-projection + tracking against the
+    initial map (bit-exact: mismatches must be 0)."""
+    from ovo_amd import synthetic as syn
+    from ovo_amd.entities.ovo import OVO
+    from ovo_amd.pipeline import ResidentMasks
+    from ovo_amd.slam.vanilla_mapper import VanillaMapper
+    _, desc_ref, used_masks, upd_ref, pm_ref = oracle_out
+    dev = pipe.device
+    tr = pipe.clip.textregion
+    img = frame.rgb.permute(2, 0, 1).contiguous()
+    desc = tr.predict(img, torch.from_numpy(np.ascontiguousarray(used_masks)).to(dev), scale=1.0 / 255.0).cpu().numpy()
+    ok = ~np.isnan(desc_ref).any(1)
+    err = float(np.abs(desc[ok] - desc_ref[ok]).max()) if ok.any() else None
+    K = torch.from_numpy(syn.scannet_intrinsics(1.0)).to(dev)
+    vm = VanillaMapper({"device": str(dev), "mapping": {"k_pooling": 3}}, K)
+    n0 = map_xyz.shape[0]
+    vm.set_map_dict({"xyz": torch.from_numpy(map_xyz), "obj_ids": torch.full((n0, 1), -1, dtype=torch.int32),
+                     "ids": torch.arange(n0, dtype=torch.int32)[:, None], "max_id": n0, "color": torch.zeros((n0, 3), dtype=torch.uint8)})
+    seam = ResidentMasks()
+    seam.frames = {frame.index: frame}
+    cfg = {"match_distance_th": 0.05, "track_th": 100, "depth_filter": True, "log": False, "kf_queue_delay": 0, "debug_info": False,
+           "clip": {"embed_type": "TextRegion", "k_top_views": 10000, "fusion": "avg_pooling"}, "sam": {"precomputed": True}}
+    ovo = OVO(cfg, None, "parity", K, device=str(dev), clip_generator=pipe.clip, mask_generator=seam)
+    fd = [frame.index, frame.rgb_lr, frame.depth, frame.c2w]
+    vm.track_camera(fd)
+    vm.map(fd, vm._c2w_host[frame.index])
+    upd = ovo.detect_and_track_objects([frame.index, frame.rgb, frame.depth, (1.0, 1.0, pipe.crop_edge)], vm.get_map(), vm._c2w_host[frame.index])
+    upd = upd.cpu().numpy().reshape(-1)
+    same_points = bool(vm.pcd.shape[0] == pm_ref.xyz.shape[0] and np.array_equal(vm.pcd.cpu().numpy(), pm_ref.xyz))
+    mism = int((upd != upd_ref.reshape(-1)).sum()) if upd.shape == upd_ref.reshape(-1).shape else -1
+    return {"max_abs_desc_err": None if err is None else round(err, 6), "descriptors": int(ok.sum()), "index_mismatches": mism,
+            "points": int(upd.shape[0]), "map_points_identical": same_points,
+            "note": "one frame of this workload: GPU TextRegion descriptors vs the fp32 oracle on the same masks; per-point instance ids after "
+                    "back-projection + tracking on the initial map vs the oracle (bit-exact expected)"}
 
 
 def pmc_traffic(tile: str):
@@ -111,21 +169,20 @@ def pmc_traffic(tile: str):
     bm, bn = tile.split(",")
     with open(path) as fh:
         kernels = json.load(fh)["kernels"]
-    hits = [v for k, v in kernels.items() if (f"k_gemmILi{bm}ELi{bn}ELi64E" in k or f"k_gemm8pILi{bm}ELi{bn}E" in k) and "DF16b" in k]
+    hits = [v for k, v in kernels.items() if (f"k_gemmILi{bm}ELi{bn}ELi64E" in k or f"k_gemm8pILi{bm}ELi{bn}E" in k or f"k_gemm8p<{bm}, {bn}" in k)
+            and ("DF16b" in k or "__bf16" in k or "bool _Accum" in k)]
     n = sum(v["launches"] for v in hits)
     return round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n) if n else None
 
 
-def profile_pass(pipe, it, steps, lib):
-    """hipEvent pairs around every GEMM / attention / track_project launch of `steps` frames (on the launching streams)."""
+def profile_pass(pipe, feed, rounds, lib):
+    """hipEvent pairs around every GEMM / attention / track_project launch of `rounds` steps (on the launching streams)."""
     from ovo_amd import _lib as L
     L.check(lib.ovo_profile_start())
-    it.region(steps)
-    for _ in range(steps):
-        f, upcoming = next(it)
-        pipe.step(f, upcoming)
+    feed.run(pipe, rounds)
     ms, work, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
     L.check(lib.ovo_profile_stop(ms, work, n, 8))
+    steps = rounds                                                # per frame of THIS rank: one owned keyframe per round
     tiles = {3: "256,256", 0: "256,128", 4: "128,128", 5: "128,64", 6: "64,128", 7: "64,64"}     # 256-row tiles: the ping-pong kernel (gemm8p.hip)
     dom = max(tiles, key=lambda k: ms[k])                      # the GEMM instantiation with the most time = dominant kernel
     tf = work[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
@@ -136,19 +193,81 @@ def profile_pass(pipe, it, steps, lib):
             "traffic": pmc_traffic(tiles[dom]),
             "launches_per_frame": n[dom] / steps, "avg_launch_us": round(1e3 * ms[dom] / max(n[dom], 1), 2),
             "gemm_tiles_ms_per_frame": {tiles[k]: round(ms[k] / steps, 3) for k in tiles},
+            "gemm_tiles_tflops": {tiles[k]: round(work[k] / (ms[k] * 1e-3) / 1e12, 1) for k in tiles if ms[k] > 0},
             "gemm_all_ms_per_frame": round(gemm_ms / steps, 3),
             "gemm_all_tflops": round(gemm_work / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms > 0 else 0.0,
             "attention_ms_per_frame": round(ms[1] / steps, 3),
             "attention_tflops": round(work[1] / (ms[1] * 1e-3) / 1e12, 1) if ms[1] > 0 else 0.0,
-            "track_project_ms_per_frame": round(ms[2] / steps, 4),
+            "track_project_ms_per_frame": round(ms[2] / steps / max(pipe.world, 1), 4),
             "track_project_gbs": round(work[2] / (ms[2] * 1e-3) / 1e9, 1) if ms[2] > 0 else 0.0,
             "hbm_peak_gbs": HBM_PEAK_GBS}
+
+
+def measured_peaks(dev, lib):
+    """Stream copy and a plain 8192^3 bf16 GEMM measured in THIS job, beside the nominal peaks."""
+    from ovo_amd import _lib as L
+    n = 1 << 28                                                    # 1 GiB of f32
+    a, b = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+    a.fill_(1.0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+    m = 8192
+    x = torch.randn(m, m, device=dev).to(torch.bfloat16)
+    w = torch.randn(m, m, device=dev).to(torch.bfloat16)
+    o = torch.empty(m, m, dtype=torch.bfloat16, device=dev)
+    g = L.Gemm()
+    g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, g.add, g.ld_add = x.data_ptr(), m, w.data_ptr(), m, None, o.data_ptr(), m, None, 0
+    g.M, g.N, g.K, g.in_dtype, g.out_dtype, g.act, g.alpha = m, m, m, 2, 2, 0, 1.0
+    for _ in range(2):
+        L.check(lib.ovo_gemm(C.byref(g), L.stream()))
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        L.check(lib.ovo_gemm(C.byref(g), L.stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    tf = 5 * 2.0 * m ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    return {"hbm_copy_gbs": round(copy_gbs, 1), "hbm_copy_frac_of_8tbs": round(copy_gbs / HBM_PEAK_GBS, 3),
+            "gemm_8192_bf16_tflops": round(tf, 1), "gemm_8192_frac_of_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 3),
+            "note": "torch device copy of 1 GiB f32 (read + write bytes) and ovo_gemm 8192^3 bf16 on random operands, measured in this job"}
+
+
+class Feed:
+    """Rounds of `world` frames in order.  A step also sees the frames that follow it INSIDE the same region (warm-up / timed /
+    profiled / sustained), so the encoder look-ahead never does work of a timed frame outside the timed region, nor work of later
+    frames inside it."""
+
+    def __init__(self, frames, world):
+        self.frames, self.world, self.pos = frames, world, 0
+
+    def left(self):
+        return (len(self.frames) - self.pos) // self.world
+
+    def run(self, pipe, rounds, stamp=None):
+        end = self.pos + rounds * self.world
+        assert end <= len(self.frames), "frame stream exhausted"
+        for _ in range(rounds):
+            group = self.frames[self.pos:self.pos + self.world]
+            self.pos += self.world
+            pipe.step_round(group, self.frames[self.pos:end])
+            if stamp is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                stamp.append(ev)
 
 
 def main():
     args = parse()
     from ovo_amd import _lib as L, parallel
-    from ovo_amd.pipeline import FramePipeline, synthetic_frames
+    from ovo_amd.pipeline import Frame, FramePipeline, synthetic_frames
     rank, local_rank, world = parallel.init_distributed()
     assert torch.cuda.is_available(), "bench.py needs a GPU (ovo_amd has no CPU path)"
     dev_index = parallel.local_device(local_rank)
@@ -156,93 +275,99 @@ def main():
     dev = torch.device("cuda", dev_index)
     lib = L.load()
 
-    total = args.warmup + args.steps + (0 if args.no_roofline else 2 * args.profile_steps)
+    prof_rounds = 0 if args.no_roofline else args.profile_steps
+    base_rounds = args.warmup + args.steps + 2 * prof_rounds
+    # the sustained continuation re-uses the resident frames (new keyframe ids, same pixels): budget its map growth up front
+    sustain_rounds = int(args.sustain_seconds * 450 / world) if args.sustain_seconds > 0 else 0
     sam = None if args.sam == "none" else args.sam
     pipe = FramePipeline(dev, vit_card=args.vit, sam_card=sam, n_map=args.map_points, n_text=args.texts, dense=not args.no_dense, sam_full=args.sam_full,
-                         extra_capacity=(total + 2) * 72_000, seed=0, encoder_batch=args.encoder_batch)
-    frames = synthetic_frames(total, dev, seed=100 * rank + int(os.environ.get("OVO_BENCH_SEED", "0")))   # each rank streams its own frames (weak scaling)
+                         extra_capacity=(base_rounds * world + 2) * 72_000 + sustain_rounds * world * 16_000, seed=0, encoder_batch=args.encoder_batch)
+    # every rank holds the whole stream: the order-dependent passes run replicated (pipeline.py); rank k owns frame k of a round
+    frames = synthetic_frames(base_rounds * world, dev, seed=int(os.environ.get("OVO_BENCH_SEED", "0")))
     H, W = frames[0].rgb.shape[:2]
-    map0 = pipe.slam.pcd.cpu().numpy().copy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    map0 = pipe.slam.pcd.cpu().numpy().copy() if want_cpu else None
 
-    class Feed:
-        """Frames in order; a step also sees the frames that follow it INSIDE the same region (warm-up / timed / profiled), so the
-        encoder look-ahead never does work of a timed frame outside the timed region, nor work of later frames inside it."""
-        def __init__(self, frames):
-            self.frames, self.pos, self.end = frames, 0, 0
-
-        def region(self, n):
-            self.end = self.pos + n
-
-        def __next__(self):
-            f = self.frames[self.pos]
-            self.pos += 1
-            return f, self.frames[self.pos:self.end]
-
-    it = Feed(frames)
-
-    def run(n):
-        it.region(n)
-        for _ in range(n):
-            f, upcoming = next(it)
-            pipe.step(f, upcoming)
-
-    run(args.warmup)
+    feed = Feed(frames, world)
+    feed.run(pipe, args.warmup)
     torch.cuda.synchronize()
     parallel.barrier()
+    stamps = []
+    first = torch.cuda.Event(enable_timing=True)
+    first.record()
     t0 = time.perf_counter()
-    if os.environ.get("OVO_BENCH_PER_STEP"):                       # diagnosis only: sync + stamp every step
-        stamps = []
-        it.region(args.steps)
-        for _ in range(args.steps):
-            f, upcoming = next(it)
-            pipe.step(f, upcoming)
-            torch.cuda.synchronize()
-            stamps.append(time.perf_counter())
-        print("per-step ms:", [round(1e3 * (b - a), 2) for a, b in zip([t0] + stamps, stamps)], file=sys.stderr)
-    else:
-        run(args.steps)
+    x0, n0 = pipe.exchange_ms, pipe.exchanges
+    feed.run(pipe, args.steps, stamps)
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
-    merge_calls = 0
-    t_merge = 0.0
-    if world > 1:                                                 # dense accumulator merge: once per batch, reported separately
-        tm = time.perf_counter()
-        merge_calls = pipe.merge_dense()
-        torch.cuda.synchronize()
-        t_merge = parallel.max_over_ranks(time.perf_counter() - tm, dev)
+    xchg_ms = (pipe.exchange_ms - x0) / max(pipe.exchanges - n0, 1)
+    cadence = sorted(a.elapsed_time(b) for a, b in zip([first] + stamps[:-1], stamps))
 
     roof = None
-    if not args.no_roofline and args.profile_steps > 0:
-        roof = profile_pass(pipe, it, args.profile_steps, lib)                 # as timed: three concurrent HIP streams
+    if prof_rounds > 0:
+        roof = profile_pass(pipe, feed, prof_rounds, lib)                        # as timed: three concurrent HIP streams
         torch.cuda.synchronize()
-        if args.encoder_batch > 1:
+        if args.encoder_batch > 1 or world > 1:
             pipe.serial = True                                                 # one stream: every kernel has the chip to itself
-            iso = profile_pass(pipe, it, args.profile_steps, lib)
+            iso = profile_pass(pipe, feed, prof_rounds, lib)
             pipe.serial = False
         else:
             streams = (pipe.sam_stream, pipe.prefetch)
             pipe.sam_stream, pipe.prefetch = None, False
-            iso = profile_pass(pipe, it, args.profile_steps, lib)
+            iso = profile_pass(pipe, feed, prof_rounds, lib)
             pipe.sam_stream, pipe.prefetch = streams
-        roof["isolated"] = {k: iso[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "gemm_all_ms_per_frame", "gemm_all_tflops",
+        roof["isolated"] = {k: iso[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "gemm_tiles_tflops", "gemm_all_ms_per_frame", "gemm_all_tflops",
                                                 "attention_ms_per_frame", "attention_tflops", "track_project_gbs")}
-        roof["isolated"]["note"] = "same kernels, second profiled pass with the SAM2 / ViT-prefetch streams folded into one"
+        roof["isolated"]["note"] = "same kernels, second profiled pass with the SAM2 / ViT streams folded into one"
+        torch.cuda.synchronize()
 
-    cpu = None
-    if map0 is not None:
-        f = frames[args.warmup]
-        fnp = (f.rgb.cpu().numpy(), f.rgb_lr.cpu().numpy(), f.depth.cpu().numpy(), f.c2w, f.seg_map.cpu().numpy(), f.masks.cpu().numpy())
+    sustained = None
+    if sustain_rounds > 0:                                        # >= 2 s of the same stream: long enough for an external sampler to see
+        nxt = frames[-1].index + 1
+        pool = frames * (sustain_rounds * world // len(frames) + 1)
+        more = [Frame(nxt + i, f.rgb, f.rgb_lr, f.depth, f.c2w, f.seg_map, f.masks) for i, f in enumerate(pool[:sustain_rounds * world])]
+        sfeed = Feed(more, world)
+        chunk = max(args.encoder_batch, 1) * 4
+        parallel.barrier()
+        ts = time.perf_counter()
+        done = 0
+        while sfeed.left() >= chunk and time.perf_counter() - ts < args.sustain_seconds and pipe.slam._n + chunk * world * 16_000 < pipe.slam._cap:
+            sfeed.run(pipe, chunk)
+            done += chunk
+            if done % (chunk * 4) == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        dt = parallel.max_over_ranks(time.perf_counter() - ts, dev)
+        sustained = {"rounds": done, "seconds": round(dt, 3), "frames_per_s": round(done * world / dt, 2) if dt > 0 else None,
+                     "points_end": int(pipe.slam._n), "instances_end": len(pipe.ovo.objects),
+                     "note": "the same frame stream continued (map and instance table keep growing), host-timed with a sync every 16 x encoder_batch rounds"}
+
+    peaks = measured_peaks(dev, lib) if (rank == 0 and not args.no_roofline) else None
+
+    cpu, parity = None, None
+    if want_cpu:
+        idx = [args.warmup + i for i in range(4)]
+        fnp = [(f.rgb.cpu().numpy(), f.rgb_lr.cpu().numpy(), f.depth.cpu().numpy(), f.c2w, f.seg_map.cpu().numpy(), f.masks.cpu().numpy())
+               for f in (frames[i] for i in idx)]
         try:
-            v, cores = cpu_baseline(args, fnp, map0, pipe.texts.cpu().numpy())
-            cpu = {"value": round(v, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-                   "sample": "1 frame of the same workload through oracle/ (fp32 torch-CPU encoders + C geometry), after the GPU run"}
+            v, cores, times, last = cpu_baseline(args, fnp, map0, pipe.texts.cpu().numpy())
+            cpu = {"value": round(v, 4), "unit": "frames/s", "cores": cores, "kind": "port", "seconds_per_frame": [round(t, 2) for t in times],
+                   "sample": "4 frames of the same workload through oracle/ (fp32 torch-CPU encoders + C geometry): 1 warm-up, median of the other 3, "
+                             f"torch.set_num_threads({cores}), after the GPU run"}
+            parity = parity_block(pipe, frames[idx[-1]], map0, last)
         except Exception as e:                                     # the baseline must never take the bench down
             cpu = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
 
     if rank == 0:
         fl = pipe.flops_per_frame(H, W)
         ms_step = 1e3 * elapsed / args.steps
+        frame_tflops = sum(fl.values()) * world / (ms_step * 1e-3) / 1e12
+        if roof is not None:
+            roof["frame_frac"] = round(frame_tflops / world / MFMA_BF16_PEAK_TFLOPS, 4)
+            roof["frame_frac_note"] = "(ViT + SAM2 encoder flops of one frame) / (step time per frame and GPU) / 2.5 PFLOP/s: the whole step against the MFMA peak"
+            roof["measured_peaks"] = peaks
         line = {
             "metric": "frames/s (CLIP+SAM2+fusion+query), 640x480 ScanNet, 1/2/4/8 MI355X",
             "value": round(world * args.steps / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -254,14 +379,22 @@ def main():
                                    f"instance and dense-map query; every frame a keyframe; masks from the precomputed-mask seam (32/frame)",
                        "frames_per_step_per_gpu": 1, "map_points": args.map_points, "texts": args.texts, "masks_per_frame": int(frames[0].masks.shape[0]),
                        "sam2": "image encoder + mask decoder (256 clicks) + automatic-mask-generator filters" if args.sam_full else "image encoder",
-                       "parallelism": f"frame-sharded x{world}, per-step RCCL all-reduce of descriptor accumulators" if world > 1 else "single GPU",
+                       "encoder_batch": pipe.encoder_batch,
+                       "dense_query": "resident class map, rows touched by the keyframe re-evaluated" if (pipe.dense and pipe.incremental_query) else "all rows",
+                       "parallelism": (f"rounds of {world} keyframes: rank k owns keyframe k (SAM2 + ViT + pooling), tracking / back-projection replicated in "
+                                       f"keyframe order, one all-gather of descriptors per round inside the step, dense accumulators sharded by point "
+                                       f"(block-cyclic, no reduce)") if world > 1 else "single GPU",
                        "gflop_per_frame": {k: round(v / 1e9, 1) for k, v in fl.items()},
                        "points_end": pipe.last.get("n_points"), "instances_end": pipe.last.get("n_instances")},
-            "model_tflops_effective": round(sum(fl.values()) / (ms_step * 1e-3) / 1e12, 1),
-            "roofline": roof, "cpu_baseline": cpu,
+            "model_tflops_effective": round(frame_tflops, 1),
+            "per_step_ms": {"median": round(cadence[len(cadence) // 2], 3), "min": round(cadence[0], 3), "max": round(cadence[-1], 3),
+                            "note": "intervals between hipEvents recorded on the main stream at the end of every timed step"},
+            "sustained": sustained,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         if world > 1:
-            line["dense_merge"] = {"collectives": merge_calls, "ms": round(1e3 * t_merge, 2)}
+            line["exchange"] = {"collectives_per_round": 1, "bytes_per_rank": int(pipe.xchg.numel() * 4), "host_ms_per_round": round(xchg_ms, 3),
+                                "note": "all-gather of the round's descriptors (RCCL), issued inside the timed step"}
         print(json.dumps(line))
     parallel.barrier()
 

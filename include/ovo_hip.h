@@ -148,11 +148,18 @@ int ovo_fuse_views(const float *store, int D, const int32_t *csr_off, const int3
 int ovo_scatter_accum(const int16_t *point_seg, int64_t n, const int32_t *mask_row, int n_masks,
                       const float *desc, int D, float *acc, int32_t *cnt, ovo_stream_t stream);
 /* The same pass, also emitting WHICH points it changed: touched i32[>= n] receives their indices (in any order), n_touched i32[1]
- * (zeroed by the caller) their number.  Only those points can change class in the dense query of this keyframe
- * (ovo.py:473-492 semantics per point): feed the list to ovo_similarity_rows instead of re-querying the whole map. */
+ * (zero on entry) their number.  Only those points can change class in the dense query of this keyframe
+ * (ovo.py:473-492 semantics per point): feed the list to ovo_similarity_rows instead of re-querying the whole map.
+ * n_next (optional i32[1]) is set to zero by this call: alternate two counters and no fill launch is ever needed.
+ * touched / n_touched may both be NULL (no list).
+ * Multi-GPU: with shard_count > 1, acc / cnt hold only THIS rank's block-cyclic shard of the points -- blocks of
+ * shard_block points (a power of two), block b owned by rank b % shard_count at local block b / shard_count -- other ranks' points are
+ * skipped and `touched` receives local row numbers.  Every rank applies every keyframe's descriptors (all-gathered, KBs) to its own
+ * rows in keyframe order, so the shards equal the rows of a single accumulator bit for bit: the "merge" of the per-GPU accumulators
+ * needs no floating-point reduce.  shard_count = 1, shard_rank = 0: the unsharded form. */
 int ovo_scatter_accum_touched(const int16_t *point_seg, int64_t n, const int32_t *mask_row, int n_masks,
                               const float *desc, int D, float *acc, int32_t *cnt, int32_t *touched, int32_t *n_touched,
-                              ovo_stream_t stream);
+                              int32_t *n_next, int shard_rank, int shard_count, int shard_block, ovo_stream_t stream);
 
 /* ---- a21 + a22: similarity query (clip_utils.py:10-19, ovo.py:487-491) ---------------------------
  * S[i,q] = row_scale(i) * sum_k F[i,k] T[q,k];  siglip: S = sigmoid(S * exp(logit_scale) + logit_bias).

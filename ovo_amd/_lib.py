@@ -119,7 +119,7 @@ _SIGNATURES = {
     "ovo_scatter_accum": (_I32, [_P, _I64, _P, _I32, _P, _I32, _P, _P, _P]),
     "ovo_similarity": (_I32, [_P, _I32, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P, _P]),
     "ovo_similarity_rows": (_I32, [_P, _I32, _P, _P, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P]),
-    "ovo_scatter_accum_touched": (_I32, [_P, _I64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P]),
+    "ovo_scatter_accum_touched": (_I32, [_P, _I64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "ovo_mask_boxes": (_I32, [_P, _I32, _I32, _I32, _P, _P]),
     "ovo_mask_crops": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "ovo_row_argmax": (_I32, [_P, _I64, _I32, _I32, _F32, _F32, _F32, _P, _P, _P]),

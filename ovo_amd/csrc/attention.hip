@@ -316,7 +316,7 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     OVO_REQUIRE(p->q_st % 8 == 0 && p->k_st % 8 == 0 && p->v_st % 8 == 0 && p->q_sh % 8 == 0 && p->k_sh % 8 == 0 && p->v_sh % 8 == 0 &&
                 p->q_sb % 8 == 0 && p->k_sb % 8 == 0 && p->v_sb % 8 == 0, "q/k/v rows must be 16-byte aligned");
     OVO_REQUIRE(((((uintptr_t)p->q | (uintptr_t)p->k | (uintptr_t)p->v) & 15) == 0) && (((uintptr_t)p->o & 7) == 0), "misaligned base pointer");
-    OVO_REQUIRE((long long)p->B * p->H <= 65535, "B*H exceeds the grid y limit");
+    OVO_REQUIRE((long long)p->B * p->H * ((p->Tq + 63) / 64) < (1ll << 31) - 8, "too many workgroups");
     AttnArgs a;
     a.q = (const uint16_t *)p->q; a.k = (const uint16_t *)p->k; a.v = (const uint16_t *)p->v; a.o = (uint16_t *)p->o;
     a.q_sb = p->q_sb; a.q_sh = p->q_sh; a.q_st = p->q_st; a.k_sb = p->k_sb; a.k_sh = p->k_sh; a.k_st = p->k_st;
@@ -332,7 +332,8 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     const int qpb = wide ? 128 : 64;
     dim3 grid((p->Tq + qpb - 1) / qpb, p->B * p->H);
     a.q_tiles = (int)grid.x; a.chunk = 0;
-    if (grid.x > 1 && !getenv("OVO_ATTN_NO_CHUNK")) {             // several q-tiles share a head's K / V: keep them on one XCD's L2
+    // (also the form for more than 65535 batch x head rows -- windowed attention of several frames at once: the y dimension of a grid ends there)
+    if ((grid.x > 1 && !getenv("OVO_ATTN_NO_CHUNK")) || grid.y > 65535) {   // several q-tiles share a head's K / V: keep them on one XCD's L2
         const long long total = (long long)grid.x * grid.y;
         a.chunk = (int)((total + 7) / 8);
         grid = dim3((unsigned)(a.chunk * 8), 1);

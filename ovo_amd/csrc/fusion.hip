@@ -69,30 +69,39 @@ __global__ void __launch_bounds__(256) k_scatter_accum(const int16_t *__restrict
                                                        const int32_t *__restrict__ mask_row, int n_masks,
                                                        const float *__restrict__ desc, int D, float *__restrict__ acc,
                                                        int32_t *__restrict__ cnt, int32_t *__restrict__ touched = nullptr,
-                                                       int32_t *__restrict__ n_touched = nullptr) {
+                                                       int32_t *__restrict__ n_touched = nullptr, int32_t *__restrict__ n_next = nullptr,
+                                                       int shard_rank = 0, int shard_count = 1, int block_log2 = 0) {
     const int lane = threadIdx.x & 63;
+    if (n_next && blockIdx.x == 0 && threadIdx.x == 0) *n_next = 0;   // the NEXT keyframe's counter (nobody reads it before that launch)
     const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int D4 = D >> 2;
     for (int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64; base < n; base += waves * 64) {
         // each lane inspects one point of the 64-point chunk, then the wave serves the hits one by one
         const int64_t i = base + lane;
         int row = -1;
+        int64_t li = i;                                            // row of acc / cnt: the point itself, or its slot in this rank's shard
         if (i < n) {
             const int s = point_seg[i];
             if (s >= 0 && s < n_masks) row = mask_row[s];
+            if (shard_count > 1) {
+                // block-cyclic point shards (blocks of 2^block_log2 points): rank r owns blocks r, r + R, ...; appended points spread evenly
+                const int64_t blk = i >> block_log2;
+                if (blk % shard_count != shard_rank) row = -1;
+                li = ((blk / shard_count) << block_log2) | (i & ((1ll << block_log2) - 1));
+            }
         }
         unsigned long long hits = __ballot(row >= 0);
-        if (touched && hits) {                                     // compacted list of the points this keyframe changed: one atomic per chunk
+        if (touched && hits) {                                     // compacted list of the rows this keyframe changed: one atomic per chunk
             int at = 0;
             if (lane == 0) at = atomicAdd(n_touched, __popcll(hits));
             at = __shfl(at, 0, 64);
-            if (row >= 0) touched[at + __popcll(hits & ((1ull << lane) - 1ull))] = (int32_t)i;
+            if (row >= 0) touched[at + __popcll(hits & ((1ull << lane) - 1ull))] = (int32_t)li;
         }
         while (hits) {
             const int src = __ffsll((long long)hits) - 1;
             hits &= hits - 1;
             const int r = __shfl(row, src, 64);
-            const int64_t p = base + src;
+            const int64_t p = __shfl(li, src, 64);
             const float4 *d4 = (const float4 *)(desc + (int64_t)r * D);
             float4 *a4 = (float4 *)(acc + p * D);
             for (int k = lane; k < D4; k += 64) {
@@ -122,15 +131,26 @@ int ovo_fuse_views(const float *store, int D, const int32_t *csr_off, const int3
 }
 
 // ovo_scatter_accum that also emits WHICH points it changed: touched i32[>= n] receives their indices (any order), n_touched i32[1]
-// (zeroed by the caller) their number -- the row list of ovo_similarity_rows, so that only those points are re-queried.
+// (zero on entry) their number -- the row list of ovo_similarity_rows, so that only those points are re-queried.  n_next (optional)
+// is set to zero: with two counters used alternately every call prepares the next one's and no fill launch is needed.
+// shard_count > 1: acc / cnt hold only this rank's block-cyclic shard of the points (blocks of shard_block points, a power of two;
+// block b belongs to rank b % shard_count and sits at local block b / shard_count); points of other ranks are skipped and `touched`
+// receives LOCAL row numbers.  Every rank applies every keyframe's descriptors to its own rows, in keyframe order: the shards hold,
+// bit for bit, the rows a single accumulator would (no floating-point reduction across ranks).
 int ovo_scatter_accum_touched(const int16_t *point_seg, int64_t n, const int32_t *mask_row, int n_masks, const float *desc,
-                              int D, float *acc, int32_t *cnt, int32_t *touched, int32_t *n_touched, ovo_stream_t stream) {
+                              int D, float *acc, int32_t *cnt, int32_t *touched, int32_t *n_touched, int32_t *n_next,
+                              int shard_rank, int shard_count, int shard_block, ovo_stream_t stream) {
     OVO_REQUIRE(n >= 0 && n < (1ll << 31) && D > 0 && n_masks > 0, "bad argument");
+    OVO_REQUIRE(shard_count >= 1 && shard_rank >= 0 && shard_rank < shard_count && shard_block > 0 && (shard_block & (shard_block - 1)) == 0,
+                "bad shard description (shard_block must be a power of two)");
+    int block_log2 = 0;
+    while ((1 << block_log2) < shard_block) ++block_log2;
     if (n == 0) return OVO_OK;
-    OVO_REQUIRE(point_seg && mask_row && desc && acc && cnt && touched && n_touched, "null pointer");
+    OVO_REQUIRE(point_seg && mask_row && desc && acc && cnt && (touched == nullptr) == (n_touched == nullptr), "null pointer");
     OVO_REQUIRE((((uintptr_t)desc | (uintptr_t)acc) & 15) == 0 && D % 4 == 0, "acc/desc must be 16-byte aligned, D % 4 == 0");
     k_scatter_accum<<<ovo_grid((n + 63) / 64 * 64, 256), 256, 0, (hipStream_t)stream>>>(point_seg, n, mask_row, n_masks,
-                                                                                       desc, D, acc, cnt, touched, n_touched);
+                                                                                       desc, D, acc, cnt, touched, n_touched, n_next,
+                                                                                       shard_rank, shard_count, block_log2);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

@@ -88,6 +88,7 @@ class OVO:
         self.keyframes = {"ins_descriptors": dict(), "frame_id": list(), "ins_maps": list()}
         self.keyframes_queue = deque([])
         self._prefetched_batch: Dict[int, tuple] = {}
+        self._planned_kfs: set = set()                # keyframes whose descriptors are planned (rows decided) but not stored yet
         self.objects: Dict[int, Instance3D] = dict()
         self._time_cache: List[float] = []
         self.next_ins_id = 0
@@ -275,25 +276,51 @@ class OVO:
             self._compute_semantic_info()
 
     def _compute_semantic_info(self) -> None:
-        """Reference: ovo.py:334-364."""
-        matched_ins_ids, binary_maps, image, kf_id = self.keyframes_queue.popleft()
-        if len(matched_ins_ids) == 0:
+        """Reference: ovo.py:334-364 = plan (which descriptors, which instances re-fuse from which keyframes) -> extract -> apply."""
+        plan = self._plan_semantic_info()
+        if plan is None:
             return
-        if self.n_top_views > 0:
-            rows = [j for j, i in enumerate(matched_ins_ids) if self.objects[i].is_top_kf(kf_id)]
-            if not rows:
-                return
-            if len(rows) != len(matched_ins_ids):
-                matched_ins_ids = [matched_ins_ids[j] for j in rows]
-                binary_maps = binary_maps[torch.tensor(rows, device=binary_maps.device)]
-        clip_embeds = self._extract_clip(image, binary_maps)
-        self.last_clip_embeds, self.last_clip_ins_ids, self.last_clip_kf = clip_embeds, matched_ins_ids, kf_id
-        self._update_matched_objects_clip(clip_embeds, matched_ins_ids, kf_id)
+        clip_embeds = self._extract_clip(plan["image"], plan["binary_maps"])
+        self._apply_semantic_plan(plan, clip_embeds)
         if self.config.get("log", False) and self.logger is not None:
-            self.logger.log_ovo_stats({"frame_id": self.keyframes["frame_id"][kf_id],
+            self.logger.log_ovo_stats({"frame_id": self.keyframes["frame_id"][plan["kf_id"]],
                                        "t_clip": round(self._time_cache[0], 2), "t_up": round(self._time_cache[1], 3)},
                                       print_output=True)
         self._time_cache = []
+
+    def _plan_semantic_info(self) -> Optional[Dict[str, Any]]:
+        """The host half of ovo.py:334-364 / :440-461 for the oldest queued keyframe, decided NOW from the instances' state: which masks
+        get a descriptor (top-k view filter, :342-349) and which instances re-fuse from which keyframes' descriptors (`to_update`, the
+        top-k heap / keyframe list: instance3d.py:157-189).  Nothing here needs the descriptors themselves, so a frame-sharded run
+        (pipeline.py) plans every keyframe on every rank right after tracking it and applies the descriptors --
+        computed by the rank that owns the frame -- later, in keyframe order, with exactly the result of the one-process order."""
+        matched_ins_ids, binary_maps, image, kf_id = self.keyframes_queue.popleft()
+        if len(matched_ins_ids) == 0:
+            return None
+        if self.n_top_views > 0:
+            rows = [j for j, i in enumerate(matched_ins_ids) if self.objects[i].is_top_kf(kf_id)]
+            if not rows:
+                return None
+            if len(rows) != len(matched_ins_ids):
+                matched_ins_ids = [matched_ins_ids[j] for j in rows]
+                binary_maps = binary_maps[torch.tensor(rows, device=binary_maps.device)]
+        self._planned_kfs.add(kf_id)
+        updates = []
+        for ins_id in matched_ins_ids:
+            obj = self.objects[ins_id]
+            if not obj.to_update:
+                continue
+            views = [kf for kf in obj.fusion_views() if kf in self._planned_kfs or kf in self.keyframes["ins_descriptors"]]
+            if views:
+                updates.append((ins_id, views))
+                obj.to_update = False
+        return {"kf_id": kf_id, "matched_ins_ids": matched_ins_ids, "binary_maps": binary_maps, "image": image, "updates": updates}
+
+    def _apply_semantic_plan(self, plan: Dict[str, Any], clip_embeds: torch.Tensor) -> None:
+        """The device half: store the keyframe's descriptors, then re-fuse the planned instances in ONE launch (ovo.py:440-461)."""
+        kf_id, matched_ins_ids = plan["kf_id"], plan["matched_ins_ids"]
+        self.last_clip_embeds, self.last_clip_ins_ids, self.last_clip_kf = clip_embeds, matched_ins_ids, kf_id
+        self._store_and_fuse(clip_embeds, matched_ins_ids, kf_id, plan["updates"])
 
     def prefetch_image_features(self, image, image_ready=None) -> bool:
         """MI355X extension (no counterpart in the reference): start the mask-independent half of `_extract_clip` -- the
@@ -406,22 +433,27 @@ class OVO:
         return out
 
     @_timed("t_up")
-    def _update_matched_objects_clip(self, clip_embeds: torch.Tensor, matched_ins_ids: List[int], kf_id: int) -> None:
-        """Reference: ovo.py:440-461; all touched instances are fused in one launch."""
+    def _store_and_fuse(self, clip_embeds: torch.Tensor, matched_ins_ids: List[int], kf_id: int, updates) -> None:
         rows = self.bank.append(clip_embeds)
         self.keyframes["ins_descriptors"][kf_id] = KeyframeView(
             self.bank, {i: rows[j] for j, i in enumerate(matched_ins_ids) if i != -1})
+        self._planned_kfs.discard(kf_id)
+        self.bank.fuse([(ins_id, [self.keyframes["ins_descriptors"][kf].row(ins_id) for kf in views]) for ins_id, views in updates],
+                       Instance3D.mv_fusion)
+
+    def _update_matched_objects_clip(self, clip_embeds: torch.Tensor, matched_ins_ids: List[int], kf_id: int) -> None:
+        """Reference: ovo.py:440-461; all touched instances are fused in one launch."""
+        self._planned_kfs.add(kf_id)
         updates = []
         for ins_id in matched_ins_ids:
             obj = self.objects[ins_id]
             if not obj.to_update:
                 continue
-            views = [self.keyframes["ins_descriptors"][kf].row(ins_id) for kf in obj.fusion_views()
-                     if kf in self.keyframes["ins_descriptors"]]
+            views = [kf for kf in obj.fusion_views() if kf in self._planned_kfs or kf in self.keyframes["ins_descriptors"]]
             if views:
                 updates.append((ins_id, views))
                 obj.to_update = False
-        self.bank.fuse(updates, Instance3D.mv_fusion)
+        self._store_and_fuse(clip_embeds, matched_ins_ids, kf_id, updates)
 
     def update_objects_clip(self, force_update: bool = False) -> None:
         for obj in self.objects.values():

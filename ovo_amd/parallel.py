@@ -1,13 +1,13 @@
 """Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm) / gloo on CPU.
 
 The reference is single-process (no collective anywhere).  The path shards at frame granularity
-(SURVEY.md §8e): the heavy per-frame work -- SAM2 encoder, ViT forward, region pooling, project / match / vote --
-is independent per frame, so rank r takes frames r, r+N, ...  The ONE exchange step is a sum-reduce of the
-descriptor accumulators (`avg_pooling` fusion is a mean = sum / count, instance3d.py:19-21, hence all-reducible):
-    * per step  : instance-level delta tables  sum f32[S, D] + cnt f32[S]   (a few MB -- latency bound)
-    * on demand : the dense per-point accumulators acc f32[N, D] + cnt i32[N] (GBs; bucketed so that every xGMI
-                  link carries 1/N of each bucket -- RCCL picks the direct all-to-all algorithm on a fully
-                  connected 8-GPU node; we only choose the bucket size)
+(SURVEY.md §8e): the heavy per-frame work -- SAM2 encoder (+ mask generator), ViT forward, region pooling -- is independent per
+frame, so in a round of N keyframes rank r owns keyframe r; the order-dependent integer passes run replicated (pipeline.py).
+The ONE exchange of a round is `allgather` of the owners' descriptors (f32[128, D] per rank: KBs, latency-bound over xGMI); the dense
+per-point accumulators are SHARDED by point, never reduced: every rank applies the gathered descriptors to its own rows in keyframe
+order, so the shards equal a single accumulator bit for bit (a floating-point all-reduce of per-GPU partial sums would not).
+`allreduce_dense_` (the bucketed sum of whole accumulators, north_star's "single RCCL reduce") stays for accumulators that were built
+independently -- e.g. two maps of the same scene merged offline; it is not on the keyframe path.
 No NCCL call pattern is translated from anywhere: there is none in the reference.
 """
 from __future__ import annotations
@@ -84,6 +84,23 @@ def allgather_rows(rows: torch.Tensor) -> torch.Tensor:
     out[r].copy_(rows)
     dist.all_reduce(out, op=dist.ReduceOp.SUM)
     return out.reshape(w * rows.shape[0], *rows.shape[1:])
+
+
+def allgather(t: torch.Tensor) -> torch.Tensor:
+    """Every rank contributes `t` (same shape and dtype everywhere) and receives all of them, [world, *t.shape], rank-major -- the
+    exchange of a round of keyframes (descriptors: KBs) and of the dense shards (export / tests).  RCCL: one all_gather.  gloo (CPU
+    tests, two ranks on one GPU): the sum-reduce of a zero buffer in which each rank fills its slice -- the bytes are exact either way
+    (x + 0 = x; the sign of a zero is not preserved, NaN stays NaN)."""
+    w = world_size()
+    if w == 1:
+        return t[None]
+    out = torch.zeros((w,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, t.contiguous())
+        return out
+    out[dist.get_rank()].copy_(t)
+    dist.all_reduce(out, op=dist.ReduceOp.SUM)
+    return out
 
 
 def allreduce_dense_(acc: torch.Tensor, cnt: torch.Tensor, bucket_bytes: int = DENSE_BUCKET_BYTES) -> int:

@@ -11,10 +11,24 @@ keyframe (map_every = segment_every = 1, kf_queue_delay = 0), wired from this pa
     query                                 instance table x texts (+argmax) and dense map x texts (a21-a22)
 
 It is what bench.py times and what smoke() runs small; it adds no arithmetic of its own.
+
+Several GPUs (one process each): a ROUND is `world` consecutive keyframes, keyframe k of the round OWNED by rank k.
+  * heavy, frame-independent work -- SAM2 encoder (+ mask generator), ViT tokens, region pooling -- runs on the owner only;
+  * the order-dependent integer passes -- back-projection append (vanilla_mapper.py:81-85), cull / project / vote / instance-id
+    allocation (ovo.py:255-282) -- run on EVERY rank for EVERY keyframe of the round in keyframe order against a replicated map: they
+    are deterministic, so all replicas stay bit-identical with no message at all (what they need of a foreign frame is its depth, pose
+    and masks: inputs every rank receives; masks produced by a rank's own SAM2 are exchanged bit-packed, `share_masks`);
+  * the ONE exchange of a round: an all-gather of the owners' descriptors f32[<= 128, D] (KBs over xGMI / RCCL); every rank then stores and
+    re-fuses them in keyframe order (`OVO._apply_semantic_plan`), so the instance tables are identical too;
+  * the dense per-point accumulators are SHARDED by point (block-cyclic): each rank applies every keyframe's descriptors to its own
+    rows, in keyframe order -- the merged accumulator is the concatenation of the shards and equals the one-process accumulator bit
+    for bit (a floating-point all-reduce of per-GPU partial sums would not); the dense query runs on the local rows only.
+tests/test_gpu_multirank.py runs two ranks on one GPU and asserts equality with the one-process run.
 """
 from __future__ import annotations
 
 import os
+import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -74,12 +88,17 @@ def synthetic_frames(n: int, device, scale: float = 1.0, n_masks_grid=(4, 6), n_
 
 
 class FramePipeline:
+    SHARD_BLOCK = 4096          # points per block of the block-cyclic dense-accumulator shards
+    MAX_DESC = 128              # descriptor rows a keyframe contributes to the exchange (masks per frame <= 128)
+
     def __init__(self, device="cuda", vit_card: str = "PE-Core-L14-336", sam_card: Optional[str] = "hiera_b+",
                  n_map: int = 1_000_000, n_text: int = 10, dense: bool = True, scale: float = 1.0, extra_capacity: int = 4_000_000,
                  seed: int = 0, depth_filter: bool = True, track_th: int = 100, sam_full: bool = False, points_per_side: int = 16,
-                 encoder_batch: int = 1):
+                 encoder_batch: int = 1, k_top_views: int = 10000):
         self.device = torch.device(device)
         self.scale = scale
+        self.rank = torch.distributed.get_rank() if parallel.world_size() > 1 else 0
+        self.world = parallel.world_size()
         self.crop_edge = int(round(syn.SCANNET["crop_edge"] * scale))
         K = torch.from_numpy(syn.scannet_intrinsics(scale)).to(self.device)
         self.slam = VanillaMapper({"device": str(self.device), "mapping": {"k_pooling": 3}}, K)
@@ -90,7 +109,7 @@ class FramePipeline:
                                     "color": torch.zeros((n_map, 3), dtype=torch.uint8)})
         self.slam._reserve(n_map + extra_capacity)
         self.masks = ResidentMasks()
-        clip_cfg = {"embed_type": "TextRegion", "model_card": vit_card, "k_top_views": 10000, "fusion": "avg_pooling", "seed": seed}
+        clip_cfg = {"embed_type": "TextRegion", "model_card": vit_card, "k_top_views": k_top_views, "fusion": "avg_pooling", "seed": seed}
         self.clip = CLIPGenerator(clip_cfg, device=str(self.device), encoder=HipViT(VIT_SPECS[vit_card], None, self.device, seed))
         cfg = {"match_distance_th": 0.05, "track_th": track_th, "depth_filter": depth_filter, "log": False, "kf_queue_delay": 0,
                "debug_info": False, "clip": clip_cfg, "sam": {"precomputed": True}}
@@ -102,52 +121,47 @@ class FramePipeline:
             from .encoders.sam_decoder import SPECS as DEC_SPECS, HipSamDecoder
             from .entities.sam_amg import HipSam2AutomaticMaskGenerator
             self.amg = HipSam2AutomaticMaskGenerator(self.sam, HipSamDecoder(DEC_SPECS["sam2"], None, self.device, seed), points_per_side=points_per_side)
-        # encoder look-ahead: the two encoders of `encoder_batch` consecutive keyframes run as ONE batched forward each (step() is
-        # handed the upcoming frames).  Nothing of the encoders depends on the map, and the reference itself computes a keyframe's
-        # descriptors kf_queue_delay = 10 keyframes late (ovo.yaml:53), so this changes no result -- only the GEMM height.
+        # encoder look-ahead: the two encoders of `encoder_batch` consecutive keyframes (of this rank) run as ONE batched forward each
+        # (step() is handed the upcoming frames).  Nothing of the encoders depends on the map, and the reference itself computes a
+        # keyframe's descriptors kf_queue_delay = 10 keyframes late (ovo.yaml:53), so this changes no result -- only the GEMM height.
         self.encoder_batch = max(1, int(encoder_batch)) if not sam_full else 1
         self._encoded: Dict[int, bool] = {}
         self.serial = False                                        # measurement only: both encoders on the caller's stream
         self._group_first: Dict[int, int] = {}
         self._sam_in = None
+        self._sam_by_frame: Dict[int, tuple] = {}
+        self.sam_frame = None                                      # SAM2 features (f0, f1, f2) of the keyframe this rank last stepped
         self.prefetch = not os.environ.get("OVO_NO_PREFETCH")
         self.join_each_step = bool(os.environ.get("OVO_JOIN_EACH_STEP"))
         self.sam_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("OVO_SAM_PRIORITY", "0"))) if (sam_card and not os.environ.get("OVO_SAM_SAME_STREAM")) else None
         self.D = self.clip.clip_dim
         self.texts = torch.from_numpy(syn.unit_vectors(n_text, self.D, seed=seed + 7)).to(self.device)
         self.dense = dense
-        self.n_shared = n_map
+        self.exchange_ms = 0.0                                     # host wall time spent in the rounds' collectives (bench.py reports it)
+        self.exchanges = 0
         if dense:
             cap = self.slam._cap
-            self.acc = torch.zeros((cap, self.D), dtype=torch.float32, device=self.device)
-            self.cnt = torch.zeros(cap, dtype=torch.int32, device=self.device)
-        self.inst_delta = torch.zeros((4096, self.D), dtype=torch.float32, device=self.device)
-        self.inst_delta_cnt = torch.zeros(4096, dtype=torch.float32, device=self.device)
-        self.xchg = torch.zeros((128, 1 + self.D), dtype=torch.float32, device=self.device)     # per-step exchange rows: slot | descriptor
+            blocks = -(-cap // self.SHARD_BLOCK)
+            self.rows_local = -(-blocks // self.world) * self.SHARD_BLOCK if self.world > 1 else cap    # rows of THIS rank's shard
+            self.acc = torch.zeros((self.rows_local, self.D), dtype=torch.float32, device=self.device)
+            self.cnt = torch.zeros(self.rows_local, dtype=torch.int32, device=self.device)
+            # The dense class / confidence map stays RESIDENT: a keyframe changes the accumulators of the points it matched (10-20 % of
+            # the map) and only those rows can change class, so the scatter pass emits their indices and the query re-evaluates just
+            # them (`ovo_similarity_rows`) -- bit-identical to re-querying all rows (tests/test_gpu_pipeline.py), a fraction of the 5 GB
+            # stream.  Initial state = the query of the empty accumulators, computed once here over the whole capacity.
+            self.incremental_query = self.D % 16 == 0 and not os.environ.get("OVO_DENSE_FULL_QUERY")
+            if self.incremental_query:
+                _, self.dense_cls, self.dense_conf = clip_utils.similarity(self.acc, self.texts, cnt=self.cnt, want_sim=False, want_argmax=True)
+                self.touched = torch.empty(self.rows_local, dtype=torch.int32, device=self.device)
+                self.n_touched = torch.zeros(2, dtype=torch.int32, device=self.device)     # two counters, used alternately
+                self._touch_parity = 0
         self.last: Dict[str, object] = {}
-        if parallel.world_size() > 1:
-            # one exchange with nothing to send: every torch kernel variant of the fold is loaded here, not inside a timed
-            # step (a first use costs 100-150 ms on ROCm; with several ranks loading at once, seconds were measured)
-            self._exchange(torch.zeros((1, self.D), dtype=torch.float32, device=self.device), [0])
-            self.inst_delta.zero_(); self.inst_delta_cnt.zero_()
+        if self.world > 1:
+            self.xchg = torch.zeros((self.MAX_DESC, self.D), dtype=torch.float32, device=self.device)
+            parallel.allgather(self.xchg)                          # first use of the collective (and of its kernels) outside any timed step
             torch.cuda.synchronize()
 
-    def _exchange(self, desc: Optional[torch.Tensor], slots: List[int]) -> None:
-        """The one exchange step of the frame-sharded ranks: this keyframe's descriptor contributions as a FIXED-SIZE gather
-        of the touched rows (slot | descriptor), issued by EVERY rank on EVERY step -- a rank whose frame matched nothing
-        sends rows flagged -1, it never skips the collective.  Every rank folds everyone's rows into its instance table."""
-        self.xchg[:, 0] = -1.0
-        if desc is not None:
-            k = min(desc.shape[0], self.xchg.shape[0])
-            self.xchg[:k, 0] = torch.tensor(slots[:k], dtype=torch.float32).to(self.device, non_blocking=True)
-            self.xchg[:k, 1:] = desc[:k]
-        rows = parallel.allgather_rows(self.xchg)
-        valid = rows[:, 0] >= 0
-        idx = rows[:, 0].clamp(min=0).long()
-        self.inst_delta.index_add_(0, idx, rows[:, 1:] * valid[:, None])
-        self.inst_delta_cnt.index_add_(0, idx, valid.float())
-
-    # ------------------------------------------------------------------ one keyframe
+    # ------------------------------------------------------------------ encoders
     def _launch_encoders(self, group: List[Frame]) -> None:
         """SAM2 image encoder and ViT forward of a group of keyframes, each as one batched forward on its side stream."""
         if self.sam is not None:
@@ -162,6 +176,8 @@ class FramePipeline:
                 for k, g in enumerate(group):
                     self.sam.preprocess(g.rgb.permute(2, 0, 1).contiguous(), out=self._sam_in[k:k + 1])
                 self.sam_out = self.sam.forward(self._sam_in[:len(group)])
+                for k, g in enumerate(group):                      # a frame's features = slice k of the batched output
+                    self._sam_by_frame[g.index] = (self.sam_out, k)
         if self.prefetch:
             self.ovo.prefetch_image_features_batch([g.rgb for g in group], [g.ready for g in group if g.ready is not None],
                                                    stream=torch.cuda.current_stream() if self.serial else None)
@@ -169,25 +185,22 @@ class FramePipeline:
             self._encoded[g.index] = True
         self._group_first[group[0].index] = len(group)
 
-    def step(self, f: Frame, upcoming: Optional[List[Frame]] = None) -> Dict[str, object]:
-        """One keyframe.  `upcoming`: the frames that follow (only read when encoder_batch > 1: the next encoder_batch - 1 of them
-        are encoded together with `f` when `f` has not been encoded yet)."""
-        lib = L.load()
-        self.masks.frames = {f.index: f}
-        amg_pending = None
+    def _encoders_for(self, f: Frame, mine_upcoming: List[Frame]):
+        """Start the encoders `f` needs (and, with look-ahead batching, those of this rank's next frames).  Returns the pending mask
+        generator call of `f`, if the pipeline runs SAM2 end to end."""
         if self.encoder_batch > 1:
-            upcoming = list(upcoming or [])
             if f.index not in self._encoded:
-                self._launch_encoders([f] + upcoming[:self.encoder_batch - 1])
+                self._launch_encoders([f] + mine_upcoming[:self.encoder_batch - 1])
             n_group = self._group_first.pop(f.index, 0)
             if n_group:                                            # first frame of its group: the NEXT group's encoders start now, so
-                nxt = [g for g in upcoming[n_group - 1:n_group - 1 + self.encoder_batch] if g.index not in self._encoded]   # that they
+                nxt = [g for g in mine_upcoming[n_group - 1:n_group - 1 + self.encoder_batch] if g.index not in self._encoded]   # that they
                 if nxt:                                            # run beside this group's tracking / pooling / fusion / queries
                     self._launch_encoders(nxt)
             self._encoded.pop(f.index, None)
-            return self._step_main(f, lib, amg_pending)
-        # The two encoders first: nothing of theirs depends on the map, and the map update below ends in a host sync (the
-        # count of new points) behind which the host could not launch them.
+            return None
+        amg_pending = None
+        # The two encoders first: nothing of theirs depends on the map, and the map update ends in a host sync (the count of new
+        # points) behind which the host could not launch them.
         if self.sam is not None:                                   # SAM2 image encoder (masks come from the seam)
             # Independent of the tracking / descriptor work of this frame: it runs on its own HIP stream so that the two
             # kernel sequences fill each other's tails (most launches here are one or two workgroup rounds long).
@@ -199,38 +212,92 @@ class FramePipeline:
                     amg_pending = self.amg.generate_launch(f.rgb)
                 else:
                     self.sam_out = self.sam.forward(self.sam.preprocess(f.rgb.permute(2, 0, 1).contiguous()))
+                    self._sam_by_frame[f.index] = (self.sam_out, 0)
         if self.prefetch:                                          # ViT tokens do not depend on the masks: start them now
             self.ovo.prefetch_image_features(f.rgb, f.ready)
-        return self._step_main(f, lib, amg_pending)
+        return amg_pending
 
-    def _step_main(self, f: Frame, lib, amg_pending) -> Dict[str, object]:
-        fd = [f.index, f.rgb_lr, f.depth, f.c2w]
-        self.slam.track_camera(fd)
-        c2w = self.slam._c2w_host[f.index]                         # host copy: no D2H for the frustum set-up
-        self.slam.map(fd, c2w)
-        ratio = (1.0, 1.0, self.crop_edge) if self.crop_edge else ()
-        updated = self.ovo.detect_and_track_objects([f.index, f.rgb, f.depth, ratio], self.slam.get_map(), c2w)
-        if updated is not None:
-            self.slam.update_pcd_obj_ids(updated)
-        self.ovo.compute_semantic_info()
+    # ------------------------------------------------------------------ one keyframe (one process) / one round (several)
+    def step(self, f: Frame, upcoming: Optional[List[Frame]] = None) -> Dict[str, object]:
+        """One keyframe on one GPU.  `upcoming`: the frames that follow (only read when encoder_batch > 1: the next ones are encoded
+        together with `f` when `f` has not been encoded yet)."""
+        if self.world > 1:
+            raise L.OvoHipError("several ranks step whole rounds: use step_round()")
+        return self.step_round([f], upcoming)
+
+    def step_round(self, group: List[Frame], upcoming: Optional[List[Frame]] = None) -> Dict[str, object]:
+        """`world` consecutive keyframes, keyframe k owned by rank k (one process: a round is one keyframe).  `upcoming`: the frames
+        after the round, in order (their owners follow the same k = position % world rule)."""
+        lib = L.load()
+        if len(group) != self.world:
+            raise L.OvoHipError(f"a round is {self.world} keyframes, got {len(group)}")
+        upcoming = list(upcoming or [])
+        mine = group[self.rank]
+        self.masks.frames = {f.index: f for f in group}
+        amg_pending = self._encoders_for(mine, upcoming[self.rank::self.world])
+        hit = self._sam_by_frame.pop(mine.index, None)
+        if hit is not None:
+            self.sam_frame = tuple(t[hit[1]:hit[1] + 1] for t in hit[0])
+        # ---- the order-dependent passes, for every keyframe of the round, on every rank (replicated map and tracker)
+        plans, segs = [], []
+        for f in group:
+            fd = [f.index, f.rgb_lr, f.depth, f.c2w]
+            self.slam.track_camera(fd)
+            c2w = self.slam._c2w_host[f.index]                     # host copy: no D2H for the frustum set-up
+            self.slam.map(fd, c2w)
+            ratio = (1.0, 1.0, self.crop_edge) if self.crop_edge else ()
+            updated = self.ovo.detect_and_track_objects([f.index, f.rgb, f.depth, ratio], self.slam.get_map(), c2w)
+            if updated is not None:
+                self.slam.update_pcd_obj_ids(updated)
+            plans.append(self.ovo._plan_semantic_info() if len(self.ovo.keyframes_queue) > 0 else None)
+            segs.append((self.ovo.last_point_seg, self.ovo.last_mask_rows))
         n = self.slam._n
-        desc = getattr(self.ovo, "last_clip_embeds", None)
-        if desc is not None and self.ovo.last_clip_kf == self.ovo.kf_id - 1 and desc.shape[0] > 0:
-            if self.dense:
-                rows = torch.tensor(self.ovo.last_mask_rows, dtype=torch.int32).to(self.device, non_blocking=True)
-                L.check(lib.ovo_scatter_accum(L.ptr(self.ovo.last_point_seg), self.ovo.last_point_seg.shape[0], L.ptr(rows), rows.shape[0],
-                                              L.ptr(desc), self.D, L.ptr(self.acc), L.ptr(self.cnt), L.stream()))
+        # ---- descriptors of the keyframe this rank owns, then the round's one exchange
+        plan = plans[self.rank]
+        desc_mine = self.ovo._extract_clip(plan["image"], plan["binary_maps"]) if plan is not None else None
+        if self.world > 1:
+            t0 = time.perf_counter()
+            self.xchg.zero_()
+            if desc_mine is not None:
+                if desc_mine.shape[0] > self.MAX_DESC:
+                    raise L.OvoHipError(f"{desc_mine.shape[0]} descriptors in one keyframe: raise FramePipeline.MAX_DESC")
+                self.xchg[:desc_mine.shape[0]].copy_(desc_mine)
+            gathered = parallel.allgather(self.xchg)               # [world, MAX_DESC, D]: every owner's descriptors, rank-major = keyframe order
+            descs = [gathered[k, :len(p["matched_ins_ids"])] if p is not None else None for k, p in enumerate(plans)]
+            self.exchange_ms += 1e3 * (time.perf_counter() - t0)
+            self.exchanges += 1
         else:
-            desc = None
-        if parallel.world_size() > 1:
-            self._exchange(desc, [self.ovo.bank.slot_of[i] % 4096 for i in self.ovo.last_clip_ins_ids] if desc is not None else [])
+            descs = [desc_mine]
+        # ---- every rank: store + re-fuse in keyframe order (identical instance tables), dense accumulate on its own rows
+        for p, d, (point_seg, mask_rows) in zip(plans, descs, segs):
+            if p is None:
+                continue
+            self.ovo._apply_semantic_plan(p, d)
+            if self.dense and d.shape[0] > 0:
+                rows = torch.tensor(mask_rows, dtype=torch.int32).to(self.device, non_blocking=True)
+                touched, n_cur, n_nxt = None, None, None
+                if self.incremental_query:
+                    k = self._touch_parity
+                    self._touch_parity ^= 1
+                    touched, n_cur, n_nxt = L.ptr(self.touched), self.n_touched[k:].data_ptr(), self.n_touched[k ^ 1:].data_ptr()
+                L.check(lib.ovo_scatter_accum_touched(L.ptr(point_seg), point_seg.shape[0], L.ptr(rows), rows.shape[0], L.ptr(d), self.D,
+                                                      L.ptr(self.acc), L.ptr(self.cnt), touched, n_cur, n_nxt, self.rank, self.world,
+                                                      self.SHARD_BLOCK, L.stream()))
+                if self.incremental_query:                         # only the rows this keyframe changed can change class
+                    L.check(lib.ovo_similarity_rows(L.ptr(self.acc), 0, touched, n_cur, min(point_seg.shape[0], self.rows_local), self.D,
+                                                    L.ptr(self.texts), self.texts.shape[0], L.ptr(self.cnt), 0, 0.0, 0.0, 0.0,
+                                                    L.ptr(self.dense_cls), L.ptr(self.dense_conf), L.stream()))
         out: Dict[str, object] = {"n_points": n, "n_instances": len(self.ovo.objects)}
         if len(self.ovo.objects) > 0:                              # query: instances x texts, fused argmax
             table = self.ovo.get_objs_clips()
             out["sim"], out["cls"], out["conf"] = clip_utils.similarity(table, self.texts, want_argmax=True)
-        if self.dense:                                             # dense query: per-point mean descriptor x texts
-            _, out["dense_cls"], out["dense_conf"] = clip_utils.similarity(self.acc[:n], self.texts, cnt=self.cnt[:n], want_sim=False,
-                                                                           want_argmax=True)
+        if self.dense:
+            nl = self.local_rows(n)
+            if self.incremental_query:                             # the resident map, patched above for the rows the round changed
+                out["dense_cls"], out["dense_conf"] = self.dense_cls[:nl], self.dense_conf[:nl]
+            else:                                                  # dense query: per-point mean descriptor x texts, every (local) row
+                _, out["dense_cls"], out["dense_conf"] = clip_utils.similarity(self.acc[:nl], self.texts, cnt=self.cnt[:nl], want_sim=False,
+                                                                               want_argmax=True)
         if amg_pending is not None:                                # host filter + NMS + binarise: by now the statistics are long there
             self.sam_out = self.amg.generate_finish(amg_pending)
         if self.join_each_step:                                    # strict frame boundaries (tests); the stream of frames is
@@ -238,17 +305,41 @@ class FramePipeline:
         self.last = out
         return out
 
+    # ------------------------------------------------------------------ dense shards
+    def local_rows(self, n: int) -> int:
+        """Rows of this rank's shard that hold points of a map with n points (block-cyclic, blocks of SHARD_BLOCK points)."""
+        if self.world == 1:
+            return n
+        B, R, r = self.SHARD_BLOCK, self.world, self.rank
+        full, rem = divmod(n, B)                                   # `full` complete blocks, then one of `rem` points
+        mine = (full - r + R - 1) // R if full > r else 0          # complete blocks owned by r
+        return mine * B + (rem if full % R == r else 0)
+
+    def gather_dense(self, n: Optional[int] = None):
+        """The whole dense state on every rank, in point order: (acc f32[n, D], cnt i32[n], cls i64[n], conf f32[n]).  The concatenation
+        of the shards -- no arithmetic, so it equals the one-process accumulators bit for bit.  A map-sized collective: for export /
+        tests, never inside the keyframe loop (queries run on the shards)."""
+        n = self.slam._n if n is None else n
+        if self.world == 1:
+            inc = getattr(self, "incremental_query", False)
+            return self.acc[:n], self.cnt[:n], self.dense_cls[:n] if inc else None, self.dense_conf[:n] if inc else None
+        B, R = self.SHARD_BLOCK, self.world
+        nb = -(-n // B)
+        per = -(-nb // R)                                          # blocks per rank (the last rank's may be short / absent)
+        rows = per * B
+
+        def merge(local: torch.Tensor) -> torch.Tensor:
+            g = parallel.allgather(local[:rows].contiguous())      # [R, per * B, ...]
+            g = g.reshape(R, per, B, *local.shape[1:]).transpose(0, 1).reshape(per * R * B, *local.shape[1:])   # block b = (b // R, b % R)
+            return g[:n]
+        return merge(self.acc), merge(self.cnt), merge(self.dense_cls) if self.incremental_query else None, \
+            merge(self.dense_conf) if self.incremental_query else None
+
     def join(self) -> None:
         """Make the main stream wait for the SAM2 and ViT streams (everything of the frames stepped so far)."""
         for side in (self.sam_stream, self.ovo._vit_stream):
             if side is not None and side != torch.cuda.current_stream():
                 torch.cuda.current_stream().wait_stream(side)
-
-    def merge_dense(self) -> int:
-        """Merge the per-GPU dense accumulators over xGMI (called once per batch of frames / before a global query).
-        Only the points every rank shares -- the map all replicas started from -- are merged: each rank appends its own
-        frames' points after them, so sizes beyond `n_shared` differ per rank and a collective over them would mismatch."""
-        return parallel.allreduce_dense_(self.acc[:self.n_shared], self.cnt[:self.n_shared]) if self.dense else 0
 
     # ------------------------------------------------------------------ workload accounting (DESIGN.md §5)
     def flops_per_frame(self, h: int, w: int) -> Dict[str, float]:

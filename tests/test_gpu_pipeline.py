@@ -7,25 +7,25 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _run(prefetch: bool, side_stream: bool, pipelined: bool = False, n_frames: int = 4):
+def _run(prefetch: bool, side_stream: bool, pipelined: bool = False, n_frames: int = 4, encoder_batch: int = 1):
     from ovo_amd.pipeline import FramePipeline, synthetic_frames
     pipe = FramePipeline(DEV, vit_card="tiny-pe", sam_card="hiera_test", n_map=60_000, n_text=7, scale=0.35, extra_capacity=200_000,
-                         track_th=40)
+                         track_th=40, encoder_batch=encoder_batch)
     pipe.prefetch = prefetch
     pipe.join_each_step = not pipelined
     if not side_stream:
         pipe.sam_stream = None
     frames = synthetic_frames(n_frames, DEV, scale=0.35, n_masks_grid=(3, 4), n_blobs=4)
     trace = []
-    for f in frames:
-        out = pipe.step(f)
+    for i, f in enumerate(frames):
+        out = pipe.step(f, frames[i + 1:])
         if not pipelined:
             torch.cuda.synchronize()
         with torch.cuda.stream(pipe.sam_stream or torch.cuda.current_stream()):      # the SAM2 features live in a reused workspace
-            sam = [t.clone() for t in pipe.sam_out]
+            sam = [t.clone() for t in pipe.sam_frame]                                   # this frame's slice of the (batched) forward
         desc = pipe.ovo.last_clip_embeds
         trace.append({"n_points": out["n_points"], "n_instances": out["n_instances"], "cls": out.get("cls"), "sim": out.get("sim"),
-                      "dense_cls": out["dense_cls"], "dense_conf": out["dense_conf"], "desc": desc, "sam": sam})
+                      "dense_cls": out["dense_cls"].clone(), "dense_conf": out["dense_conf"].clone(), "desc": desc, "sam": sam})   # (the dense map is resident: copy this frame's state)
     torch.cuda.synchronize()                                     # pipelined: the only sync of the run
     for r in trace:
         for k in ("cls", "sim", "dense_cls", "dense_conf", "desc"):
@@ -67,3 +67,34 @@ def test_prefetch_falls_back_for_other_images():
     assert torch.equal(d_other, d_plain)
     assert pipe.ovo.prefetch_image_features(f0.rgb)
     assert torch.equal(pipe.ovo._extract_clip(f0.rgb, f0.masks[:5]), d_plain)
+
+
+def test_encoder_lookahead_batching_does_not_change_results():
+    """Several keyframes' crops per ViT forward and several frames per SAM2 forward (encoder_batch = 3, one group of look-ahead): every
+    descriptor, class, dense map and SAM2 feature is bit-identical to the frame-by-frame run -- a row of a GEMM / attention / LayerNorm
+    does not depend on how many other rows the launch carries (same k-order in every tile shape)."""
+    ref, _ = _run(prefetch=True, side_stream=True, n_frames=7)
+    got, pipe = _run(prefetch=True, side_stream=True, n_frames=7, encoder_batch=3, pipelined=True)
+    assert pipe.ovo._batch_slots is not None, "the batched prefetch did not run"
+    _check(ref, got, pipe)
+
+
+def test_incremental_dense_query_equals_full_requery():
+    """The resident dense class / confidence map, patched only for the rows a keyframe's scatter pass touched (ovo_scatter_accum_touched
+    -> ovo_similarity_rows), against a full re-query of every row after every keyframe: equal bit for bit, and the touched set is a
+    small part of the map."""
+    from ovo_amd.pipeline import FramePipeline, synthetic_frames
+    from ovo_amd.utils import clip_utils
+    pipe = FramePipeline(DEV, vit_card="tiny-pe", sam_card=None, n_map=60_000, n_text=7, scale=0.35, extra_capacity=200_000, track_th=40)
+    assert pipe.incremental_query
+    frames = synthetic_frames(5, DEV, scale=0.35, n_masks_grid=(3, 4), n_blobs=4)
+    fractions = []
+    for f in frames:
+        out = pipe.step(f)
+        n = out["n_points"]
+        _, cls, conf = clip_utils.similarity(pipe.acc[:n], pipe.texts, cnt=pipe.cnt[:n], want_sim=False, want_argmax=True)
+        assert torch.equal(out["dense_cls"], cls) and torch.equal(out["dense_conf"], conf)
+        touched = int(pipe.n_touched[pipe._touch_parity ^ 1].item())
+        assert touched == int((pipe.ovo.last_point_seg >= 0).sum().item()) or touched <= n      # every matched point of a kept mask, once
+        fractions.append(touched / n)
+    assert (out["dense_cls"] >= 0).any() and max(fractions) > 0 and max(fractions) < 0.6

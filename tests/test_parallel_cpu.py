@@ -34,6 +34,11 @@ def _worker(rank, world, port, out):
     # per-step exchange of the touched descriptor rows: fixed-size all-gather, rank-major
     rows = torch.full((4, 3), float(rank))
     rows[:, 0] = torch.tensor([rank, -1.0, rank + 10, -1.0])
+    g2 = parallel.allgather(torch.arange(6, dtype=torch.int32).reshape(2, 3) + 100 * rank)      # the round's exchange (any dtype)
+    assert g2.shape == (world, 2, 3) and all(torch.equal(g2[r2], torch.arange(6, dtype=torch.int32).reshape(2, 3) + 100 * r2) for r2 in range(world))
+    nan_row = torch.tensor([float("nan"), 1.5 + rank])
+    g3 = parallel.allgather(nan_row)                               # descriptors of empty masks are NaN: they must survive the exchange
+    assert torch.isnan(g3[:, 0]).all() and torch.equal(g3[:, 1], torch.tensor([1.5 + r2 for r2 in range(world)]))
     gathered = parallel.allgather_rows(rows)
     assert gathered.shape == (world * 4, 3)
     for r2 in range(world):
@@ -63,3 +68,31 @@ def test_single_process_is_a_noop():
     parallel.allreduce_sum_([x])
     assert parallel.world_size() == 1 and torch.equal(x, torch.ones(4)) and parallel.max_over_ranks(2.5, "cpu") == 2.5
     assert parallel.allreduce_dense_(torch.ones(4, 2), torch.ones(4, dtype=torch.int32)) == 0
+
+
+def test_dense_shard_bookkeeping():
+    """Block-cyclic point shards of the dense accumulators (pipeline.FramePipeline.local_rows / gather_dense): every point has exactly one
+    owner and one local row, local rows of a rank are dense in [0, local_rows(n)), and the merge order restores point order."""
+    from ovo_amd.pipeline import FramePipeline
+    B = 8
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 7, 8, 9, 16, 17, 63, 64, 65, 200):
+            owners = [[] for _ in range(world)]
+            for p in range(n):
+                blk = p // B
+                owners[blk % world].append(((blk // world) * B + p % B, p))
+            for r in range(world):
+                fake = type("P", (), {"world": world, "rank": r, "SHARD_BLOCK": B})()
+                nl = FramePipeline.local_rows(fake, n)
+                rows = sorted(lr for lr, _ in owners[r])
+                assert rows == list(range(nl)), (world, n, r, nl, rows[:5])
+            # merge: [world, per * B] -> block b = (b // world, b % world)
+            nb = -(-n // B)
+            per = -(-nb // world) if nb else 0
+            if per:
+                local = torch.full((world, per * B), -1, dtype=torch.int64)
+                for r in range(world):
+                    for lr, p in owners[r]:
+                        local[r, lr] = p
+                merged = local.reshape(world, per, B).transpose(0, 1).reshape(per * world * B)[:n]
+                assert torch.equal(merged, torch.arange(n))
