@@ -60,10 +60,11 @@ __device__ __forceinline__ bool depth_match(const ovo_camera_t &c, const float *
 // Ordered stream compaction: (A) one ballot word per 64 items, (B) single-block exclusive scan of the
 // word popcounts, (C) emit at offset + rank-in-word.  Output order == input order, which the reference's
 // boolean-mask indexing guarantees and pcd_ids depend on.
-// ws layout: u64 words[n_words] | i64 offs[n_words]
+// ws layout: u64 words[n_words] | i64 offs[n_words] | i64 sums[chunks]
 struct CompactWs {
     unsigned long long *words;
     long long *offs;
+    long long *sums;           // one total per SCAN_CHUNK words
     int64_t n_words;
 };
 
@@ -72,35 +73,115 @@ __host__ CompactWs carve(void *ws, int64_t n) {
     c.n_words = (n + 63) / 64;
     c.words = (unsigned long long *)ws;
     c.offs = (long long *)(c.words + c.n_words);
+    c.sums = c.offs + c.n_words;
     return c;
 }
 
-__global__ void __launch_bounds__(1024) k_scan_words(const unsigned long long *__restrict__ words, long long *__restrict__ offs,
-                                                     int64_t n_words, long long *__restrict__ total) {
-    __shared__ long long part[1024];
-    const int t = threadIdx.x;
-    const int64_t per = (n_words + 1023) / 1024;
-    const int64_t lo = t * per, hi = lo + per < n_words ? lo + per : n_words;
-    long long s = 0;
-    for (int64_t i = lo; i < hi; ++i) s += __popcll(words[i]);
-    part[t] = s;
+// (B) as three small launches (a single workgroup walking 156k words took 330 us of a 370 us frustum cull at 10 M points):
+//   k_scan_sums   one workgroup per SCAN_CHUNK words: total popcount of its chunk            -> sums[b]
+//   k_scan_bases  one workgroup: exclusive scan of the (few hundred) chunk totals, in place    -> sums[b] = base of chunk b, *total
+//   k_scan_words  one workgroup per chunk: exclusive scan of its words' popcounts + its base   -> offs[w]
+constexpr int SCAN_CHUNK = 2048;     // words per workgroup (256 threads x 8 consecutive words)
+
+__device__ __forceinline__ long long block_exclusive_scan(long long v, long long *sh, long long &block_total) {
+    // 256 threads: wave-level inclusive scan by shuffles, then the 4 wave totals through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) sh[wave] = inc;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan
-        long long v = t >= o ? part[t - o] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    long long before = 0;
+    for (int k = 0; k < wave; ++k) before += sh[k];
+    block_total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return before + inc - v;
+}
+
+__global__ void __launch_bounds__(256) k_scan_sums(const unsigned long long *__restrict__ words, int64_t n_words, long long *__restrict__ sums) {
+    __shared__ long long sh[4];
+    const int64_t w0 = (int64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x * 8;
+    long long c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (w0 + k < n_words) c += __popcll(words[w0 + k]);
+    long long total;
+    block_exclusive_scan(c, sh, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) k_scan_bases(long long *__restrict__ sums, int64_t n_chunks, long long *__restrict__ total) {
+    __shared__ long long sh[4];
+    long long run = 0;
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += 256) {             // 256 chunk totals per trip (10 M points: one trip)
+        const int64_t c = c0 + threadIdx.x;
+        const long long v = c < n_chunks ? sums[c] : 0;
+        long long tot;
+        const long long ex = block_exclusive_scan(v, sh, tot);
+        if (c < n_chunks) sums[c] = run + ex;
+        run += tot;
     }
-    long long run = part[t] - s;
-    for (int64_t i = lo; i < hi; ++i) {
-        offs[i] = run;
-        run += __popcll(words[i]);
+    if (threadIdx.x == 0 && total) *total = run;
+}
+
+__global__ void __launch_bounds__(256) k_scan_words(const unsigned long long *__restrict__ words, long long *__restrict__ offs,
+                                                    int64_t n_words, const long long *__restrict__ bases) {
+    __shared__ long long sh[4];
+    const int64_t w0 = (int64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x * 8;
+    int pc[8];
+    long long c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        pc[k] = w0 + k < n_words ? __popcll(words[w0 + k]) : 0;
+        c += pc[k];
     }
-    if (t == 1023 && total) *total = part[1023];
+    long long total;
+    long long run = bases[blockIdx.x] + block_exclusive_scan(c, sh, total);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (w0 + k < n_words) offs[w0 + k] = run;
+        run += pc[k];
+    }
+}
+
+// the scan of one compaction: words -> offs, *total = number of set bits
+__host__ void scan_words(const unsigned long long *words, long long *offs, long long *sums, int64_t n_words, long long *total, hipStream_t s) {
+    const int64_t chunks = (n_words + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    k_scan_sums<<<(unsigned)chunks, 256, 0, s>>>(words, n_words, sums);
+    k_scan_bases<<<1, 256, 0, s>>>(sums, chunks, total);
+    k_scan_words<<<(unsigned)chunks, 256, 0, s>>>(words, offs, n_words, sums);
+}
+
+template <typename Load, typename Pred>
+__device__ __forceinline__ void flag_words(int64_t n, unsigned long long *words, Load load, Pred pred) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t n_words = (n + 63) >> 6;
+    // four words (4 x 64 items) per wave and trip, the items' loads issued before any arithmetic (bytes in flight, see k_track_project)
+    for (int64_t wd0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wd0 < n_words; wd0 += 4 * waves) {
+        float4 p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = (wd0 + k * waves) * 64 + lane;
+            if (i < n) p[k] = load(i);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t wd = wd0 + k * waves;
+            if (wd >= n_words) break;
+            const int64_t i = wd * 64 + lane;
+            const bool ok = i < n && pred(p[k]);
+            const unsigned long long m = __ballot(ok);
+            if (lane == 0) words[wd] = m;
+        }
+    }
 }
 
 template <typename Pred>
-__device__ __forceinline__ void flag_words(int64_t n, unsigned long long *words, Pred pred) {
+__device__ __forceinline__ void flag_words_idx(int64_t n, unsigned long long *words, Pred pred) {     // pred(index): small inputs
     const int lane = threadIdx.x & 63;
     const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t n_words = (n + 63) >> 6;
@@ -129,7 +210,8 @@ __device__ __forceinline__ void emit_words(int64_t n, const unsigned long long *
 // ---- a2 ----
 __global__ void __launch_bounds__(256) k_frustum_flag(const float *__restrict__ pts, int64_t n, ovo_camera_t cam,
                                                       unsigned long long *words) {
-    flag_words(n, words, [&](int64_t i) { return in_frustum(cam, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]); });
+    flag_words(n, words, [&](int64_t i) { return make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], 1.0f); },
+               [&](float4 p) { return in_frustum(cam, p.x, p.y, p.z); });
 }
 __global__ void __launch_bounds__(256) k_frustum_emit(int64_t n, const unsigned long long *words, const long long *offs,
                                                       int64_t *out_idx) {
@@ -151,8 +233,10 @@ __global__ void __launch_bounds__(256) k_match_flag(const float *__restrict__ pt
                                                     const float *__restrict__ depth, unsigned long long *words) {
     flag_words(n, words, [&](int64_t i) {
         const float *p = pts + i * stride;
+        return make_float4(p[0], p[1], p[2], stride == 4 ? p[3] : 1.0f);
+    }, [&](float4 p) {
         float zc; int u, v;
-        project(cam, p[0], p[1], p[2], stride == 4 ? p[3] : 1.0f, zc, u, v);
+        project(cam, p.x, p.y, p.z, p.w, zc, u, v);
         return depth_match(cam, depth, zc, u, v);
     });
 }
@@ -184,24 +268,64 @@ __device__ __forceinline__ void wave_hist_add(int32_t *hist, int cell, bool acti
     }
 }
 
+// A workgroup's survivors of the cheap frustum test are compacted through LDS before the expensive part runs.  PMC at 10 M points
+// (profiles/r02_geom_sq_counters.txt): with every lane walking the whole chain the pass issued 4.5x the VALU instructions of the plain
+// frustum flag pass -- nearly every wave holds a few in-frustum lanes, so the projection (five IEEE divisions, strict-rounding FMA
+// chains) ran for all of them at ~8 % lane use, and the pass sat at 1.7 TB/s VALU-bound.  Compacted, that chain runs on full waves.
+struct Survivor { float x, y, z; int i_lo, i_hi; };
+
+__device__ __forceinline__ int queue_push(bool keep, int *s_count) {
+    // wave-aggregated append: one LDS atomic per wave; returns this lane's slot (-1 if it does not push)
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(keep);
+    if (!m) return -1;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(s_count, (int)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1, 64);
+    return keep ? base + (int)__popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
 __global__ void __launch_bounds__(256) k_track_project(const float *__restrict__ pts, const int32_t *__restrict__ point_ins,
                                                        int64_t n, ovo_camera_t cam, const float *__restrict__ depth,
                                                        const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
                                                        ovo_ratio_t ratio, int16_t *__restrict__ point_seg,
                                                        int32_t *__restrict__ hist, int n_masks, int hist_cols,
                                                        unsigned long long *__restrict__ counters) {
+    __shared__ float s_x[1024], s_y[1024], s_z[1024];
+    __shared__ long long s_i[1024];
+    __shared__ int s_n;
     const int lane = threadIdx.x & 63;
     long long n_in = 0, n_match = 0;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n_round = ((n + 63) / 64) * 64;      // keep whole waves in the loop (ballots inside)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += step) {
-        int seg = -2;
-        int cell = 0;
-        bool vote = false;
-        if (i < n) {
-            const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-            if (in_frustum(cam, x, y, z)) {
-                ++n_in;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    // trip: 4 points per thread (loads first: bytes in flight), the frustum test, survivors -> LDS queue; then the queue, densely
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 - threadIdx.x < n; i0 += 4 * step) {     // block-uniform trip count
+        float px[4], py[4], pz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = i0 + k * step;
+            if (i < n) { px[k] = pts[3 * i]; py[k] = pts[3 * i + 1]; pz[k] = pts[3 * i + 2]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = i0 + k * step;
+            const bool in = i < n && in_frustum(cam, px[k], py[k], pz[k]);
+            if (i < n && !in) point_seg[i] = (int16_t)-2;
+            const int slot = queue_push(in, &s_n);
+            if (slot >= 0) { s_x[slot] = px[k]; s_y[slot] = py[k]; s_z[slot] = pz[k]; s_i[slot] = i; }
+        }
+        __syncthreads();
+        const int q = s_n;
+        n_in += (threadIdx.x < q) + (threadIdx.x + 256 < q) + (threadIdx.x + 512 < q) + (threadIdx.x + 768 < q);
+        for (int e0 = 0; e0 < q; e0 += 256) {                      // whole waves stay in the loop (ballots inside)
+            const int e = e0 + threadIdx.x;
+            int seg = -2;
+            int cell = 0;
+            bool vote = false;
+            if (e < q) {
+                const float x = s_x[e], y = s_y[e], z = s_z[e];
+                const int64_t i = s_i[e];
                 float zc; int u, v;
                 project(cam, x, y, z, 1.0f, zc, u, v);
                 if (depth_match(cam, depth, zc, u, v)) {
@@ -220,10 +344,13 @@ __global__ void __launch_bounds__(256) k_track_project(const float *__restrict__
                         vote = true;
                     }
                 }
+                point_seg[i] = (int16_t)seg;
             }
-            point_seg[i] = (int16_t)seg;
+            if (e0 + (threadIdx.x & ~63) < q) wave_hist_add(hist, cell, vote);     // wave-uniform condition
         }
-        wave_hist_add(hist, cell, vote);
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
     }
     // the two counters: wave reduction, then across the workgroup's waves through LDS -> one atomic pair per workgroup
     // (every wave of the grid adding to the same two addresses serialises in the L2 atomic unit: 16k same-address atomics)
@@ -309,12 +436,34 @@ __global__ void __launch_bounds__(256) k_assign(const int32_t *__restrict__ poin
 // ---- a9 ----
 __global__ void __launch_bounds__(256) k_map_explained(const float *__restrict__ pts, int64_t n, ovo_camera_t cam,
                                                        const float *__restrict__ depth, uint8_t *__restrict__ explained) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-        if (!in_frustum(cam, x, y, z)) continue;
-        float zc; int u, v;
-        project(cam, x, y, z, 1.0f, zc, u, v);
-        if (depth_match(cam, depth, zc, u, v)) explained[(int64_t)v * cam.w + u] = 1;
+    __shared__ float s_x[1024], s_y[1024], s_z[1024];
+    __shared__ int s_n;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 - threadIdx.x < n; i0 += 4 * step) {     // as k_track_project
+        float px[4], py[4], pz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = i0 + k * step;
+            if (i < n) { px[k] = pts[3 * i]; py[k] = pts[3 * i + 1]; pz[k] = pts[3 * i + 2]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = i0 + k * step;
+            const int slot = queue_push(i < n && in_frustum(cam, px[k], py[k], pz[k]), &s_n);
+            if (slot >= 0) { s_x[slot] = px[k]; s_y[slot] = py[k]; s_z[slot] = pz[k]; }
+        }
+        __syncthreads();
+        const int q = s_n;
+        for (int e = threadIdx.x; e < q; e += 256) {
+            float zc; int u, v;
+            project(cam, s_x[e], s_y[e], s_z[e], 1.0f, zc, u, v);
+            if (depth_match(cam, depth, zc, u, v)) explained[(int64_t)v * cam.w + u] = 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
     }
 }
 
@@ -330,7 +479,7 @@ __device__ __forceinline__ bool px_valid(const float *depth, const uint8_t *expl
 
 __global__ void __launch_bounds__(256) k_backproj_flag(const float *__restrict__ depth, const uint8_t *__restrict__ explained,
                                                        BackprojArgs a, int64_t n_sub, unsigned long long *words) {
-    flag_words(n_sub, words, [&](int64_t k) {
+    flag_words_idx(n_sub, words, [&](int64_t k) {
         const int y = (int)(k / a.ws_w) * a.ds, x = (int)(k % a.ws_w) * a.ds;
         if (!px_valid(depth, explained, (int64_t)y * a.w + x)) return false;
         if (a.erode) {
@@ -376,7 +525,7 @@ extern "C" {
 
 size_t ovo_compact_workspace_bytes(int64_t n) {
     const int64_t w = (n + 63) / 64 + 1;
-    return (size_t)w * 16;
+    return (size_t)w * 16 + (size_t)(w / 2048 + 2) * 8;           // words + offsets + one total per 2048-word scan chunk
 }
 
 int ovo_frustum_ids(const float *pts, int64_t n, const ovo_camera_t *cam, int64_t *out_idx, int64_t *out_count,
@@ -388,7 +537,7 @@ int ovo_frustum_ids(const float *pts, int64_t n, const ovo_camera_t *cam, int64_
     CompactWs c = carve(ws, n);
     const int g = ovo_grid(n, 256);
     k_frustum_flag<<<g, 256, 0, s>>>(pts, n, *cam, c.words);
-    k_scan_words<<<1, 1024, 0, s>>>(c.words, c.offs, c.n_words, (long long *)out_count);
+    scan_words(c.words, c.offs, c.sums, c.n_words, (long long *)out_count, s);
     k_frustum_emit<<<g, 256, 0, s>>>(n, c.words, c.offs, out_idx);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
@@ -414,7 +563,7 @@ int ovo_match_points(const float *pts, int64_t n, int stride, const ovo_camera_t
     CompactWs c = carve(ws, n);
     const int g = ovo_grid(n, 256);
     k_match_flag<<<g, 256, 0, s>>>(pts, n, stride, *cam, depth, c.words);
-    k_scan_words<<<1, 1024, 0, s>>>(c.words, c.offs, c.n_words, (long long *)out_count);
+    scan_words(c.words, c.offs, c.sums, c.n_words, (long long *)out_count, s);
     k_match_emit<<<g, 256, 0, s>>>(pts, n, stride, *cam, c.words, c.offs, out_idx, out_uv);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
@@ -495,7 +644,7 @@ int ovo_map_backproject(const float *depth, const uint8_t *rgb, const uint8_t *e
     CompactWs c = carve(ws, n_sub);
     const int g = ovo_grid(n_sub, 256);
     k_backproj_flag<<<g, 256, 0, s>>>(depth, explained, a, n_sub, c.words);
-    k_scan_words<<<1, 1024, 0, s>>>(c.words, c.offs, c.n_words, (long long *)out_count);
+    scan_words(c.words, c.offs, c.sums, c.n_words, (long long *)out_count, s);
     k_backproj_emit<<<g, 256, 0, s>>>(depth, rgb, a, n_sub, c.words, c.offs, base, first_id, xyz, ids, ins, out_rgb);
     OVO_CHECK_LAUNCH();
     return OVO_OK;

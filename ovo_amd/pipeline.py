@@ -81,8 +81,9 @@ def synthetic_frames(n: int, device, scale: float = 1.0, n_masks_grid=(4, 6), n_
         rgb = syn.render_rgb(H, W, seed + t)
         depth = syn.render_depth(c2w, K, h, w, seed + t)
         masks = syn.make_masks(H, W, grid=n_masks_grid, n_blobs=n_blobs, seed=seed + t)
+        from .utils import geometry_utils as G
         out.append(Frame(t, torch.from_numpy(rgb).to(device), torch.from_numpy(np.ascontiguousarray(rgb[e:H - e, e:W - e])).to(device),
-                         torch.from_numpy(depth).to(device), c2w, torch.from_numpy(syn.masks_to_segmap(masks)).to(device),
+                         G.tag_depth_range(torch.from_numpy(depth).to(device), depth), c2w, torch.from_numpy(syn.masks_to_segmap(masks)).to(device),
                          torch.from_numpy(masks).to(device)))
     return out
 

@@ -33,22 +33,38 @@ def to_device(arr, dtype: torch.dtype, device) -> torch.Tensor:
     """Frame arrays arrive as numpy (the reference's dataset tuples) or as tensors already resident on the GPU."""
     if isinstance(arr, torch.Tensor):
         t = arr if arr.dtype == dtype else arr.to(dtype)
-        return (t if t.is_cuda else t.to(device, non_blocking=True)).contiguous()
+        out = (t if t.is_cuda else t.to(device, non_blocking=True)).contiguous()
+        if out is not arr and hasattr(arr, "_ovo_range"):
+            out._ovo_range = arr._ovo_range
+        return out
     np_dtype = {torch.float32: np.float32, torch.uint8: np.uint8, torch.int32: np.int32}[dtype]
     return torch.from_numpy(np.ascontiguousarray(arr, dtype=np_dtype)).to(device, non_blocking=True)
 
 
 def depth_range(depth) -> Tuple[float, float]:
-    """min / max of the valid (> 0) depths (inf, <= 0 when there is none); numpy input costs no device sync."""
+    """min / max of the valid (> 0) depths (inf, <= 0 when there is none).  numpy input costs no device sync; a device tensor is
+    reduced once and the pair is remembered ON the tensor (`depth._ovo_range`): the mapper and the tracker both need it for the same
+    frame (vanilla_mapper.py:60, ovo.py:209), and whoever uploads a frame from host memory can attach it for free (`tag_depth_range`)
+    -- each device-side evaluation is a host sync in the middle of the keyframe."""
     if isinstance(depth, np.ndarray):
         v = depth[depth > 0]
         if v.size == 0:
             return float("inf"), 0.0
         return float(v.min()), float(v.max())
+    cached = getattr(depth, "_ovo_range", None)
+    if cached is not None:
+        return cached
     big = torch.where(depth > 0, depth, torch.full_like(depth, float("inf"))).min()
     top = depth.max()
     lo, hi = torch.stack([big, top]).tolist()
+    depth._ovo_range = (lo, hi)
     return lo, hi
+
+
+def tag_depth_range(depth_dev: torch.Tensor, depth_host: np.ndarray) -> torch.Tensor:
+    """Attach the (min valid, max) range of a depth map, computed from its HOST copy, to the device tensor of the same frame."""
+    depth_dev._ovo_range = depth_range(np.asarray(depth_host))
+    return depth_dev
 
 
 def frustum_corners_from_range(near: float, far: float, h: int, w: int, pose, intrinsics) -> torch.Tensor:

@@ -12,6 +12,12 @@ import torch
 from conftest import golden, unpack
 
 pytestmark = pytest.mark.gpu
+
+
+def _bound(out_dim: int) -> float:
+    """north_star's feature bound: |unit-descriptor error| <= 1e-3, flat, for every model the reference can select (out_dim >= 512);
+    the reduced test towers (out_dim 64 / 128) have proportionally larger elements, 1/sqrt(out_dim)."""
+    return 1e-3 if out_dim >= 512 else 1e-3 * (512 / out_dim) ** 0.5 * 1.5
 DEV = "cuda"
 
 
@@ -276,9 +282,10 @@ def test_vit_forward_vs_hf_golden():
     torch.testing.assert_close(tok, ref, atol=5e-2, rtol=5e-2)
 
 
-@pytest.mark.parametrize("card,batch", [("tiny-pe", 3), ("ViT-B-16-qg", 2), ("ViT-L-14-qg", 1), ("PE-Core-L14-336", 2)])
+@pytest.mark.parametrize("card,batch", [("tiny-pe", 3), ("ViT-B-16-qg", 2), ("ViT-L-14-qg", 1), ("PE-Core-L14-336", 2), ("ViT-H-14", 1), ("ViT-H-14-378qg", 1)])
 def test_vit_forward_vs_oracle_full_size(card, batch):
-    """Unit-normalised descriptor error vs the fp32 oracle: north_star bound 1e-3 (features) on ViT-B/16 and PE-L/14-336."""
+    """Unit-normalised descriptor error vs the fp32 oracle: north_star bound 1e-3 (features) on every card of clip_utils.py:53-63
+    (ViT-B/16, ViT-L/14, ViT-H/14 at 224 and 378, PE-L/14-336)."""
     from oracle import vit as OV
     from ovo_amd.encoders.vit import SPECS, HipViT, random_state, rope_tables
     spec = SPECS[card]
@@ -294,8 +301,7 @@ def test_vit_forward_vs_oracle_full_size(card, batch):
     err = (nr - no).abs().max().item()
     cos = (nr * no).sum(-1).min().item()
     print(f"{card}: max |unit feature error| = {err:.2e}, min cosine = {cos:.6f}")
-    # bound scales with the element magnitude 1/sqrt(out_dim): 1e-3 at out_dim >= 512 (the BASELINE models)
-    assert err < 1e-3 * max(1.0, (512 / spec.out_dim) ** 0.5 * 1.5) and cos > 0.9999
+    assert err < _bound(spec.out_dim) and cos > 0.9999
 
 
 def test_siglip_forward_vs_hf_golden():
@@ -337,7 +343,7 @@ def test_siglip_forward_vs_oracle(card, batch, layers):
     nr, no = torch.nn.functional.normalize(ref, dim=-1), torch.nn.functional.normalize(out, dim=-1)
     err, cos = (nr - no).abs().max().item(), (nr * no).sum(-1).min().item()
     print(f"{card}: max |unit feature error| = {err:.2e}, min cosine = {cos:.6f}")
-    assert err < 1e-3 * max(1.0, (512 / spec.out_dim) ** 0.5 * 1.5) and cos > 0.9999
+    assert err < _bound(spec.out_dim) and cos > 0.9999
     got_tok = vit.forward(x.to(DEV), tokens=True).cpu()
     torch.testing.assert_close(got_tok, tok, atol=5e-2, rtol=5e-2)
 
@@ -475,3 +481,39 @@ def test_textregion_remove_global_patch_vs_reference_golden(tag, hw):
     err = np.abs(out - d[f"{tag}_out"]).max()
     print(f"textregion {tag} (remove_global_patch): max |unit descriptor error| vs the reference = {err:.2e}")
     assert err < 3e-3
+
+
+def test_textregion_full_size_640x480_vs_oracle():
+    """The whole TextRegion path at the benchmark's size -- 640 x 480 frame, PE-Core-L14-336, global crop + 1 x 1 tile (2 crops of
+    336^2), 32 masks -- HIP vs the fp32 oracle (resize, ViT tokens, stitch, feature masks, masked-mean pooling, folded projection, L2):
+    |unit-descriptor error| <= 1e-3 (north_star), i.e. what bench.py's `parity.max_abs_desc_err` reports, as a test."""
+    from oracle import features as OF, vit as OV
+    from ovo_amd import synthetic as syn
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state, rope_tables
+    from ovo_amd.entities.textregion import PETextRegion
+    spec = SPECS["PE-Core-L14-336"]
+    sd = random_state(spec, seed=0)
+    vit = HipViT(spec, sd, device=DEV)
+    tr = PETextRegion(vit, "PE-Core-L14-336", remove_global_patch=False)
+    H, W = 480, 640
+    rgb = syn.render_rgb(H, W, 5)
+    masks = syn.make_masks(H, W, grid=(4, 6), n_blobs=8, seed=5)
+    assert masks.shape[0] == 32
+    img = torch.from_numpy(rgb.transpose(2, 0, 1).copy())
+    out = tr.predict(img.to(DEV), torch.from_numpy(masks).to(DEV), scale=1 / 255.0).cpu().numpy()
+    nh, nw = max(H // spec.image_size, 1), max(W // spec.image_size, 1)
+    ch, cw = -(-H // nh), -(-W // nw)
+    crops = [(0, 0, H, W)] + [(max(min(i * ch + ch, H) - ch, 0), max(min(j * cw + cw, W) - cw, 0), ch, cw) for i in range(nh) for j in range(nw)]
+    batch = torch.stack([OV.resize_normalize(img, spec.image_size, spec.mean, spec.std, c, 1 / 255.0) for c in crops])
+    tok = OV.vit_forward(sd, batch, patch=spec.patch, heads=spec.heads, act=spec.act, rope=rope_tables(spec), tokens=True)
+    P = spec.grid
+    xs = OF.stitch_tokens(tok[:, 1:].numpy(), P, P * nh, P * nw, nh, nw)
+    fm = OF.feature_masks(masks, P * nh, P * nw)
+    d = spec.width
+    ref = OF.region_pool(xs, fm, sd["attn_pool.attn.in_proj_weight"][2 * d:], sd["attn_pool.attn.in_proj_bias"][2 * d:],
+                         sd["attn_pool.attn.out_proj.weight"], sd["attn_pool.attn.out_proj.bias"], sd["proj"])
+    ok = ~np.isnan(ref).any(1)
+    assert ok.sum() >= 28 and np.array_equal(np.isnan(out).any(1), ~ok)
+    err = np.abs(out[ok] - ref[ok]).max()
+    print(f"TextRegion 640x480 / PE-L/14-336 / 32 masks: max |unit descriptor error| = {err:.2e}")
+    assert err <= 1e-3

@@ -9,6 +9,12 @@ import torch
 from conftest import golden, unpack
 
 pytestmark = pytest.mark.gpu
+
+
+def _bound(out_dim: int) -> float:
+    """north_star's feature bound: |unit-descriptor error| <= 1e-3, flat, for every model the reference can select (out_dim >= 512);
+    the reduced test towers (out_dim 64 / 128) have proportionally larger elements, 1/sqrt(out_dim)."""
+    return 1e-3 if out_dim >= 512 else 1e-3 * (512 / out_dim) ** 0.5 * 1.5
 DEV = "cuda"
 
 
@@ -239,5 +245,5 @@ def test_extract_clip_crop_modes_vs_oracle(mode, card):
     assert got.shape == ref.shape == (len(masks), spec.out_dim)
     err = np.abs(got - ref).max()
     print(f"{mode}: max |unit descriptor error| = {err:.2e}")
-    assert err < 1e-3 * max(1.0, (512 / spec.out_dim) ** 0.5 * 1.5)               # bf16 encoder vs fp32 oracle, as in test_gpu_encoder
+    assert err < _bound(spec.out_dim)               # bf16 encoder vs fp32 oracle, as in test_gpu_encoder
     np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)

@@ -33,8 +33,11 @@ def test_hiera_vs_hf_golden():
         assert r < 0.08
 
 
-@pytest.mark.parametrize("card,batch", [("hiera_test", 2), ("hiera_b+", 1)])
+@pytest.mark.parametrize("card,batch", [("hiera_test", 2), ("hiera_b+", 1), ("hiera_t", 1), ("hiera_l", 1)])
 def test_hiera_vs_oracle(card, batch):
+    """Every SAM2 trunk the reference can select (segment_utils.py:274: hiera_l -- its default, ovo.yaml:35 -- and hiera_t) and
+    BASELINE.json's hiera_b+, at 1024^2, against the fp32 oracle; hiera_l's window spec (8, 4, 16, 8) and 48 blocks exercise window /
+    un-window shapes the others do not."""
     from oracle import hiera as OH
     from ovo_amd.encoders.hiera import SPECS, HipHiera, random_state
     spec = SPECS[card]

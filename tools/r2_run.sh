@@ -1,5 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out
-timeout 900 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_multirank.py tests/test_gpu_e2e.py -x -q > $OUT/r2_pytest.log 2>&1; tail -15 $OUT/r2_pytest.log
-for b in 4 8; do timeout 900 python bench.py --encoder-batch $b --steps 24 --warmup 8 --no-cpu-baseline > $OUT/r2_bench_b$b.json 2> $OUT/r2_bench_b$b.err; tail -3 $OUT/r2_bench_b$b.err; cut -c1-3000 $OUT/r2_bench_b$b.json; done
+# full default bench (cpu baseline + parity + sustained), then 2 ranks sharing the GPU (gloo) to exercise --gpus 2
+timeout 1200 python bench.py > $OUT/r2_bench_full.json 2> $OUT/r2_bench_full.err; tail -3 $OUT/r2_bench_full.err; cat $OUT/r2_bench_full.json
+OVO_DIST_BACKEND=gloo OVO_FORCE_DEVICE=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 10 --warmup 4 --no-roofline --sustain-seconds 0 > $OUT/r2_bench_2rank.json 2> $OUT/r2_bench_2rank.err; tail -5 $OUT/r2_bench_2rank.err | cut -c1-300; cat $OUT/r2_bench_2rank.json | cut -c1-1800
