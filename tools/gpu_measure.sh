@@ -1,26 +1,38 @@
 #!/bin/bash
-# One GPU-box session: parity tests, smoke, bench, kernel-trace stats and the PMC traffic passes.
+# One GPU-box session: parity tests, smoke, bench, kernel-trace stats and the PMC traffic passes (summaries go to profiles/ by hand).
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+R=$GRAFT_REPO_ROOT
+timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
 timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 python bench.py --sam hiera_l --no-cpu-baseline --sustain-seconds 0 > $OUT/bench_hiera_l.json 2> $OUT/bench_hiera_l.err
+timeout 600 python bench.py --sam-full --no-cpu-baseline --sustain-seconds 0 > $OUT/bench_sam_full.json 2> $OUT/bench_sam_full.err
 timeout 300 python tools/query_bench.py > $OUT/query_bench.log 2>&1
 timeout 300 python tools/amg_bench.py 16 > $OUT/amg_bench.log 2>&1
-timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 600 python bench.py --sam-full --no-cpu-baseline > $OUT/bench_sam_full.json 2> $OUT/bench_sam_full.err
-R=$GRAFT_REPO_ROOT
+timeout 300 python tools/geom_bench.py > $OUT/geom_bench.txt 2>&1
+TILES="auto,ring,256x256,256x128" SHAPES="4616,3072,1024;4616,1024,1024;4616,4096,1024;4616,1024,4096;16384,1792,448;16384,448,1792;19600,1344,448;4096,4096,4096;8192,8192,8192" timeout 600 python tools/gemm_bench.py > $OUT/gemm_sweep.txt 2>&1
+(python tools/gemm8p_stamps.py 4616 3072 1024 256x256; python tools/gemm8p_stamps.py 4616 4096 1024 256x128; python tools/gemm8p_stamps.py 4096 4096 4096 256x256) > $OUT/gemm8p_timeline.txt 2>&1
+(python tools/enc_table.py vit 4; python tools/enc_table.py sam 4) > $OUT/enc_tables_b4.txt 2>&1
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $R/bench.py --no-cpu-baseline --steps 10 > $OUT/prof_bench.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sam_full -- python $R/bench.py --no-cpu-baseline --no-roofline --sam-full --steps 10 > $OUT/prof_sam_full.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 3 --warmup 2 > $OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 3 --warmup 2 > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $R/bench.py --no-cpu-baseline --steps 12 --sustain-seconds 0 > $OUT/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- python $R/tools/pmc_calib.py > $OUT/calib_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- python $R/tools/pmc_calib.py > $OUT/calib_write.log 2>&1
+ITERS=5 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/geom_stats -- python $R/tools/geom_bench.py 10000000 > $OUT/geom_stats.log 2>&1
+ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/geom_fetch -- python $R/tools/geom_bench.py 10000000 > $OUT/geom_fetch.log 2>&1
+ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/geom_write -- python $R/tools/geom_bench.py 10000000 > $OUT/geom_write.log 2>&1
+ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU --output-format csv -d $OUT/geom_sq -- python $R/tools/geom_bench.py 10000000 > $OUT/geom_sq.log 2>&1
 cd $R
 python tools/pmc_traffic.py --fetch-dir $OUT/pmc_fetch --write-dir $OUT/pmc_write --calib-fetch-dir $OUT/calib_fetch --calib-write-dir $OUT/calib_write --out $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
+python tools/pmc_traffic.py --fetch-dir $OUT/geom_fetch --write-dir $OUT/geom_write --out $OUT/geom_10m_pmc_traffic.json > $OUT/geom_pmc.log 2>&1
+python tools/sq_counters.py $OUT/geom_sq > $OUT/geom_10m_sq_counters.txt 2>&1
+cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_n1_kernel_stats.csv
+cp $(find $OUT/geom_stats -name "*kernel_stats.csv" | head -1) $OUT/geom_10m_kernel_stats.csv
 # keep the merge-back small: drop the per-dispatch traces, keep stats + reduced PMC
-find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +8M -delete; find $OUT -name "*agent_info.csv" -delete
-tail -3 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log; cat $OUT/query_bench.log; head -4 $OUT/amg_bench.log; cat $OUT/bench.json; cut -c1-260 $OUT/bench_sam_full.json; tail -16 $OUT/pmc_traffic.log
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
+tail -3 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log; cat $OUT/bench.json | cut -c1-1500; cut -c1-400 $OUT/bench_hiera_l.json; cut -c1-400 $OUT/bench_sam_full.json; tail -16 $OUT/pmc_traffic.log; cat $OUT/geom_bench.txt
