@@ -328,7 +328,11 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     // two q-tiles per wave once there are enough 128-query workgroups to fill the chip
     // (tools/attn_bench.py: 128-query workgroups win once there are >= 2 of them per CU; below that the 64-query form's
     // 3 waves/SIMD hide more latency: 4096 x 4096, 8 heads, hd 56: 100 us narrow vs 114 us wide)
-    const bool wide = p->Tq >= 512 && (long long)((p->Tq + 127) / 128) * p->B * p->H >= 512 && !getenv("OVO_ATTN_NARROW");
+    // -- and only for head_dim > 64: the 128-query form needs 198 VGPRs at head_dim 64 (2 waves per SIMD) against 128 (3-4) for the
+    // 64-query form, and with several frames per launch there are always enough workgroups; tools/attn_bench.py, round 2:
+    // 8 x 16 heads x 577^2 (four keyframes' ViT crops) 59.8 us wide vs 37.4 narrow, 4 x 8 x 4096^2 x 56 394 vs 292, while
+    // 8 x 16 x 2048^2 x 128 stays 703 wide vs 849 narrow
+    const bool wide = p->hd > 64 && p->Tq >= 512 && (long long)((p->Tq + 127) / 128) * p->B * p->H >= 512 && !getenv("OVO_ATTN_NARROW");
     const int qpb = wide ? 128 : 64;
     dim3 grid((p->Tq + qpb - 1) / qpb, p->B * p->H);
     a.q_tiles = (int)grid.x; a.chunk = 0;

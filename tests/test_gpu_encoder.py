@@ -76,7 +76,8 @@ def test_gemm_epilogues_and_padding():
 
 @pytest.mark.parametrize("tile", ["256x256", "256x128"])
 @pytest.mark.parametrize("m,n,k,dtype", [(4616, 3072, 1024, torch.bfloat16), (1154, 1024, 448, torch.bfloat16), (300, 260, 64, torch.bfloat16),
-                                         (2308, 1344, 192, torch.float16), (700, 132, 1792, torch.bfloat16), (257, 516, 128, torch.bfloat16)])
+                                         (2308, 1344, 192, torch.float16), (700, 132, 1792, torch.bfloat16), (257, 516, 128, torch.bfloat16),
+                                         (513, 260, 320, torch.bfloat16)])
 def test_gemm_pingpong_kernel_vs_ring_kernel_and_torch(monkeypatch, tile, m, n, k, dtype):
     """The 256-row ping-pong kernel (gemm8p.hip, forced through OVO_GEMM_TILE) against the fp32 product of the same rounded operands
     and against the 128-row ring kernel: every output element is accumulated over k in the same order (32-wide MFMA steps in

@@ -4,7 +4,7 @@ sys.path.insert(0, os.getcwd())
 import torch
 from ovo_amd import _lib as L
 dev = torch.device("cuda", 0); lib = L.load()
-def run(B, H, Tq, Tk, hd, iters=20):
+def run(B, H, Tq, Tk, hd, iters=50):
     D = H * hd; T = max(Tq, Tk)
     qkv = torch.randn(B, T, 3, H, hd, device=dev).to(torch.bfloat16)
     out = torch.zeros(B, Tq, D, dtype=torch.bfloat16, device=dev)
@@ -20,7 +20,8 @@ def run(B, H, Tq, Tk, hd, iters=20):
     e1.record(); torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / iters
     return us, 4.0 * B * H * Tq * Tk * hd / us / 1e6
-for shape in [(2, 16, 577, 577, 64), (1, 8, 4096, 4096, 56), (25, 8, 196, 196, 56), (1024, 2, 64, 64, 56), (1024, 4, 16, 64, 56), (8, 16, 2048, 2048, 128)]:
+shapes = [(2, 16, 577, 577, 64), (8, 16, 577, 577, 64), (1, 8, 4096, 4096, 56), (4, 8, 4096, 4096, 56), (25, 8, 196, 196, 56), (100, 8, 196, 196, 56), (1024, 2, 64, 64, 56), (1024, 4, 16, 64, 56), (8, 16, 2048, 2048, 128)]
+for shape in shapes:
     row = "%-28s" % str(shape)
     for mode in ("auto", "narrow"):
         if mode == "narrow": os.environ["OVO_ATTN_NARROW"] = "1"
