@@ -138,6 +138,22 @@ __global__ void __launch_bounds__(256) k_pool_unwindow(const float *__restrict__
 
 // f32 [rows, C] -> bf16 [rows, kp] with zero padding columns
 __global__ void __launch_bounds__(256) k_cast_pad(const float *__restrict__ x, long long rows, int C, int kp, uint16_t *__restrict__ y) {
+    if (C % 4 == 0 && kp % 4 == 0) {                        // four columns per thread: 16-byte loads, 8-byte stores
+        const int k4 = kp >> 2;
+        const long long total = rows * k4;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % k4) * 4;
+            const long long r = i / k4;
+            uint2 p = make_uint2(0u, 0u);
+            if (c < C) {
+                const float4 v = *(const float4 *)(x + r * C + c);
+                p.x = f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+                p.y = f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+            }
+            *(uint2 *)(y + r * kp + c) = p;
+        }
+        return;
+    }
     const long long total = rows * kp;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % kp);

@@ -67,10 +67,12 @@ class HipSam2AutomaticMaskGenerator:
             self.decoder.set_points(self.grid01 * self.decoder.spec.image_size)
 
     @torch.no_grad()
-    def generate_launch(self, image) -> Dict[str, Any]:
+    def generate_launch(self, image, embeddings: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
         """Enqueue encoder -> decoder -> candidate statistics on the current stream and start the (small) device->host copy of
         the statistics into pinned memory.  Nothing waits; `generate_finish` does.  Lets the caller overlap the generator with
-        other streams' work (the ViT forward, back-projection) instead of parking the host in a sync."""
+        other streams' work (the ViT forward, back-projection) instead of parking the host in a sync.
+        `embeddings`: the image encoder's output for this frame when it was computed elsewhere (one batched Hiera forward for
+        several frames: dict(image_embed [1, s, s, C], high_res_feats (f0 [1, 4s, 4s, C/8], f1 [1, 2s, 2s, C/4])))."""
         self._set_grid()
         lib = L.load()
         if isinstance(image, np.ndarray):
@@ -79,7 +81,7 @@ class HipSam2AutomaticMaskGenerator:
             H, W = (image.shape[0], image.shape[1]) if image.shape[-1] == 3 else (image.shape[1], image.shape[2])
             if image.shape[-1] == 3:
                 image = image.permute(2, 0, 1).contiguous()
-        emb = self.encoder.encode_frame(image)
+        emb = embeddings if embeddings is not None else self.encoder.encode_frame(image)
         self.last_embeddings = emb
         f0, f1 = emb["high_res_feats"]
         logits, iou = self.decoder.forward(emb["image_embed"][0], f1[0], f0[0], multimask=True)       # [P, 3, h, w], [P, 3]

@@ -125,7 +125,7 @@ class FramePipeline:
         # encoder look-ahead: the two encoders of `encoder_batch` consecutive keyframes (of this rank) run as ONE batched forward each
         # (step() is handed the upcoming frames).  Nothing of the encoders depends on the map, and the reference itself computes a
         # keyframe's descriptors kf_queue_delay = 10 keyframes late (ovo.yaml:53), so this changes no result -- only the GEMM height.
-        self.encoder_batch = max(1, int(encoder_batch)) if not sam_full else 1
+        self.encoder_batch = max(1, int(encoder_batch))
         self._encoded: Dict[int, bool] = {}
         self.serial = False                                        # measurement only: both encoders on the caller's stream
         self._group_first: Dict[int, int] = {}
@@ -198,7 +198,15 @@ class FramePipeline:
                 if nxt:                                            # run beside this group's tracking / pooling / fusion / queries
                     self._launch_encoders(nxt)
             self._encoded.pop(f.index, None)
-            return None
+            if self.amg is None:
+                return None
+            # SAM2 end to end: the encoder ran batched for the group; decoder + generator filters run per frame on the SAM2 stream
+            hit = self._sam_by_frame.get(f.index)
+            outs, k = hit
+            emb = {"image_embed": outs[2][k:k + 1], "high_res_feats": (outs[0][k:k + 1], outs[1][k:k + 1])}
+            side = torch.cuda.current_stream() if self.serial else (self.sam_stream or torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                return self.amg.generate_launch(f.rgb, embeddings=emb)
         amg_pending = None
         # The two encoders first: nothing of theirs depends on the map, and the map update ends in a host sync (the count of new
         # points) behind which the host could not launch them.
