@@ -144,3 +144,95 @@ def test_automatic_mask_generator_end_to_end():
     assert np.array_equal(seg_map.cpu().numpy(), ref_seg)
     assert np.array_equal(bmaps.cpu().numpy(), ref_maps)
     assert seg_map.dtype == torch.int32 and bmaps.dtype == torch.bool and seg_map.is_cuda
+
+
+def test_full_size_generator_feeds_tracking_640x480():
+    """Row f1 at the benchmark's size: hiera_b+ encoder @1024^2 + the full SAM2 decoder on a 16 x 16 click grid (768 candidates) on a
+    640 x 480 frame, generator filters, box NMS, mask NMS and seg-map painting -- against the oracle post-processing of the device's own
+    logits -- and then the hand-over the reference makes (mask_generator.py:102-120 -> ovo.py:121-166): the NATIVE masks drive the
+    tracker on a point map, whose per-point instance ids must equal the oracle tracker's on the same masks, bit for bit.
+    Random-init SAM2 keeps nothing at the reference's thresholds (0.8 / 0.95), so the two score thresholds are placed in gaps of this
+    fixture's own score distributions such that >= 16 masks survive; everything else is the reference's setting."""
+    from oracle import features as OF, sam2_amg as OA, semantic as OS
+    from ovo_amd import synthetic as syn
+    from ovo_amd.entities.mask_generator import MaskGenerator
+    from ovo_amd.entities.ovo import OVO
+    from ovo_amd.slam.vanilla_mapper import VanillaMapper
+    cfg = {"sam_encoder": "hiera_b+", "sam_decoder": "sam2", "points_per_side": 16, "nms_iou_th": 0.8, "stability_score_th": 0.95,
+           "nms_score_th": 0.0, "nms_inner_th": 0.5, "seed": 2}
+    mg = MaskGenerator(cfg, None, device=DEV)
+    amg = mg.mask_generator
+    amg.box_nms_thresh = 1.0                           # random weights: near-identical boxes (box NMS itself: test_amg_filters_vs_oracle)
+    scale = 1.0
+    h, w = syn.scannet_depth_hw(scale)
+    e = syn.SCANNET["crop_edge"]
+    H, W = h + 2 * e, w + 2 * e
+    assert (H, W) == (480, 640)
+    fid, rgb_lr, depth, c2w = syn.frame(2, scale=scale, seed=9)
+    rgb = syn.render_rgb(H, W, 9)
+    amg.generate_device(rgb)
+    logits, iou = amg.last_logits.cpu().numpy(), amg.last_iou.cpu().numpy()
+    assert logits.shape == (256, 3, 256, 256)
+    post = OA.amg_postprocess(logits, iou, H, W, 0.0, 0.0)
+    # thresholds in gaps of the fixture's own scores: predicted IoU around its median, stability so that >= 16 of those survive
+    pi = np.sort(iou.reshape(-1))
+    k = len(pi) // 2 + int(np.argmax(np.diff(pi[len(pi) // 2: len(pi) // 2 + 60])))
+    th_iou = float((pi[k] + pi[k + 1]) / 2)
+    st = np.sort(post["stab_all"][(iou.reshape(-1) > th_iou) & np.isfinite(post["stab_all"])])
+    assert len(st) > 40
+    cut = len(st) - 24                                 # keep roughly the 24 most stable candidates
+    j = cut - 10 + int(np.argmax(np.diff(st[cut - 10: cut + 4])))
+    th_st = float((st[j] + st[j + 1]) / 2)
+    assert st[j + 1] - st[j] > 1e-4
+    amg.pred_iou_thresh, amg.stability_score_thresh = th_iou, th_st
+    mg.nms_iou_th, mg.nms_inner_th = 1.01, 0.0         # mask NMS (a11): random-weight masks are near copies of each other; the rule runs
+                                                       # (and is compared with the oracle's) but suppresses nothing
+    seg_map, bmaps = mg.get_masks(rgb, 0)
+    got = amg.generate_device(rgb)
+    ref = OA.amg_postprocess(logits, iou, H, W, pred_iou_thresh=th_iou, stability_score_thresh=th_st, box_nms_thresh=1.0)
+    print(f"640x480: thresholds iou {th_iou:.4f} / stability {th_st:.4f}: {len(ref['index'])} of {iou.size} candidates kept, {bmaps.shape[0]} after mask NMS")
+    assert len(ref["index"]) >= 16
+    assert np.array_equal(np.sort(got["point_index"]), np.sort(ref["index"] // 3))
+    gm = got["masks"].cpu().numpy().astype(bool)
+    assert gm.shape == ref["masks"].shape and (gm != ref["masks"]).mean() < 1e-5
+    keep = np.sort(np.asarray(OF.mask_nms(ref["masks"], ref["stability_score"] * ref["predicted_iou"], 1.01, 0.0, 0.0)))
+    ref_seg, ref_maps = OF.paint_segmap(ref["masks"][keep], ref["stability_score"][keep])
+    if not np.array_equal(gm, ref["masks"]):           # a logit within an ulp of 0 flipped a pixel: compare the hand-over on the device's masks
+        keep = np.sort(np.asarray(OF.mask_nms(gm, got["stability_score"] * got["predicted_iou"], 1.01, 0.0, 0.0)))
+        ref_seg, ref_maps = OF.paint_segmap(gm[keep], got["stability_score"][keep])
+    assert np.array_equal(seg_map.cpu().numpy(), ref_seg) and np.array_equal(bmaps.cpu().numpy(), ref_maps)
+    assert bmaps.shape[0] >= 8
+    # ---- the native masks drive the tracker (two keyframes), ids bit-exact against the oracle tracker on the same masks
+    K = syn.scannet_intrinsics(scale)
+    Kd = torch.from_numpy(K).to(DEV)
+
+    class Native:                                      # what OVO._get_masks calls: the generator above, per frame
+        def get_masks(self, image, frame_id):
+            return mg.get_masks(image, frame_id)
+
+    class Clip:
+        clip_dim = 32
+    # depth_filter off: the Gaussian high-pass is float arithmetic whose last bit differs between the two sides, and a depth pixel ON its
+    # threshold flips one match (the filter has its own test with a tolerance, test_gpu_geometry.py); everything else is integer-exact
+    ocfg = {"match_distance_th": 0.05, "track_th": 100, "depth_filter": False, "clip": {"k_top_views": 0, "fusion": "avg_pooling"}, "sam": {}}
+    ovo = OVO(ocfg, None, None, Kd, device=DEV, clip_generator=Clip(), mask_generator=Native())
+    vm = VanillaMapper({"device": DEV, "mapping": {}}, Kd)
+    pm, tr = OS.PointMap(K), OS.SemanticTracker(K, 0.05, 100, False, 0)
+    n_inst = 0
+    for t in (2, 3):
+        fid, rgb_lr, depth, c2w = syn.frame(t, scale=scale, seed=9)
+        img = rgb                                      # the thresholds above were placed for THIS image's candidates
+        fd = [fid, rgb_lr, depth, c2w]
+        vm.track_camera(fd)
+        vm.map(fd, vm.get_c2w(fid))
+        pm.integrate(rgb_lr, depth, c2w)
+        assert np.array_equal(vm.pcd.cpu().numpy(), pm.xyz)
+        upd = ovo.detect_and_track_objects([fid, img, depth, (1.0, 1.0, e)], vm.get_map(), vm.get_c2w(fid))
+        seg_t, maps_t = mg.get_masks(img, fid)         # the same masks, for the oracle tracker
+        matched, _, _, ref_ids = tr.step(depth, (1.0, 1.0, e), pm.xyz, pm.ids, pm.ins, c2w, seg_t.cpu().numpy(), maps_t.cpu().numpy())
+        pm.ins = ref_ids
+        vm.update_pcd_obj_ids(upd)
+        assert np.array_equal(upd.cpu().numpy().reshape(-1), ref_ids.reshape(-1)), f"instance ids differ at frame {t}"
+        n_inst = len(ovo.objects)
+    print(f"native masks -> {n_inst} instances, {int((pm.ins >= 0).sum())} labelled points")
+    assert n_inst >= 1 and int((pm.ins >= 0).sum()) > 1000, "the native masks labelled too few points to mean anything"
