@@ -1,5 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-export TILES="ring,128x128,128x64,256x128" SHAPES="262144,448,128;65536,896,256;262144,336,128;65536,224,896"
-echo "--- bf16 out"; timeout 600 python tools/gemm_bench.py 2>&1 | grep -v amdgpu
-echo "--- f32 out"; OUT=f32 timeout 600 python tools/gemm_bench.py 2>&1 | grep -v amdgpu
+OVO_8P_PF=1 timeout 600 python -m pytest tests/test_gpu_encoder.py -x -q -k "pingpong" 2>&1 | tail -2
+export TILES="256x256,256x128" SHAPES="4616,3072,1024;4616,4096,1024;4616,1024,4096;16384,1792,448;4096,4096,4096;8192,8192,8192"
+echo "--- no prefetch"; timeout 600 python tools/gemm_bench.py 2>&1 | grep -v amdgpu
+echo "--- L2 prefetch"; OVO_8P_PF=1 timeout 600 python tools/gemm_bench.py 2>&1 | grep -v amdgpu
+OVO_8P_PF=1 python tools/gemm8p_stamps.py 4616 3072 1024 256x256 2>&1 | grep -v amdgpu | grep "k-loop  "
