@@ -281,7 +281,8 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
         const double t_mem = bytes / 4.0e6;                                            // us at 4 TB/s
         const double t_ring = flop / 650.0e6 + 4.0;
         const double r256 = (double)((blocks(256, 256) + 255) / 256), r128 = (double)((blocks(256, 128) + 255) / 256);
-        double t256 = r256 * (8.0 + 1.5 * kt), t128 = r128 * (9.0 + 0.62 * kt);
+        // per-K-tile cost of the 256x128 form rises once every CU holds a tile (measured: 0.62 us with <= 192 tiles in flight, 0.74-0.86 us on a full chip)
+        double t256 = r256 * (8.0 + 1.5 * kt), t128 = r128 * (9.0 + (blocks(256, 128) <= 192 ? 0.62 : 0.78) * kt);
         t256 = t256 > t_mem ? t256 : t_mem; t128 = t128 > t_mem ? t128 : t_mem;
         const double t8 = t256 < t128 ? t256 : t128;
         if (t8 < 0.93 * (t_ring > t_mem ? t_ring : t_mem)) {

@@ -70,7 +70,14 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
         tile = (blockIdx.x & 7) * g.chunk + (blockIdx.x >> 3);
         if (tile >= g.tiles) return;
     }
-    const int m0 = (tile / g.nbn) * BM, n0 = (tile % g.nbn) * BN;
+    int tm = tile / g.nbn, tn = tile % g.nbn;
+    if (g.strip > 0) {                                   // column strips: an XCD's chunk of consecutive tiles is a compact block of the product
+        const int nbm = (g.M + BM - 1) / BM, per = nbm * g.strip, sidx = tile / per, r = tile - sidx * per;
+        const int ws = min(g.strip, g.nbn - sidx * g.strip);
+        tm = r / ws;
+        tn = sidx * g.strip + (r - tm * ws);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
     const int fr = lane & 15, fq = lane >> 4;
     if (g.dbg & 1) return;
     auto stamp = [&](int k) { if (g.stamps && tid == 0) g.stamps[(long long)tile * 4 + k] = __builtin_amdgcn_s_memrealtime(); };
@@ -334,6 +341,10 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     if (prof) { ovo_prof_begin(BN == 256 ? 3 : 0, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); }     // kinds 3 / 0: 256x256 / 256x128
     g.tiles = nbm * g.nbn;
     g.chunk = (g.M > g.N || g.nbn % 8 != 0) && !getenv("OVO_GEMM_NO_CHUNK") ? (g.tiles + 7) / 8 : 0;
+    // tile order: measured to matter little (the K-loop is bound by the L2->LDS arrival rate, not by L2 misses); column strips of 8 n-tiles
+    // gain ~5% on the widest products (N/BN >= 16: the per-XCD working set of a round drops under the 4 MB L2), nothing elsewhere
+    g.strip = getenv("OVO_GEMM_STRIP") ? atoi(getenv("OVO_GEMM_STRIP")) : (g.nbn >= 16 ? 8 : 0);
+    if (g.strip > 0) g.chunk = (g.tiles + 7) / 8;
     const int grid = g.chunk > 0 ? g.chunk * 8 : g.tiles;
     k_gemm8p<BM, BN, WARPS_M, VT, STAGED><<<grid, 512, lds, s>>>(g);
     if (prof) ovo_prof_end(s);

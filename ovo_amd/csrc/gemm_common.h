@@ -23,6 +23,7 @@ struct GemmArgs {
     float alpha;
     int nbn;
     int chunk, tiles;          // chunk > 0: XCD-chunked tile order (see launch())
+    int strip;                 // gemm8p: > 0 = tiles ordered in column strips of this many n-tiles (m fastest across a strip's rows)
     unsigned long long *best;  // ovo_gemm_argmax: packed (score, column) running maximum per row, or NULL
     int store, n_valid;        // with best: also store C?; columns >= n_valid (vocabulary padding) never win
     const float *rope_cos, *rope_sin;   // ovo_gemm_rope: rotary embedding of columns [0, rope_cols) in the epilogue, or NULL
