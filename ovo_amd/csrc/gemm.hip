@@ -273,7 +273,9 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
     ns2 = ns2_ok && bm == 128 && bn == 64 && r768 <= r512;
     // The 256-row ping-pong kernels (gemm8p.hip) for the batched forwards.  One workgroup per CU, so their cost is
     //   rounds x (fixed + K-tiles x per-tile), fixed ~8-9 us (prologue from HBM, epilogue, nothing overlaps them), per 64-deep K-tile
-    //   1.5 us (256x256) / 0.62 us (256x128), floored by the HBM time of the operands and the output;
+    //   1.5 us (256x256) / 0.62-0.86 us (256x128), floored by the HBM time of the operands and the output;
+    //   (a 256x128, BK = 32, 3-stage form of the ring kernel below with TWO workgroups per CU -- so that one tile's epilogue would overlap
+    //   the other's K-loop -- measured 1.4-1.6x SLOWER than the ping-pong kernel: 16 MFMAs per barrier do not keep the K-loop fed)
     // the ring kernels above run ~650 TFLOP/s + 4 us at these sizes (tools/gemm_bench.py on MI355X, profiles/r02*_gemm_sweep.txt).
     if (k64 && g.M >= 2048 && g.N >= 256 && !getenv("OVO_GEMM_TILE") && !getenv("OVO_GEMM_NO_8P")) {
         const double flop = 2.0 * g.M * (double)g.N * g.K, kt = g.K / 64;
@@ -281,8 +283,10 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
         const double t_mem = bytes / 4.0e6;                                            // us at 4 TB/s
         const double t_ring = flop / 650.0e6 + 4.0;
         const double r256 = (double)((blocks(256, 256) + 255) / 256), r128 = (double)((blocks(256, 128) + 255) / 256);
-        // per-K-tile cost of the 256x128 form rises once every CU holds a tile (measured: 0.62 us with <= 192 tiles in flight, 0.74-0.86 us on a full chip)
-        double t256 = r256 * (8.0 + 1.5 * kt), t128 = r128 * (9.0 + (blocks(256, 128) <= 192 ? 0.62 : 0.78) * kt);
+        // per-K-tile cost of the 256x128 form rises once every CU holds a tile and stays in its K-loop (measured: 0.62 us with <= 192 tiles
+        // in flight, ~0.70 on a full chip with short K-loops whose phases interleave, 0.86 at K >= 3072: every CU in its K-loop at once)
+        const double s128 = blocks(256, 128) <= 192 ? 0.62 : (kt >= 48 ? 0.86 : 0.70);
+        double t256 = r256 * (8.0 + 1.5 * kt), t128 = r128 * (9.0 + s128 * kt);
         t256 = t256 > t_mem ? t256 : t_mem; t128 = t128 > t_mem ? t128 : t_mem;
         const double t8 = t256 < t128 ? t256 : t128;
         if (t8 < 0.93 * (t_ring > t_mem ? t_ring : t_mem)) {

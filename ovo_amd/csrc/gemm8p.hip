@@ -241,15 +241,19 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                 constexpr int LPR = WTN / 4, RPI = 64 / LPR;
                 const int c = (lane % LPR) * 4, n = nw + c;
                 const float4 bias = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 2
+                int tok = 0, nh = 0, tstep = 0;           // rotary position of the lane's row, advanced RPI rows per trip
+                if (g.rope_cos) { tok = (mw + lane / LPR) % g.rope_T; nh = n % g.rope_hd; tstep = RPI % g.rope_T; }
+#pragma unroll 4
                 for (int it = 0; it < HM / RPI; ++it) {
-                    const int r = it * RPI + lane / LPR, m = mw + r;
+                    const int r = it * RPI + lane / LPR, m = mw + r, tk = tok;
+                    tok += tstep;
+                    if (tok >= g.rope_T) tok -= g.rope_T;
                     const f32x4 a = *(const f32x4 *)(slab + r * ROWB + c * 4);
                     const long long md = (m < g.M && n < g.N) ? row_dest(g, m) : -1;
                     if (md < 0) continue;
                     const float4 addv = g.add ? *(const float4 *)(g.add + md * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                     float v[4] = {a[0], a[1], a[2], a[3]};
-                    math4(g, m, n, v, bias, addv);
+                    math4(g, tk, nh, n, v, bias, addv);
                     *(float4 *)((float *)g.C + md * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             } else {                                      // 2-byte rows: 8 lanes x 16 bytes per row, 8 rows per instruction
@@ -258,9 +262,13 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                 const bool in0 = n < g.N, in1 = n + 4 < g.N;
                 const float4 bias0 = (g.bias && in0) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 bias1 = (g.bias && in1) ? *(const float4 *)(g.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 2
+                int tok = 0, nh0 = 0, nh1 = 0, tstep = 0;
+                if (g.rope_cos) { tok = (mw + lane / LPR) % g.rope_T; nh0 = n % g.rope_hd; nh1 = (n + 4) % g.rope_hd; tstep = RPI % g.rope_T; }
+#pragma unroll 4
                 for (int it = 0; it < HM / RPI; ++it) {
-                    const int r = it * RPI + lane / LPR, m = mw + r;
+                    const int r = it * RPI + lane / LPR, m = mw + r, tk = tok;
+                    tok += tstep;
+                    if (tok >= g.rope_T) tok -= g.rope_T;
                     const f32x4 a0 = *(const f32x4 *)(slab + r * ROWB + c * 4), a1 = *(const f32x4 *)(slab + r * ROWB + c * 4 + 16);
                     const long long md = (m < g.M && in0) ? row_dest(g, m) : -1;
                     if (md < 0) continue;
@@ -270,8 +278,8 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                         if (in1) add1 = *(const float4 *)(g.add + md * g.ld_add + n + 4);
                     }
                     float v0[4] = {a0[0], a0[1], a0[2], a0[3]}, v1[4] = {a1[0], a1[1], a1[2], a1[3]};
-                    math4(g, m, n, v0, bias0, add0);
-                    math4(g, m, n + 4, v1, bias1, add1);
+                    math4(g, tk, nh0, n, v0, bias0, add0);
+                    math4(g, tk, nh1, n + 4, v1, bias1, add1);
                     uint4 p;
                     if (g.out_dtype == 2) { p.x = pack_bf16(v0[0], v0[1]); p.y = pack_bf16(v0[2], v0[3]); p.z = pack_bf16(v1[0], v1[1]); p.w = pack_bf16(v1[2], v1[3]); }
                     else { p.x = pack_f16(v0[0], v0[1]); p.y = pack_f16(v0[2], v0[3]); p.z = pack_f16(v1[0], v1[1]); p.w = pack_f16(v1[2], v1[3]); }

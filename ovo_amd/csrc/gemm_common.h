@@ -111,11 +111,11 @@ __device__ __forceinline__ void act4(float *v, int act) {
     }
 }
 
+// two f32 -> packed bf16 (round-to-nearest-even): v_cvt_pk_bf16_f32 on gfx950, one instruction per pair
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
-    const uint32_t ra = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;         // round-to-nearest-even (finite values)
-    const uint32_t rb = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
-    return ra | (rb << 16);
+    const bf16x2_t h = __builtin_convertvector(f32x2{a, b}, bf16x2_t);
+    return *(const uint32_t *)&h;
 }
 __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
     const __half2 h = __floats2half2_rn(a, b);
@@ -125,23 +125,25 @@ __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
 // One 4-column group of the epilogue (shared by the kernels): v = act(alpha * acc + bias) -> rotary embedding -> + residual ->
 // running first-max argmax and/or the store of 4 consecutive columns of C row `mdst` (8 / 16 bytes).
 // The arithmetic of one 4-column group of the epilogue: v = act(alpha * acc + bias) -> rotary embedding -> + residual.
-__device__ __forceinline__ void math4(const GemmArgs &g, int m, int n, float (&v)[4], float4 bias, float4 addv) {
+// `tok` = m % rope_T and `nh` = n % rope_hd (only read with rope_cos set): callers that walk rows keep them incrementally -- an integer
+// division by a run-time value is ~35 VALU instructions, once per 4 outputs it was a third of the QKV epilogue.
+__device__ __forceinline__ void math4(const GemmArgs &g, int tok, int nh, int n, float (&v)[4], float4 bias, float4 addv) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
     v[0] += bias.x; v[1] += bias.y; v[2] += bias.z; v[3] += bias.w;
     if (g.act) act4(v, g.act);
-    if (g.rope_cos && n < g.rope_cols) {
+    if (g.rope_cos && n < g.rope_cols && tok >= g.rope_t0) {
         // rotary embedding of the (2i, 2i+1) pairs this lane holds: row = token m % T, column within the head n % hd
-        const int t = m % g.rope_T;
-        if (t >= g.rope_t0) {
-            const long long at = (long long)t * g.rope_hd + n % g.rope_hd;
-            const float4 c = *(const float4 *)(g.rope_cos + at), sn = *(const float4 *)(g.rope_sin + at);
-            const float y0 = v[0] * c.x - v[1] * sn.x, y1 = v[1] * c.y + v[0] * sn.y;
-            const float y2 = v[2] * c.z - v[3] * sn.z, y3 = v[3] * c.w + v[2] * sn.w;
-            v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
-        }
+        const long long at = (long long)tok * g.rope_hd + nh;
+        const float4 c = *(const float4 *)(g.rope_cos + at), sn = *(const float4 *)(g.rope_sin + at);
+        const float y0 = v[0] * c.x - v[1] * sn.x, y1 = v[1] * c.y + v[0] * sn.y;
+        const float y2 = v[2] * c.z - v[3] * sn.z, y3 = v[3] * c.w + v[2] * sn.w;
+        v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
     }
     if (g.add) { v[0] += addv.x; v[1] += addv.y; v[2] += addv.z; v[3] += addv.w; }
+}
+__device__ __forceinline__ void math4(const GemmArgs &g, int m, int n, float (&v)[4], float4 bias, float4 addv) {
+    math4(g, g.rope_cos ? m % g.rope_T : 0, g.rope_cos ? n % g.rope_hd : 0, n, v, bias, addv);
 }
 
 // One 4-column group of the epilogue straight from the accumulators (a lane owns 4 consecutive columns of one row): math4, then the

@@ -9,9 +9,9 @@
 namespace {
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
-__device__ __forceinline__ uint16_t f2bf(float x) {
-    const uint32_t u = __float_as_uint(x);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+__device__ __forceinline__ uint16_t f2bf(float x) {      // v_cvt_pk_bf16_f32 (RNE)
+    const __bf16 h = (__bf16)x;
+    return *(const uint16_t *)&h;
 }
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
     return make_uint2((uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16), (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16));

@@ -11,11 +11,15 @@ bm, bn = (int(v) for v in tile.split("x"))
 dev = torch.device("cuda", 0)
 lib = L.load()
 a = torch.randn(m, k, device=dev).to(torch.bfloat16); w = (torch.randn(n, k, device=dev) * k ** -0.5).to(torch.bfloat16)
-out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+f32 = os.environ.get('OUT') == 'f32'
+out = torch.empty(m, n, dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
+bias = torch.randn(n, device=dev)
 tiles = -(-m // bm) * -(-n // bn)
 st = torch.zeros(tiles + 8, 4, dtype=torch.int64, device=dev)
 g = L.Gemm(); g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, g.add, g.ld_add = a.data_ptr(), k, w.data_ptr(), k, None, out.data_ptr(), n, None, 0
-g.M, g.N, g.K, g.in_dtype, g.out_dtype, g.act, g.alpha = m, n, k, 2, 2, 0, 1.0
+g.M, g.N, g.K, g.in_dtype, g.out_dtype, g.act, g.alpha = m, n, k, 2, 0 if f32 else 2, int(os.environ.get('ACT', '0')), 1.0
+if os.environ.get('BIAS'): g.bias = bias.data_ptr()
+if os.environ.get('ADD'): g.add, g.ld_add = out.data_ptr(), n      # in-place residual
 for _ in range(5): L.check(lib.ovo_gemm(C.byref(g), L.stream()))
 torch.cuda.synchronize()
 os.environ["OVO_8P_STAMPS"] = hex(st.data_ptr())

@@ -17,12 +17,18 @@ def run(m, n, k, iters=int(os.environ.get('ITERS', '100'))):
         bias = torch.randn(n, device=dev); g.bias = bias.data_ptr()
     if os.environ.get('ADD'):
         add = out if os.environ.get('INPLACE') else torch.randn(m, n, device=dev); g.add, g.ld_add = add.data_ptr(), n
-    for _ in range(10): L.check(lib.ovo_gemm(C.byref(g), L.stream()))
+    call = lambda: lib.ovo_gemm(C.byref(g), L.stream())
+    if os.environ.get('ROPE'):          # PE's QKV projection: rotary embedding of the q and k columns in the epilogue (T = 577, head_dim 64)
+        T, hd = 577, 64
+        cs, sn = torch.rand(T, hd, device=dev), torch.rand(T, hd, device=dev)
+        rope = L.Rope(); rope.cos, rope.sin, rope.T, rope.hd, rope.cols, rope.t0 = cs.data_ptr(), sn.data_ptr(), T, hd, 2 * n // 3, 1
+        call = lambda: lib.ovo_gemm_rope(C.byref(g), C.byref(rope), L.stream())
+    for _ in range(10): L.check(call())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     for i in range(iters):
         g.W = ws[i % ROT].data_ptr()
-        L.check(lib.ovo_gemm(C.byref(g), L.stream()))
+        L.check(call())
     e1.record(); torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / iters
     return us, 2.0 * m * n * k / us / 1e6
