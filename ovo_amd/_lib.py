@@ -13,7 +13,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libovo_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
+E_UNSUPPORTED = -3          # OVO_E_UNSUPPORTED: the entry point does not cover this shape; the caller takes its general path
 
 
 class OvoHipError(RuntimeError):
@@ -150,6 +151,9 @@ _SIGNATURES = {
     "ovo_row_epilogue": (_I32, [_P, _I64, _I32, _P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _P]),
     "ovo_sam_upscale_ln": (_I32, [_P, _P, _P, _P, _P, _F32, _I64, _I32, _I32, _P, _P]),
     "ovo_sam_upscale_masks": (_I32, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _P, _P]),
+    "ovo_sam_proj_ln": (_I32, [_P, _P, _P, _P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _P]),
+    "ovo_sam_up1_ln": (_I32, [_P, _P, _P, _P, _P, _P, _F32, _I64, _I32, _I32, _I32, _P, _P]),
+    "ovo_sam_up2_masks": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "ovo_instance_moments": (_I32, [_P, _P, _I64, _I32, _P, _P, _P]),
     "ovo_near_fraction": (_I32, [_P, _P, _P, _I32, _I64, _F32, _P, _P]),
     "ovo_remap_instances": (_I32, [_P, _I64, _P, _I32, _P]),

@@ -51,7 +51,7 @@ void ovo_prof_end(hipStream_t s) {
 
 extern "C" {
 const char *ovo_hip_last_error(void) { return g_err; }
-int ovo_hip_abi_version(void) { return 4; }
+int ovo_hip_abi_version(void) { return 5; }
 
 int ovo_profile_start(void) {
     g_prof.recs.clear();

@@ -248,6 +248,7 @@ class HipSamDecoder:
         f1 = L.dev(feat_s1.reshape(4 * S, c // 4), torch.float32, "feat_s1")
         f0 = L.dev(feat_s0.reshape(16 * S, c // 8), torch.float32, "feat_s0")
         bf, f32 = torch.bfloat16, torch.float32
+        lib = L.load()
         key_pe, tok0 = self.w["key_pe"], self.tokens0
         R = P * T
 
@@ -304,15 +305,30 @@ class HipSamDecoder:
             else:
                 self._attn((qi, 0), (kt, 0), (vt, 0), (oi, 0), P, H, S, T, hd_c, (0 if shared else S * ci, hd_c, ci), (T * ci, hd_c, ci),
                            (T * ci, hd_c, ci), (S * ci, hd_c, ci))
+            # out-projection + residual + norm4 (+ the bf16 copies the next products read): one fused launch (samfuse.hip); widths it
+            # does not cover run the product and the row pass separately
+            last = i == spec.depth - 1
             if shared:                                            # the prompts diverge here: materialise per-prompt keys
-                keys = self._gemm(oi, a + "out_proj", f32)
+                keys = None if last else torch.empty((P * S, c), dtype=f32, device=dev)
                 k16 = torch.empty((P * S, c), dtype=bf, device=dev)
                 kpe16 = torch.empty((P * S, c), dtype=bf, device=dev)
-                self._rows(keys, P * S, c, base=keys0, base_rows=S, norm=b + "norm4", pe=key_pe, pe_rows=S, y=keys, y16=k16, ype16=kpe16)
-                shared = False
+                res, res_rows = keys0, S
             else:
-                self._gemm(oi, a + "out_proj", f32, add=keys, out=keys)
-                self._rows(keys, P * S, c, norm=b + "norm4", pe=key_pe, pe_rows=S, y=keys, y16=k16, ype16=kpe16)
+                res, res_rows = keys, P * S
+            y32 = None if last else keys                          # the f32 residual stream is not read after the last layer
+            rc = lib.ovo_sam_proj_ln(L.ptr(oi), L.ptr(self.w[a + "out_proj.w"]), L.ptr(self.w[a + "out_proj.b"]), L.ptr(res), res_rows,
+                                     L.ptr(self.w[b + "norm4.g"]), L.ptr(self.w[b + "norm4.b"]), 1e-5, L.ptr(key_pe), S, L.ptr(y32), L.ptr(k16),
+                                     L.ptr(kpe16), P * S, c, ci, L.stream())
+            if rc == L.E_UNSUPPORTED:
+                if shared:
+                    x = self._gemm(oi, a + "out_proj", f32)
+                    self._rows(x, P * S, c, base=keys0, base_rows=S, norm=b + "norm4", pe=key_pe, pe_rows=S, y=y32, y16=k16, ype16=kpe16)
+                else:
+                    self._gemm(oi, a + "out_proj", f32, add=keys, out=keys)
+                    self._rows(keys, P * S, c, norm=b + "norm4", pe=key_pe, pe_rows=S, y=y32, y16=k16, ype16=kpe16)
+            else:
+                L.check(rc)
+            shared = False
         token_to_image(t + "final_attn_token_to_image.", qpe16)
         self._rows(q, R, c, norm=t + "norm_final_attn", y=q, y16=q16)
 
@@ -327,20 +343,26 @@ class HipSamDecoder:
             x = self._gemm(q16, pre + "layers.0", bf, act=3, rows=P, lda=T * c, a_off=(2 + m) * c)
             x = self._gemm(x, pre + "layers.1", bf, act=3)
             self._gemm(x, pre + "layers.2", f32, out=hyper, ldc=nm * (c // 8), c_off=m * (c // 8))
-        # ---- upscaling: two transposed convolutions as GEMMs, the second fused with the hyper-network product
-        lib = L.load()
-        g1 = self._gemm(k16, "up1", bf, bias=False)                                       # [P*S, 4 * c/4]
+        # ---- upscaling: two transposed convolutions as skinny products fused with what follows them (LayerNorm2d + GELU; GELU + the
+        # hyper-network product), samfuse.hip
         up1 = torch.empty((P * 4 * S, c // 4), dtype=bf, device=dev)
-        L.check(lib.ovo_sam_upscale_ln(L.ptr(g1), L.ptr(self.w["up1.b"]), L.ptr(f1), L.ptr(self.w["up_ln.g"]), L.ptr(self.w["up_ln.b"]), 1e-6,
-                                       P, s, c // 4, L.ptr(up1), L.stream()))
-        g2 = self._gemm(up1, "up2", bf, bias=False)                                       # [P*4S, 4 * c/8]
+        rc = lib.ovo_sam_up1_ln(L.ptr(k16), L.ptr(self.w["up1.w"]), L.ptr(self.w["up1.b"]), L.ptr(f1), L.ptr(self.w["up_ln.g"]),
+                                L.ptr(self.w["up_ln.b"]), 1e-6, P, s, c // 4, c, L.ptr(up1), L.stream())
+        if rc == L.E_UNSUPPORTED:
+            g1 = self._gemm(k16, "up1", bf, bias=False)                                   # [P*S, 4 * c/4]
+            rc = lib.ovo_sam_upscale_ln(L.ptr(g1), L.ptr(self.w["up1.b"]), L.ptr(f1), L.ptr(self.w["up_ln.g"]), L.ptr(self.w["up_ln.b"]), 1e-6,
+                                        P, s, c // 4, L.ptr(up1), L.stream())
+        L.check(rc)
         first = 1 if multimask else 0
         n_out = nm - first if multimask else 1
         masks = torch.empty((P, n_out, 4 * s, 4 * s), dtype=f32, device=dev)
-        if multimask:
-            L.check(lib.ovo_sam_upscale_masks(L.ptr(g2), L.ptr(self.w["up2.b"]), L.ptr(f0), L.ptr(hyper), nm, 1, P, 2 * s, c // 8, L.ptr(masks),
-                                              L.stream()))
-            return masks, iou[:, 1:]
-        h0 = hyper[:, :1].contiguous()
-        L.check(lib.ovo_sam_upscale_masks(L.ptr(g2), L.ptr(self.w["up2.b"]), L.ptr(f0), L.ptr(h0), 1, 0, P, 2 * s, c // 8, L.ptr(masks), L.stream()))
-        return masks, iou[:, :1]
+        hy = hyper if multimask else hyper[:, :1].contiguous()
+        n_m, fst = (nm, 1) if multimask else (1, 0)
+        rc = lib.ovo_sam_up2_masks(L.ptr(up1), L.ptr(self.w["up2.w"]), L.ptr(self.w["up2.b"]), L.ptr(f0), L.ptr(hy), n_m, fst, P, 2 * s, c // 8,
+                                   c // 4, L.ptr(masks), L.stream())
+        if rc == L.E_UNSUPPORTED:
+            g2 = self._gemm(up1, "up2", bf, bias=False)                                   # [P*4S, 4 * c/8]
+            rc = lib.ovo_sam_upscale_masks(L.ptr(g2), L.ptr(self.w["up2.b"]), L.ptr(f0), L.ptr(hy), n_m, fst, P, 2 * s, c // 8, L.ptr(masks),
+                                           L.stream())
+        L.check(rc)
+        return (masks, iou[:, 1:]) if multimask else (masks, iou[:, :1])
