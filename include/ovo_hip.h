@@ -230,6 +230,9 @@ typedef struct {
     int32_t T, hd, cols, t0;
 } ovo_rope_t;
 int ovo_gemm_rope(const ovo_gemm_t *g, const ovo_rope_t *rope, ovo_stream_t stream);
+/* ovo_gemm with a row-periodic `add`: product row m adds add[m % add_rows] (ld_add columns apart).  The SAM2 decoder's k_proj(keys + pe) over
+ * every prompt is keys . Wk^T + (pe . Wk^T)[pixel]: the per-pixel constant is added here instead of materialising (keys + pe). */
+int ovo_gemm_periodic(const ovo_gemm_t *g, int64_t add_rows, ovo_stream_t stream);
 /* ovo_gemm for Hiera's attention output projection (sam2 `window_unpartition` + residual, inside the encoder the reference
  * reaches at mask_generator.py:113): product row m is a token in WINDOW-major order -- windows of wh x ww tiling a B x H x W
  * token grid padded up to whole windows, M = B * ceil(H/wh) * ceil(W/ww) * wh * ww -- while C and add are addressed by the
@@ -456,9 +459,15 @@ int ovo_sam_up2_masks(const void *A, const void *W, const float *bias, const flo
                       int s2, int C2, int K, float *out, ovo_stream_t stream);
 
 /* image -> token cross attention of the two-way transformer (head_dim 16, T <= 16 token keys per prompt):
- * q bf16 [P (stride q_batch_stride elements; 0 = shared), S, 16 H], k / v bf16 [P, T, 16 H] -> o bf16 [P, S, 16 H]. */
-int ovo_sam_i2t_attention(const void *q, int64_t q_batch_stride, const void *k, const void *v, void *o, int64_t P, int S, int T, int H,
-                          float scale, ovo_stream_t stream);
+ * q bf16 rows of 16 H channels at (prompt p, pixel s) = q + p * q_batch_stride + s * q_token_stride elements (0 batch stride = shared by every
+ * prompt; a column block of a wider matrix is fine), k / v bf16 [P, T, 16 H] -> o bf16 [P, S, 16 H]. */
+int ovo_sam_i2t_attention(const void *q, int64_t q_batch_stride, int q_token_stride, const void *k, const void *v, void *o, int64_t P, int S, int T,
+                          int H, float scale, ovo_stream_t stream);
+/* token -> image cross attention (head_dim 16): q bf16 [P, T, 16 H], k / v bf16 rows of 16 H channels at (prompt p, key s) = base +
+ * p * kv_batch_stride + s * kv_token_stride elements (0 batch stride = keys shared by every prompt; k and v may be column blocks of one
+ * wider matrix) -> o bf16 [P, T, 16 H].  OVO_E_UNSUPPORTED unless H * T divides 64 (then use ovo_attention). */
+int ovo_sam_t2i_attention(const void *q, const void *k, const void *v, int64_t kv_batch_stride, int kv_token_stride, void *o, int64_t P, int S, int T,
+                          int H, float scale, ovo_stream_t stream);
 
 /* Automatic-mask-generator filters on the low-resolution logits f32 [n, h, w], evaluated on their H x W bilinear
  * upsampling (torch F.interpolate, align_corners = False) without materialising it:

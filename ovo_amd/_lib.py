@@ -132,6 +132,7 @@ _SIGNATURES = {
     "ovo_gemm": (_I32, [C.POINTER(Gemm), _P]),
     "ovo_gemm_argmax": (_I32, [C.POINTER(Gemm), _P, _I32, _I32, _P]),
     "ovo_gemm_rope": (_I32, [C.POINTER(Gemm), C.POINTER(Rope), _P]),
+    "ovo_gemm_periodic": (_I32, [C.POINTER(Gemm), _I64, _P]),
     "ovo_gemm_unwindow": (_I32, [C.POINTER(Gemm), C.POINTER(Window), _P]),
     "ovo_decode_best": (_I32, [_P, _I64, _F32, _P, _P, _P]),
     "ovo_attention": (_I32, [C.POINTER(Attention), _P]),
@@ -157,7 +158,8 @@ _SIGNATURES = {
     "ovo_instance_moments": (_I32, [_P, _P, _I64, _I32, _P, _P, _P]),
     "ovo_near_fraction": (_I32, [_P, _P, _P, _I32, _I64, _F32, _P, _P]),
     "ovo_remap_instances": (_I32, [_P, _I64, _P, _I32, _P]),
-    "ovo_sam_i2t_attention": (_I32, [_P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P]),
+    "ovo_sam_i2t_attention": (_I32, [_P, _I64, _I32, _P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P]),
+    "ovo_sam_t2i_attention": (_I32, [_P, _P, _P, _I64, _I32, _P, _I64, _I32, _I32, _I32, _F32, _P]),
     "ovo_paint_segmap": (_I32, [_P, _I32, _I64, _P, _P]),
     "ovo_amg_mask_stats": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _F32, _F32, _P, _P]),
     "ovo_amg_binarize": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _F32, _P, _P]),

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n = n0 + wn0 + j * 16 + fq * 4;
-                    if (md[i] >= 0 && n < g.N) add_r[i][j] = *(const float4 *)(g.add + md[i] * g.ld_add + n);
+                    if (md[i] >= 0 && n < g.N) add_r[i][j] = *(const float4 *)(g.add + add_row(g, m, md[i]) * g.ld_add + n);
                 }
             }
         }
@@ -319,7 +319,7 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
 }  // namespace
 
 static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, int n_valid, ovo_stream_t stream, const ovo_rope_t *rope = nullptr,
-                      const ovo_window_t *win = nullptr) {
+                      const ovo_window_t *win = nullptr, long long add_rows = 0) {
     OVO_REQUIRE(p, "null descriptor");
     OVO_REQUIRE(p->M >= 0 && p->N > 0 && p->K > 0, "bad shape");
     if (p->M == 0) return OVO_OK;
@@ -336,7 +336,7 @@ static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, 
     g.A = (const char *)p->A; g.lda = p->lda; g.W = (const char *)p->W; g.ldw = p->ldw; g.bias = p->bias;
     g.C = p->C; g.ldc = p->ldc; g.add = p->add; g.ld_add = p->ld_add;
     g.M = p->M; g.N = p->N; g.K = p->K; g.out_dtype = p->out_dtype; g.act = p->act; g.alpha = p->alpha; g.nbn = 0;
-    g.best = best; g.store = store; g.n_valid = n_valid;
+    g.best = best; g.store = store; g.n_valid = n_valid; g.add_rows = (int)add_rows; g.strip = 0;
     g.rope_cos = g.rope_sin = nullptr; g.rope_T = 1; g.rope_hd = 4; g.rope_cols = 0; g.rope_t0 = 0;
     g.dbg = 0; g.stamps = nullptr; g.win_per = 0; g.win_ww = g.win_wh = g.win_nww = g.win_nwin = 1; g.win_H = g.win_W = 0;
     if (win) {
@@ -370,6 +370,13 @@ extern "C" int ovo_gemm_rope(const ovo_gemm_t *p, const ovo_rope_t *rope, ovo_st
 extern "C" int ovo_gemm_unwindow(const ovo_gemm_t *p, const ovo_window_t *win, ovo_stream_t stream) {
     OVO_REQUIRE(win, "null window descriptor");
     return gemm_entry(p, nullptr, 1, 0, stream, nullptr, win);
+}
+
+// ovo_gemm whose `add` operand is periodic in the rows: product row m adds add[m % add_rows] (a per-pixel constant shared by every prompt of
+// the SAM2 decoder: the projection of the positional code, so that k_proj(keys + pe) = keys . Wk^T + (pe . Wk^T)[pixel] needs no (keys + pe) tensor).
+extern "C" int ovo_gemm_periodic(const ovo_gemm_t *p, int64_t add_rows, ovo_stream_t stream) {
+    OVO_REQUIRE(p && p->add && add_rows > 0 && add_rows < (1ll << 31), "periodic add needs add and 0 < add_rows < 2^31");
+    return gemm_entry(p, nullptr, 1, 0, stream, nullptr, nullptr, add_rows);
 }
 
 // C as ovo_gemm, plus a fused per-row first-max argmax over columns [0, n_valid): best u64 [M] must be ZERO on entry and holds, per

@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     const f32x4 a = *(const f32x4 *)(slab + r * ROWB + c * 4);
                     const long long md = (m < g.M && n < g.N) ? row_dest(g, m) : -1;
                     if (md < 0) continue;
-                    const float4 addv = g.add ? *(const float4 *)(g.add + md * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 addv = g.add ? *(const float4 *)(g.add + add_row(g, m, md) * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                     float v[4] = {a[0], a[1], a[2], a[3]};
                     math4(g, tk, nh, n, v, bias, addv);
                     *(float4 *)((float *)g.C + md * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -274,8 +274,9 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     if (md < 0) continue;
                     float4 add0 = make_float4(0.f, 0.f, 0.f, 0.f), add1 = add0;
                     if (g.add) {
-                        add0 = *(const float4 *)(g.add + md * g.ld_add + n);
-                        if (in1) add1 = *(const float4 *)(g.add + md * g.ld_add + n + 4);
+                        const float *ap = g.add + add_row(g, m, md) * g.ld_add + n;
+                        add0 = *(const float4 *)ap;
+                        if (in1) add1 = *(const float4 *)(ap + 4);
                     }
                     float v0[4] = {a0[0], a0[1], a0[2], a0[3]}, v1[4] = {a1[0], a1[1], a1[2], a1[3]};
                     math4(g, tk, nh0, n, v0, bias0, add0);
@@ -311,7 +312,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2 * TNH; ++j) {
                     const int n = n0 + wc * WTN + j * 16 + fq * 4;
-                    add_r[j] = (g.add && n < g.N) ? *(const float4 *)(g.add + md * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    add_r[j] = (g.add && n < g.N) ? *(const float4 *)(g.add + add_row(g, m, md) * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 float row_best = -3.0e38f;
                 int row_arg = 0x7fffffff;

@@ -23,6 +23,7 @@ struct GemmArgs {
     float alpha;
     int nbn;
     int chunk, tiles;          // chunk > 0: XCD-chunked tile order (see launch())
+    int add_rows;              // ovo_gemm_periodic: > 0 = `add` holds add_rows rows and product row m reads row m % add_rows
     int strip;                 // gemm8p: > 0 = tiles ordered in column strips of this many n-tiles (m fastest across a strip's rows)
     unsigned long long *best;  // ovo_gemm_argmax: packed (score, column) running maximum per row, or NULL
     int store, n_valid;        // with best: also store C?; columns >= n_valid (vocabulary padding) never win
@@ -125,6 +126,9 @@ __device__ __forceinline__ uint32_t pack_f16(float a, float b) {
 // One 4-column group of the epilogue (shared by the kernels): v = act(alpha * acc + bias) -> rotary embedding -> + residual ->
 // running first-max argmax and/or the store of 4 consecutive columns of C row `mdst` (8 / 16 bytes).
 // The arithmetic of one 4-column group of the epilogue: v = act(alpha * acc + bias) -> rotary embedding -> + residual.
+// row of `add` that product row m (destination row md) reads
+__device__ __forceinline__ long long add_row(const GemmArgs &g, int m, long long md) { return g.add_rows > 0 ? (long long)(m % g.add_rows) : md; }
+
 // `tok` = m % rope_T and `nh` = n % rope_hd (only read with rope_cos set): callers that walk rows keep them incrementally -- an integer
 // division by a run-time value is ~35 VALU instructions, once per 4 outputs it was a third of the QKV epilogue.
 __device__ __forceinline__ void math4(const GemmArgs &g, int tok, int nh, int n, float (&v)[4], float4 bias, float4 addv) {

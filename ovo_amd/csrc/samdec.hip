@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) k_upscale_masks(const uint16_t *__restric
 // The generic flash kernel pads T = 8 keys to a 64-key tile and head_dim 16 to 64 (5 TFLOP/s, 0.9 ms per call at 256 clicks);
 // here one thread owns one (pixel, head): 8 dot products of length 16 against the prompt's keys in LDS, softmax in registers,
 // 16 outputs.  HBM-bound: 256 B read + 256 B written per pixel.  Lanes run head-fastest, so a wave touches 8 whole pixels.
-__global__ void __launch_bounds__(256) k_i2t_attention(const uint16_t *__restrict__ q, long long q_sb, const uint16_t *__restrict__ k,
+__global__ void __launch_bounds__(256) k_i2t_attention(const uint16_t *__restrict__ q, long long q_sb, int q_st, const uint16_t *__restrict__ k,
                                                        const uint16_t *__restrict__ v, uint16_t *__restrict__ o, int S, int T, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) float kv[];   // [T][ci] keys, then [T][ci] values (ci = 16 H)
     const int ci = 16 * H;
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) k_i2t_attention(const uint16_t *__restric
     const int chunk = (S + gridDim.x - 1) / gridDim.x;
     const int s_end = min(S, (int)(blockIdx.x + 1) * chunk);
     for (int s = blockIdx.x * chunk + threadIdx.x / H; s < s_end; s += per_iter) {
-        const uint16_t *qp = q + p * q_sb + (long long)s * ci + head * 16;
+        const uint16_t *qp = q + p * q_sb + (long long)s * q_st + head * 16;
         const uint4 r0 = *(const uint4 *)qp, r1 = *(const uint4 *)(qp + 8);
         float x[16];
         const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
@@ -327,14 +327,14 @@ __global__ void __launch_bounds__(256) k_paint_segmap(const uint8_t *__restrict_
 
 }  // namespace
 
-extern "C" int ovo_sam_i2t_attention(const void *q, int64_t q_batch_stride, const void *k, const void *v, void *o, int64_t P, int S, int T, int H,
-                                     float scale, ovo_stream_t stream) {
+extern "C" int ovo_sam_i2t_attention(const void *q, int64_t q_batch_stride, int q_token_stride, const void *k, const void *v, void *o, int64_t P, int S,
+                                     int T, int H, float scale, ovo_stream_t stream) {
     OVO_REQUIRE(P >= 0 && P <= 65535 && S > 0 && T > 0 && T <= 16 && H > 0 && 256 % H == 0, "T <= 16 tokens, H a divisor of 256");
     if (P == 0) return OVO_OK;
-    OVO_REQUIRE(q && k && v && o && q_batch_stride % 8 == 0, "null / misaligned argument");
+    OVO_REQUIRE(q && k && v && o && q_batch_stride % 8 == 0 && q_token_stride % 8 == 0 && q_token_stride >= 16 * H, "null / misaligned argument");
     int bx = (S + 511) / 512;
     k_i2t_attention<<<dim3(bx, (unsigned)P), 256, (size_t)2 * T * 16 * H * sizeof(float), (hipStream_t)stream>>>(
-        (const uint16_t *)q, q_batch_stride, (const uint16_t *)k, (const uint16_t *)v, (uint16_t *)o, S, T, H, scale);
+        (const uint16_t *)q, q_batch_stride, q_token_stride, (const uint16_t *)k, (const uint16_t *)v, (uint16_t *)o, S, T, H, scale);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

@@ -287,6 +287,106 @@ __global__ void __launch_bounds__(512, 4) k_up2_masks(Up2Args a) {
     }
 }
 
+
+// ---- token -> image cross attention of the two-way transformer: T token queries x S image keys per prompt, head_dim 16 ----------
+// The generic flash kernel pads the 8 query rows to a 64-row tile and head_dim 16 to 64 and ran at half the HBM rate of its K / V
+// stream (2 MB per prompt).  Here one workgroup owns a prompt; lane = (key parity, head, token): a lane walks its wave's share of the
+// keys with the 16-wide query in registers -- a wave instruction reads the 16 H-channel K (V) row of 64 / (H T) keys, each 32-byte
+// head segment shared by the T token lanes -- keeping a running (max, sum, 16 outputs); the waves' partial states are merged through
+// LDS.  K and V may be column blocks of one wider matrix (row stride kv_st): the fused K|V|Q projection is consumed in place.
+struct T2iArgs {
+    const uint16_t *q, *k, *v; long long kv_sb; int kv_st;
+    uint16_t *o;
+    int S, T, H; float scale;
+};
+__device__ __forceinline__ void unpack8(const uint4 r, f32x2 (&x)[4]) {
+    x[0] = f32x2{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
+    x[1] = f32x2{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+    x[2] = f32x2{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u)};
+    x[3] = f32x2{__uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
+}
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_t2i_attention(T2iArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float part[];  // [NW][64][18]: max, sum, 16 outputs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HT = a.H * a.T, G = 64 / HT, ci = 16 * a.H;
+    const int sub = lane / HT, ht = lane % HT, h = ht / a.T, t = ht % a.T;
+    const long long p = blockIdx.x;
+    f32x2 qv[8];
+    {
+        const uint16_t *qp = a.q + (p * a.T + t) * ci + h * 16;
+        f32x2 lo[4], hi[4];
+        unpack8(*(const uint4 *)qp, lo); unpack8(*(const uint4 *)(qp + 8), hi);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { qv[i] = lo[i] * a.scale; qv[4 + i] = hi[i] * a.scale; }
+    }
+    const int chunk = (a.S + NW - 1) / NW, s0 = wave * chunk, s1 = min(a.S, s0 + chunk);
+    const uint16_t *kp = a.k + p * a.kv_sb + h * 16, *vp = a.v + p * a.kv_sb + h * 16;
+    float mx = -3.0e38f, den = 0.f;
+    f32x2 out[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = f32x2{0.f, 0.f};
+    constexpr int U = 4;                                          // keys per softmax update (one rescale of the running state per U keys)
+    for (int s = s0 + sub; s < s1; s += U * G) {
+        uint4 kr[U][2], vr[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int sk = min(s + u * G, a.S - 1);               // clamped: masked below
+            const uint16_t *kk = kp + (long long)sk * a.kv_st, *vv = vp + (long long)sk * a.kv_st;
+            kr[u][0] = *(const uint4 *)kk; kr[u][1] = *(const uint4 *)(kk + 8);
+            vr[u][0] = *(const uint4 *)vv; vr[u][1] = *(const uint4 *)(vv + 8);
+        }
+        float sc[U], mloc = mx;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x2 x[4], y[4];
+            unpack8(kr[u][0], x); unpack8(kr[u][1], y);
+            f32x2 d = x[0] * qv[0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) d = __builtin_elementwise_fma(x[i], qv[i], d);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d = __builtin_elementwise_fma(y[i], qv[4 + i], d);
+            sc[u] = s + u * G < s1 ? d.x + d.y : -3.0e38f;
+            mloc = fmaxf(mloc, sc[u]);
+        }
+        const float corr = __expf(mx - mloc);
+        mx = mloc;
+        den *= corr;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[i] *= corr;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float pe = s + u * G < s1 ? __expf(sc[u] - mx) : 0.f;
+            den += pe;
+            f32x2 x[4], y[4];
+            unpack8(vr[u][0], x); unpack8(vr[u][1], y);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { out[i] = __builtin_elementwise_fma(x[i], (f32x2)(pe), out[i]); out[4 + i] = __builtin_elementwise_fma(y[i], (f32x2)(pe), out[4 + i]); }
+        }
+    }
+    float *mp = part + (wave * 64 + lane) * 18;
+    mp[0] = mx; mp[1] = den;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { mp[2 + 2 * i] = out[i].x; mp[3 + 2 * i] = out[i].y; }
+    __syncthreads();
+    if (tid < HT * 16) {                                          // thread = (head-token, output channel): merge NW x G partial states
+        const int e = tid / 16, d = tid % 16;
+        float M = -3.0e38f;
+        for (int w = 0; w < NW; ++w)
+            for (int g = 0; g < G; ++g) M = fmaxf(M, part[(w * 64 + g * HT + e) * 18]);
+        float L = 0.f, O = 0.f;
+        for (int w = 0; w < NW; ++w)
+            for (int g = 0; g < G; ++g) {
+                const float *pp = part + (w * 64 + g * HT + e) * 18;
+                const float f = __expf(pp[0] - M);
+                L += pp[1] * f; O += pp[2 + d] * f;
+            }
+        const int eh = e / a.T, et = e % a.T;
+        const __bf16 r = (__bf16)(O / L);
+        a.o[(p * a.T + et) * ci + eh * 16 + d] = *(const uint16_t *)&r;
+    }
+}
+
 template <typename KernelT>
 int set_lds(KernelT k, size_t lds, const char *who) {
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -371,6 +471,26 @@ extern "C" int ovo_sam_up2_masks(const void *A, const void *W, const float *bias
     }
     if (C2 == 32) GO(64, 32) else GO(32, 16)
 #undef GO
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+extern "C" int ovo_sam_t2i_attention(const void *q, const void *k, const void *v, int64_t kv_batch_stride, int kv_token_stride, void *o, int64_t P,
+                                     int S, int T, int H, float scale, ovo_stream_t stream) {
+    OVO_REQUIRE(P >= 0 && S > 0 && T > 0 && H > 0, "bad shape");
+    if (H * T > 64 || 64 % (H * T) != 0 || H * T * 16 > 1024) return OVO_E_UNSUPPORTED;
+    if (P == 0) return OVO_OK;
+    OVO_REQUIRE(q && k && v && o && kv_batch_stride % 8 == 0 && kv_token_stride % 8 == 0 && kv_token_stride >= 16 * H, "null / misaligned argument");
+    OVO_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0, "16-byte alignment");
+    T2iArgs a;
+    a.q = (const uint16_t *)q; a.k = (const uint16_t *)k; a.v = (const uint16_t *)v; a.kv_sb = kv_batch_stride; a.kv_st = kv_token_stride;
+    a.o = (uint16_t *)o; a.S = S; a.T = T; a.H = H; a.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int NW = 16;
+    const size_t lds = (size_t)NW * 64 * 18 * sizeof(float);
+    static bool done = false;
+    if (!done) { if (int rc = set_lds(k_t2i_attention<NW>, lds, __func__)) return rc; done = true; }
+    k_t2i_attention<NW><<<(unsigned)P, 64 * NW, lds, st>>>(a);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

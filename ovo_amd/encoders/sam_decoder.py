@@ -168,6 +168,24 @@ class HipSamDecoder:
         if "no_mem_embed" in sd:                                  # SAM2ImagePredictor adds it to the lowest-resolution feature
             dense = dense + sd["no_mem_embed"].reshape(1, c).float()
         up("dense", dense, torch.float32)
+        # Image-side projections once the prompts have diverged (layers >= 1 and the final attention): K | V (| Q of the image -> token
+        # attention) read the same keys, so they are ONE product over them; the positional code enters as its own projection, a per-pixel
+        # constant added in the epilogue (ovo_gemm_periodic): k_proj(keys + pe) = keys . Wk^T + (pe . Wk^T)[pixel].
+        pe64 = self.w["key_pe"].double().cpu()
+
+        def fuse(name, parts):                                     # parts: (projection, adds the positional code?)
+            ws = [sd[pn + ".weight"] for pn, _ in parts]
+            up(name + ".w", torch.cat(ws), torch.bfloat16)
+            up(name + ".b", torch.cat([sd[pn + ".bias"] for pn, _ in parts]).float(), torch.float32)
+            cols = [pe64 @ w.to(torch.bfloat16).double().T if with_pe else torch.zeros(pe64.shape[0], w.shape[0], dtype=torch.float64)
+                    for w, (_, with_pe) in zip(ws, parts)]
+            up(name + ".add", torch.cat(cols, dim=1).float(), torch.float32)
+
+        for i in range(1, spec.depth):
+            b = blocks[i]
+            fuse(b + "kvq", [(b + "cross_attn_token_to_image.k_proj", True), (b + "cross_attn_token_to_image.v_proj", False),
+                             (b + "cross_attn_image_to_token.q_proj", True)])
+        fuse(t + "final_kv", [(t + "final_attn_token_to_image.k_proj", True), (t + "final_attn_token_to_image.v_proj", False)])
         self._gauss = gauss
         self.tokens0: Optional[torch.Tensor] = None
         self.tok16: Optional[torch.Tensor] = None
@@ -199,7 +217,7 @@ class HipSamDecoder:
     # ------------------------------------------------------------------ launches
     def _gemm(self, a: torch.Tensor, wname: str, out_dtype, act: int = 0, add: Optional[torch.Tensor] = None,
               out: Optional[torch.Tensor] = None, rows: Optional[int] = None, lda: Optional[int] = None, ldc: Optional[int] = None,
-              a_off: int = 0, c_off: int = 0, bias: bool = True) -> torch.Tensor:
+              a_off: int = 0, c_off: int = 0, bias: bool = True, add_rows: int = 0) -> torch.Tensor:
         w = self.w[wname + ".w"]
         m = a.shape[0] if rows is None else rows
         n, k = w.shape
@@ -212,7 +230,10 @@ class HipSamDecoder:
         g.add, g.ld_add = (add.data_ptr(), add.stride(0)) if add is not None else (None, 0)
         g.M, g.N, g.K = m, n, k
         g.in_dtype, g.out_dtype, g.act, g.alpha = 2, L.DTYPE_CODE[out.dtype], act, 1.0
-        L.check(L.load().ovo_gemm(C.byref(g), L.stream()))
+        if add_rows:                                              # add[m % add_rows]: a per-pixel constant shared by every prompt
+            L.check(L.load().ovo_gemm_periodic(C.byref(g), add_rows, L.stream()))
+        else:
+            L.check(L.load().ovo_gemm(C.byref(g), L.stream()))
         return out
 
     @staticmethod
@@ -267,18 +288,34 @@ class HipSamDecoder:
         hd_s, hd_c = c // H, ci // H
         t = MD + "transformer."
 
-        def token_to_image(pre, qin16):
+        def t2i_attention(tq, K, V, kv_sb, kv_st, o):
+            rc = lib.ovo_sam_t2i_attention(L.ptr(tq), K, V, kv_sb, kv_st, L.ptr(o), P, S, T, H, hd_c ** -0.5, L.stream()) if hd_c == 16 \
+                else L.E_UNSUPPORTED
+            return rc
+
+        def token_to_image(pre, qin16, kv=None):
+            """kv: the fused per-prompt projection bf16 [P*S, n * ci] (K | V | ...), or None while the keys are shared (layer 0)."""
             nonlocal q
             tq = self._gemm(qin16, pre + "q_proj", bf)                                    # [R, ci]
-            K = self._gemm(kpe16, pre + "k_proj", bf)                                     # [S | P*S, ci]
-            V = self._gemm(k16, pre + "v_proj", bf)
+            if kv is None:
+                K = self._gemm(kpe16, pre + "k_proj", bf)                                 # [S, ci]
+                V = self._gemm(k16, pre + "v_proj", bf)
+                kt_, vt_, kb, ks = (K, 0), (V, 0), 0, ci
+            else:
+                kt_, vt_, kb, ks = (kv, 0), (kv, ci), S * kv.shape[1], kv.shape[1]
             o = torch.empty((R, ci), dtype=bf, device=dev)
-            kb = 0 if shared else S * ci
-            self._attn((tq, 0), (K, 0), (V, 0), (o, 0), P, H, T, S, hd_c, (T * ci, hd_c, ci), (kb, hd_c, ci), (kb, hd_c, ci), (T * ci, hd_c, ci))
+            kptr, vptr = (C.c_void_p(t_.data_ptr() + off * 2) for t_, off in (kt_, vt_))
+            rc = t2i_attention(tq, kptr, vptr, kb, ks, o)
+            if rc == L.E_UNSUPPORTED:
+                self._attn((tq, 0), kt_, vt_, (o, 0), P, H, T, S, hd_c, (T * ci, hd_c, ci), (kb, hd_c, ks), (kb, hd_c, ks), (T * ci, hd_c, ci))
+            else:
+                L.check(rc)
             self._gemm(o, pre + "out_proj", f32, add=q, out=q)
 
         for i in range(spec.depth):
             b = t + f"layers.{i}."
+            # per-prompt keys: K | V of the token -> image attention and Q of the image -> token attention in one product over them
+            kvq = None if shared else self._gemm(k16, b + "kvq", bf, add=self.w[b + "kvq.add"], add_rows=S)      # [P*S, 3 ci]
             # ---- self attention on the tokens (first layer: no positional code, no residual)
             qk = self._gemm(self.tok16 if i == 0 else qpe16, b + "self_attn.qk", bf)      # [R, 2c]
             v = self._gemm(self.tok16 if i == 0 else q16, b + "self_attn.v_proj", bf)     # [R, c]
@@ -287,7 +324,7 @@ class HipSamDecoder:
             self._gemm(o_tok, b + "self_attn.out_proj", f32, add=None if i == 0 else q, out=q)
             self._rows(q, R, c, norm=b + "norm1", pe=tok0, pe_rows=R, y=q, y16=q16, ype16=qpe16)
             # ---- tokens attend to the image
-            token_to_image(b + "cross_attn_token_to_image.", qpe16)
+            token_to_image(b + "cross_attn_token_to_image.", qpe16, kvq)
             self._rows(q, R, c, norm=b + "norm2", y=q, y16=q16)
             # ---- MLP
             h = self._gemm(q16, b + "mlp.layers.0", bf, act=3)
@@ -297,13 +334,16 @@ class HipSamDecoder:
             a = b + "cross_attn_image_to_token."
             kt = self._gemm(qpe16, a + "k_proj", bf)                                      # [R, ci]
             vt = self._gemm(q16, a + "v_proj", bf)
-            qi = self._gemm(kpe16, a + "q_proj", bf)                                      # [S | P*S, ci]
+            if shared:
+                qi, q_off, q_sb, q_st = self._gemm(kpe16, a + "q_proj", bf), 0, 0, ci     # [S, ci]
+            else:
+                qi, q_off, q_sb, q_st = kvq, 2 * ci, S * 3 * ci, 3 * ci
             oi = torch.empty((P * S, ci), dtype=bf, device=dev)
             if hd_c == 16 and T <= 16 and 256 % H == 0:           # S queries x 8 keys: the dedicated HBM-bound kernel
-                L.check(L.load().ovo_sam_i2t_attention(L.ptr(qi), 0 if shared else S * ci, L.ptr(kt), L.ptr(vt), L.ptr(oi), P, S, T, H,
-                                                       hd_c ** -0.5, L.stream()))
+                L.check(lib.ovo_sam_i2t_attention(C.c_void_p(qi.data_ptr() + 2 * q_off), q_sb, q_st, L.ptr(kt), L.ptr(vt), L.ptr(oi), P, S, T, H,
+                                                  hd_c ** -0.5, L.stream()))
             else:
-                self._attn((qi, 0), (kt, 0), (vt, 0), (oi, 0), P, H, S, T, hd_c, (0 if shared else S * ci, hd_c, ci), (T * ci, hd_c, ci),
+                self._attn((qi, q_off), (kt, 0), (vt, 0), (oi, 0), P, H, S, T, hd_c, (q_sb, hd_c, q_st), (T * ci, hd_c, ci),
                            (T * ci, hd_c, ci), (S * ci, hd_c, ci))
             # out-projection + residual + norm4 (+ the bf16 copies the next products read): one fused launch (samfuse.hip); widths it
             # does not cover run the product and the row pass separately
@@ -311,7 +351,7 @@ class HipSamDecoder:
             if shared:                                            # the prompts diverge here: materialise per-prompt keys
                 keys = None if last else torch.empty((P * S, c), dtype=f32, device=dev)
                 k16 = torch.empty((P * S, c), dtype=bf, device=dev)
-                kpe16 = torch.empty((P * S, c), dtype=bf, device=dev)
+                kpe16 = None                                      # (keys + pe) is never formed per prompt: see `fuse` in __init__
                 res, res_rows = keys0, S
             else:
                 res, res_rows = keys, P * S
@@ -329,7 +369,8 @@ class HipSamDecoder:
             else:
                 L.check(rc)
             shared = False
-        token_to_image(t + "final_attn_token_to_image.", qpe16)
+        kv = None if shared else self._gemm(k16, t + "final_kv", bf, add=self.w[t + "final_kv.add"], add_rows=S)        # [P*S, 2 ci]
+        token_to_image(t + "final_attn_token_to_image.", qpe16, kv)
         self._rows(q, R, c, norm=t + "norm_final_attn", y=q, y16=q16)
 
         # ---- heads: IoU prediction and hyper-network rows straight from strided token rows

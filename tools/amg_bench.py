@@ -20,10 +20,11 @@ def timed(name, fn, n=5):
     torch.cuda.synchronize()
     print(f"{name:30s} {1e3 * (time.perf_counter() - t0) / n:8.2f} ms")
     return out
-emb = timed("encoder", lambda: enc.encode_frame(img.permute(2, 0, 1).contiguous()))
+emb = timed("encoder", lambda: enc.encode_frame(img.permute(2, 0, 1).contiguous()), n=1 if os.environ.get("DEC_ONLY") else 5)
 amg._set_grid()
 f0, f1 = emb["high_res_feats"]
 timed(f"decoder ({pps * pps} clicks)", lambda: dec.forward(emb["image_embed"][0], f1[0], f0[0]))
+if os.environ.get("DEC_ONLY"): sys.exit(0)      # rocprofv3 of the decoder alone (1 encoder + 6 decoder forwards)
 r = timed("generate_device (all)", lambda: amg.generate_device(img))
 print("kept", r["masks"].shape[0], "of", pps * pps * 3, "| peak memory GB", torch.cuda.max_memory_allocated() / 2**30)
 if os.environ.get("OVO_PROF_DUMP"):
