@@ -451,6 +451,10 @@ int ovo_sam_upscale_masks(const void *g, const float *bias, const float *feat, c
  * ovo_sam_up1_ln:    A bf16 [P s s, K] . W[4 C1, K]^T (+ bias, + feat, LayerNorm2d, GELU) -> out bf16 [P, 2s, 2s, C1]   (= ovo_gemm + ovo_sam_upscale_ln)
  * ovo_sam_up2_masks: A bf16 [P s2 s2, K] . W[4 C2, K]^T (+ bias, + feat, GELU, hyper-network dot) -> out f32 [P, n_mask - first, 2 s2, 2 s2]
  *                    (= ovo_gemm + ovo_sam_upscale_masks). */
+/* ovo_sam_linear: C bf16 [M, N] (row stride ldc) = A bf16 [M, K] . W[N, K]^T + bias + add[m % add_rows] (f32, row stride ld_add; NULL = none):
+ * the K | V and Q projections over the per-prompt keys ((K, N) = (256, 256 | 128) or (128, 128 | 64); else OVO_E_UNSUPPORTED -> ovo_gemm_periodic). */
+int ovo_sam_linear(const void *A, const void *W, const float *bias, const float *add, int64_t add_rows, int ld_add, void *C, int ldc, int64_t M,
+                   int N, int K, ovo_stream_t stream);
 int ovo_sam_proj_ln(const void *A, const void *W, const float *bias, const float *res, int64_t res_rows, const float *gamma, const float *beta,
                     float eps, const float *pe, int64_t pe_rows, float *y32, void *y16, void *ype16, int64_t M, int N, int K, ovo_stream_t stream);
 int ovo_sam_up1_ln(const void *A, const void *W, const float *bias, const float *feat, const float *gamma, const float *beta, float eps,

@@ -387,6 +387,47 @@ __global__ void __launch_bounds__(64 * NW) k_t2i_attention(T2iArgs a) {
     }
 }
 
+// ---- C bf16 [M, N] (row stride ldc) = A . W^T + bias + add[m % add_rows] ---------------------------------------------------------
+// The K | V (| Q) projections over the per-prompt keys: at K = 256 and N <= 256 the tiled GEMMs spend their time in prologues and
+// epilogues (2 TB/s); with the weights resident this is a plain stream of A in, C out.
+struct LinArgs {
+    const uint16_t *A, *W;
+    const float *bias, *add; int add_rows, ld_add;
+    uint16_t *C; int ldc;
+    int M;
+};
+template <int K, int N, int NTHREADS>
+__global__ void __launch_bounds__(NTHREADS, NTHREADS == 512 ? 4 : 1) k_skinny_linear(LinArgs a) {
+    using S = Skinny<K, N>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *cs = (float *)(smem + S::W_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    S::load_w(smem, a.W, tid, NTHREADS);
+    for (int i = tid; i < N; i += NTHREADS) cs[i] = a.bias ? a.bias[i] : 0.f;
+    __syncthreads();
+    const float *cl = cs + fq * 4;
+    const int blocks = (a.M + 15) / 16;
+    for (int b = blockIdx.x * (NTHREADS / 64) + wave; b < blocks; b += gridDim.x * (NTHREADS / 64)) {
+        const int m = b * 16 + fr, mc = m < a.M ? m : a.M - 1;
+        bf16x8 af[S::KS];
+        S::load_a(af, a.A, mc, fq);
+        f32x4 acc[S::NT];
+        const float *ap = a.add ? a.add + (long long)(mc % a.add_rows) * a.ld_add + fq * 4 : nullptr;
+#pragma unroll
+        for (int j = 0; j < S::NT; ++j) {
+            f32x4 v = *(const f32x4 *)(cl + j * 16);
+            if (ap) v += *(const f32x4 *)(ap + j * 16);
+            acc[j] = v;
+            if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        S::mma(acc, af, smem, fr, fq);
+        if (m >= a.M) continue;
+        uint16_t *cp = a.C + (long long)m * a.ldc + fq * 4;
+#pragma unroll
+        for (int j = 0; j < S::NT; ++j) *(uint2 *)(cp + j * 16) = make_uint2(pack2(acc[j][0], acc[j][1]), pack2(acc[j][2], acc[j][3]));
+    }
+}
+
 template <typename KernelT>
 int set_lds(KernelT k, size_t lds, const char *who) {
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -491,6 +532,36 @@ extern "C" int ovo_sam_t2i_attention(const void *q, const void *k, const void *v
     static bool done = false;
     if (!done) { if (int rc = set_lds(k_t2i_attention<NW>, lds, __func__)) return rc; done = true; }
     k_t2i_attention<NW><<<(unsigned)P, 64 * NW, lds, st>>>(a);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+extern "C" int ovo_sam_linear(const void *A, const void *W, const float *bias, const float *add, int64_t add_rows, int ld_add, void *C, int ldc,
+                              int64_t M, int N, int K, ovo_stream_t stream) {
+    OVO_REQUIRE(M >= 0 && M < (1ll << 31) - 16, "bad row count");
+    if (!((K == 256 && (N == 256 || N == 128)) || (K == 128 && (N == 128 || N == 64)))) return OVO_E_UNSUPPORTED;
+    if (M == 0) return OVO_OK;
+    OVO_REQUIRE(A && W && C && ldc >= N && ldc % 4 == 0, "null pointer / bad ldc");
+    OVO_REQUIRE(!add || (add_rows > 0 && add_rows < (1ll << 31) && ld_add >= N && ld_add % 4 == 0), "periodic add needs its row count and stride");
+    OVO_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)add | (uintptr_t)bias) % 16 == 0 && (uintptr_t)C % 8 == 0, "alignment");
+    LinArgs a;
+    a.A = (const uint16_t *)A; a.W = (const uint16_t *)W; a.bias = bias; a.add = add; a.add_rows = (int)add_rows; a.ld_add = ld_add;
+    a.C = (uint16_t *)C; a.ldc = ldc; a.M = (int)M;
+    const int blocks = (int)((M + 15) / 16);
+    hipStream_t st = (hipStream_t)stream;
+#define GO(KK, NN, NTH, WGS)                                                                                          \
+    {                                                                                                                 \
+        const size_t lds = (size_t)NN * KK * 2 + NN * sizeof(float);                                                  \
+        static bool done = false;                                                                                     \
+        if (!done) { if (int rc = set_lds(k_skinny_linear<KK, NN, NTH>, lds, __func__)) return rc; done = true; }     \
+        const int wpb = NTH / 64, grid = blocks < WGS * wpb ? (blocks + wpb - 1) / wpb : WGS;                         \
+        k_skinny_linear<KK, NN, NTH><<<grid, NTH, lds, st>>>(a);                                                      \
+    }
+    if (K == 256 && N == 256) GO(256, 256, 1024, 256)       // 128 KB of weights: one 16-wave workgroup per CU
+    else if (K == 256) GO(256, 128, 512, 512)
+    else if (N == 128) GO(128, 128, 512, 512)
+    else GO(128, 64, 512, 512)
+#undef GO
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

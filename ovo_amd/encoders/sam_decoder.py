@@ -236,6 +236,24 @@ class HipSamDecoder:
             L.check(L.load().ovo_gemm(C.byref(g), L.stream()))
         return out
 
+    def _image_proj(self, a16: torch.Tensor, wname: str, groups) -> torch.Tensor:
+        """bf16 [rows, N] = a16 . W^T + bias + add[row % S] for the fused image-side projection `wname` (see `fuse`), computed as one
+        LDS-resident-weight stream per column group (`groups`: widths summing to N; ovo_sam_linear) or, for widths that has no
+        instantiation for, as one tiled GEMM with the periodic add."""
+        w, bias, add = self.w[wname + ".w"], self.w[wname + ".b"], self.w[wname + ".add"]
+        n, k = w.shape
+        rows, S = a16.shape[0], add.shape[0]
+        out = torch.empty((rows, n), dtype=torch.bfloat16, device=a16.device)
+        lib, lo = L.load(), 0
+        for width in groups:
+            rc = lib.ovo_sam_linear(L.ptr(a16), C.c_void_p(w.data_ptr() + 2 * lo * k), C.c_void_p(bias.data_ptr() + 4 * lo),
+                                    C.c_void_p(add.data_ptr() + 4 * lo), S, n, C.c_void_p(out.data_ptr() + 2 * lo), n, rows, width, k, L.stream())
+            if rc == L.E_UNSUPPORTED:
+                return self._gemm(a16, wname, torch.bfloat16, add=add, add_rows=S, out=out)
+            L.check(rc)
+            lo += width
+        return out
+
     @staticmethod
     def _attn(q, k, v, o, B, H, Tq, Tk, hd, qs, ks, vs, os_):
         """q/k/v/o: (tensor, element offset); *s: (batch, head, token) strides in elements."""
@@ -315,7 +333,7 @@ class HipSamDecoder:
         for i in range(spec.depth):
             b = t + f"layers.{i}."
             # per-prompt keys: K | V of the token -> image attention and Q of the image -> token attention in one product over them
-            kvq = None if shared else self._gemm(k16, b + "kvq", bf, add=self.w[b + "kvq.add"], add_rows=S)      # [P*S, 3 ci]
+            kvq = None if shared else self._image_proj(k16, b + "kvq", (2 * ci, ci))                            # [P*S, 3 ci]
             # ---- self attention on the tokens (first layer: no positional code, no residual)
             qk = self._gemm(self.tok16 if i == 0 else qpe16, b + "self_attn.qk", bf)      # [R, 2c]
             v = self._gemm(self.tok16 if i == 0 else q16, b + "self_attn.v_proj", bf)     # [R, c]
@@ -369,7 +387,7 @@ class HipSamDecoder:
             else:
                 L.check(rc)
             shared = False
-        kv = None if shared else self._gemm(k16, t + "final_kv", bf, add=self.w[t + "final_kv.add"], add_rows=S)        # [P*S, 2 ci]
+        kv = None if shared else self._image_proj(k16, t + "final_kv", (2 * ci,))                               # [P*S, 2 ci]
         token_to_image(t + "final_attn_token_to_image.", qpe16, kv)
         self._rows(q, R, c, norm=t + "norm_final_attn", y=q, y16=q16)
 
