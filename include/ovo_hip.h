@@ -446,7 +446,8 @@ int ovo_sam_upscale_masks(const void *g, const float *bias, const float *feat, c
 /* The three HBM-bound products of the decoder's image side fused with the row passes above (samfuse.hip): the weights stay in LDS, the
  * product never reaches HBM.  Each returns OVO_E_UNSUPPORTED for widths other than SAM2's (hidden 256) and the test card's (128); the
  * caller then runs the unfused chain (ovo_gemm + the pass).
- * ovo_sam_proj_ln:   y = LayerNorm(res[m % res_rows] + A[M,K] . W[N,K]^T + bias) -> y32 f32 / y16 bf16 / ype16 bf16 (+ pe[m % pe_rows])
+ * ovo_sam_proj_ln:   y = LayerNorm(res[m % res_rows] + A[M,K] . W[N,K]^T + bias) -> y32 f32 / y16 bf16 / ype16 bf16 (+ pe[m % pe_rows]);
+ *                    the residual is f32 `res` or bf16 `res16` (at most one of them)
  *                    (attention out-projection + residual + norm4 of TwoWayAttentionBlock; (N, K) = (256, 128) | (128, 64)).
  * ovo_sam_up1_ln:    A bf16 [P s s, K] . W[4 C1, K]^T (+ bias, + feat, LayerNorm2d, GELU) -> out bf16 [P, 2s, 2s, C1]   (= ovo_gemm + ovo_sam_upscale_ln)
  * ovo_sam_up2_masks: A bf16 [P s2 s2, K] . W[4 C2, K]^T (+ bias, + feat, GELU, hyper-network dot) -> out f32 [P, n_mask - first, 2 s2, 2 s2]
@@ -455,7 +456,7 @@ int ovo_sam_upscale_masks(const void *g, const float *bias, const float *feat, c
  * the K | V and Q projections over the per-prompt keys ((K, N) = (256, 256 | 128) or (128, 128 | 64); else OVO_E_UNSUPPORTED -> ovo_gemm_periodic). */
 int ovo_sam_linear(const void *A, const void *W, const float *bias, const float *add, int64_t add_rows, int ld_add, void *C, int ldc, int64_t M,
                    int N, int K, ovo_stream_t stream);
-int ovo_sam_proj_ln(const void *A, const void *W, const float *bias, const float *res, int64_t res_rows, const float *gamma, const float *beta,
+int ovo_sam_proj_ln(const void *A, const void *W, const float *bias, const float *res, const void *res16, int64_t res_rows, const float *gamma, const float *beta,
                     float eps, const float *pe, int64_t pe_rows, float *y32, void *y16, void *ype16, int64_t M, int N, int K, ovo_stream_t stream);
 int ovo_sam_up1_ln(const void *A, const void *W, const float *bias, const float *feat, const float *gamma, const float *beta, float eps,
                    int64_t P, int s, int C1, int K, void *out, ovo_stream_t stream);

@@ -153,7 +153,7 @@ _SIGNATURES = {
     "ovo_sam_upscale_ln": (_I32, [_P, _P, _P, _P, _P, _F32, _I64, _I32, _I32, _P, _P]),
     "ovo_sam_upscale_masks": (_I32, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _P, _P]),
     "ovo_sam_linear": (_I32, [_P, _P, _P, _P, _I64, _I32, _P, _I32, _I64, _I32, _I32, _P]),
-    "ovo_sam_proj_ln": (_I32, [_P, _P, _P, _P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _P]),
+    "ovo_sam_proj_ln": (_I32, [_P, _P, _P, _P, _P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _P]),
     "ovo_sam_up1_ln": (_I32, [_P, _P, _P, _P, _P, _P, _F32, _I64, _I32, _I32, _I32, _P, _P]),
     "ovo_sam_up2_masks": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "ovo_instance_moments": (_I32, [_P, _P, _I64, _I32, _P, _P, _P]),

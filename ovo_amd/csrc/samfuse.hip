@@ -86,7 +86,7 @@ struct Skinny {
 // ---- y = LayerNorm(res[m % res_rows] + A . W^T + bias) -------------------------------------------------------------------------
 struct ProjLnArgs {
     const uint16_t *A, *W;
-    const float *bias, *res; int res_rows;
+    const float *bias, *res; const uint16_t *res16; int res_rows;   // residual: f32 `res` or bf16 `res16` (at most one)
     const float *gamma, *beta; float eps;
     const float *pe; int pe_rows;
     float *y32; uint16_t *y16, *ype16;
@@ -108,12 +108,18 @@ __global__ void __launch_bounds__(512, 4) k_proj_ln(ProjLnArgs a) {
         bf16x8 af[S::KS];
         S::load_a(af, a.A, mc, fq);
         f32x4 acc[S::NT];
-        const float *rp = a.res ? a.res + (long long)(mc % a.res_rows) * N : nullptr;
+        const long long rrow = (a.res || a.res16) ? (long long)(mc % a.res_rows) * N : 0;
+        const float *rp = a.res ? a.res + rrow : nullptr;
+        const uint16_t *rp16 = a.res16 ? a.res16 + rrow : nullptr;
 #pragma unroll
         for (int j = 0; j < S::NT; ++j) {                        // the residual and the bias seed the accumulators
             const int c = j * 16 + fq * 4;
             f32x4 v = *(const f32x4 *)(cl + j * 16);
             if (rp) v += *(const f32x4 *)(rp + c);
+            if (rp16) {
+                const uint2 r = *(const uint2 *)(rp16 + c);
+                v += f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+            }
             acc[j] = v;
             if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // bounds the loads in flight (registers)
         }
@@ -437,17 +443,18 @@ int set_lds(KernelT k, size_t lds, const char *who) {
 
 }  // namespace
 
-extern "C" int ovo_sam_proj_ln(const void *A, const void *W, const float *bias, const float *res, int64_t res_rows, const float *gamma,
+extern "C" int ovo_sam_proj_ln(const void *A, const void *W, const float *bias, const float *res, const void *res16, int64_t res_rows, const float *gamma,
                                const float *beta, float eps, const float *pe, int64_t pe_rows, float *y32, void *y16, void *ype16,
                                int64_t M, int N, int K, ovo_stream_t stream) {
     OVO_REQUIRE(M >= 0 && M < (1ll << 31) - 16, "bad row count");
     if (!((N == 256 && K == 128) || (N == 128 && K == 64))) return OVO_E_UNSUPPORTED;
     if (M == 0) return OVO_OK;
     OVO_REQUIRE(A && W && gamma && beta && (y32 || y16 || ype16), "null pointer");
-    OVO_REQUIRE((!res || (res_rows > 0 && res_rows <= M)) && (!ype16 || (pe && pe_rows > 0)), "broadcast sources need their row counts");
+    OVO_REQUIRE(!(res && res16) && (!(res || res16) || (res_rows > 0 && res_rows <= M)) && (!ype16 || (pe && pe_rows > 0)),
+                "one residual at most; broadcast sources need their row counts");
     OVO_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)res | (uintptr_t)pe | (uintptr_t)y32 | (uintptr_t)y16 | (uintptr_t)ype16) % 16 == 0, "16-byte alignment");
     ProjLnArgs a;
-    a.A = (const uint16_t *)A; a.W = (const uint16_t *)W; a.bias = bias; a.res = res; a.res_rows = (int)res_rows; a.gamma = gamma; a.beta = beta;
+    a.A = (const uint16_t *)A; a.W = (const uint16_t *)W; a.bias = bias; a.res = res; a.res16 = (const uint16_t *)res16; a.res_rows = (int)res_rows; a.gamma = gamma; a.beta = beta;
     a.eps = eps; a.pe = pe; a.pe_rows = (int)pe_rows; a.y32 = y32; a.y16 = (uint16_t *)y16; a.ype16 = (uint16_t *)ype16; a.M = (int)M;
     const int blocks = (int)((M + 15) / 16), grid = blocks < 512 * 8 ? (blocks + 7) / 8 : 512;
     hipStream_t st = (hipStream_t)stream;

@@ -22,6 +22,12 @@ import torch
 
 from .. import _lib as L
 
+import os
+# The per-prompt keys [P * S, C] between the two-way layers are kept in bf16 only: the tensor every product reads is bf16 anyway, and reading it
+# back as the residual instead of a second f32 copy saves 1.6 GB of traffic per layer at 256 prompts.  The reference runs the decoder under bf16
+# autocast (mask_generator.py:46,112: every nn.Linear output is bf16 there); measured against the fp32 oracle the mask-logit error is unchanged
+# (max err / rms 4.1e-2 -> 4.0e-2, tests/test_gpu_sam_decoder.py).  OVO_SAM_RES16=0 keeps the f32 residual stream.
+RES16 = os.environ.get("OVO_SAM_RES16", "1") == "1"
 PE = "sam_prompt_encoder."
 MD = "sam_mask_decoder."
 
@@ -367,14 +373,16 @@ class HipSamDecoder:
             # does not cover run the product and the row pass separately
             last = i == spec.depth - 1
             if shared:                                            # the prompts diverge here: materialise per-prompt keys
-                keys = None if last else torch.empty((P * S, c), dtype=f32, device=dev)
+                keys = None if last or RES16 else torch.empty((P * S, c), dtype=f32, device=dev)
                 k16 = torch.empty((P * S, c), dtype=bf, device=dev)
                 kpe16 = None                                      # (keys + pe) is never formed per prompt: see `fuse` in __init__
-                res, res_rows = keys0, S
+                res, res16, res_rows = keys0, None, S
+            elif RES16:
+                res, res16, res_rows, k16 = None, k16, P * S, torch.empty((P * S, c), dtype=bf, device=dev)
             else:
-                res, res_rows = keys, P * S
+                res, res16, res_rows = keys, None, P * S
             y32 = None if last else keys                          # the f32 residual stream is not read after the last layer
-            rc = lib.ovo_sam_proj_ln(L.ptr(oi), L.ptr(self.w[a + "out_proj.w"]), L.ptr(self.w[a + "out_proj.b"]), L.ptr(res), res_rows,
+            rc = lib.ovo_sam_proj_ln(L.ptr(oi), L.ptr(self.w[a + "out_proj.w"]), L.ptr(self.w[a + "out_proj.b"]), L.ptr(res), L.ptr(res16), res_rows,
                                      L.ptr(self.w[b + "norm4.g"]), L.ptr(self.w[b + "norm4.b"]), 1e-5, L.ptr(key_pe), S, L.ptr(y32), L.ptr(k16),
                                      L.ptr(kpe16), P * S, c, ci, L.stream())
             if rc == L.E_UNSUPPORTED:
