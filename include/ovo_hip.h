@@ -281,7 +281,8 @@ int ovo_im2col(const float *img, int B, int C, int H, int W, int ksz, int stride
 
 /* Crop + resize (bilinear, align_corners = False, optional antialias exactly as torch's
  * F.interpolate(..., antialias=True)) + per-channel normalise: out[c] = (resize(src[c]) * scale - mean[c]) / std[c].
- * src is CHW, u8 (src_dtype 3) or f32 (0); the crop is rows [y0, y0+ch) x cols [x0, x0+cw). out f32 [C, oh, ow]. */
+ * src is CHW, u8 (src_dtype 3) or f32 (0), or an interleaved u8 [H, W, C] frame as the camera delivers it (src_dtype 4: no permute
+ * pass before the encoders); the crop is rows [y0, y0+ch) x cols [x0, x0+cw). out f32 [C, oh, ow]. */
 int ovo_resize_normalize(const void *src, int src_dtype, int C, int H, int W, int y0, int x0, int ch, int cw,
                          float *out, int oh, int ow, int antialias, float scale, const float *mean3_host,
                          const float *std3_host, ovo_stream_t stream);

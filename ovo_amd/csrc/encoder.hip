@@ -110,11 +110,11 @@ __global__ void __launch_bounds__(256) k_im2col(const float *__restrict__ img, i
 
 // ---- crop + resize + normalise ----
 struct ResizeArgs {
-    const void *src; int src_u8; int C, H, W, y0, x0, ch, cw, oh, ow, aa;
+    const void *src; int src_u8, hwc; int C, H, W, y0, x0, ch, cw, oh, ow, aa;     // hwc: interleaved [H, W, C] source (a camera frame as it arrives)
     float scale, mean[4], std[4];
 };
 __device__ __forceinline__ float src_px(const ResizeArgs &a, int c, int y, int x) {
-    const long long i = ((long long)c * a.H + (a.y0 + y)) * a.W + (a.x0 + x);
+    const long long i = a.hwc ? ((long long)(a.y0 + y) * a.W + (a.x0 + x)) * a.C + c : ((long long)c * a.H + (a.y0 + y)) * a.W + (a.x0 + x);
     return a.src_u8 ? (float)((const uint8_t *)a.src)[i] : ((const float *)a.src)[i];
 }
 __device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
@@ -459,11 +459,11 @@ int ovo_im2col(const float *img, int B, int C, int H, int W, int ksz, int stride
 int ovo_resize_normalize(const void *src, int src_dtype, int C, int H, int W, int y0, int x0, int ch, int cw, float *out,
                          int oh, int ow, int antialias, float scale, const float *mean3_host, const float *std3_host,
                          ovo_stream_t stream) {
-    OVO_REQUIRE(src && out && (src_dtype == 0 || src_dtype == 3), "src_dtype: 0 = f32, 3 = u8");
+    OVO_REQUIRE(src && out && (src_dtype == 0 || src_dtype == 3 || src_dtype == 4), "src_dtype: 0 = f32 [C,H,W], 3 = u8 [C,H,W], 4 = u8 [H,W,C]");
     OVO_REQUIRE(C >= 1 && C <= 4 && ch > 0 && cw > 0 && oh > 0 && ow > 0, "bad shape");
     OVO_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + ch <= H && x0 + cw <= W, "crop outside the image");
     ResizeArgs a;
-    a.src = src; a.src_u8 = src_dtype == 3; a.C = C; a.H = H; a.W = W; a.y0 = y0; a.x0 = x0; a.ch = ch; a.cw = cw;
+    a.src = src; a.src_u8 = src_dtype >= 3; a.hwc = src_dtype == 4; a.C = C; a.H = H; a.W = W; a.y0 = y0; a.x0 = x0; a.ch = ch; a.cw = cw;
     a.oh = oh; a.ow = ow; a.aa = antialias; a.scale = scale;
     for (int c = 0; c < 4; ++c) { a.mean[c] = mean3_host && c < C ? mean3_host[c] : 0.f; a.std[c] = std3_host && c < C ? std3_host[c] : 1.f; }
     dim3 grid((ow + 63) / 64, (oh + 3) / 4);

@@ -193,15 +193,16 @@ class HipHiera:
 
     # ---------------------------------------------------------------- preprocessing (SAM2Transforms: Resize + Normalize)
     def preprocess(self, image: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """CHW u8 (0..255) or f32 ([0,1]) image on the GPU -> f32 [1, 3, S, S]."""
+        """CHW u8 (0..255) or f32 ([0,1]) image on the GPU, or an HWC u8 frame (read in place) -> f32 [1, 3, S, S]."""
         s = self.spec.image_size
         img = L.dev(image, image.dtype, "image")
-        _, h, w = img.shape
+        hwc = img.dtype == torch.uint8 and img.shape[-1] == 3 and img.shape[0] != 3
+        h, w = (img.shape[0], img.shape[1]) if hwc else (img.shape[1], img.shape[2])
         if out is None:
             out = torch.empty((1, 3, s, s), dtype=torch.float32, device=img.device)
         mean, std = (C.c_float * 3)(*IMAGENET_MEAN), (C.c_float * 3)(*IMAGENET_STD)
         scale = 1.0 / 255.0 if img.dtype == torch.uint8 else 1.0
-        L.check(L.load().ovo_resize_normalize(L.ptr(img), L.DTYPE_CODE[img.dtype], 3, h, w, 0, 0, h, w, L.ptr(out), s, s, 1, scale,
+        L.check(L.load().ovo_resize_normalize(L.ptr(img), 4 if hwc else L.DTYPE_CODE[img.dtype], 3, h, w, 0, 0, h, w, L.ptr(out), s, s, 1, scale,
                                               mean, std, L.stream()))
         return out
 

@@ -257,21 +257,24 @@ class HipViT:
     # ---------------------------------------------------------------- preprocessing
     def preprocess(self, image: torch.Tensor, crops: Optional[Sequence[Tuple[int, int, int, int]]] = None,
                    scale: float = 1.0, antialias: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """CHW image (u8 0..255 or f32) -> f32 [len(crops), 3, S, S]: squash-resize each crop (y0, x0, h, w) to the
+        """CHW image (u8 0..255 or f32), or an HWC u8 frame (last dim 3: read in place, no permute copy) -> f32 [len(crops), 3, S, S]:
+        squash-resize each crop (y0, x0, h, w) to the
         model resolution (bilinear, antialiased like torchvision's tensor Resize) and normalise with mean / std.
         `scale` multiplies pixel values first (1/255 for u8 input expected in [0, 1])."""
         s = self.spec
         img = L.dev(image, image.dtype, "image")
         if img.dtype not in (torch.uint8, torch.float32):
             raise L.OvoHipError("image must be u8 or f32")
-        _, h, w = img.shape
+        hwc = img.dtype == torch.uint8 and img.shape[-1] == 3 and img.shape[0] != 3
+        h, w = (img.shape[0], img.shape[1]) if hwc else (img.shape[1], img.shape[2])
         crops = list(crops) if crops is not None else [(0, 0, h, w)]
         if out is None:
             out = torch.empty((len(crops), 3, s.image_size, s.image_size), dtype=torch.float32, device=img.device)
         mean, std = (C.c_float * 3)(*s.mean), (C.c_float * 3)(*s.std)
         lib = L.load()
+        code = 4 if hwc else L.DTYPE_CODE[img.dtype]
         for i, (y0, x0, ch, cw) in enumerate(crops):
-            L.check(lib.ovo_resize_normalize(L.ptr(img), L.DTYPE_CODE[img.dtype], 3, h, w, y0, x0, ch, cw, L.ptr(out[i]),
+            L.check(lib.ovo_resize_normalize(L.ptr(img), code, 3, h, w, y0, x0, ch, cw, L.ptr(out[i]),
                                              s.image_size, s.image_size, int(antialias), float(scale), mean, std, L.stream()))
         return out
 

@@ -385,7 +385,8 @@ class OVO:
             side.wait_event(ev)                                   # nothing to wait for -- and no wait on the caller's stream, whose queue
         with torch.cuda.stream(side):                             # holds the previous keyframes' tails this forward should overlap)
             for k, image in enumerate(images):
-                tr.vlm.preprocess(image.permute(2, 0, 1).contiguous(), crops, scale=1.0 / 255.0, out=slot["batch"][k * nc:(k + 1) * nc])
+                src = image if image.dtype == torch.uint8 and image.is_contiguous() else image.permute(2, 0, 1).contiguous()     # HWC u8: read in place
+                tr.vlm.preprocess(src, crops, scale=1.0 / 255.0, out=slot["batch"][k * nc:(k + 1) * nc])
             tr.vlm.forward(slot["batch"][:n], tokens=True, out=slot["tokens"][:n])
             done = torch.cuda.Event()
             done.record(side)

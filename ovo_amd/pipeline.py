@@ -88,6 +88,11 @@ def synthetic_frames(n: int, device, scale: float = 1.0, n_masks_grid=(4, 6), n_
     return out
 
 
+def _hwc(rgb: torch.Tensor) -> torch.Tensor:
+    """An HWC u8 frame as the resize kernel reads it in place; anything else goes through a CHW copy."""
+    return rgb if rgb.dtype == torch.uint8 and rgb.is_contiguous() else rgb.permute(2, 0, 1).contiguous()
+
+
 class FramePipeline:
     SHARD_BLOCK = 4096          # points per block of the block-cyclic dense-accumulator shards
     MAX_DESC = 128              # descriptor rows a keyframe contributes to the exchange (masks per frame <= 128)
@@ -175,7 +180,7 @@ class FramePipeline:
                 if self._sam_in is None or self._sam_in.shape[0] < len(group):
                     self._sam_in = torch.empty((len(group), 3, s, s), dtype=torch.float32, device=self.device)
                 for k, g in enumerate(group):
-                    self.sam.preprocess(g.rgb.permute(2, 0, 1).contiguous(), out=self._sam_in[k:k + 1])
+                    self.sam.preprocess(_hwc(g.rgb), out=self._sam_in[k:k + 1])      # the HWC frame is read in place
                 self.sam_out = self.sam.forward(self._sam_in[:len(group)])
                 for k, g in enumerate(group):                      # a frame's features = slice k of the batched output
                     self._sam_by_frame[g.index] = (self.sam_out, k)
@@ -220,7 +225,7 @@ class FramePipeline:
                 if self.amg is not None:                           # the whole generator: encoder + 256-click decoder + filters
                     amg_pending = self.amg.generate_launch(f.rgb)
                 else:
-                    self.sam_out = self.sam.forward(self.sam.preprocess(f.rgb.permute(2, 0, 1).contiguous()))
+                    self.sam_out = self.sam.forward(self.sam.preprocess(_hwc(f.rgb)))
                     self._sam_by_frame[f.index] = (self.sam_out, 0)
         if self.prefetch:                                          # ViT tokens do not depend on the masks: start them now
             self.ovo.prefetch_image_features(f.rgb, f.ready)

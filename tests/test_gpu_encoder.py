@@ -262,6 +262,9 @@ def test_resize_normalize_vs_torch(aa, src, crop, out):
     torch.testing.assert_close(got, ref, atol=2e-5, rtol=1e-5)
     got_f = HipViT.preprocess(vit, img.float().to(DEV), [crop or (0, 0, *src)], scale=1 / 255.0, antialias=aa)[0].cpu()
     assert torch.equal(got, got_f)
+    # the interleaved HWC frame read in place (what the pipeline hands over) == the planar copy of it, bit for bit
+    got_hwc = HipViT.preprocess(vit, img.permute(1, 2, 0).contiguous().to(DEV), [crop or (0, 0, *src)], scale=1 / 255.0, antialias=aa)[0].cpu()
+    assert torch.equal(got, got_hwc)
 
 
 def test_vit_forward_vs_hf_golden():
