@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--map-points", type=int, default=1_000_000)
     ap.add_argument("--texts", type=int, default=10)
     ap.add_argument("--no-dense", action="store_true", help="skip the dense per-point accumulate / query")
-    ap.add_argument("--encoder-batch", type=int, default=int(os.environ.get("OVO_ENCODER_BATCH", "4")),
+    ap.add_argument("--encoder-batch", type=int, default=int(os.environ.get("OVO_ENCODER_BATCH", "8")),
                     help="keyframes (per GPU) whose SAM2 / ViT forwards run as ONE batched forward each (encoder look-ahead; 1 = per frame). "
                          "The reference defers a keyframe's descriptors by kf_queue_delay = 10 keyframes (ovo.yaml:53), so results do not change")
     ap.add_argument("--sam-full", action="store_true", help="not the headline workload: also run SAM2's mask decoder on a 16x16 click grid and the "
@@ -288,6 +288,7 @@ def main():
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     map0 = pipe.slam.pcd.cpu().numpy().copy() if want_cpu else None
 
+    pipe.prime(H, W)                                               # allocator / first-launch set-up at the full encoder-batch width
     feed = Feed(frames, world)
     feed.run(pipe, args.warmup)
     torch.cuda.synchronize()

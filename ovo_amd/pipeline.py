@@ -168,6 +168,23 @@ class FramePipeline:
             torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ encoders
+    def prime(self, H: int, W: int) -> None:
+        """Set-up, not work of any frame: one batched forward of both encoders at the full look-ahead width on blank H x W frames, once per
+        token slot, so that workspaces / slots have their final size (device allocations, first launches of the batch-sized kernel
+        variants) before the first real group -- which may arrive inside a timed region after a shorter warm-up group."""
+        if self.encoder_batch <= 1:
+            return
+        for _ in range(2):                                         # two token slots (double-buffered batches)
+            blank = [Frame(-1 - k, torch.zeros((H, W, 3), dtype=torch.uint8, device=self.device), None, None, None, None, None)
+                     for k in range(self.encoder_batch)]
+            self._launch_encoders(blank)
+            torch.cuda.synchronize()
+            for f in blank:
+                self.ovo._prefetched_batch.pop(id(f.rgb), None)
+            for slot in (self.ovo._batch_slots or []):
+                slot["left"], slot["free"] = 0, None
+        self._sam_by_frame.clear(); self._encoded.clear(); self._group_first.clear()
+
     def _launch_encoders(self, group: List[Frame]) -> None:
         """SAM2 image encoder and ViT forward of a group of keyframes, each as one batched forward on its side stream."""
         if self.sam is not None:

@@ -14,9 +14,9 @@ timeout 600 python bench.py --sam-full --no-cpu-baseline --sustain-seconds 0 > $
 timeout 300 python tools/query_bench.py > $OUT/query_bench.log 2>&1
 timeout 300 python tools/amg_bench.py 16 > $OUT/amg_bench.log 2>&1
 timeout 300 python tools/geom_bench.py > $OUT/geom_bench.txt 2>&1
-TILES="auto,ring,256x256,256x128" SHAPES="4616,3072,1024;4616,1024,1024;4616,4096,1024;4616,1024,4096;16384,1792,448;16384,448,1792;19600,1344,448;4096,4096,4096;8192,8192,8192" timeout 600 python tools/gemm_bench.py > $OUT/gemm_sweep.txt 2>&1
-(python tools/gemm8p_stamps.py 4616 3072 1024 256x256; python tools/gemm8p_stamps.py 4616 4096 1024 256x128; python tools/gemm8p_stamps.py 4096 4096 4096 256x256) > $OUT/gemm8p_timeline.txt 2>&1
-(python tools/enc_table.py vit 4; python tools/enc_table.py sam 4) > $OUT/enc_tables_b4.txt 2>&1
+TILES="auto,ring,256x256,256x128" SHAPES="9232,3072,1024;9232,1024,1024;9232,4096,1024;9232,1024,4096;32768,1792,448;32768,448,1792;39200,1344,448;4616,3072,1024;4616,4096,1024;4096,4096,4096;8192,8192,8192" timeout 600 python tools/gemm_bench.py > $OUT/gemm_sweep.txt 2>&1
+(python tools/gemm8p_stamps.py 9232 3072 1024 256x256; python tools/gemm8p_stamps.py 9232 4096 1024 256x128; python tools/gemm8p_stamps.py 4096 4096 4096 256x256) > $OUT/gemm8p_timeline.txt 2>&1
+(python tools/enc_table.py vit 8; python tools/enc_table.py sam 8) > $OUT/enc_tables_b8.txt 2>&1
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $R/bench.py --no-cpu-baseline --steps 12 --sustain-seconds 0 > $OUT/prof_bench.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 > $OUT/pmc_fetch.log 2>&1
