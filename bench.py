@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--vit", default="PE-Core-L14-336", help="ViT card (ovo_amd.encoders.vit.SPECS)")
     ap.add_argument("--sam", default="hiera_b+", help="SAM2 image encoder card, or 'none'")

@@ -20,6 +20,7 @@
 //   * operands are swapped (a = W fragment, b = activation fragment): the accumulator holds C^T tiles, i.e.
 //     each lane owns 4 consecutive output columns of one output row -> 8/16-byte epilogue stores.
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -277,6 +278,13 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
     //   (a 256x128, BK = 32, 3-stage form of the ring kernel below with TWO workgroups per CU -- so that one tile's epilogue would overlap
     //   the other's K-loop -- measured 1.4-1.6x SLOWER than the ping-pong kernel: 16 MFMAs per barrier do not keep the K-loop fed)
     // the ring kernels above run ~650 TFLOP/s + 4 us at these sizes (tools/gemm_bench.py on MI355X, profiles/r02*_gemm_sweep.txt).
+    // Tall short-K products are HBM streams: the weights-resident streaming kernel (gemm_stream.hip) runs them at 3+ TB/s, the tiled
+    // kernels below at ~2 (tools/gemm_bench.py, profiles/r02c_gemm_stream.txt).
+    const char *force_tile = getenv("OVO_GEMM_TILE");
+    if (g.M >= 16384 && g.K <= 256 && ((!force_tile && !getenv("OVO_GEMM_NO_STREAM")) || (force_tile && !strcmp(force_tile, "stream")))) {
+        const int rc = gemm_stream_launch(g, std::is_same<VT, bf16x8>::value ? 2 : 1, s);
+        if (rc != OVO_E_UNSUPPORTED) return rc;
+    }
     if (k64 && g.M >= 2048 && g.N >= 256 && !getenv("OVO_GEMM_TILE") && !getenv("OVO_GEMM_NO_8P")) {
         const double flop = 2.0 * g.M * (double)g.N * g.K, kt = g.K / 64;
         const double bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (double)g.M * g.N * (g.out_dtype == 0 ? 4.0 : 2.0) * (g.add ? 2.0 : 1.0);

@@ -11,12 +11,12 @@
 //   * k_up1_ln      : ConvTranspose2d(2x2, s2) + skip + LayerNorm2d + GELU -> bf16 [P, 2s, 2s, C1]   (output_upscaling.0-2)
 //   * k_up2_masks   : ConvTranspose2d(2x2, s2) + skip + GELU + hyper-network product -> mask logits  (output_upscaling.3-4 + hypernets)
 // Reference path: sam2 MaskDecoder.predict_masks / TwoWayAttentionBlock, reached at segment_utils.py:291-308, mask_generator.py:113.
-#include "common.h"
+#include "skinny.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+using ovo_gemm_detail::bf16x8;
+using ovo_gemm_detail::f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) {     // v_cvt_pk_bf16_f32 (RNE)
@@ -43,45 +43,7 @@ __device__ __forceinline__ float quad_sum(float v) {             // over the 4 l
     return v + __shfl_xor(v, 32, 64);
 }
 
-// A [M, K] bf16 (rows contiguous), W [N, K] bf16 resident in LDS, one wave = 16 rows x N columns.
-template <int K, int N>
-struct Skinny {
-    static constexpr int CPR = K / 8, KS = K / 32, NT = N / 16, W_BYTES = N * K * 2;
-    static_assert(K % 32 == 0 && N % 16 == 0 && CPR >= 4, "shape");
-    // ds_read_b128 of a fragment: 16 lanes read the same 16-byte chunk of 16 consecutive rows; rows are K * 2 bytes apart, so the
-    // chunk index is XORed with a row function that spreads those 16 reads over all 64 banks (applied when W is copied in, too)
-    static __device__ __forceinline__ int swz(int n) { return CPR >= 16 ? (n & 15) : CPR == 8 ? ((n >> 1) & 7) : ((n >> 2) & 3); }
-    static __device__ __forceinline__ void load_w(char *lds, const uint16_t *W, int tid, int nthreads) {
-        for (int id = tid; id < N * CPR; id += nthreads) {
-            const int n = id / CPR, c = id % CPR;
-            *(uint4 *)(lds + (n * CPR + (c ^ swz(n))) * 16) = *(const uint4 *)(W + (long long)n * K + c * 8);
-        }
-    }
-    static __device__ __forceinline__ void load_a(bf16x8 (&a)[KS], const uint16_t *A, long long row, int fq) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a[ks] = *(const bf16x8 *)(A + row * K + (ks * 4 + fq) * 8);
-    }
-    // acc[j][r] += sum_k A[row fr][k] W[16 j + 4 fq + r][k]   (operands swapped: the accumulator holds 4 consecutive columns of one row)
-    static __device__ __forceinline__ void mma(f32x4 (&acc)[NT], const bf16x8 (&a)[KS], const char *lds, int fr, int fq) {
-        // groups of JG weight fragments (4 VGPRs each) are read, then multiplied; the scheduling fences keep the compiler from hoisting
-        // every ds_read of the product ahead of the first MFMA (N / 16 x K / 32 fragments = 256+ VGPRs: it spilled the accumulators).
-        // Four waves per SIMD cover a group's LDS latency.
-        constexpr int JG = NT < 8 ? NT : 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int j0 = 0; j0 < NT; j0 += JG) {
-                bf16x8 w[JG];
-                // swz() depends on the row only through fr (16 j drops out), so a fragment address is (lane part for this ks) + j * constant
-                const char *wp = lds + (fr * CPR + ((ks * 4 + fq) ^ swz(fr))) * 16;
-#pragma unroll
-                for (int jj = 0; jj < JG; ++jj) w[jj] = *(const bf16x8 *)(wp + (j0 + jj) * (16 * CPR * 16));
-#pragma unroll
-                for (int jj = 0; jj < JG; ++jj) acc[j0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[jj], a[ks], acc[j0 + jj], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-    }
-};
+using ovo_skinny::Skinny;
 
 // ---- y = LayerNorm(res[m % res_rows] + A . W^T + bias) -------------------------------------------------------------------------
 struct ProjLnArgs {
@@ -98,7 +60,7 @@ __global__ void __launch_bounds__(512, 4) k_proj_ln(ProjLnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *gs = (float *)(smem + S::W_BYTES), *bs = gs + N, *cs = bs + N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    S::load_w(smem, a.W, tid, 512);
+    S::load_w(smem, a.W, K, tid, 512);
     for (int i = tid; i < N; i += 512) { gs[i] = a.gamma[i]; bs[i] = a.beta[i]; cs[i] = a.bias ? a.bias[i] : 0.f; }
     __syncthreads();
     const int blocks = (a.M + 15) / 16;
@@ -106,7 +68,7 @@ __global__ void __launch_bounds__(512, 4) k_proj_ln(ProjLnArgs a) {
     for (int b = blockIdx.x * 8 + wave; b < blocks; b += gridDim.x * 8) {
         const int m = b * 16 + fr, mc = m < a.M ? m : a.M - 1;
         bf16x8 af[S::KS];
-        S::load_a(af, a.A, mc, fq);
+        S::load_a(af, a.A, K, mc, fq);
         f32x4 acc[S::NT];
         const long long rrow = (a.res || a.res16) ? (long long)(mc % a.res_rows) * N : 0;
         const float *rp = a.res ? a.res + rrow : nullptr;
@@ -168,7 +130,7 @@ __global__ void __launch_bounds__(NTHREADS) k_up1_ln(Up1Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *gs = (float *)(smem + S::W_BYTES), *bs = gs + C1, *cs = bs + C1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    S::load_w(smem, a.W, tid, NTHREADS);
+    S::load_w(smem, a.W, K, tid, NTHREADS);
     for (int i = tid; i < C1; i += NTHREADS) { gs[i] = a.gamma[i]; bs[i] = a.beta[i]; cs[i] = a.bias[i]; }
     __syncthreads();
     const int ss = a.s * a.s, M = a.P * ss, blocks = (M + 15) / 16, side = 2 * a.s;
@@ -176,7 +138,7 @@ __global__ void __launch_bounds__(NTHREADS) k_up1_ln(Up1Args a) {
     for (int b = blockIdx.x * (NTHREADS / 64) + wave; b < blocks; b += gridDim.x * (NTHREADS / 64)) {
         const int m = b * 16 + fr, mc = m < M ? m : M - 1;
         bf16x8 af[S::KS];
-        S::load_a(af, a.A, mc, fq);
+        S::load_a(af, a.A, K, mc, fq);
         const int p = mc / ss, rem = mc - p * ss, y = rem / a.s, x = rem - y * a.s;
         f32x4 acc[S::NT];
 #pragma unroll
@@ -230,7 +192,7 @@ __global__ void __launch_bounds__(512, 4) k_up2_masks(Up2Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *cs = (float *)(smem + S::W_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    S::load_w(smem, a.W, tid, 512);
+    S::load_w(smem, a.W, K, tid, 512);
     for (int i = tid; i < C2; i += 512) cs[i] = a.bias[i];
     __syncthreads();
     const int ss = a.s2 * a.s2, M = a.P * ss, blocks = (M + 15) / 16, side = 2 * a.s2;
@@ -238,7 +200,7 @@ __global__ void __launch_bounds__(512, 4) k_up2_masks(Up2Args a) {
     for (int b = blockIdx.x * 8 + wave; b < blocks; b += gridDim.x * 8) {
         const int m = b * 16 + fr, mc = m < M ? m : M - 1;
         bf16x8 af[S::KS];
-        S::load_a(af, a.A, mc, fq);
+        S::load_a(af, a.A, K, mc, fq);
         const int p = mc / ss, rem = mc - p * ss, y = rem / a.s2, x = rem - y * a.s2;
         f32x4 acc[S::NT];
 #pragma unroll
@@ -408,7 +370,7 @@ __global__ void __launch_bounds__(NTHREADS, NTHREADS == 512 ? 4 : 1) k_skinny_li
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *cs = (float *)(smem + S::W_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    S::load_w(smem, a.W, tid, NTHREADS);
+    S::load_w(smem, a.W, K, tid, NTHREADS);
     for (int i = tid; i < N; i += NTHREADS) cs[i] = a.bias ? a.bias[i] : 0.f;
     __syncthreads();
     const float *cl = cs + fq * 4;
@@ -416,7 +378,7 @@ __global__ void __launch_bounds__(NTHREADS, NTHREADS == 512 ? 4 : 1) k_skinny_li
     for (int b = blockIdx.x * (NTHREADS / 64) + wave; b < blocks; b += gridDim.x * (NTHREADS / 64)) {
         const int m = b * 16 + fr, mc = m < a.M ? m : a.M - 1;
         bf16x8 af[S::KS];
-        S::load_a(af, a.A, mc, fq);
+        S::load_a(af, a.A, K, mc, fq);
         f32x4 acc[S::NT];
         const float *ap = a.add ? a.add + (long long)(mc % a.add_rows) * a.ld_add + fq * 4 : nullptr;
 #pragma unroll

@@ -28,6 +28,7 @@ import torch
 
 from .. import _lib as L
 from ..utils import geometry_utils as G
+from ..utils.streams import side_stream
 from .descriptor_bank import DescriptorBank, KeyframeView
 from .instance3d import Instance3D
 
@@ -333,7 +334,7 @@ class OVO:
             return False
         if self._vit_stream is None:
             # (a high stream priority for this forward was measured: no effect on MI355X, 167 vs 168 frames/s)
-            self._vit_stream = torch.cuda.Stream(device=image.device, priority=int(os.environ.get("OVO_VIT_PRIORITY", "0")))
+            self._vit_stream = side_stream(image.device, "OVO_VIT_CUS", int(os.environ.get("OVO_VIT_PRIORITY", "0")))
         # the ViT workspace is shared between keyframes: wait for its last reader (the previous pooling), not for the whole
         # main stream -- the previous keyframe's fusion / query tail then overlaps this forward
         if self._tokens_free is not None:
@@ -363,7 +364,7 @@ class OVO:
             return False
         dev = images[0].device
         if self._vit_stream is None:
-            self._vit_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("OVO_VIT_PRIORITY", "0")))
+            self._vit_stream = side_stream(dev, "OVO_VIT_CUS", int(os.environ.get("OVO_VIT_PRIORITY", "0")))
         if self._batch_slots is None:
             self._batch_slots = [dict(batch=None, tokens=None, free=None, left=0) for _ in range(2)]
             self._batch_next = 0

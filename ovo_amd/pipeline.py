@@ -43,6 +43,7 @@ from .entities.clip_generator import CLIPGenerator
 from .entities.ovo import OVO
 from .slam.vanilla_mapper import VanillaMapper
 from .utils import clip_utils
+from .utils.streams import side_stream
 
 
 @dataclass
@@ -139,7 +140,7 @@ class FramePipeline:
         self.sam_frame = None                                      # SAM2 features (f0, f1, f2) of the keyframe this rank last stepped
         self.prefetch = not os.environ.get("OVO_NO_PREFETCH")
         self.join_each_step = bool(os.environ.get("OVO_JOIN_EACH_STEP"))
-        self.sam_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("OVO_SAM_PRIORITY", "0"))) if (sam_card and not os.environ.get("OVO_SAM_SAME_STREAM")) else None
+        self.sam_stream = side_stream(self.device, "OVO_SAM_CUS", int(os.environ.get("OVO_SAM_PRIORITY", "0"))) if (sam_card and not os.environ.get("OVO_SAM_SAME_STREAM")) else None
         self.D = self.clip.clip_dim
         self.texts = torch.from_numpy(syn.unit_vectors(n_text, self.D, seed=seed + 7)).to(self.device)
         self.dense = dense

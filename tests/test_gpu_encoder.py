@@ -105,6 +105,70 @@ def test_gemm_pingpong_kernel_vs_ring_kernel_and_torch(monkeypatch, tile, m, n, 
     torch.testing.assert_close(x, add + a.float() @ w.float().T + bias, atol=3e-4, rtol=3e-4)
 
 
+@pytest.mark.parametrize("m,n,k", [(16400, 448, 128), (20000, 336, 128), (16390, 112, 192), (17000, 896, 256), (16384, 256, 256),
+                                   (16500, 64, 256), (16384, 32, 256), (16385, 112, 128), (16384, 672, 256), (16384, 256, 128), (16400, 336, 128)])
+def test_gemm_stream_kernel_vs_tiled_kernel_and_torch(monkeypatch, m, n, k):
+    """The weights-resident streaming kernel (gemm_stream.hip: tall short-K products, the automatic choice at M >= 16384, K <= 256) against
+    the fp32 product of the same rounded operands and against the tiled kernels (OVO_GEMM_NO_STREAM): both accumulate every output
+    element over k in ascending 32-wide MFMA steps, so they agree bit for bit -- GELU, residual, bf16 stores, ragged M, lda > K included."""
+    dtype = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(m + 3 * n + 7 * k)
+    a = torch.randn(m, k + 64, generator=g).to(DEV, dtype)[:, :k]
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(DEV, dtype)
+    bias, add = torch.randn(n, generator=g).to(DEV), torch.randn(m, n, generator=g).to(DEV)
+    monkeypatch.setenv("OVO_GEMM_NO_STREAM", "1")
+    tiled = _gemm(a, w, bias, add=add, act=1)
+    tiled_b = _gemm(a, w, bias, out_dtype=torch.bfloat16)
+    monkeypatch.delenv("OVO_GEMM_NO_STREAM")
+    monkeypatch.setenv("OVO_GEMM_TILE", "stream")                  # forced: an unsupported shape would fall through to a tiled kernel silently
+    out = _gemm(a, w, bias, add=add, act=1)
+    out_b = _gemm(a, w, bias, out_dtype=torch.bfloat16)
+    out_nb = _gemm(a, w, None, out_dtype=torch.bfloat16, alpha=0.5)
+    ref = torch.nn.functional.gelu(a.float() @ w.float().T + bias) + add
+    torch.testing.assert_close(out, ref, atol=3e-4, rtol=3e-4)
+    torch.testing.assert_close(out_nb.float(), 0.5 * (a.float() @ w.float().T), atol=0.03, rtol=0.01)
+    assert torch.equal(out, tiled) and torch.equal(out_b, tiled_b)
+    x = add.clone()                                                # in-place residual: C aliases add
+    from ovo_amd import _lib as L
+    gg = L.Gemm()
+    gg.A, gg.lda, gg.W, gg.ldw, gg.bias = a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr()
+    gg.C, gg.ldc, gg.add, gg.ld_add = x.data_ptr(), n, x.data_ptr(), n
+    gg.M, gg.N, gg.K, gg.in_dtype, gg.out_dtype, gg.act, gg.alpha = m, n, k, 2, 0, 0, 1.0
+    L.check(L.load().ovo_gemm(C.byref(gg), L.stream()))
+    torch.testing.assert_close(x, add + a.float() @ w.float().T + bias, atol=3e-4, rtol=3e-4)
+
+
+def test_gemm_stream_kernel_unwindow_rows(monkeypatch):
+    """ovo_gemm_unwindow on the streaming kernel: window-major product rows land on their spatial rows, padding rows are dropped."""
+    from ovo_amd import _lib as L
+    B, H, W, wh, ww, n, k = 3, 100, 60, 8, 8, 112, 128              # 13 x 8 windows per image: M = 3 * 104 * 64 = 19968, H and W padded
+    nwh, nww = -(-H // wh), -(-W // ww)
+    M = B * nwh * nww * wh * ww
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, k, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(DEV, torch.bfloat16)
+    bias = torch.randn(n, generator=g).to(DEV)
+    res = torch.randn(B * H * W, n, generator=g).to(DEV)
+    outs = []
+    for mode in ("tiled", "stream"):
+        if mode == "tiled":
+            monkeypatch.setenv("OVO_GEMM_NO_STREAM", "1")
+        else:
+            monkeypatch.delenv("OVO_GEMM_NO_STREAM")
+            monkeypatch.setenv("OVO_GEMM_TILE", "stream")
+        x = res.clone()
+        gg, win = L.Gemm(), L.Window()
+        gg.A, gg.lda, gg.W, gg.ldw, gg.bias = a.data_ptr(), k, w.data_ptr(), k, bias.data_ptr()
+        gg.C, gg.ldc, gg.add, gg.ld_add = x.data_ptr(), n, x.data_ptr(), n
+        gg.M, gg.N, gg.K, gg.in_dtype, gg.out_dtype, gg.act, gg.alpha = M, n, k, 2, 0, 0, 1.0
+        win.B, win.H, win.W, win.wh, win.ww = B, H, W, wh, ww
+        L.check(L.load().ovo_gemm_unwindow(C.byref(gg), C.byref(win), L.stream()))
+        outs.append(x)
+    assert torch.equal(outs[0], outs[1])
+    prod = (a.float() @ w.float().T + bias).reshape(B, nwh, nww, wh, ww, n).permute(0, 1, 3, 2, 4, 5).reshape(B, nwh * wh, nww * ww, n)[:, :H, :W]
+    torch.testing.assert_close(outs[1], res + prod.reshape(B * H * W, n), atol=3e-4, rtol=3e-4)
+
+
 @pytest.mark.parametrize("B,H,W,wh,ww,n,k", [(2, 64, 64, 14, 14, 448, 448), (1, 20, 12, 8, 8, 96, 64), (3, 16, 16, 16, 16, 64, 128), (2, 9, 13, 4, 7, 32, 32)])
 def test_gemm_unwindow_epilogue_vs_torch(B, H, W, wh, ww, n, k):
     """ovo_gemm_unwindow: rows of the product in window order (padding rows included) land on their spatial rows with the
