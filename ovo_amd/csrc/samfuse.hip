@@ -44,6 +44,7 @@ __device__ __forceinline__ float quad_sum(float v) {             // over the 4 l
 }
 
 using ovo_skinny::Skinny;
+using ovo_skinny::store_pair16;
 
 // ---- y = LayerNorm(res[m % res_rows] + A . W^T + bias) -------------------------------------------------------------------------
 struct ProjLnArgs {
@@ -99,18 +100,24 @@ __global__ void __launch_bounds__(512, 4) k_proj_ln(ProjLnArgs a) {
         const float rstd = rsqrtf(quad_sum(sq) * (1.0f / N) + a.eps);
         if (m >= a.M) continue;
         const float *pp = a.ype16 ? a.pe + (long long)(m % a.pe_rows) * N : nullptr;
+        static_assert(S::NT % 2 == 0, "column tiles are stored in pairs");
 #pragma unroll
-        for (int j = 0; j < S::NT; ++j) {
-            const int c = j * 16 + fq * 4;
-            const f32x4 v = acc[j] * rstd * *(const f32x4 *)(gl + j * 16) + *(const f32x4 *)(bl + j * 16);
-            const long long at = (long long)m * N + c;
-            if (a.y32) *(f32x4 *)(a.y32 + at) = v;
-            if (a.y16) *(uint2 *)(a.y16 + at) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-            if (pp) {
-                const f32x4 p = v + *(const f32x4 *)(pp + c);
-                *(uint2 *)(a.ype16 + at) = make_uint2(pack2(p[0], p[1]), pack2(p[2], p[3]));
+        for (int j = 0; j < S::NT; j += 2) {
+            uint2 o16[2], pe16[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = (j + h) * 16 + fq * 4;
+                const f32x4 v = acc[j + h] * rstd * *(const f32x4 *)(gl + (j + h) * 16) + *(const f32x4 *)(bl + (j + h) * 16);
+                if (a.y32) *(f32x4 *)(a.y32 + (long long)m * N + c) = v;
+                o16[h] = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                if (pp) {
+                    const f32x4 p = v + *(const f32x4 *)(pp + c);
+                    pe16[h] = make_uint2(pack2(p[0], p[1]), pack2(p[2], p[3]));
+                }
             }
-            if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+            if (a.y16) store_pair16(a.y16 + (long long)m * N + j * 16, fq, o16[0], o16[1]);
+            if (pp) store_pair16(a.ype16 + (long long)m * N + j * 16, fq, pe16[0], pe16[1]);
+            if (j % 4 == 2) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -165,12 +172,17 @@ __global__ void __launch_bounds__(NTHREADS) k_up1_ln(Up1Args a) {
             const float rstd = rsqrtf(quad_sum(sq) * (1.0f / C1) + a.eps);
             if (m >= M) continue;
             const long long pix = ((long long)p * side + 2 * y + (g >> 1)) * side + 2 * x + (g & 1);
+            static_assert(JPG % 2 == 0, "column tiles are stored in pairs");
 #pragma unroll
-            for (int jj = 0; jj < JPG; ++jj) {
-                const int c = jj * 16 + fq * 4;
-                const f32x4 v = acc[g * JPG + jj] * rstd * *(const f32x4 *)(gl + jj * 16) + *(const f32x4 *)(bl + jj * 16);
-                const f32x2 lo = gelu2(f32x2{v[0], v[1]}), hi = gelu2(f32x2{v[2], v[3]});
-                *(uint2 *)(a.out + pix * C1 + c) = make_uint2(pack2(lo.x, lo.y), pack2(hi.x, hi.y));
+            for (int jj = 0; jj < JPG; jj += 2) {
+                uint2 o16[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 v = acc[g * JPG + jj + h] * rstd * *(const f32x4 *)(gl + (jj + h) * 16) + *(const f32x4 *)(bl + (jj + h) * 16);
+                    const f32x2 lo = gelu2(f32x2{v[0], v[1]}), hi = gelu2(f32x2{v[2], v[3]});
+                    o16[h] = make_uint2(pack2(lo.x, lo.y), pack2(hi.x, hi.y));
+                }
+                store_pair16(a.out + pix * C1 + jj * 16, fq, o16[0], o16[1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -390,9 +402,12 @@ __global__ void __launch_bounds__(NTHREADS, NTHREADS == 512 ? 4 : 1) k_skinny_li
         }
         S::mma(acc, af, smem, fr, fq);
         if (m >= a.M) continue;
-        uint16_t *cp = a.C + (long long)m * a.ldc + fq * 4;
+        uint16_t *cp = a.C + (long long)m * a.ldc;
+        static_assert(S::NT % 2 == 0, "column tiles are stored in pairs");
 #pragma unroll
-        for (int j = 0; j < S::NT; ++j) *(uint2 *)(cp + j * 16) = make_uint2(pack2(acc[j][0], acc[j][1]), pack2(acc[j][2], acc[j][3]));
+        for (int j = 0; j < S::NT; j += 2)
+            store_pair16(cp + j * 16, fq, make_uint2(pack2(acc[j][0], acc[j][1]), pack2(acc[j][2], acc[j][3])),
+                         make_uint2(pack2(acc[j + 1][0], acc[j + 1][1]), pack2(acc[j + 1][2], acc[j + 1][3])));
     }
 }
 
@@ -510,9 +525,9 @@ extern "C" int ovo_sam_linear(const void *A, const void *W, const float *bias, c
     OVO_REQUIRE(M >= 0 && M < (1ll << 31) - 16, "bad row count");
     if (!((K == 256 && (N == 256 || N == 128)) || (K == 128 && (N == 128 || N == 64)))) return OVO_E_UNSUPPORTED;
     if (M == 0) return OVO_OK;
-    OVO_REQUIRE(A && W && C && ldc >= N && ldc % 4 == 0, "null pointer / bad ldc");
+    OVO_REQUIRE(A && W && C && ldc >= N && ldc % 8 == 0, "null pointer / bad ldc (a multiple of 8 elements)");
     OVO_REQUIRE(!add || (add_rows > 0 && add_rows < (1ll << 31) && ld_add >= N && ld_add % 4 == 0), "periodic add needs its row count and stride");
-    OVO_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)add | (uintptr_t)bias) % 16 == 0 && (uintptr_t)C % 8 == 0, "alignment");
+    OVO_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)add | (uintptr_t)bias | (uintptr_t)C) % 16 == 0, "16-byte alignment");
     LinArgs a;
     a.A = (const uint16_t *)A; a.W = (const uint16_t *)W; a.bias = bias; a.add = add; a.add_rows = (int)add_rows; a.ld_add = ld_add;
     a.C = (uint16_t *)C; a.ldc = ldc; a.M = (int)M;

@@ -56,4 +56,13 @@ struct Skinny {
     }
 };
 
+// Two adjacent column tiles' packed two-byte results (a lane holds 4 columns = 2 dwords of each).  v_permlane16_swap trades halves between
+// the lane pairs (fq, fq ^ 1): lane (fr, fq) ends with 8 consecutive columns of tile j + (fq & 1), from column 8 (fq >> 1) -- one 16-byte
+// store per lane and 64 contiguous bytes per row and instruction instead of two 8-byte stores of 32.  `tile_j` = address of column 0 of
+// tile j in this lane's row (16-byte aligned); every lane of a row must call it (the exchange is within the row's 4 lanes).
+__device__ __forceinline__ void store_pair16(uint16_t *tile_j, int fq, uint2 tj, uint2 tj1) {
+    const auto s0 = __builtin_amdgcn_permlane16_swap(tj.x, tj1.x, false, false), s1 = __builtin_amdgcn_permlane16_swap(tj.y, tj1.y, false, false);
+    *(uint4 *)(tile_j + (fq & 1) * 16 + (fq >> 1) * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+}
+
 }  // namespace ovo_skinny
