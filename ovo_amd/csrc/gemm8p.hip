@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     const float4 addv = g.add ? *(const float4 *)(g.add + add_row(g, m, md) * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                     float v[4] = {a[0], a[1], a[2], a[3]};
                     math4(g, tk, nh, n, v, bias, addv);
-                    *(float4 *)((float *)g.C + md * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    { const f32x4 vv = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(vv, (f32x4 *)((float *)g.C + md * g.ldc + n)); }
                 }
             } else {                                      // 2-byte rows: 8 lanes x 16 bytes per row, 8 rows per instruction
                 constexpr int LPR = WTN / 8, RPI = 64 / LPR;
@@ -285,7 +285,9 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     if (g.out_dtype == 2) { p.x = pack_bf16(v0[0], v0[1]); p.y = pack_bf16(v0[2], v0[3]); p.z = pack_bf16(v1[0], v1[1]); p.w = pack_bf16(v1[2], v1[3]); }
                     else { p.x = pack_f16(v0[0], v0[1]); p.y = pack_f16(v0[2], v0[3]); p.z = pack_f16(v1[0], v1[1]); p.w = pack_f16(v1[2], v1[3]); }
                     uint16_t *dst = (uint16_t *)g.C + md * g.ldc + n;
-                    if (in1 && ((uintptr_t)dst & 15) == 0) *(uint4 *)dst = p;
+                    // non-temporal: the tile is written once and read by a later kernel; keeping it out of the way of the operands the
+                    // other workgroups are still streaming through L2 measured 4-10 % on the FC1 products (tools/gemm_bench.py)
+                    if (in1 && ((uintptr_t)dst & 15) == 0) __builtin_nontemporal_store(*(const __attribute__((ext_vector_type(4))) unsigned *)&p, (__attribute__((ext_vector_type(4))) unsigned *)dst);
                     else {
                         *(uint2 *)dst = make_uint2(p.x, p.y);
                         if (in1) *(uint2 *)(dst + 4) = make_uint2(p.z, p.w);

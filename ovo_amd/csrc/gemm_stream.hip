@@ -74,8 +74,7 @@ __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_grou
                 if (g.out_dtype == 2) { p0 = pack_bf16(v[0], v[1]); p1 = pack_bf16(v[2], v[3]); q0 = pack_bf16(u[0], u[1]); q1 = pack_bf16(u[2], u[3]); }
                 else { p0 = pack_f16(v[0], v[1]); p1 = pack_f16(v[2], v[3]); q0 = pack_f16(u[0], u[1]); q1 = pack_f16(u[2], u[3]); }
                 if (wide) {
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(p0, q0, false, false), s1 = __builtin_amdgcn_permlane16_swap(p1, q1, false, false);
-                    *(uint4 *)(c16 + (j + (fq & 1)) * 16 + (fq >> 1) * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    ovo_skinny::store_pair16(c16 + j * 16, fq, make_uint2(p0, p1), make_uint2(q0, q1));
                 } else {
                     *(uint2 *)(c16 + j * 16 + fq * 4) = make_uint2(p0, p1);
                     *(uint2 *)(c16 + (j + 1) * 16 + fq * 4) = make_uint2(q0, q1);

@@ -62,7 +62,7 @@ struct Skinny {
 // tile j in this lane's row (16-byte aligned); every lane of a row must call it (the exchange is within the row's 4 lanes).
 __device__ __forceinline__ void store_pair16(uint16_t *tile_j, int fq, uint2 tj, uint2 tj1) {
     const auto s0 = __builtin_amdgcn_permlane16_swap(tj.x, tj1.x, false, false), s1 = __builtin_amdgcn_permlane16_swap(tj.y, tj1.y, false, false);
-    *(uint4 *)(tile_j + (fq & 1) * 16 + (fq >> 1) * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    *(uint4 *)(tile_j + (fq & 1) * 16 + (fq >> 1) * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);     // (a non-temporal store measured 2 % slower here)
 }
 
 }  // namespace ovo_skinny
