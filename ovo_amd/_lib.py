@@ -200,7 +200,13 @@ def check(status: int) -> None:
         raise OvoHipError(f"libovo_hip error {status}: {load().ovo_hip_last_error().decode()}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> C.c_void_p:
+    """hipStream_t of torch's current stream (the raw handle: ~1 us instead of ~9 us for a torch.cuda.Stream object, 20+ times per keyframe)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

