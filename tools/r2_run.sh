@@ -1,6 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python tools/prof_host.py 24 2>&1 | grep -v amdgpu | cut -c1-150 | head -24
-for i in 1 2; do timeout 300 python bench.py --no-cpu-baseline --no-roofline --sustain-seconds 0 2>/dev/null | python -c "import sys,json; b=json.loads(sys.stdin.read()); print('bench', b['value'], b['ms_per_step'], b['per_step_ms'])"; done
-timeout 1200 python -m pytest tests/test_gpu_e2e.py tests/test_gpu_geometry.py tests/test_gpu_pipeline.py tests/test_gpu_multirank.py -x -q 2>&1 | tail -3
-python __graft_entry__.py --smoke 2>&1 | tail -1
+python -c "import torch; print('priority range', torch.cuda.Stream.priority_range())"
+run() { timeout 300 python bench.py --no-cpu-baseline --no-roofline --sustain-seconds 0 2>/dev/null | python -c "import sys,json; b=json.loads(sys.stdin.read()); print('$1', b['value'], b['ms_per_step'], b['per_step_ms']['median'], b['per_step_ms']['max'])"; }
+run base
+OVO_MAIN_PRIORITY=-1 run "main high"
+OVO_MAIN_PRIORITY=-1 OVO_SAM_PRIORITY=0 OVO_VIT_PRIORITY=0 run "main high, sides 0"
+OVO_SAM_PRIORITY=-1 OVO_VIT_PRIORITY=-1 run "sides high"
+run base2
