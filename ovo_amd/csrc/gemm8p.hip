@@ -82,6 +82,10 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     if (g.dbg & 1) return;
     auto stamp = [&](int k) { if (g.stamps && tid == 0) g.stamps[(long long)tile * 4 + k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
+    if ((g.dbg >> 8) && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {      // tools/ only (OVO_8P_DELAY us): de-phase every other CU's tile sequence
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), ticks = (unsigned long long)(g.dbg >> 8) * 100;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    }
 
     // ---- DMA sources: half h, piece (it * 8 + wave) = local rows [8 * piece, +8), lane -> (row, swizzled 16-byte chunk).
     // 32-bit byte offsets from the (wave-uniform) operand base: the launch checks that both operands span < 4 GB.
@@ -335,7 +339,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
 template <int BM, int BN, int WARPS_M, typename VT, bool STAGED>
 int launch8p_(const GemmArgs &g0, hipStream_t s) {
     GemmArgs g = g0;
-    g.dbg = getenv("OVO_8P_DEBUG") ? atoi(getenv("OVO_8P_DEBUG")) : 0;
+    g.dbg = (getenv("OVO_8P_DEBUG") ? atoi(getenv("OVO_8P_DEBUG")) : 0) | ((getenv("OVO_8P_DELAY") ? atoi(getenv("OVO_8P_DELAY")) : 0) << 8);
     g.stamps = getenv("OVO_8P_STAMPS") ? (unsigned long long *)strtoull(getenv("OVO_8P_STAMPS"), nullptr, 0) : nullptr;
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;

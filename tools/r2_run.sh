@@ -1,9 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python -c "import torch; print('priority range', torch.cuda.Stream.priority_range())"
-run() { timeout 300 python bench.py --no-cpu-baseline --no-roofline --sustain-seconds 0 2>/dev/null | python -c "import sys,json; b=json.loads(sys.stdin.read()); print('$1', b['value'], b['ms_per_step'], b['per_step_ms']['median'], b['per_step_ms']['max'])"; }
-run base
-OVO_MAIN_PRIORITY=-1 run "main high"
-OVO_MAIN_PRIORITY=-1 OVO_SAM_PRIORITY=0 OVO_VIT_PRIORITY=0 run "main high, sides 0"
-OVO_SAM_PRIORITY=-1 OVO_VIT_PRIORITY=-1 run "sides high"
-run base2
+export TILES="auto" ROUNDS=3
+for d in 0 4 8 12 16 24; do echo "== delay $d us"; OVO_8P_DELAY=$d BIAS=1 ACT=1 SHAPES="9232,4096,1024;32768,1792,448;9232,3072,1024;16384,4096,1024;8192,8192,8192" python tools/gemm_bench.py 2>&1 | grep "^("; done
