@@ -17,12 +17,18 @@ timeout 300 python tools/geom_bench.py > $OUT/geom_bench.txt 2>&1
 TILES="auto,ring,256x256,256x128" SHAPES="9232,3072,1024;9232,1024,1024;9232,4096,1024;9232,1024,4096;32768,1792,448;32768,448,1792;39200,1344,448;4616,3072,1024;4616,4096,1024;4096,4096,4096;8192,8192,8192" timeout 600 python tools/gemm_bench.py > $OUT/gemm_sweep.txt 2>&1
 (python tools/gemm8p_stamps.py 9232 3072 1024 256x256; python tools/gemm8p_stamps.py 9232 4096 1024 256x128; python tools/gemm8p_stamps.py 4096 4096 4096 256x256) > $OUT/gemm8p_timeline.txt 2>&1
 (python tools/enc_table.py vit 8; python tools/enc_table.py sam 8) > $OUT/enc_tables_b8.txt 2>&1
+(export TILES="tiled,stream" ROUNDS=3 ITERS=30
+ echo "== bf16 out, bias"; BIAS=1 SHAPES="524288,336,128;524288,448,128;524288,672,128;131072,896,256;131072,672,256;131072,1344,256;131072,448,256;524288,32,256;131072,64,256" python tools/gemm_bench.py
+ echo "== bf16 out, bias + GELU"; BIAS=1 ACT=1 SHAPES="524288,448,128;131072,896,256" python tools/gemm_bench.py
+ echo "== f32 out, bias + in-place residual"; BIAS=1 ADD=1 INPLACE=1 OUT=f32 SHAPES="524288,112,128;131072,224,256;524288,256,128;524288,224,128;131072,256,256;65536,112,192" python tools/gemm_bench.py) > $OUT/gemm_stream.txt 2>&1
+timeout 300 python tools/replicated_cost.py 32 > $OUT/replicated_cost.txt 2>&1
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $R/bench.py --no-cpu-baseline --steps 12 --sustain-seconds 0 > $OUT/prof_bench.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- python $R/tools/pmc_calib.py > $OUT/calib_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- python $R/tools/pmc_calib.py > $OUT/calib_write.log 2>&1
+DEC_ONLY=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/amg_prof -- python $R/tools/amg_bench.py 16 > $OUT/amg_prof.log 2>&1
 ITERS=5 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/geom_stats -- python $R/tools/geom_bench.py 10000000 > $OUT/geom_stats.log 2>&1
 ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/geom_fetch -- python $R/tools/geom_bench.py 10000000 > $OUT/geom_fetch.log 2>&1
 ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/geom_write -- python $R/tools/geom_bench.py 10000000 > $OUT/geom_write.log 2>&1
@@ -33,6 +39,7 @@ python tools/pmc_traffic.py --fetch-dir $OUT/geom_fetch --write-dir $OUT/geom_wr
 python tools/sq_counters.py $OUT/geom_sq > $OUT/geom_10m_sq_counters.txt 2>&1
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_n1_kernel_stats.csv
 cp $(find $OUT/geom_stats -name "*kernel_stats.csv" | head -1) $OUT/geom_10m_kernel_stats.csv
+cp $(find $OUT/amg_prof -name "*kernel_stats.csv" | head -1) $OUT/sam_decoder_kernel_stats.csv
 # keep the merge-back small: drop the per-dispatch traces, keep stats + reduced PMC
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 tail -3 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log; cat $OUT/bench.json | cut -c1-1500; cut -c1-400 $OUT/bench_hiera_l.json; cut -c1-400 $OUT/bench_sam_full.json; tail -16 $OUT/pmc_traffic.log; cat $OUT/geom_bench.txt
