@@ -119,42 +119,67 @@ __device__ __forceinline__ float src_px(const ResizeArgs &a, int c, int y, int x
 }
 __device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
 
+// One thread per output pixel; the tap weights do not depend on the channel, so they are computed once (the first version recomputed them,
+// divisions included, per channel and per tap: 30 us for a 1024^2 output that is 13 MB of stores) and the channels run innermost.
+#define OVO_RS_TAPS 10                                  // taps per axis held in registers: down-scaling up to ~4.5x; beyond that the generic loop
 __global__ void __launch_bounds__(256) k_resize_norm(ResizeArgs a, float *__restrict__ out) {
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ox >= a.ow || oy >= a.oh) return;
     const float sy = (float)a.ch / (float)a.oh, sx = (float)a.cw / (float)a.ow;
-    for (int c = 0; c < a.C; ++c) {
-        float v;
-        if (!a.aa) {                                    // torch upsample_bilinear2d, align_corners = False
-            float fy = sy * ((float)oy + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
-            float fx = sx * ((float)ox + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
-            const int y0 = (int)fy, x0 = (int)fx;
-            const int y1 = y0 + (y0 < a.ch - 1 ? 1 : 0), x1 = x0 + (x0 < a.cw - 1 ? 1 : 0);
-            const float ly = fy - (float)y0, lx = fx - (float)x0;
-            v = (1.f - ly) * ((1.f - lx) * src_px(a, c, y0, x0) + lx * src_px(a, c, y0, x1)) +
-                ly * ((1.f - lx) * src_px(a, c, y1, x0) + lx * src_px(a, c, y1, x1));
-        } else {                                        // torch _upsample_bilinear2d_aa (separable triangle filter)
-            const float supy = sy >= 1.f ? sy : 1.f, supx = sx >= 1.f ? sx : 1.f;
-            const float ivy = sy >= 1.f ? 1.f / sy : 1.f, ivx = sx >= 1.f ? 1.f / sx : 1.f;
-            const float cy = sy * ((float)oy + 0.5f), cx = sx * ((float)ox + 0.5f);
-            int ymin = (int)(cy - supy + 0.5f); ymin = ymin < 0 ? 0 : ymin;
-            int ymax = (int)(cy + supy + 0.5f); ymax = ymax > a.ch ? a.ch : ymax;
-            int xmin = (int)(cx - supx + 0.5f); xmin = xmin < 0 ? 0 : xmin;
-            int xmax = (int)(cx + supx + 0.5f); xmax = xmax > a.cw ? a.cw : xmax;
-            float wy_tot = 0.f, wx_tot = 0.f;
-            for (int y = ymin; y < ymax; ++y) wy_tot += tri(((float)y - cy + 0.5f) * ivy);
-            for (int x = xmin; x < xmax; ++x) wx_tot += tri(((float)x - cx + 0.5f) * ivx);
-            float acc = 0.f;
-            for (int y = ymin; y < ymax; ++y) {
-                const float wy = tri(((float)y - cy + 0.5f) * ivy) / wy_tot;
-                float rowacc = 0.f;
-                for (int x = xmin; x < xmax; ++x) rowacc += (tri(((float)x - cx + 0.5f) * ivx) / wx_tot) * src_px(a, c, y, x);
-                acc += wy * rowacc;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!a.aa) {                                        // torch upsample_bilinear2d, align_corners = False
+        float fy = sy * ((float)oy + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+        float fx = sx * ((float)ox + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < a.ch - 1 ? 1 : 0), x1 = x0 + (x0 < a.cw - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        for (int c = 0; c < a.C; ++c)
+            v[c] = (1.f - ly) * ((1.f - lx) * src_px(a, c, y0, x0) + lx * src_px(a, c, y0, x1)) +
+                   ly * ((1.f - lx) * src_px(a, c, y1, x0) + lx * src_px(a, c, y1, x1));
+    } else {                                            // torch _upsample_bilinear2d_aa (separable triangle filter)
+        const float supy = sy >= 1.f ? sy : 1.f, supx = sx >= 1.f ? sx : 1.f;
+        const float ivy = sy >= 1.f ? 1.f / sy : 1.f, ivx = sx >= 1.f ? 1.f / sx : 1.f;
+        const float cy = sy * ((float)oy + 0.5f), cx = sx * ((float)ox + 0.5f);
+        int ymin = (int)(cy - supy + 0.5f); ymin = ymin < 0 ? 0 : ymin;
+        int ymax = (int)(cy + supy + 0.5f); ymax = ymax > a.ch ? a.ch : ymax;
+        int xmin = (int)(cx - supx + 0.5f); xmin = xmin < 0 ? 0 : xmin;
+        int xmax = (int)(cx + supx + 0.5f); xmax = xmax > a.cw ? a.cw : xmax;
+        float wy_tot = 0.f, wx_tot = 0.f;
+        for (int y = ymin; y < ymax; ++y) wy_tot += tri(((float)y - cy + 0.5f) * ivy);
+        for (int x = xmin; x < xmax; ++x) wx_tot += tri(((float)x - cx + 0.5f) * ivx);
+        const int ny = ymax - ymin, nx = xmax - xmin;
+        if (ny <= OVO_RS_TAPS && nx <= OVO_RS_TAPS) {
+            float wy[OVO_RS_TAPS], wx[OVO_RS_TAPS];
+#pragma unroll
+            for (int i = 0; i < OVO_RS_TAPS; ++i) {
+                wy[i] = i < ny ? tri(((float)(ymin + i) - cy + 0.5f) * ivy) / wy_tot : 0.f;
+                wx[i] = i < nx ? tri(((float)(xmin + i) - cx + 0.5f) * ivx) / wx_tot : 0.f;
             }
-            v = acc;
+#pragma unroll
+            for (int iy = 0; iy < OVO_RS_TAPS; ++iy) {
+                if (iy >= ny) break;
+                float rowacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ix = 0; ix < OVO_RS_TAPS; ++ix) {
+                    if (ix >= nx) break;
+                    for (int c = 0; c < a.C; ++c) rowacc[c] += wx[ix] * src_px(a, c, ymin + iy, xmin + ix);
+                }
+                for (int c = 0; c < a.C; ++c) v[c] += wy[iy] * rowacc[c];
+            }
+        } else {
+            for (int c = 0; c < a.C; ++c) {
+                float acc = 0.f;
+                for (int y = ymin; y < ymax; ++y) {
+                    const float wyy = tri(((float)y - cy + 0.5f) * ivy) / wy_tot;
+                    float rowacc = 0.f;
+                    for (int x = xmin; x < xmax; ++x) rowacc += (tri(((float)x - cx + 0.5f) * ivx) / wx_tot) * src_px(a, c, y, x);
+                    acc += wyy * rowacc;
+                }
+                v[c] = acc;
+            }
         }
-        out[((long long)c * a.oh + oy) * a.ow + ox] = (v * a.scale - a.mean[c]) / a.std[c];
     }
+    for (int c = 0; c < a.C; ++c) out[((long long)c * a.oh + oy) * a.ow + ox] = (v[c] * a.scale - a.mean[c]) / a.std[c];
 }
 
 // ---- a14: per-mask crops for the crop-mode descriptors (segment_utils.py:29-41, 118-170) ----

@@ -1,4 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-export TILES="auto" ROUNDS=3
-for d in 0 4 8 12 16 24; do echo "== delay $d us"; OVO_8P_DELAY=$d BIAS=1 ACT=1 SHAPES="9232,4096,1024;32768,1792,448;9232,3072,1024;16384,4096,1024;8192,8192,8192" python tools/gemm_bench.py 2>&1 | grep "^("; done
+timeout 600 python -m pytest tests/test_gpu_encoder.py -x -q -k "resize" 2>&1 | tail -2
+python tools/resize_bench.py 2>&1 | grep -v amdgpu
+cp ovo_amd/lib/libovo_hip.so /tmp/new.so; cp ovo_amd/lib/libovo_hip_prev.so ovo_amd/lib/libovo_hip.so; echo "prev lib:"; python tools/resize_bench.py 2>&1 | grep -v amdgpu | grep us; cp /tmp/new.so ovo_amd/lib/libovo_hip.so
