@@ -166,6 +166,11 @@ def pmc_traffic(tile: str):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
+    if tile == "stream":
+        with open(path) as fh:
+            hits = [v for k, v in json.load(fh)["kernels"].items() if "k_gemm_stream" in k]
+        n = sum(v["launches"] for v in hits)
+        return round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n) if n else None
     bm, bn = tile.split(",")
     with open(path) as fh:
         kernels = json.load(fh)["kernels"]
@@ -180,14 +185,15 @@ def profile_pass(pipe, feed, rounds, lib):
     from ovo_amd import _lib as L
     L.check(lib.ovo_profile_start())
     feed.run(pipe, rounds)
-    ms, work, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
-    L.check(lib.ovo_profile_stop(ms, work, n, 8))
+    ms, work, n = (C.c_double * 9)(), (C.c_double * 9)(), (C.c_int64 * 9)()
+    L.check(lib.ovo_profile_stop(ms, work, n, 9))
     steps = rounds                                                # per frame of THIS rank: one owned keyframe per round
-    tiles = {3: "256,256", 0: "256,128", 4: "128,128", 5: "128,64", 6: "64,128", 7: "64,64"}     # 256-row tiles: the ping-pong kernel (gemm8p.hip)
+    tiles = {3: "256,256", 0: "256,128", 4: "128,128", 5: "128,64", 6: "64,128", 7: "64,64", 8: "stream"}     # 256-row tiles: the ping-pong kernel (gemm8p.hip); stream: gemm_stream.hip
     dom = max(tiles, key=lambda k: ms[k])                      # the GEMM instantiation with the most time = dominant kernel
     tf = work[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
     gemm_ms, gemm_work = sum(ms[k] for k in tiles), sum(work[k] for k in tiles)
-    name = f"k_gemm8p<{tiles[dom]},64,bf16> (ovo_amd/csrc/gemm8p.hip)" if dom in (0, 3) else f"k_gemm<{tiles[dom]},64,bf16> (ovo_amd/csrc/gemm.hip)"
+    name = f"k_gemm8p<{tiles[dom]},64,bf16> (ovo_amd/csrc/gemm8p.hip)" if dom in (0, 3) else \
+        ("k_gemm_stream<bf16> (ovo_amd/csrc/gemm_stream.hip)" if dom == 8 else f"k_gemm<{tiles[dom]},64,bf16> (ovo_amd/csrc/gemm.hip)")
     return {"bound": "mfma", "kernel": name, "achieved": round(tf, 1),
             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
             "traffic": pmc_traffic(tiles[dom]),

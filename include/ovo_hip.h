@@ -37,8 +37,9 @@ const char *ovo_hip_last_error(void);
 int ovo_hip_abi_version(void); /* bumped when a signature changes */
 
 /* Optional profiler for bench.py's roofline figures: between start and stop every launch of a profiled kernel
- * family is bracketed by hipEvents on its own stream.  Kinds (n_kinds <= 8): 1 = fused attention (work = flops),
- * 2 = fused point-map tracking pass (bytes), 4..7 = MFMA GEMM with tile 128x128 / 128x64 / 64x128 / 64x64 (flops).
+ * family is bracketed by hipEvents on its own stream.  Kinds (n_kinds <= 9): 1 = fused attention (work = flops),
+ * 2 = fused point-map tracking pass (bytes), 4..7 = MFMA GEMM with tile 128x128 / 128x64 / 64x128 / 64x64, 3 / 0 = the 256x256 /
+ * 256x128 ping-pong GEMM, 8 = the weights-resident streaming GEMM (flops).
  * stop synchronises the device and returns, per kind, total milliseconds, total work and launch count. */
 int ovo_profile_start(void);
 int ovo_profile_stop(double *ms, double *work, int64_t *launches, int n_kinds);

@@ -11,8 +11,8 @@
 void ovo_set_error(const char *fmt, ...);
 
 // optional hipEvent profiler (core.hip): kinds 1 = attention (flops), 2 = point-map tracking pass (bytes), 4..7 = MFMA GEMM tiles 128x128 / 128x64 / 64x128 / 64x64,
-// 3 / 0 = the 256x256 / 256x128 ping-pong GEMM (flops)
-#define OVO_PROF_KINDS 8
+// 3 / 0 = the 256x256 / 256x128 ping-pong GEMM (flops), 8 = the weights-resident streaming GEMM (flops)
+#define OVO_PROF_KINDS 9
 bool ovo_prof_enabled();
 void ovo_prof_begin(int kind, double work, hipStream_t s);
 void ovo_prof_shape(int a, int b, int c);       // optional: shape of the launch just begun (OVO_PROF_DUMP lines)

@@ -110,7 +110,7 @@ int launch_stream(const GemmArgs &g, hipStream_t s) {
     if (slots > need) slots = need;
     if (slots < 1) slots = 1;
     const bool prof = ovo_prof_enabled();
-    if (prof) { ovo_prof_begin(5, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); }     // counted with the 128x64 family
+    if (prof) { ovo_prof_begin(8, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); }
     k_gemm_stream<KS, NT, VT, NTHREADS><<<slots * n_groups, NTHREADS, lds, s>>>(g, n_groups);
     if (prof) ovo_prof_end(s);
     return OVO_OK;

@@ -506,9 +506,9 @@ def test_vit_flops_accounting_matches_the_launched_work():
     lib = L.load()
     L.check(lib.ovo_profile_start())
     enc.forward(x, tokens=True)
-    ms, work, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
-    L.check(lib.ovo_profile_stop(ms, work, n, 8))
-    launched = work[1] + sum(work[k] for k in (3, 4, 5, 6, 7))
+    ms, work, n = (C.c_double * 9)(), (C.c_double * 9)(), (C.c_int64 * 9)()
+    L.check(lib.ovo_profile_stop(ms, work, n, 9))
+    launched = work[1] + sum(work[k] for k in (0, 3, 4, 5, 6, 7, 8))            # attention + every GEMM family (tiled, ping-pong, streaming)
     model = 2 * spec.flops_per_image()
     assert abs(launched - model) / model < 0.03, (launched, model)
 

@@ -32,8 +32,8 @@ if os.environ.get("OVO_PROF_DUMP"):
     from ovo_amd import _lib as L
     lib = L.load(); open(os.environ["OVO_PROF_DUMP"], "w").close()
     L.check(lib.ovo_profile_start()); dec.forward(emb["image_embed"][0], f1[0], f0[0])
-    ms, work, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
-    L.check(lib.ovo_profile_stop(ms, work, n, 8))
+    ms, work, n = (C.c_double * 9)(), (C.c_double * 9)(), (C.c_int64 * 9)()
+    L.check(lib.ovo_profile_stop(ms, work, n, 9))
     agg = collections.OrderedDict()
     for line in open(os.environ["OVO_PROF_DUMP"]):
         k, a, b, c, w, t = line.split(); e = agg.setdefault((int(k), int(a), int(b), int(c)), [0, 0.0, 0.0]); e[0] += 1; e[1] += float(t); e[2] += float(w)

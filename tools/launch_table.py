@@ -16,8 +16,8 @@ torch.cuda.synchronize()
 lib = L.load()
 L.check(lib.ovo_profile_start())
 for f in frames[3:]: pipe.step(f)
-ms, work, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
-L.check(lib.ovo_profile_stop(ms, work, n, 8))
+ms, work, n = (C.c_double * 9)(), (C.c_double * 9)(), (C.c_int64 * 9)()
+L.check(lib.ovo_profile_stop(ms, work, n, 9))
 agg = collections.OrderedDict()
 for line in open(dump):
     k, a, b, c, w, t = line.split()

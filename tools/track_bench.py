@@ -15,6 +15,6 @@ lib = L.load()
 L.check(lib.ovo_profile_start())
 for f in frames[4:]: pipe.step(f)
 if hasattr(pipe, "join"): pipe.join()
-ms, work, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
-L.check(lib.ovo_profile_stop(ms, work, n, 8))
+ms, work, n = (C.c_double * 9)(), (C.c_double * 9)(), (C.c_int64 * 9)()
+L.check(lib.ovo_profile_stop(ms, work, n, 9))
 print(f"track_project: {n[2]} launches, {1e3 * ms[2] / max(n[2], 1):.1f} us each, {work[2] / ms[2] / 1e6:.1f} GB/s algorithmic, points {pipe.slam._n if hasattr(pipe, 'slam') else '?'}")
