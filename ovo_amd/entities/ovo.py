@@ -153,8 +153,7 @@ class OVO:
         depth = G.to_device(depth_in, torch.float32, dev)
         pose = self._pose_host(c2w)
         near, far = G.depth_range(depth_in)                       # frustum uses the raw depth (:209)
-        corners = G.frustum_corners_from_range(near, far, h, w, pose, self._K_host)
-        cam = G.make_camera(corners, torch.linalg.inv(pose), self._K_host, self.config["match_distance_th"], h, w)
+        cam = G.frame_camera(near, far, h, w, pose, self._K_host, self.config["match_distance_th"])
         if self.config.get("depth_filter", False):
             depth = G.depth_filter(depth)
 

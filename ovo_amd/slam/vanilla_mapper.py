@@ -115,8 +115,7 @@ class VanillaMapper:
             near, far = G.depth_range(depth_in)
             if not far > 0:
                 return
-            corners = G.frustum_corners_from_range(near, far, h, w, pose, self._K_host)
-            cam = G.make_camera(corners, torch.linalg.inv(pose), self._K_host, self.match_distance_th, h, w)
+            cam = G.frame_camera(near, far, h, w, pose, self._K_host, self.match_distance_th)
             explained = torch.empty((h, w), dtype=torch.uint8, device=dev)
             L.check(lib.ovo_map_explained(L.ptr(self._xyz), self._n, cam, L.ptr(depth), L.ptr(explained), L.stream()))
         ds = self.downscale

@@ -1,5 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_encoder.py -x -q -k "resize" 2>&1 | tail -2
-python tools/resize_bench.py 2>&1 | grep -v amdgpu
-cp ovo_amd/lib/libovo_hip.so /tmp/new.so; cp ovo_amd/lib/libovo_hip_prev.so ovo_amd/lib/libovo_hip.so; echo "prev lib:"; python tools/resize_bench.py 2>&1 | grep -v amdgpu | grep us; cp /tmp/new.so ovo_amd/lib/libovo_hip.so
+timeout 900 python -m pytest tests/test_gpu_geometry.py tests/test_gpu_e2e.py tests/test_gpu_pipeline.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -2
+python tools/replicated_cost.py 32 2>&1 | grep -v amdgpu | tail -2

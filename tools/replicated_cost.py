@@ -47,3 +47,11 @@ torch.cuda.synchronize()
 total = time.perf_counter() - T0
 print({k: round(1e3 * v / N, 3) for k, v in acc.items()})
 print(f"replicated cost per keyframe: {1e3 * total / N:.3f} ms wall (host + its syncs, idle GPU)")
+if os.environ.get("PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for f in frames[4:4 + N]:
+        f2 = type(f)(f.index + 1000, f.rgb, f.rgb_lr, f.depth, f.c2w, f.seg_map, f.masks)
+        one(f2, False)
+    pr.disable(); torch.cuda.synchronize()
+    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
