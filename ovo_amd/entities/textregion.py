@@ -97,7 +97,8 @@ class PETextRegion(torch.nn.Module):
 
     def get_features_mask(self, region_masks: torch.Tensor):
         """bool [N, H, W] -> (bf16 [N, gpad] {0,1} token weights, f32 [N] counts)."""
-        m = region_masks if region_masks.dtype == torch.uint8 else region_masks.to(torch.uint8)
+        m = region_masks.view(torch.uint8) if region_masks.dtype == torch.bool else \
+            (region_masks if region_masks.dtype == torch.uint8 else region_masks.to(torch.uint8))       # bool -> u8: the same bytes, no copy
         m = L.dev(m.contiguous(), torch.uint8, "region_masks")
         n, h, w = m.shape
         g = self.points_per_h * self.points_per_w
