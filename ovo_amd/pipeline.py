@@ -213,12 +213,16 @@ class FramePipeline:
         """Start the encoders `f` needs (and, with look-ahead batching, those of this rank's next frames).  Returns the pending mask
         generator call of `f`, if the pipeline runs SAM2 end to end."""
         if self.encoder_batch > 1:
+            def width(rem):                                        # balanced groups: 20 frames left at batch 8 -> 7 + 7 + 6, not 8 + 8 + 4
+                groups = -(-rem // self.encoder_batch)
+                return -(-rem // groups) if groups else 0
             if f.index not in self._encoded:
-                self._launch_encoders([f] + mine_upcoming[:self.encoder_batch - 1])
+                self._launch_encoders([f] + mine_upcoming[:width(1 + len(mine_upcoming)) - 1])
             n_group = self._group_first.pop(f.index, 0)
             if n_group:                                            # first frame of its group: the NEXT group's encoders start now, so
-                nxt = [g for g in mine_upcoming[n_group - 1:n_group - 1 + self.encoder_batch] if g.index not in self._encoded]   # that they
-                if nxt:                                            # run beside this group's tracking / pooling / fusion / queries
+                rest = [g for g in mine_upcoming[n_group - 1:] if g.index not in self._encoded]                                  # that they
+                nxt = rest[:width(len(rest))]                      # run beside this group's tracking / pooling / fusion / queries
+                if nxt:
                     self._launch_encoders(nxt)
             self._encoded.pop(f.index, None)
             if self.amg is None:

@@ -1,10 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-python tools/replicated_cost.py 32 2>&1 | grep -v amdgpu | tail -1
-OVO_SMALL_TORCH=1 python tools/replicated_cost.py 32 2>&1 | grep -v amdgpu | tail -1
-done
-for i in 1 2; do
-timeout 300 python bench.py --no-cpu-baseline --no-roofline --sustain-seconds 0 2>/dev/null | python -c "import sys,json; b=json.loads(sys.stdin.read()); print('bench kernarg', b['value'], b['ms_per_step'], b['per_step_ms']['median'])"
-OVO_SMALL_TORCH=1 timeout 300 python bench.py --no-cpu-baseline --no-roofline --sustain-seconds 0 2>/dev/null | python -c "import sys,json; b=json.loads(sys.stdin.read()); print('bench torch  ', b['value'], b['ms_per_step'], b['per_step_ms']['median'])"
-done
+timeout 900 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_multirank.py -x -q 2>&1 | tail -2
+for a in "--steps 20 --warmup 5" "--steps 24 --warmup 3" "--steps 20 --warmup 5"; do timeout 300 python bench.py --gpus 1 $a --no-cpu-baseline --no-roofline --sustain-seconds 0 2>/dev/null | python -c "import sys,json; b=json.loads(sys.stdin.read()); print('$a', b['value'], b['ms_per_step'])"; done
