@@ -13,6 +13,8 @@
 // (async-stage split), so HBM/L2 latency hides under the MFMAs even at one workgroup per CU.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -65,7 +67,7 @@ __device__ unsigned long long g_attn_trace[256];
 #define ATTN_STAMP(i) do { } while (0)
 #endif
 
-template <int HD, int QT>
+template <int HD, int QT, bool TRIM = false>
 __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
     constexpr int KT = 64;                 // keys per tile
     constexpr int KROW = HD + 8;           // padded K-tile row (elements)
@@ -154,7 +156,15 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
             *(uint4 *)(sV + ((row >> 2) * VB + (c >> 1)) * 64 + (row & 3) * 16 + (c & 1) * 8) = vr[it];
         }
     };
+    // TRIM (the instantiation for Tk <= 64: Hiera's 16-token windows and pooled 4 x 16 blocks, one ragged key tile): a wave whose
+    // query rows all lie past Tq only helps to stage K / V, and 16-key sub-tiles past Tk are neither multiplied nor exponentiated --
+    // results unchanged (their probabilities are +0), 126 -> 94 us on 8 frames' (16, 16) windows.  On multi-tile problems the same
+    // tests cost more than they save (577 x 577: 69 -> 73 us), so the general instantiation carries none.
+    const bool wave_active = !TRIM || (qtile * 4 + wave) * (16 * QT) < a.Tq;
     auto compute = [&](int k0) {
+        if (TRIM && !wave_active) return;
+        constexpr bool TAIL = TRIM;
+        const int nkt = TAIL ? (a.Tk - k0 + 15) >> 4 : 4;           // 16-key sub-tiles of this tile that hold a key
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             // ---- S^T = K Q^T : 4 tiles of 16 keys ----
@@ -162,10 +172,12 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!TAIL || kt < nkt) {
 #pragma unroll
-                for (int ks = 0; ks < HD / 32; ++ks) {
-                    const bf16x8 kf = *(const bf16x8 *)(sK + (kt * 16 + fr) * KROW + ks * 32 + fq * 8);
-                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[kt], 0, 0, 0);
+                    for (int ks = 0; ks < HD / 32; ++ks) {
+                        const bf16x8 kf = *(const bf16x8 *)(sK + (kt * 16 + fr) * KROW + ks * 32 + fq * 8);
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[kt], 0, 0, 0);
+                    }
                 }
             }
             ATTN_STAMP(100 + 4 * (k0 / KT));
@@ -192,13 +204,18 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
             const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
             float ps = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) {
+                if (!TAIL || kt < nkt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], a.scale_log2e, -m_new));   // v_exp_f32, one FMA in front
-                    s[kt][r] = p;
-                    ps += p;
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], a.scale_log2e, -m_new));   // v_exp_f32, one FMA in front
+                        s[kt][r] = p;
+                        ps += p;
+                    }
+                } else {
+                    s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};            // masked sub-tile: p = exp2(-huge) = +0 exactly
                 }
+            }
             ps = sum_xor16_32(ps);
             l_run[t] = l_run[t] * alpha + ps;
             m_run[t] = m_new;
@@ -224,6 +241,7 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
             for (int dt = 0; dt < HD / 16; ++dt) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
+                    if (TAIL && kk * 2 >= nkt) continue;            // both sub-tiles of this k-step hold no key: P = 0
                     // lane (d = dt*16 + fr, fq) needs V[keys (kk*2+h)*16 + fq*4 .. +4][d], h = 0,1: the transposing read of
                     // block (kg = (kk*2+h)*4 + fq, dg = dt) with every lane pointing at its own 8-byte slot of the block
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -332,7 +350,8 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     // 64-query form, and with several frames per launch there are always enough workgroups; tools/attn_bench.py, round 2:
     // 8 x 16 heads x 577^2 (four keyframes' ViT crops) 59.8 us wide vs 37.4 narrow, 4 x 8 x 4096^2 x 56 394 vs 292, while
     // 8 x 16 x 2048^2 x 128 stays 703 wide vs 849 narrow
-    const bool wide = p->hd > 64 && p->Tq >= 512 && (long long)((p->Tq + 127) / 128) * p->B * p->H >= 512 && !getenv("OVO_ATTN_NARROW");
+    const bool wide = (getenv("OVO_ATTN_WIDE") != nullptr) ||
+                      (p->hd > 64 && p->Tq >= 512 && (long long)((p->Tq + 127) / 128) * p->B * p->H >= 512 && !getenv("OVO_ATTN_NARROW"));
     const int qpb = wide ? 128 : 64;
     dim3 grid((p->Tq + qpb - 1) / qpb, p->B * p->H);
     a.q_tiles = (int)grid.x; a.chunk = 0;
@@ -350,7 +369,8 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
         if (wide) k_attention<HD, 2><<<grid, 256, 0, s>>>(a);        \
         else k_attention<HD, 1><<<grid, 256, 0, s>>>(a);             \
     } while (0)
-    if (p->hd <= 64) GO(64);
+    if (p->hd <= 64 && p->Tk <= 64 && !wide) k_attention<64, 1, true><<<grid, 256, 0, s>>>(a);     // one ragged key tile: the trimmed form
+    else if (p->hd <= 64) GO(64);
     else if (p->hd <= 96) GO(96);
     else GO(128);
 #undef GO

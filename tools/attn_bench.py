@@ -20,12 +20,13 @@ def run(B, H, Tq, Tk, hd, iters=50):
     e1.record(); torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / iters
     return us, 4.0 * B * H * Tq * Tk * hd / us / 1e6
-shapes = [(2, 16, 577, 577, 64), (8, 16, 577, 577, 64), (1, 8, 4096, 4096, 56), (4, 8, 4096, 4096, 56), (25, 8, 196, 196, 56), (100, 8, 196, 196, 56), (1024, 2, 64, 64, 56), (1024, 4, 16, 64, 56), (8, 16, 2048, 2048, 128)]
+shapes = [(8, 16, 577, 577, 64), (16, 16, 577, 577, 64), (4, 8, 4096, 4096, 56), (8, 8, 4096, 4096, 56), (100, 8, 196, 196, 56), (200, 8, 196, 196, 56), (8192, 2, 64, 64, 56), (8192, 4, 16, 64, 56), (8192, 4, 16, 16, 56), (8192, 8, 4, 16, 56), (8, 16, 2048, 2048, 128)]
 for shape in shapes:
     row = "%-28s" % str(shape)
-    for mode in ("auto", "narrow"):
+    for mode in ("auto", "narrow", "wide"):
+        os.environ.pop("OVO_ATTN_NARROW", None); os.environ.pop("OVO_ATTN_WIDE", None)
         if mode == "narrow": os.environ["OVO_ATTN_NARROW"] = "1"
-        else: os.environ.pop("OVO_ATTN_NARROW", None)
+        if mode == "wide": os.environ["OVO_ATTN_WIDE"] = "1"
         us, tf = run(*shape)
         row += "  %s %8.1fus %6.0fTF" % (mode, us, tf)
     print(row)
