@@ -124,17 +124,19 @@ namespace ovo_gemm_detail {
 int gemm_stream_launch(const GemmArgs &g, int in_dtype, hipStream_t s) {
     if (g.best || g.rope_cos || in_dtype != 2) return OVO_E_UNSUPPORTED;
     if (g.M < 16384 || ((uintptr_t)g.C & 15) != 0 || g.ldc % 4 != 0) return OVO_E_UNSUPPORTED;
-    // column groups: the widest of 256 / 224 / 112 / 64 / 32 that divides N (Hiera's 112-multiples, powers of two)
+    // column groups: the widest of 256 / 224 / 112 / 64 / 32 that divides N (hiera_b+'s 112-multiples, powers of two); 288 / 144 for
+    // hiera_l's stage 1 (K = 192: 144 channels padded)
     int ng = 0;
     for (int c : {256, 224, 112, 64, 32})
         if (g.N % c == 0) { ng = c; break; }
+    if (g.K == 192 && g.N % 144 == 0 && g.N % 256 != 0) ng = g.N % 288 == 0 ? 288 : 144;
     if (g.K == 128 && g.N == 336) ng = 336;                          // Hiera stage-1 QKV: one group (86 KB of weights), A read once
     // measured (tools/gemm_bench.py, profiles/r02c_gemm_stream.txt): no gain over the tiled kernels with 6+ column groups (A re-read per group)
     // or for the narrow f32-residual product (524288, 112, 128), which both forms run at the HBM rate of its in-place C traffic
     if (g.N / (ng ? ng : 1) >= 6 || (g.K == 128 && g.N == 112 && g.out_dtype == 0)) return OVO_E_UNSUPPORTED;
 #define GO(KK, NGG) if (g.K == KK && ng == NGG) return launch_stream<KK / 32, NGG / 16, bf16x8>(g, s);
     GO(128, 336) GO(128, 256) GO(128, 224) GO(128, 112) GO(128, 64)
-    GO(192, 112)
+    GO(192, 288) GO(192, 256) GO(192, 144) GO(192, 112)
     GO(256, 256) GO(256, 224) GO(256, 112) GO(256, 64) GO(256, 32)
 #undef GO
     return OVO_E_UNSUPPORTED;

@@ -38,7 +38,7 @@ struct Skinny {
         // groups of JG weight fragments (4 VGPRs each) are read, then multiplied; the scheduling fences keep the compiler from hoisting
         // every ds_read of the product ahead of the first MFMA (N / 16 x K / 32 fragments = 256+ VGPRs: it spilled the accumulators).
         // Four waves per SIMD cover a group's LDS latency.
-        constexpr int JG = NT < 8 ? NT : (NT % 8 == 0 ? 8 : 7);
+        constexpr int JG = NT <= 8 ? NT : (NT % 8 == 0 ? 8 : NT % 7 == 0 ? 7 : NT % 6 == 0 ? 6 : NT % 5 == 0 ? 5 : 3);   // the largest divisor <= 8
         static_assert(NT % JG == 0, "column tiles per read group");
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)

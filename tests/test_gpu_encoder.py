@@ -106,7 +106,8 @@ def test_gemm_pingpong_kernel_vs_ring_kernel_and_torch(monkeypatch, tile, m, n, 
 
 
 @pytest.mark.parametrize("m,n,k", [(16400, 448, 128), (20000, 336, 128), (16390, 112, 192), (17000, 896, 256), (16384, 256, 256),
-                                   (16500, 64, 256), (16384, 32, 256), (16385, 112, 128), (16384, 672, 256), (16384, 256, 128), (16400, 336, 128)])
+                                   (16500, 64, 256), (16384, 32, 256), (16385, 112, 128), (16384, 672, 256), (16384, 256, 128), (16400, 336, 128),
+                                   (16400, 576, 192), (16384, 432, 192), (16390, 864, 192), (16384, 256, 192)])
 def test_gemm_stream_kernel_vs_tiled_kernel_and_torch(monkeypatch, m, n, k):
     """The weights-resident streaming kernel (gemm_stream.hip: tall short-K products, the automatic choice at M >= 16384, K <= 256) against
     the fp32 product of the same rounded operands and against the tiled kernels (OVO_GEMM_NO_STREAM): both accumulate every output
