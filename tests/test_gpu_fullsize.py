@@ -129,3 +129,35 @@ def test_dense_query_10m_points_1k_texts():
     agree = cls[idx] == rarg
     assert float(agree.float().mean()) > 0.999             # a near-tie may resolve differently in fp32 accumulation order
     assert float((ref.gather(1, cls[idx][:, None]).squeeze(1) - rmax).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("m,n,k,act", [(524288, 448, 128, 1), (524288, 336, 128, 0), (131072, 896, 256, 1), (524288, 576, 192, 0)])
+def test_streaming_gemm_full_size_equals_tiled(monkeypatch, m, n, k, act):
+    """The Hiera stage-1 / stage-2 products at the bench's size (8 frames x 65 536 / 16 384 tokens): the weights-resident streaming kernel
+    and the tiled kernels accumulate every output element in the same k-order, so the full-size outputs are bit-identical; a sampled set
+    of rows is also checked against the fp32 product of the same rounded operands."""
+    import ctypes as C
+    from ovo_amd import _lib as L
+    g = torch.Generator().manual_seed(m % 1000 + n + k)
+    a = torch.randn(m, k, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    outs = []
+    for mode in ("tiled", "stream"):
+        if mode == "tiled":
+            monkeypatch.setenv("OVO_GEMM_NO_STREAM", "1")
+        else:
+            monkeypatch.delenv("OVO_GEMM_NO_STREAM")
+            monkeypatch.setenv("OVO_GEMM_TILE", "stream")
+        out = torch.empty((m, n), dtype=torch.bfloat16, device=DEV)
+        gg = L.Gemm()
+        gg.A, gg.lda, gg.W, gg.ldw, gg.bias, gg.C, gg.ldc, gg.add, gg.ld_add = a.data_ptr(), k, w.data_ptr(), k, bias.data_ptr(), out.data_ptr(), n, None, 0
+        gg.M, gg.N, gg.K, gg.in_dtype, gg.out_dtype, gg.act, gg.alpha = m, n, k, 2, 2, act, 1.0
+        L.check(L.load().ovo_gemm(C.byref(gg), L.stream()))
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    rows = torch.randint(0, m, (2048,), generator=g).to(DEV)
+    ref = a[rows].float() @ w.float().T + bias
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    torch.testing.assert_close(outs[1][rows].float(), ref, atol=0.03, rtol=0.01)
