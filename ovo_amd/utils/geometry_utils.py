@@ -117,15 +117,18 @@ _frame_cam_key, _frame_cam = None, None
 
 
 def frame_camera(near: float, far: float, h: int, w: int, pose: torch.Tensor, intrinsics: torch.Tensor, th: float) -> L.Camera:
-    """`make_camera` of a frame's frustum (corners from its depth range) -- remembered for the last frame: the mapper and the tracker ask
-    for the same camera within a keyframe, and the ~40 small torch-CPU ops behind it are 0.15 ms of host time per call."""
+    """`make_camera` of a frame's frustum (corners from its depth range).  The frustum, its planes and the inverse pose are remembered for
+    the last frame -- the mapper and the tracker ask for the same camera within a keyframe (with their own match thresholds), and the
+    ~40 small torch-CPU ops behind it are 0.15 ms of host time per call; a caller gets its own copy of the struct with its `th`."""
     global _frame_cam_key, _frame_cam
     p = _cpu32(pose)
-    key = (float(near), float(far), int(h), int(w), float(th), p.numpy().tobytes(), _cpu32(intrinsics).numpy().tobytes())
+    key = (float(near), float(far), int(h), int(w), p.numpy().tobytes(), _cpu32(intrinsics).numpy().tobytes())
     if key != _frame_cam_key:
         corners = frustum_corners_from_range(near, far, h, w, p, intrinsics)
-        _frame_cam, _frame_cam_key = make_camera(corners, torch.linalg.inv(p), intrinsics, th, h, w), key
-    return _frame_cam
+        _frame_cam, _frame_cam_key = make_camera(corners, torch.linalg.inv(p), intrinsics, 0.0, h, w), key
+    cam = L.Camera.from_buffer_copy(_frame_cam)
+    cam.th = float(th)
+    return cam
 
 
 def _count(t: torch.Tensor) -> int:
