@@ -67,14 +67,21 @@ def tag_depth_range(depth_dev: torch.Tensor, depth_host: np.ndarray) -> torch.Te
     return depth_dev
 
 
+_corner_px = {}
+
+
 def frustum_corners_from_range(near: float, far: float, h: int, w: int, pose, intrinsics) -> torch.Tensor:
-    """8 world-frame frustum corners, f32[8,3] on the CPU (geometry_utils.py:99-129)."""
+    """8 world-frame frustum corners, f32[8,3] on the CPU (geometry_utils.py:99-129).  Same float32 arithmetic as the reference's
+    op-by-op form, batched: the pose product is written as the left-to-right sum torch's einsum evaluates
+    (tools/host_camera_check.py: bit-equal on random cameras on this host)."""
     K, T = _cpu32(intrinsics), _cpu32(pose)
-    px = torch.tensor(_CORNER_X * 2, dtype=torch.float32) * float(w)
-    py = torch.tensor(_CORNER_Y * 2, dtype=torch.float32) * float(h)
+    pxy = _corner_px.get((h, w))
+    if pxy is None:
+        pxy = _corner_px[(h, w)] = (torch.tensor(_CORNER_X * 2, dtype=torch.float32) * float(w), torch.tensor(_CORNER_Y * 2, dtype=torch.float32) * float(h))
     z = torch.tensor([near] * 4 + [far] * 4, dtype=torch.float32)
-    cam = torch.stack([(px - K[0, 2]) * z / K[0, 0], (py - K[1, 2]) * z / K[1, 1], z, torch.ones(8)], dim=1)
-    return torch.einsum("ij,mj->mi", T, cam)[:, :3].contiguous()
+    x, y = (pxy[0] - K[0, 2]) * z / K[0, 0], (pxy[1] - K[1, 2]) * z / K[1, 1]
+    Tt = T[:3].t()                                                  # [4, 3]: row j = column j of the pose
+    return (((x[:, None] * Tt[0] + y[:, None] * Tt[1]) + z[:, None] * Tt[2]) + Tt[3]).contiguous()
 
 
 def compute_camera_frustum_corners(depth_map, pose, intrinsics) -> torch.Tensor:
@@ -85,11 +92,17 @@ def compute_camera_frustum_corners(depth_map, pose, intrinsics) -> torch.Tensor:
     return out.to(pose.device) if isinstance(pose, torch.Tensor) else out
 
 
+_PLANE_IDX = tuple(torch.tensor([p[i] for p in _PLANE_DEF]) for i in range(4))
+
+
 def compute_camera_frustum_planes(frustum_corners) -> torch.Tensor:
-    """Reference: geometry_utils.py:163-202.  f32[6,4] rows (a,b,c,d), inside <=> plane.(p,1) <= 0."""
+    """Reference: geometry_utils.py:163-202.  f32[6,4] rows (a,b,c,d), inside <=> plane.(p,1) <= 0.  The six cross products and
+    offsets as one batched call each (bit-equal to six separate torch.linalg.cross / torch.dot calls: tools/host_camera_check.py)."""
     c = _cpu32(frustum_corners)
-    n = torch.stack([torch.linalg.cross(c[a] - c[b], c[e] - c[f]) for a, b, e, f in _PLANE_DEF])
-    d = torch.stack([-torch.dot(n[i], c[i]) for i in range(6)])      # offset from corner i (sic, :201)
+    a, b, e, f = _PLANE_IDX
+    n = torch.linalg.cross(c[a] - c[b], c[e] - c[f])
+    p = n * c[:6]                                                   # offset from corner i (sic, :201)
+    d = -((p[:, 0] + p[:, 1]) + p[:, 2])
     return torch.cat([n, d[:, None]], dim=1).float()
 
 
