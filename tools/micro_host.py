@@ -1,41 +1,27 @@
+"""Host micro-timings of the per-keyframe camera set-up (geometry_utils) on this machine's CPU."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
-import torch
-dev = torch.device("cuda", 0)
-def t(name, fn, n=20, sync=True):
-    fn(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n): fn()
-    if sync: torch.cuda.synchronize()
-    print(f"{name:40s} {1e6*(time.perf_counter()-t0)/n:10.1f} us")
-print("threads", torch.get_num_threads())
-a = torch.zeros(32, 480, 640, dtype=torch.bool, device=dev)
-t("logical_or [480,640] bool", lambda: torch.logical_or(a[0], a[1]))
-def setit(): a[0] = torch.logical_or(a[0], a[1])
-t("setitem logical_or", setit)
-t("a[0].sum().item()", lambda: a[0].sum().item())
-c = torch.randn(8, 3)
-t("cpu min(dim=0) [8,3]", lambda: c.min(dim=0), sync=False)
-t("cpu einsum 4x4,8x4", lambda: torch.einsum("ij,mj->mi", torch.eye(4), torch.randn(8, 4)), sync=False)
-t("cpu linalg.inv 4x4", lambda: torch.linalg.inv(torch.eye(4)), sync=False)
-t("cpu cross", lambda: torch.linalg.cross(c[0], c[1]), sync=False)
-h = torch.zeros(4, 4)
-t("H2D pageable 64B .to", lambda: h.to(dev))
-t("torch.tensor(list32).to(dev)", lambda: torch.tensor(list(range(32)), dtype=torch.int32).to(dev))
-hp = torch.zeros(32, dtype=torch.int32).pin_memory()
-d = torch.zeros(32, dtype=torch.int32, device=dev)
-t("copy_ from pinned non_blocking", lambda: d.copy_(hp, non_blocking=True))
-t("D2H .cpu() 132 ints", lambda: torch.zeros(132, dtype=torch.int32, device=dev).cpu())
-t("clone masks 9.8MB", lambda: a.clone())
-t("index_select 20 rows", lambda: a.index_select(0, torch.arange(20, device=dev)))
+import numpy as np, torch
+from ovo_amd.utils import geometry_utils as G
 torch.set_num_threads(1)
-print("threads -> 1")
-t("cpu min(dim=0) [8,3]", lambda: c.min(dim=0), sync=False)
-t("cpu einsum 4x4,8x4", lambda: torch.einsum("ij,mj->mi", torch.eye(4), torch.randn(8, 4)), sync=False)
-t("cpu linalg.inv 4x4", lambda: torch.linalg.inv(torch.eye(4)), sync=False)
-# dense similarity
-from ovo_amd.utils import clip_utils
-n, D = 1_200_000, 1024
-acc = torch.randn(n, D, device=dev); cnt = torch.ones(n, dtype=torch.int32, device=dev); T = torch.randn(10, D, device=dev)
-t("dense similarity 1.2M x 1024 (argmax only)", lambda: clip_utils.similarity(acc, T, cnt=cnt, want_sim=False, want_argmax=True), n=5)
-t("dense similarity 1.2M x 1024 (sim out)", lambda: clip_utils.similarity(acc, T), n=5)
+K = torch.tensor([[577.8, 0, 318.9], [0, 578.7, 242.7], [0, 0, 1]], dtype=torch.float32)
+P = torch.eye(4); P[:3, 3] = torch.tensor([1.0, 2.0, 0.5])
+def t(name, fn, n=2000):
+    fn(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    print(f"{name:44s} {(time.perf_counter() - t0) / n * 1e6:8.1f} us")
+c = G.frustum_corners_from_range(0.5, 3.0, 456, 616, P, K)
+t("frustum_corners_from_range", lambda: G.frustum_corners_from_range(0.5, 3.0, 456, 616, P, K))
+t("compute_camera_frustum_planes", lambda: G.compute_camera_frustum_planes(c))
+t("compute_frustum_aabb", lambda: G.compute_frustum_aabb(c))
+t("torch.linalg.inv(4x4)", lambda: torch.linalg.inv(P))
+w2c = torch.linalg.inv(P)
+t("make_camera (corners given)", lambda: G.make_camera(c, w2c, K, 0.05, 456, 616))
+i = [0]
+def miss():
+    i[0] += 1
+    return G.frame_camera(0.5 + 1e-6 * i[0], 3.0, 456, 616, P, K, 0.05)
+t("frame_camera (miss)", miss)
+t("frame_camera (hit)", lambda: G.frame_camera(0.5, 3.0, 456, 616, P, K, 0.03))
+t("_cpu32(P)", lambda: G._cpu32(P))
+t("P.numpy().tobytes()", lambda: P.numpy().tobytes())
