@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of OVO's per-frame open-vocabulary feature path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py                                   (= --gpus 1 --steps 24 --warmup 3)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
