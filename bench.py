@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--map-points", type=int, default=1_000_000)
     ap.add_argument("--texts", type=int, default=10)
     ap.add_argument("--no-dense", action="store_true", help="skip the dense per-point accumulate / query")
-    ap.add_argument("--encoder-batch", type=int, default=int(os.environ.get("OVO_ENCODER_BATCH", "8")),
+    ap.add_argument("--encoder-batch", type=int, default=int(os.environ.get("OVO_ENCODER_BATCH", "12")),
                     help="keyframes (per GPU) whose SAM2 / ViT forwards run as ONE batched forward each (encoder look-ahead; 1 = per frame). "
                          "The reference defers a keyframe's descriptors by kf_queue_delay = 10 keyframes (ovo.yaml:53), so results do not change")
     ap.add_argument("--sam-full", action="store_true", help="not the headline workload: also run SAM2's mask decoder on a 16x16 click grid and the "
@@ -335,7 +335,8 @@ def main():
     if sustain_rounds > 0:                                        # >= 2 s of the same stream: long enough for an external sampler to see
         nxt = frames[-1].index + 1
         pool = frames * (sustain_rounds * world // len(frames) + 1)
-        more = [Frame(nxt + i, f.rgb, f.rgb_lr, f.depth, f.c2w, f.seg_map, f.masks) for i, f in enumerate(pool[:sustain_rounds * world])]
+        more = [Frame(nxt + i, f.rgb[:], f.rgb_lr, f.depth, f.c2w, f.seg_map, f.masks) for i, f in enumerate(pool[:sustain_rounds * world])]   # rgb[:]: a view of its own --
+        # the look-ahead keys a frame's tokens by the identity of its image object, and the pool repeats the resident frames
         sfeed = Feed(more, world)
         chunk = max(args.encoder_batch, 1) * 4
         parallel.barrier()
