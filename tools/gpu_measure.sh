@@ -14,8 +14,8 @@ timeout 600 python bench.py --sam-full --no-cpu-baseline --sustain-seconds 0 > $
 timeout 300 python tools/query_bench.py > $OUT/query_bench.log 2>&1
 timeout 300 python tools/amg_bench.py 16 > $OUT/amg_bench.log 2>&1
 timeout 300 python tools/geom_bench.py > $OUT/geom_bench.txt 2>&1
-TILES="auto,ring,256x256,256x128" SHAPES="9232,3072,1024;9232,1024,1024;9232,4096,1024;9232,1024,4096;32768,1792,448;32768,448,1792;39200,1344,448;4616,3072,1024;4616,4096,1024;4096,4096,4096;8192,8192,8192" timeout 600 python tools/gemm_bench.py > $OUT/gemm_sweep.txt 2>&1
-(python tools/gemm8p_stamps.py 9232 3072 1024 256x256; python tools/gemm8p_stamps.py 9232 4096 1024 256x128; python tools/gemm8p_stamps.py 4096 4096 4096 256x256) > $OUT/gemm8p_timeline.txt 2>&1
+TILES="auto,ring,256x256,256x128" SHAPES="13848,3072,1024;13848,1024,1024;13848,4096,1024;13848,1024,4096;49152,1792,448;49152,448,1792;58800,1344,448;9232,3072,1024;9232,4096,1024;4616,3072,1024;4616,4096,1024;4096,4096,4096;8192,8192,8192" timeout 600 python tools/gemm_bench.py > $OUT/gemm_sweep.txt 2>&1
+(python tools/gemm8p_stamps.py 13848 3072 1024 256x256; python tools/gemm8p_stamps.py 13848 4096 1024 256x256; python tools/gemm8p_stamps.py 4096 4096 4096 256x256) > $OUT/gemm8p_timeline.txt 2>&1
 (python tools/enc_table.py vit 12; python tools/enc_table.py sam 12) > $OUT/enc_tables_b12.txt 2>&1
 (export TILES="tiled,stream" ROUNDS=3 ITERS=30
  echo "== bf16 out, bias"; BIAS=1 SHAPES="524288,336,128;524288,448,128;524288,672,128;131072,896,256;131072,672,256;131072,1344,256;131072,448,256;524288,32,256;131072,64,256" python tools/gemm_bench.py
