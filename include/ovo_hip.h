@@ -506,6 +506,72 @@ int ovo_near_fraction(const float *pts_by_instance, const int64_t *offsets, cons
 /* ins[i] = table[ins[i]] for ids in [0, n_slots): all `points_ins_ids[points_ins_ids == id2] = id1` of the merges in one pass. */
 int ovo_remap_instances(int32_t *ins, int64_t n, const int32_t *table, int n_slots, ovo_stream_t stream);
 
+
+/* =============================================================================================
+ * The keyframe chain without host round trips (MI355X extension of a6 / a9; what the reference does with a `.sum()` / vstack
+ * per mapped frame, vanilla_mapper.py:81-85, and >= 3 `.item()` syncs per mask, ovo.py:255-282).
+ * The map's size, the next point id and the next instance id live in DEVICE memory; ovo_map_step and ovo_track_step read and
+ * advance them there, size their launches from the caller's upper bound `n_upper`, take the instance decisions of ovo.py:255-282
+ * and the mask fusion of ovo.py:284-309 on the device, and publish one small result block per call into PINNED host memory
+ * (written by the last workgroup, sequence number last).  The host never has to wait between the launches of consecutive
+ * keyframes: it reads the blocks when it needs them (ovo_host_wait), e.g. after queueing a whole round of keyframes.
+ * ============================================================================================= */
+typedef struct {
+    float *xyz; int32_t *ids; int32_t *ins; uint8_t *rgb;   /* capacity buffers f32[cap,3], i32[cap], i32[cap], u8[cap,3] */
+    int64_t cap;
+    int64_t *state;      /* device i64[4] = {n points, next point id, error flags (bit 0: capacity overflow), ticket (zero)} */
+    int64_t n, next_id;  /* n >= 0: the host's exact copy of state[0..1] (no call in flight) -- used instead of reading state,
+                            which is re-seeded from it;  n < 0: read state */
+} ovo_map_ref_t;
+
+/* VanillaMapper.map (vanilla_mapper.py:46-85): explained-pixel test against the map (skipped while next point id == 0), erosion
+ * (`erode`, also only then), [::ds, ::ds] subsample, unproject, ordered append at row n; state += appended.
+ * result_host (optional, pinned i64[4]) = {seq, appended, n after, next id after}.  ws: ovo_compact_workspace_bytes(sub-sampled
+ * pixels) + 8 bytes; explained u8[h*w] scratch.  map.cap >= n_upper + sub-sampled pixels. */
+typedef struct {
+    ovo_map_ref_t map;
+    const float *depth; const uint8_t *rgb;   /* f32[h,w]; u8[h,w,3] or NULL */
+    int32_t h, w;
+    ovo_camera_t cam;                         /* frustum of the frame, th = the mapper's match distance */
+    float K[9], c2w[16];
+    int32_t ds, erode;
+    int64_t n_upper;                          /* >= the map's size when the call executes */
+    uint8_t *explained; void *ws; size_t ws_bytes;
+    int64_t *result_host; int64_t seq;
+} ovo_map_step_t;
+int ovo_map_step(const ovo_map_step_t *a, ovo_stream_t stream);
+
+/* OVO._match_and_track_instances (ovo.py:182-324) for one keyframe: [depth filter] -> ovo_track_project over the device-sized map
+ * -> vote statistics -> decisions in mask order (matched: n_assigned > track_th -> mode id; new: n_fresh > track_th -> next
+ * instance id, allocated in mask order) -> in-place assignment of map.ins -> masks of one instance OR-ed into its first mask +
+ * that mask's fused area.  result (device copy inside ws, host copy in result_host, i32[8 + 6 n_masks]):
+ *   [0] seq  [1] map points  [2] points in frustum  [3] points matched  [4] next instance id after  [5] before  [6..7] 0
+ *   per mask: {matched points, of which assigned, mode id, seg-map area, target id (-1 none), fused area (-1: no other mask joined)}
+ * point_seg i16[>= n_upper] as ovo_track_project writes it.  masks u8[n_masks, pixels] (pixels % 16 == 0) are fused IN PLACE;
+ * NULL skips the fusion.  next_ins: device i32[1]; next_ins_host >= 0 = the host's exact copy (used instead), -1 = read it. */
+typedef struct {
+    ovo_map_ref_t map;
+    const float *depth; int32_t filter_depth; float *depth_scratch;
+    ovo_camera_t cam; ovo_ratio_t ratio;
+    const int32_t *seg_map; int32_t seg_h, seg_w;
+    uint8_t *masks; int32_t n_masks; int64_t pixels;
+    int16_t *point_seg;
+    void *ws; size_t ws_bytes;                /* ovo_track_workspace_bytes(n_masks, hist_cols) */
+    int32_t hist_cols, track_th;
+    int32_t *next_ins; int32_t next_ins_host;
+    int64_t n_upper;
+    int32_t *result_host; int32_t seq;
+} ovo_track_step_t;
+size_t ovo_track_workspace_bytes(int n_masks, int hist_cols);
+int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream);
+
+/* Pinned, device-visible host memory for the result blocks, and the wait on a block's sequence word: spins (no runtime call) until
+ * *flag == value, at most timeout_us microseconds (OVO_E_LAUNCH on timeout). */
+void *ovo_host_alloc(size_t bytes);
+void ovo_host_free(void *p);
+int ovo_host_wait32(const int32_t *flag, int32_t value, int64_t timeout_us);
+int ovo_host_wait64(const int64_t *flag, int64_t value, int64_t timeout_us);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libovo_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 E_UNSUPPORTED = -3          # OVO_E_UNSUPPORTED: the entry point does not cover this shape; the caller takes its general path
 
 
@@ -99,6 +99,26 @@ class HieraWeights(C.Structure):
                 ("neck_w", _P * 4), ("neck_b", _P * 4), ("s0_w", _P), ("s0_b", _P), ("s1_w", _P), ("s1_b", _P)]
 
 
+class MapRef(C.Structure):
+    """ovo_map_ref_t"""
+    _fields_ = [("xyz", _P), ("ids", _P), ("ins", _P), ("rgb", _P), ("cap", _I64), ("state", _P), ("n", _I64), ("next_id", _I64)]
+
+
+class MapStep(C.Structure):
+    """ovo_map_step_t"""
+    _fields_ = [("map", MapRef), ("depth", _P), ("rgb", _P), ("h", C.c_int32), ("w", C.c_int32), ("cam", Camera),
+                ("K", C.c_float * 9), ("c2w", C.c_float * 16), ("ds", C.c_int32), ("erode", C.c_int32), ("n_upper", _I64),
+                ("explained", _P), ("ws", _P), ("ws_bytes", _SZ), ("result_host", _P), ("seq", _I64)]
+
+
+class TrackStep(C.Structure):
+    """ovo_track_step_t"""
+    _fields_ = [("map", MapRef), ("depth", _P), ("filter_depth", C.c_int32), ("depth_scratch", _P), ("cam", Camera), ("ratio", Ratio),
+                ("seg_map", _P), ("seg_h", C.c_int32), ("seg_w", C.c_int32), ("masks", _P), ("n_masks", C.c_int32), ("pixels", _I64),
+                ("point_seg", _P), ("ws", _P), ("ws_bytes", _SZ), ("hist_cols", C.c_int32), ("track_th", C.c_int32),
+                ("next_ins", _P), ("next_ins_host", C.c_int32), ("n_upper", _I64), ("result_host", _P), ("seq", C.c_int32)]
+
+
 DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.uint8: 3}
 
 _SIGNATURES = {
@@ -116,6 +136,13 @@ _SIGNATURES = {
     "ovo_assign_instances": (_I32, [_P, _P, _I64, _P, _I32, _P, _P, _P]),
     "ovo_map_explained": (_I32, [_P, _I64, _CAM, _P, _P, _P]),
     "ovo_map_backproject": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "ovo_map_step": (_I32, [C.POINTER(MapStep), _P]),
+    "ovo_track_step": (_I32, [C.POINTER(TrackStep), _P]),
+    "ovo_track_workspace_bytes": (_SZ, [_I32, _I32]),
+    "ovo_host_alloc": (_P, [_SZ]),
+    "ovo_host_free": (None, [_P]),
+    "ovo_host_wait32": (_I32, [_P, C.c_int32, _I64]),
+    "ovo_host_wait64": (_I32, [_P, _I64, _I64]),
     "ovo_fuse_views": (_I32, [_P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P]),
     "ovo_scatter_accum": (_I32, [_P, _I64, _P, _I32, _P, _I32, _P, _P, _P]),
     "ovo_similarity": (_I32, [_P, _I32, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P, _P]),
@@ -251,3 +278,42 @@ def workspace(nbytes: int, device) -> torch.Tensor:
         buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+class PinnedRing:
+    """Result blocks of the keyframe chain (`ovo_map_step` / `ovo_track_step`): a ring of fixed-size slots in pinned, device-visible host
+    memory (`ovo_host_alloc`).  The last workgroup of a chain writes a slot and then its sequence word; `wait` spins on that word
+    (no runtime call, GIL released) and returns the slot as a numpy view."""
+
+    def __init__(self, slot_items: int, np_dtype, slots: int = 64):
+        import numpy as np
+        self.np = np
+        self.dtype = np.dtype(np_dtype)
+        self.slot_items, self.slots = int(slot_items), int(slots)
+        nbytes = self.slot_items * self.slots * self.dtype.itemsize
+        self.base = load().ovo_host_alloc(nbytes)
+        if not self.base:
+            raise OvoHipError(load().ovo_hip_last_error().decode())
+        ctype = C.c_int64 if self.dtype.itemsize == 8 else C.c_int32
+        self.view = np.ctypeslib.as_array(C.cast(self.base, C.POINTER(ctype)), shape=(self.slots, self.slot_items))
+        self._wait = load().ovo_host_wait64 if self.dtype.itemsize == 8 else load().ovo_host_wait32
+        self.seq = 0
+
+    def next(self):
+        """(sequence number, slot pointer) of the next call; the slot's sequence word is cleared first."""
+        self.seq += 1
+        k = self.seq % self.slots
+        self.view[k, 0] = 0
+        return self.seq, self.base + k * self.slot_items * self.dtype.itemsize
+
+    def wait(self, seq: int, timeout_us: int = 20_000_000):
+        k = seq % self.slots
+        check(self._wait(self.base + k * self.slot_items * self.dtype.itemsize, seq, timeout_us))
+        return self.view[k]
+
+    def __del__(self):
+        try:
+            if getattr(self, "base", None):
+                load().ovo_host_free(self.base)
+        except Exception:
+            pass

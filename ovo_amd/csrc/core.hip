@@ -3,6 +3,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
 #include <vector>
 
 #include "common.h"
@@ -49,9 +53,25 @@ void ovo_prof_end(hipStream_t s) {
     hipEventRecord(g_prof.recs.back().b, s);
 }
 
+template <typename T>
+static int host_wait(const T *flag, T value, int64_t timeout_us) {
+    OVO_REQUIRE(flag, "null flag");
+    const volatile T *f = flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        if (*f == value) { std::atomic_thread_fence(std::memory_order_acquire); return OVO_OK; }
+        if ((spin & 255) == 255 &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_us) {
+            ovo_set_error("ovo_host_wait: timed out after %lld us (flag %lld, expected %lld)", (long long)timeout_us, (long long)*f, (long long)value);
+            return OVO_E_LAUNCH;
+        }
+        __builtin_ia32_pause();
+    }
+}
+
 extern "C" {
 const char *ovo_hip_last_error(void) { return g_err; }
-int ovo_hip_abi_version(void) { return 5; }
+int ovo_hip_abi_version(void) { return 6; }
 
 int ovo_profile_start(void) {
     g_prof.recs.clear();
@@ -77,4 +97,19 @@ int ovo_profile_stop(double *ms, double *work, int64_t *launches, int n_kinds) {
     g_prof.used = 0;
     return OVO_OK;
 }
+
+// ---- pinned result blocks of the keyframe chain -------------------------------------------------------------------------
+void *ovo_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        ovo_set_error("ovo_host_alloc: hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    memset(p, 0, bytes);
+    return p;
+}
+void ovo_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+int ovo_host_wait32(const int32_t *flag, int32_t value, int64_t timeout_us) { return host_wait(flag, value, timeout_us); }
+int ovo_host_wait64(const int64_t *flag, int64_t value, int64_t timeout_us) { return host_wait(flag, value, timeout_us); }
 }

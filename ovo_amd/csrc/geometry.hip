@@ -147,9 +147,35 @@ __global__ void __launch_bounds__(256) k_scan_words(const unsigned long long *__
     }
 }
 
+// the three steps in one workgroup when the words fit one chunk (<= 131 072 items: the back-projection of a 640 x 480 frame)
+__global__ void __launch_bounds__(256) k_scan_one(const unsigned long long *__restrict__ words, long long *__restrict__ offs, int64_t n_words,
+                                                  long long *__restrict__ total_out) {
+    __shared__ long long sh[4];
+    const int64_t w0 = (int64_t)threadIdx.x * 8;
+    int pc[8];
+    long long c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        pc[k] = w0 + k < n_words ? __popcll(words[w0 + k]) : 0;
+        c += pc[k];
+    }
+    long long total;
+    long long run = block_exclusive_scan(c, sh, total);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (w0 + k < n_words) offs[w0 + k] = run;
+        run += pc[k];
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = total;
+}
+
 // the scan of one compaction: words -> offs, *total = number of set bits
 __host__ void scan_words(const unsigned long long *words, long long *offs, long long *sums, int64_t n_words, long long *total, hipStream_t s) {
     const int64_t chunks = (n_words + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (chunks <= 1) {
+        k_scan_one<<<1, 256, 0, s>>>(words, offs, n_words, total);
+        return;
+    }
     k_scan_sums<<<(unsigned)chunks, 256, 0, s>>>(words, n_words, sums);
     k_scan_bases<<<1, 256, 0, s>>>(sums, chunks, total);
     k_scan_words<<<(unsigned)chunks, 256, 0, s>>>(words, offs, n_words, sums);
@@ -290,7 +316,8 @@ __global__ void __launch_bounds__(256) k_track_project(const float *__restrict__
                                                        const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
                                                        ovo_ratio_t ratio, int16_t *__restrict__ point_seg,
                                                        int32_t *__restrict__ hist, int n_masks, int hist_cols,
-                                                       unsigned long long *__restrict__ counters) {
+                                                       unsigned long long *__restrict__ counters, const long long *__restrict__ n_dev) {
+    if (n_dev) n = *n_dev;                                         // device-resident map size (ovo_track_step): no host round trip
     __shared__ float s_x[1024], s_y[1024], s_z[1024];
     __shared__ long long s_i[1024];
     __shared__ int s_n;
@@ -416,7 +443,9 @@ __global__ void __launch_bounds__(256) k_vote_stats(const int32_t *__restrict__ 
 
 __global__ void __launch_bounds__(256) k_assign(const int32_t *__restrict__ point_ins, const int16_t *__restrict__ point_seg,
                                                 int64_t n, const int32_t *__restrict__ mask_target, int n_masks,
-                                                int32_t *__restrict__ out_ins, unsigned long long *__restrict__ new_count) {
+                                                int32_t *__restrict__ out_ins, unsigned long long *__restrict__ new_count,
+                                                const long long *__restrict__ n_dev) {
+    if (n_dev) n = *n_dev;
     long long c = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int ins = point_ins[i];
@@ -433,9 +462,27 @@ __global__ void __launch_bounds__(256) k_assign(const int32_t *__restrict__ poin
     }
 }
 
+// k_assign with the targets read from the device-side decision block (row stride 6, column 4), in place
+__global__ void __launch_bounds__(256) k_assign_res(int32_t *__restrict__ point_ins, const int16_t *__restrict__ point_seg, int64_t n,
+                                                    const int32_t *__restrict__ res, int n_masks, const long long *__restrict__ n_dev) {
+    if (n_dev) n = *n_dev;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = point_seg[i];
+        if (s >= 0 && s < n_masks && point_ins[i] == -1) {
+            const int tgt = res[8 + 6 * s + 4];
+            if (tgt > -1) point_ins[i] = tgt;
+        }
+    }
+}
+
 // ---- a9 ----
 __global__ void __launch_bounds__(256) k_map_explained(const float *__restrict__ pts, int64_t n, ovo_camera_t cam,
-                                                       const float *__restrict__ depth, uint8_t *__restrict__ explained) {
+                                                       const float *__restrict__ depth, uint8_t *__restrict__ explained,
+                                                       const long long *__restrict__ state) {
+    if (state) {                                                   // device-resident map state {n, next point id} (ovo_map_step)
+        n = state[0];
+        if (state[1] <= 0) return;                                 // vanilla_mapper.py:56 `if self.max_id > 0`
+    }
     __shared__ float s_x[1024], s_y[1024], s_z[1024];
     __shared__ int s_n;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
@@ -478,7 +525,12 @@ __device__ __forceinline__ bool px_valid(const float *depth, const uint8_t *expl
 }
 
 __global__ void __launch_bounds__(256) k_backproj_flag(const float *__restrict__ depth, const uint8_t *__restrict__ explained,
-                                                       BackprojArgs a, int64_t n_sub, unsigned long long *words) {
+                                                       BackprojArgs a, int64_t n_sub, unsigned long long *words,
+                                                       const long long *__restrict__ state) {
+    if (state && state[1] <= 0) {                                  // empty map so far: no explained-pixel test, no erosion (vanilla_mapper.py:56,62)
+        explained = nullptr;
+        a.erode = 0;
+    }
     flag_words_idx(n_sub, words, [&](int64_t k) {
         const int y = (int)(k / a.ws_w) * a.ds, x = (int)(k % a.ws_w) * a.ds;
         if (!px_valid(depth, explained, (int64_t)y * a.w + x)) return false;
@@ -494,10 +546,24 @@ __global__ void __launch_bounds__(256) k_backproj_flag(const float *__restrict__
     });
 }
 
+// What the LAST workgroup of k_backproj_emit does for ovo_map_step: advance the device-resident map state by the number of appended
+// points and publish it to the host's pinned result block (sequence number last, after a system-scope fence).
+struct MapCommit {
+    long long *state;            // device i64[4] {n, next point id, error flags, ticket}; NULL = plain ovo_map_backproject
+    const long long *total;      // number of appended points (the scan's total)
+    volatile long long *result;  // pinned host i64[4] {seq, appended, n after, next id after} or NULL
+    long long seq, cap;
+    long long n_host, id_host;   // the host's exact copy of the state when it has one (n_host >= 0), else read `state`
+};
+
 __global__ void __launch_bounds__(256) k_backproj_emit(const float *__restrict__ depth, const uint8_t *__restrict__ rgb, BackprojArgs a,
                                                        int64_t n_sub, const unsigned long long *words, const long long *offs,
                                                        int64_t base, int32_t first_id, float *xyz, int32_t *ids, int32_t *ins,
-                                                       uint8_t *out_rgb) {
+                                                       uint8_t *out_rgb, MapCommit mc) {
+    if (mc.state) {
+        base = mc.n_host >= 0 ? mc.n_host : mc.state[0];
+        first_id = (int32_t)(mc.n_host >= 0 ? mc.id_host : mc.state[1]);
+    }
     emit_words(n_sub, words, offs, [&](int64_t k, long long pos) {
         const int y = (int)(k / a.ws_w) * a.ds, x = (int)(k % a.ws_w) * a.ds;
         const int64_t px = (int64_t)y * a.w + x;
@@ -505,6 +571,7 @@ __global__ void __launch_bounds__(256) k_backproj_emit(const float *__restrict__
         const float x3 = __fdiv_rn(__fmul_rn(__fsub_rn((float)x, a.K[2]), d), a.K[0]);
         const float y3 = __fdiv_rn(__fmul_rn(__fsub_rn((float)y, a.K[5]), d), a.K[4]);
         const int64_t r = base + pos;
+        if (mc.state && r >= mc.cap) return;                       // never taken: the host reserves n_upper + n_sub rows (flagged below)
         xyz[3 * r + 0] = dot4(a.c2w, x3, y3, d, 1.0f);
         xyz[3 * r + 1] = dot4(a.c2w + 4, x3, y3, d, 1.0f);
         xyz[3 * r + 2] = dot4(a.c2w + 8, x3, y3, d, 1.0f);
@@ -516,6 +583,200 @@ __global__ void __launch_bounds__(256) k_backproj_emit(const float *__restrict__
             out_rgb[3 * r + 2] = rgb[3 * px + 2];
         }
     });
+    if (!mc.state) return;
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd((unsigned long long *)(mc.state + 3), 1ull) == (unsigned long long)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;                       // every other workgroup has read `base` before it took its ticket
+    long long m = *mc.total;
+    if (base + m > mc.cap) { m = mc.cap - base; mc.state[2] |= 1; }
+    mc.state[0] = base + m;
+    mc.state[1] = (long long)first_id + m;
+    mc.state[3] = 0;
+    if (mc.result) {
+        mc.result[1] = m; mc.result[2] = base + m; mc.result[3] = (long long)first_id + m;
+        __threadfence_system();
+        mc.result[0] = mc.seq;
+    }
+}
+
+// ---- a6 decisions on the device (ovo.py:255-282): mask -> instance targets, instance-id allocation in mask order, the first mask of
+// every instance (the row its other masks are OR-ed into, ovo.py:284-303).  One workgroup; runs as the tail of the vote statistics.
+// res rows i32[n_masks, 6] = {matched points, already assigned, mode id, seg-map area, target (-1 none), fused area (-1: not fused)}.
+struct Decide {
+    int32_t *res;                // device result block: 8 header ints + 6 per mask
+    int32_t *dst;                // i32[n_masks]: first mask with the same target (-1: no target)
+    int32_t *next_ins;           // device i32[1] next instance id
+    int32_t next_host;           // the host's exact copy (>= 0) or -1: read next_ins
+    int32_t track_th, n_masks;
+};
+
+__device__ __forceinline__ int ld_agent(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ void decide_masks(const Decide d, const int32_t *stats) {
+    __shared__ int s_scan[256];
+    __shared__ int s_base;
+    const int t = threadIdx.x;
+    if (t == 0) s_base = d.next_host >= 0 ? d.next_host : *d.next_ins;
+    __syncthreads();
+    const int first_new = s_base;
+    for (int m0 = 0; m0 < d.n_masks; m0 += 256) {
+        const int m = m0 + t;
+        int kind = 0, mode = -1;
+        if (m < d.n_masks) {
+            const int n_pts = ld_agent(stats + 4 * m), n_as = ld_agent(stats + 4 * m + 1);
+            mode = ld_agent(stats + 4 * m + 2);
+            if (n_pts > d.track_th) kind = n_as > d.track_th ? 1 : (n_pts - n_as > d.track_th ? 2 : 0);
+        }
+        s_scan[t] = kind == 2;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {                         // inclusive scan of the "new instance" flags, mask order
+            const int v = t >= o ? s_scan[t - o] : 0;
+            __syncthreads();
+            s_scan[t] += v;
+            __syncthreads();
+        }
+        const int before = s_scan[t] - (kind == 2);
+        if (m < d.n_masks) {
+            const int target = kind == 1 ? mode : (kind == 2 ? s_base + before : -1);
+            int32_t *r = d.res + 8 + 6 * m;
+            r[0] = ld_agent(stats + 4 * m); r[1] = ld_agent(stats + 4 * m + 1); r[2] = mode; r[3] = ld_agent(stats + 4 * m + 3); r[4] = target; r[5] = -1;
+        }
+        __syncthreads();
+        if (t == 255) s_base += s_scan[255];
+        __syncthreads();
+    }
+    if (t == 0) { *d.next_ins = s_base; d.res[4] = s_base; d.res[5] = first_new; }
+    __threadfence_block();
+    __syncthreads();
+    for (int m = t; m < d.n_masks; m += 256) {                      // first mask of each target (targets of new instances are unique)
+        const int tg = d.res[8 + 6 * m + 4];
+        int first = tg < 0 ? -1 : m;
+        if (tg >= 0 && tg < first_new)
+            for (int k = 0; k < m; ++k)
+                if (d.res[8 + 6 * k + 4] == tg) { first = k; break; }
+        d.dst[m] = first;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_vote_decide(const int32_t *__restrict__ hist, int hist_cols, int32_t *__restrict__ stats,
+                                                     unsigned int *__restrict__ ticket, Decide d) {
+    __shared__ long long s_cnt[256];
+    __shared__ int s_best[256], s_arg[256];
+    __shared__ int s_last;
+    const int m = blockIdx.x, t = threadIdx.x;
+    const int32_t *row = hist + (int64_t)m * hist_cols;
+    long long assigned = 0;
+    int best = 0, arg = -1;
+    for (int c = 1 + t; c < hist_cols; c += 256) {
+        const int v = row[c];
+        assigned += v;
+        if (v > best) { best = v; arg = c - 1; }
+    }
+    s_cnt[t] = assigned; s_best[t] = best; s_arg[t] = arg;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            s_cnt[t] += s_cnt[t + o];
+            const int b2 = s_best[t + o], a2 = s_arg[t + o];
+            if (b2 > s_best[t] || (b2 == s_best[t] && b2 > 0 && (s_arg[t] < 0 || a2 < s_arg[t]))) {
+                s_best[t] = b2; s_arg[t] = a2;
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        stats[4 * m + 0] = (int)(s_cnt[0] + row[0]);
+        stats[4 * m + 1] = (int)s_cnt[0];
+        stats[4 * m + 2] = s_arg[0];
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    decide_masks(d, (const int32_t *)stats);                        // the last workgroup: every mask's statistics are in
+}
+
+// ---- a7 on the device (ovo.py:284-309): masks[first] |= masks[m] for every other mask m of the same instance, the fused area of
+// `first` for the top-k view heap; then the LAST workgroup publishes the keyframe's result block to pinned host memory.
+struct Publish {
+    const int32_t *res;          // device result block
+    volatile int32_t *host;      // pinned host copy (same layout), host[0] = seq is written last
+    const unsigned long long *counters;   // {in frustum, matched}
+    const long long *n_dev; long long n_host;
+    unsigned int *ticket;
+    int32_t seq, n_ints;
+};
+
+__device__ __forceinline__ int nonzero_bytes(unsigned int w) {
+    w |= w >> 4; w |= w >> 2; w |= w >> 1;
+    return __popc(w & 0x01010101u);
+}
+
+__global__ void __launch_bounds__(256) k_fuse_publish(uint4 *__restrict__ masks, long long px16, int n_masks, const int32_t *__restrict__ dst,
+                                                      int32_t *__restrict__ res, Publish pb) {
+    const int d = blockIdx.y;
+    __shared__ int s_follow[256], s_nf;
+    if (masks && dst[d] == d) {                                    // workgroup-uniform
+        if (threadIdx.x == 0) {
+            int c = 0;
+            for (int m = d + 1; m < n_masks; ++m)
+                if (dst[m] == d) { if (c < 256) s_follow[c] = m; ++c; }
+            s_nf = c;
+        }
+        __syncthreads();
+        const int n_follow = s_nf;
+        if (n_follow) {
+            int area = 0;
+            for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < px16; i += (long long)gridDim.x * blockDim.x) {
+                uint4 a = masks[d * px16 + i];
+                if (n_follow <= 256) {
+                    for (int k = 0; k < n_follow; ++k) {
+                        const uint4 b = masks[s_follow[k] * px16 + i];
+                        a.x |= b.x; a.y |= b.y; a.z |= b.z; a.w |= b.w;
+                    }
+                } else {
+                    for (int m = d + 1; m < n_masks; ++m)
+                        if (dst[m] == d) {
+                            const uint4 b = masks[m * px16 + i];
+                            a.x |= b.x; a.y |= b.y; a.z |= b.z; a.w |= b.w;
+                        }
+                }
+                masks[d * px16 + i] = a;
+                area += nonzero_bytes(a.x) + nonzero_bytes(a.y) + nonzero_bytes(a.z) + nonzero_bytes(a.w);
+            }
+            for (int o = 32; o > 0; o >>= 1) area += __shfl_xor(area, o, 64);
+            if ((threadIdx.x & 63) == 0) {
+                if (blockIdx.x == 0 && threadIdx.x == 0) area += 1;       // the row starts at -1 ("not fused")
+                if (area) atomicAdd(res + 8 + 6 * d + 5, area);
+            }
+        }
+    }
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(pb.ticket, 1u) == gridDim.x * gridDim.y - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) {
+        res[1] = (int32_t)(pb.n_host >= 0 ? pb.n_host : *pb.n_dev);
+        res[2] = (int32_t)pb.counters[0];
+        res[3] = (int32_t)pb.counters[1];
+    }
+    __syncthreads();
+    if (!pb.host) return;
+    for (int i = 1 + threadIdx.x; i < pb.n_ints; i += 256) pb.host[i] = ld_agent(res + i);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) pb.host[0] = pb.seq;
 }
 
 }  // namespace
@@ -584,7 +845,7 @@ int ovo_track_project(const float *pts, const int32_t *point_ins, int64_t n, con
     if (prof) ovo_prof_begin(2, 14.0 * (double)n, s);          // 12 B xyz read + 2 B mask id written per map point
     k_track_project<<<ovo_grid(n, 256), 256, 0, s>>>(pts, point_ins, n, *cam, depth, seg_map, seg_h, seg_w, ratio,
                                                       point_seg, hist, n_masks, hist_cols,
-                                                      (unsigned long long *)counters);
+                                                      (unsigned long long *)counters, nullptr);
     if (prof) ovo_prof_end(s);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
@@ -610,7 +871,7 @@ int ovo_assign_instances(const int32_t *point_ins, const int16_t *point_seg, int
     if (n == 0) return OVO_OK;
     OVO_REQUIRE(point_ins && point_seg && out_ins, "null pointer");
     k_assign<<<ovo_grid(n, 256), 256, 0, s>>>(point_ins, point_seg, n, mask_target, n_masks, out_ins,
-                                               (unsigned long long *)new_count);
+                                               (unsigned long long *)new_count, nullptr);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }
@@ -622,7 +883,7 @@ int ovo_map_explained(const float *pts, int64_t n, const ovo_camera_t *cam, cons
     OVO_HIP(hipMemsetAsync(explained, 0, (size_t)cam->h * cam->w, s));
     if (n == 0) return OVO_OK;
     OVO_REQUIRE(pts, "null pointer");
-    k_map_explained<<<ovo_grid(n, 256), 256, 0, s>>>(pts, n, *cam, depth, explained);
+    k_map_explained<<<ovo_grid(n, 256), 256, 0, s>>>(pts, n, *cam, depth, explained, nullptr);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }
@@ -643,9 +904,107 @@ int ovo_map_backproject(const float *depth, const uint8_t *rgb, const uint8_t *e
     hipStream_t s = (hipStream_t)stream;
     CompactWs c = carve(ws, n_sub);
     const int g = ovo_grid(n_sub, 256);
-    k_backproj_flag<<<g, 256, 0, s>>>(depth, explained, a, n_sub, c.words);
+    k_backproj_flag<<<g, 256, 0, s>>>(depth, explained, a, n_sub, c.words, nullptr);
     scan_words(c.words, c.offs, c.sums, c.n_words, (long long *)out_count, s);
-    k_backproj_emit<<<g, 256, 0, s>>>(depth, rgb, a, n_sub, c.words, c.offs, base, first_id, xyz, ids, ins, out_rgb);
+    MapCommit none = {};
+    k_backproj_emit<<<g, 256, 0, s>>>(depth, rgb, a, n_sub, c.words, c.offs, base, first_id, xyz, ids, ins, out_rgb, none);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+
+// ---- the keyframe chain without host round trips (ovo_map_step, ovo_track_step) ------------------------------------------------
+size_t ovo_track_workspace_bytes(int n_masks, int hist_cols) {
+    // hist | stats[4 n] | counters (2 x u64) | tickets (2 x u32) | dst[n] | result block [8 + 6 n]
+    return ((size_t)n_masks * hist_cols + 4 * (size_t)n_masks + 4 + 2 + n_masks + 8 + 6 * (size_t)n_masks + 4) * sizeof(int32_t);
+}
+
+int ovo_map_step(const ovo_map_step_t *a, ovo_stream_t stream) {
+    OVO_REQUIRE(a && a->depth && a->map.xyz && a->map.ids && a->map.ins && a->map.state && a->explained && a->ws, "null argument");
+    OVO_REQUIRE(a->h > 0 && a->w > 0 && a->ds >= 1 && a->n_upper >= 0, "bad shape");
+    const int64_t ws_w = (a->w + a->ds - 1) / a->ds;
+    const int64_t n_sub = (int64_t)((a->h + a->ds - 1) / a->ds) * ws_w;
+    OVO_REQUIRE(a->ws_bytes >= ovo_compact_workspace_bytes(n_sub) + 8, "workspace too small");
+    OVO_REQUIRE(a->map.cap >= a->n_upper + n_sub, "map capacity below n_upper + one frame of points");
+    OVO_REQUIRE(a->map.n < 0 || a->map.n <= a->n_upper, "n_upper below the known point count");
+    hipStream_t s = (hipStream_t)stream;
+    const bool known = a->map.n >= 0;
+    const bool maybe_nonempty = known ? a->map.next_id > 0 : true;
+    OVO_HIP(hipMemsetAsync(a->explained, 0, (size_t)a->h * a->w, s));
+    if (maybe_nonempty && a->n_upper > 0) {
+        if (known)
+            k_map_explained<<<ovo_grid(a->map.n, 256), 256, 0, s>>>(a->map.xyz, a->map.n, a->cam, a->depth, a->explained, nullptr);
+        else
+            k_map_explained<<<ovo_grid(a->n_upper, 256), 256, 0, s>>>(a->map.xyz, 0, a->cam, a->depth, a->explained,
+                                                                      (const long long *)a->map.state);
+    }
+    BackprojArgs b;
+    for (int i = 0; i < 9; ++i) b.K[i] = a->K[i];
+    for (int i = 0; i < 16; ++i) b.c2w[i] = a->c2w[i];
+    b.h = a->h; b.w = a->w; b.ds = a->ds; b.ws_w = (int)ws_w;
+    b.erode = a->erode && maybe_nonempty;
+    long long *total = (long long *)a->ws;
+    CompactWs c = carve((char *)a->ws + 8, n_sub);
+    const int g = ovo_grid(n_sub, 256);
+    k_backproj_flag<<<g, 256, 0, s>>>(a->depth, maybe_nonempty ? a->explained : nullptr, b, n_sub, c.words,
+                                      known ? nullptr : (const long long *)a->map.state);
+    scan_words(c.words, c.offs, c.sums, c.n_words, total, s);
+    MapCommit mc;
+    mc.state = (long long *)a->map.state; mc.total = total; mc.result = (volatile long long *)a->result_host; mc.seq = a->seq;
+    mc.cap = a->map.cap; mc.n_host = known ? a->map.n : -1; mc.id_host = a->map.next_id;
+    k_backproj_emit<<<g, 256, 0, s>>>(a->depth, a->rgb, b, n_sub, c.words, c.offs, 0, 0, a->map.xyz, a->map.ids, a->map.ins,
+                                      a->map.rgb, mc);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream) {
+    OVO_REQUIRE(a && a->depth && a->seg_map && a->point_seg && a->ws && a->map.state && a->next_ins, "null argument");
+    OVO_REQUIRE(a->n_upper == 0 || (a->map.xyz && a->map.ins), "null map");
+    OVO_REQUIRE(a->n_masks > 0 && a->n_masks <= 8192 && a->hist_cols >= 1, "bad mask / histogram shape");
+    OVO_REQUIRE(a->ws_bytes >= ovo_track_workspace_bytes(a->n_masks, a->hist_cols), "workspace too small");
+    OVO_REQUIRE(!a->masks || (a->pixels > 0 && a->pixels % 16 == 0 && ((uintptr_t)a->masks & 15) == 0), "masks: pixels must be a multiple of 16");
+    OVO_REQUIRE(a->map.n < 0 || a->map.n <= a->n_upper, "n_upper below the known point count");
+    hipStream_t s = (hipStream_t)stream;
+    const int nm = a->n_masks;
+    int32_t *hist = (int32_t *)a->ws;
+    int32_t *stats = hist + (size_t)nm * a->hist_cols;
+    unsigned long long *counters = (unsigned long long *)(stats + 4 * (size_t)nm + ((((size_t)nm * a->hist_cols) & 1) ? 1 : 0));   // 8-byte aligned
+    unsigned int *tickets = (unsigned int *)(counters + 2);
+    int32_t *dst = (int32_t *)(tickets + 2);
+    int32_t *res = dst + nm;
+    const size_t zero_bytes = (size_t)((char *)dst - (char *)hist);
+    OVO_HIP(hipMemsetAsync(hist, 0, zero_bytes, s));
+    const bool known = a->map.n >= 0;
+    const long long *n_dev = known ? nullptr : (const long long *)a->map.state;
+    const float *depth = a->depth;
+    if (a->filter_depth) {
+        OVO_REQUIRE(a->depth_scratch, "depth_scratch needed for the depth filter");
+        const int rc = ovo_depth_filter(a->depth, a->cam.h, a->cam.w, 7, 2.5f, 0.05f, a->depth_scratch, stream);
+        if (rc != OVO_OK) return rc;
+        depth = a->depth_scratch;
+    }
+    const int64_t n_grid = known ? a->map.n : a->n_upper;
+    if (n_grid > 0) {
+        const bool prof = ovo_prof_enabled();
+        if (prof) ovo_prof_begin(2, 14.0 * (double)n_grid, s);
+        k_track_project<<<ovo_grid(n_grid, 256), 256, 0, s>>>(a->map.xyz, a->map.ins, known ? a->map.n : 0, a->cam, depth, a->seg_map, a->seg_h,
+                                                           a->seg_w, a->ratio, a->point_seg, hist, nm, a->hist_cols, counters, n_dev);
+        if (prof) ovo_prof_end(s);
+    }
+    const int64_t seg_pixels = (int64_t)a->seg_h * a->seg_w;
+    k_seg_area<<<ovo_grid(seg_pixels, 256, 256), 256, nm * sizeof(int), s>>>(a->seg_map, seg_pixels, nm, stats);
+    Decide d;
+    d.res = res; d.dst = dst; d.next_ins = a->next_ins; d.next_host = a->next_ins_host; d.track_th = a->track_th; d.n_masks = nm;
+    k_vote_decide<<<nm, 256, 0, s>>>(hist, a->hist_cols, stats, tickets, d);
+    if (n_grid > 0)
+        k_assign_res<<<ovo_grid(n_grid, 256), 256, 0, s>>>(a->map.ins, a->point_seg, known ? a->map.n : 0, res, nm, n_dev);
+    Publish pb;
+    pb.res = res; pb.host = (volatile int32_t *)a->result_host; pb.counters = counters; pb.n_dev = (const long long *)a->map.state;
+    pb.n_host = known ? a->map.n : -1; pb.ticket = tickets + 1; pb.seq = a->seq; pb.n_ints = 8 + 6 * nm;
+    const long long px16 = a->masks ? a->pixels / 16 : 0;
+    dim3 grid(a->masks ? ovo_grid(px16, 256, 32) : 1, nm);
+    k_fuse_publish<<<grid, 256, 0, s>>>((uint4 *)a->masks, px16, nm, dst, res, pb);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

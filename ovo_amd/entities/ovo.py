@@ -96,6 +96,11 @@ class OVO:
         self.kf_id = 0
         self.last_point_seg: Optional[torch.Tensor] = None     # i16[N] mask id per map point of the last keyframe
         self.last_mask_rows: Optional[List[int]] = None
+        # native keyframe chain (`ovo_track_step`): the next instance id also lives on the device; results arrive in pinned blocks
+        self._track_pending: deque = deque()
+        self._track_ring = None
+        self._next_ins_dev = None
+        self._own_state = None
         # loop-closure thresholds (ovo.py:62-65); update_map itself is a "next" row
         self.th_centroid = config.get("th_centroid", 1.5)
         self.th_cossim = config.get("th_cossim", 0.81)
@@ -135,14 +140,167 @@ class OVO:
             self._time_cache = []
         return updated
 
+    def detect_and_track_launch(self, frame_data, slam, c2w) -> Optional[Dict[str, Any]]:
+        """`detect_and_track_objects` split in two (MI355X extension): this half gets the masks and QUEUES the tracking chain against
+        `slam`'s device-resident map (whose `map_launch` calls may be in flight); `detect_and_track_finish` reads the result block.
+        A round of keyframes is queued back to back and finished in order: the host never stalls the device between keyframes.
+        Only for keyframes `_native_ok` accepts (the caller checks) and without per-stage logging."""
+        frame_id, image = frame_data[:2]
+        seg_map, binary_maps = self.mask_generator.get_masks(image, frame_id)
+        if len(seg_map) == 0:
+            print(f"No mask segmented in {frame_id}!")
+            return None
+        pend = self.track_launch(frame_data[1:], None, c2w, seg_map, binary_maps, slam=slam)
+        pend["frame"] = (frame_id, image)
+        return pend
+
+    def detect_and_track_finish(self, pend: Optional[Dict[str, Any]]):
+        if pend is None:
+            return None
+        frame_id, image = pend["frame"]
+        matched, binary_maps, n_matched, updated = self.track_finish(pend)
+        self.keyframes_queue.append([matched, binary_maps, image, self.kf_id])
+        self.kf_id += 1
+        return updated
+
     @_timed("t_sam")
     def _get_masks(self, image: np.ndarray, frame_id: int):
         return self.mask_generator.get_masks(image, frame_id)
 
     # ------------------------------------------------------------------ tracking
+    MAX_RESULT_MASKS = 1024     # masks per keyframe a slot of the pinned result ring holds (more: the host-decision path below)
+
     @_timed("t_obj")
     def _match_and_track_instances(self, frame_data, map_data, c2w, seg_map: torch.Tensor, binary_maps: torch.Tensor):
-        """Reference: ovo.py:182-238 (with :240-324 inlined as device passes + a host decision loop)."""
+        """Reference: ovo.py:182-238 (with :240-324 inlined).  One C call queues the whole chain -- cull / project / depth-test / seg
+        lookup / votes / decisions / assignment / mask fusion (`ovo_track_step`) -- and one pinned result block comes back."""
+        if not self._native_ok(binary_maps):
+            return self._match_and_track_instances_host(frame_data, map_data, c2w, seg_map, binary_maps)
+        pend = self.track_launch(frame_data, map_data, c2w, seg_map, binary_maps)
+        return self.track_finish(pend)
+
+    def _native_ok(self, binary_maps: torch.Tensor) -> bool:
+        """The device-side decisions cover the ordinary state; these corners keep the host-decision path: debug exports (point-id lists,
+        instance maps), mask sizes the 16-byte kernels cannot take, and a restored checkpoint whose `next_ins_id` restarts below the
+        existing ids (the reference's own behaviour, ovo.py:559-575: new ids then overwrite old instances)."""
+        n_all = int(binary_maps.shape[0])
+        pixels = binary_maps[0].numel() if n_all else 0
+        return (not self.debug_info and not self.config.get("host_decisions", False) and 0 < n_all <= self.MAX_RESULT_MASKS and pixels % 16 == 0 and binary_maps.is_contiguous()
+                and binary_maps.element_size() == 1 and (not self.objects or self.next_ins_id > max(self.objects)))
+
+    def track_launch(self, frame_data, map_data, c2w, seg_map: torch.Tensor, binary_maps: torch.Tensor, slam=None) -> Dict[str, Any]:
+        """Queue the tracking chain of one keyframe (MI355X extension; no host round trip).  `map_data` as in the reference; with
+        `slam` (a VanillaMapper whose `map_launch` calls may still be in flight) the map's size is read on the device and the
+        instance ids are assigned in place in the mapper's buffer.  Returns the pending record `track_finish` consumes; several
+        keyframes may be queued before the first is finished (they must be finished in order)."""
+        image, depth_in, ratio = frame_data
+        lib = L.load()
+        h, w = depth_in.shape
+        if self._track_ring is None:
+            self._track_ring = L.PinnedRing(8 + 6 * self.MAX_RESULT_MASKS, np.int32, 32)
+        a = L.TrackStep()
+        if slam is not None:
+            dev = slam._xyz.device
+            a.map = slam.map_ref()
+            a.n_upper = slam._n_upper
+            ins_view = None
+        else:
+            points_3d, points_ids, points_ins_ids = map_data
+            dev = points_3d.device
+            pts = L.dev(points_3d, torch.float32, "points_3d")
+            ins_view = L.dev(points_ins_ids.reshape(-1), torch.int32, "points_ins_ids").clone()      # the reference returns a copy (:228)
+            if self._own_state is None:
+                self._own_state = torch.zeros(4, dtype=torch.int64, device=dev)
+            n = pts.shape[0]
+            a.map = L.MapRef(pts.data_ptr(), 0, ins_view.data_ptr(), 0, n, self._own_state.data_ptr(), n, 0)
+            a.n_upper = n
+        if self._next_ins_dev is None:
+            self._next_ins_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        if len(self._track_pending) >= self._track_ring.slots - 1:
+            raise L.OvoHipError("too many keyframes queued without track_finish")
+        depth = G.to_device(depth_in, torch.float32, dev)
+        pose = self._pose_host(c2w)
+        near, far = G.depth_range(depth_in)                       # frustum uses the raw depth (:209)
+        a.cam = G.frame_camera(near, far, h, w, pose, self._K_host, self.config["match_distance_th"])
+        a.depth = depth.data_ptr()
+        if self.config.get("depth_filter", False):
+            scratch = getattr(self, "_depth_scratch", None)
+            if scratch is None or scratch.numel() < h * w or scratch.device != depth.device:
+                scratch = self._depth_scratch = torch.empty(h * w, dtype=torch.float32, device=dev)
+            a.filter_depth, a.depth_scratch = 1, scratch.data_ptr()
+        seg_map = L.dev(seg_map, torch.int32, "seg_map")
+        n_masks = int(binary_maps.shape[0])
+        a.seg_map, a.seg_h, a.seg_w = seg_map.data_ptr(), seg_map.shape[0], seg_map.shape[1]
+        a.masks, a.n_masks, a.pixels = binary_maps.data_ptr(), n_masks, binary_maps[0].numel()
+        a.ratio = L.Ratio(1, float(ratio[0]), float(ratio[1]), int(ratio[2])) if len(ratio) > 0 else L.Ratio(0, 1.0, 1.0, 0)
+        queued_masks = sum(p["n_masks"] for p in self._track_pending)
+        # votes table columns: [unassigned | instance 0 .. max id]; ids the queued keyframes may still allocate are covered
+        a.hist_cols = max(self.next_ins_id + queued_masks, max(self.objects) + 1 if self.objects else 0) + 1
+        a.track_th = int(self.config["track_th"])
+        point_seg = torch.empty(max(int(a.n_upper), 1), dtype=torch.int16, device=dev)
+        a.point_seg = point_seg.data_ptr()
+        a.ws_bytes = lib.ovo_track_workspace_bytes(n_masks, a.hist_cols)
+        ws = getattr(self, "_track_ws", None)
+        if ws is None or ws.numel() < a.ws_bytes or ws.device != point_seg.device:
+            ws = self._track_ws = torch.empty(max(int(a.ws_bytes), 1 << 20), dtype=torch.uint8, device=dev)
+        a.ws = ws.data_ptr()
+        a.next_ins, a.next_ins_host = self._next_ins_dev.data_ptr(), (self.next_ins_id if not self._track_pending else -1)
+        seq, slot = self._track_ring.next()
+        a.result_host, a.seq = slot, seq
+        L.check(lib.ovo_track_step(L.C.byref(a), L.stream()))
+        pend = {"seq": seq, "n_masks": n_masks, "point_seg": point_seg, "binary_maps": binary_maps, "ins": ins_view, "slam": slam,
+                "keep": (depth, seg_map)}
+        self._track_pending.append(pend)
+        return pend
+
+    def track_finish(self, pend: Dict[str, Any]):
+        """Wait for the keyframe's result block and do the host bookkeeping of ovo.py:255-324 on it (instances, top-k heaps, kept mask
+        rows).  Returns what `_match_and_track_instances` returns."""
+        if not self._track_pending or self._track_pending[0] is not pend:
+            raise L.OvoHipError("track_finish: keyframes must be finished in the order they were launched")
+        res = self._track_ring.wait(pend["seq"])
+        self._track_pending.popleft()
+        kf_id, n_masks = self.kf_id, pend["n_masks"]
+        n, n_matched, next_after = int(res[1]), int(res[3]), int(res[4])
+        table = res[8:8 + 6 * n_masks].reshape(n_masks, 6).tolist()
+        track_th = self.config["track_th"]
+        matched_info: Dict[int, List[Tuple[int, int]]] = {}
+        for m, (n_pts, n_assigned, mode_id, area, target, _) in enumerate(table):
+            if n_pts <= track_th:
+                continue
+            if n_assigned > track_th:
+                self.objects[mode_id].update([], kf_id, area)
+                matched_info.setdefault(mode_id, []).append((m, area))
+            elif n_pts - n_assigned > track_th:
+                new_id = self.next_ins_id
+                self.next_ins_id += 1
+                if target != new_id:
+                    raise L.OvoHipError(f"instance ids diverged between host and device ({target} vs {new_id})")
+                self.objects[new_id] = Instance3D(new_id, kf_id=kf_id, points_ids=[], mask_area=area, bank=self.bank)
+                matched_info[new_id] = [(m, area)]
+        if next_after != self.next_ins_id:
+            raise L.OvoHipError(f"next instance id diverged between host and device ({next_after} vs {self.next_ins_id})")
+        binary_maps = pend["binary_maps"]                       # fused in place by the chain (ovo.py:303)
+        matched_ins_ids, keep_rows = [], []
+        mask_rows = [-1] * n_masks
+        for ins_id, hits in matched_info.items():
+            first = hits[0][0]
+            if len(hits) > 1 and self.n_top_views > 0:           # fused areas feed the top-k view heap (:305-309)
+                self.objects[ins_id].add_top_kf(kf_id, int(table[first][5]))
+            if self.n_top_views <= 0 or self.objects[ins_id].is_top_kf(kf_id):
+                for m, _ in hits:
+                    mask_rows[m] = len(matched_ins_ids)
+                matched_ins_ids.append(ins_id)
+                keep_rows.append(first)
+        kept = L.gather_rows(binary_maps, keep_rows)
+        slam = pend["slam"]
+        updated = pend["ins"] if slam is None else slam._ins[:n]
+        self.last_point_seg, self.last_mask_rows = pend["point_seg"][:n], mask_rows
+        return matched_ins_ids, kept, n_matched, updated
+
+    def _match_and_track_instances_host(self, frame_data, map_data, c2w, seg_map: torch.Tensor, binary_maps: torch.Tensor):
+        """The same stage with the decisions of ovo.py:255-280 taken on the host from the vote statistics (one D2H of 16 B per mask):
+        debug exports, odd mask sizes, restored checkpoints (`_native_ok`)."""
         kf_id = self.kf_id
         image, depth_in, ratio = frame_data
         points_3d, points_ids, points_ins_ids = map_data

@@ -42,7 +42,7 @@ from .encoders.vit import SPECS as VIT_SPECS, HipViT
 from .entities.clip_generator import CLIPGenerator
 from .entities.ovo import OVO
 from .slam.vanilla_mapper import VanillaMapper
-from .utils import clip_utils
+from .utils import clip_utils, geometry_utils as G
 from .utils.streams import side_stream
 
 
@@ -273,19 +273,37 @@ class FramePipeline:
         hit = self._sam_by_frame.pop(mine.index, None)
         if hit is not None:
             self.sam_frame = tuple(t[hit[1]:hit[1] + 1] for t in hit[0])
-        # ---- the order-dependent passes, for every keyframe of the round, on every rank (replicated map and tracker)
+        # ---- the order-dependent passes, for every keyframe of the round, on every rank (replicated map and tracker).  The whole
+        # round is QUEUED first -- map update and tracking chain of every keyframe, sizes and instance ids device-resident
+        # (`ovo_map_step` / `ovo_track_step`) -- then finished in order: the host bookkeeping of keyframe k runs while the device
+        # works on k + 1 ..., and nothing on the device ever waits for the host.
         plans, segs = [], []
-        for f in group:
-            fd = [f.index, f.rgb_lr, f.depth, f.c2w]
-            self.slam.track_camera(fd)
-            c2w = self.slam._c2w_host[f.index]                     # host copy: no D2H for the frustum set-up
-            self.slam.map(fd, c2w)
-            ratio = (1.0, 1.0, self.crop_edge) if self.crop_edge else ()
-            updated = self.ovo.detect_and_track_objects([f.index, f.rgb, f.depth, ratio], self.slam.get_map(), c2w)
-            if updated is not None:
-                self.slam.update_pcd_obj_ids(updated)
-            plans.append(self.ovo._plan_semantic_info() if len(self.ovo.keyframes_queue) > 0 else None)
-            segs.append((self.ovo.last_point_seg, self.ovo.last_mask_rows))
+        ratio = (1.0, 1.0, self.crop_edge) if self.crop_edge else ()
+        native = not self.ovo.config.get("log", False) and all(self.ovo._native_ok(f.masks) for f in group)
+        if native:
+            G.prepare_frame_cameras([(f.depth, f.c2w) for f in group], self.slam._K_host)
+            pend = []
+            for f in group:
+                fd = [f.index, f.rgb_lr, f.depth, f.c2w]
+                self.slam.track_camera(fd)
+                c2w = self.slam._c2w_host[f.index]                 # host copy: no D2H for the frustum set-up
+                self.slam.map_launch(fd, c2w)
+                pend.append(self.ovo.detect_and_track_launch([f.index, f.rgb, f.depth, ratio], self.slam, c2w))
+            for p in pend:
+                self.ovo.detect_and_track_finish(p)                # (assignment happened in place in the mapper's buffer)
+                plans.append(self.ovo._plan_semantic_info() if len(self.ovo.keyframes_queue) > 0 else None)
+                segs.append((self.ovo.last_point_seg, self.ovo.last_mask_rows))
+        else:
+            for f in group:
+                fd = [f.index, f.rgb_lr, f.depth, f.c2w]
+                self.slam.track_camera(fd)
+                c2w = self.slam._c2w_host[f.index]
+                self.slam.map(fd, c2w)
+                updated = self.ovo.detect_and_track_objects([f.index, f.rgb, f.depth, ratio], self.slam.get_map(), c2w)
+                if updated is not None:
+                    self.slam.update_pcd_obj_ids(updated)
+                plans.append(self.ovo._plan_semantic_info() if len(self.ovo.keyframes_queue) > 0 else None)
+                segs.append((self.ovo.last_point_seg, self.ovo.last_mask_rows))
         n = self.slam._n
         # ---- descriptors of the keyframe this rank owns, then the round's one exchange
         plan = plans[self.rank]

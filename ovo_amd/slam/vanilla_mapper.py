@@ -3,12 +3,16 @@
 Host-side mirror of the reference's `ovo/slam/vanilla_mapper.py:VanillaMapper` (the canonical SLAM
 duck-type `OVOSemMap.run` drives: track_camera / get_c2w / map / get_map / update_pcd_obj_ids / ...).
 The map lives in capacity-doubling device buffers (the reference re-allocates the whole map with
-`torch.vstack` on every mapped frame, vanilla_mapper.py:81-85); per frame two HIP passes run:
-  1. ovo_map_explained   -- cull + project + depth-test every map point, mark explained pixels  (:56-61)
-  2. ovo_map_backproject -- erode, [::2,::2] subsample, unproject, c2w, ordered append           (:62-85)
+`torch.vstack` on every mapped frame, vanilla_mapper.py:81-85); per frame ONE C call (`ovo_map_step`) queues
+  1. the explained-pixel pass -- cull + project + depth-test every map point, mark explained pixels  (:56-61)
+  2. the back-projection      -- erode, [::2,::2] subsample, unproject, c2w, ordered append           (:62-85)
+and the map's size / next point id advance in DEVICE memory: `map_launch` returns without a host round trip, the count of
+appended points arrives in a pinned result block that `settle` (or any read of `_n` / `max_id` / `pcd`) waits for.  `map`, the
+reference's method, is launch + settle.
 """
 from __future__ import annotations
 
+from collections import deque
 from typing import Any, Dict, List, Tuple
 
 import numpy as np
@@ -28,7 +32,7 @@ class VanillaMapper:
         mapping = config.get("mapping", {})
         self.max_frame_points = mapping.get("max_frame_points", 1e5)
         self.match_distance_th = 0.03                      # vanilla_mapper.py:17
-        self.max_id = 0
+        self._max_id = 0
         self.estimated_c2ws: Dict[int, torch.Tensor] = {}
         self._c2w_host: Dict[int, torch.Tensor] = {}
         self.kfs: Dict[int, Dict[str, Any]] = {}
@@ -38,10 +42,52 @@ class VanillaMapper:
             raise NotImplementedError("k_pooling must be 1 or 3 (the reference default is 3)")
         self.downscale = int(mapping.get("downscale_res", 2))   # sic: the yaml key `downscale_ratio` is never read (:32)
         self._K_host = G._cpu32(cam_intrinsics).contiguous()
-        self._n = 0
+        self._K9 = (L.C.c_float * 9)(*self._K_host.reshape(-1).tolist())
+        self._n_known = 0                                  # exact when nothing is in flight
+        self._n_upper = 0                                  # >= the size the map has when the queued calls have run
+        self._pending: deque = deque()                     # sequence numbers of map_launch calls not read back yet
+        self._state = torch.zeros(4, dtype=torch.int64, device=self.device)       # {n, next point id, flags, ticket}
+        self._ring = L.PinnedRing(4, np.int64, 64)
+        self._explained = None
         self._cap = 0
         self._xyz = self._ids = self._ins = self._rgb = None
         self._reserve(1 << 16)
+
+    # ------------------------------------------------------------------ size of the map (device-resident, mirrored lazily)
+    def settle(self) -> None:
+        """Read back the calls in flight: afterwards `_n` / `max_id` are exact.  Waits only for what was queued."""
+        while self._pending:
+            r = self._ring.wait(self._pending.popleft())
+            self._n_known, self._max_id = int(r[2]), int(r[3])
+        self._n_upper = self._n_known
+
+    @property
+    def _n(self) -> int:
+        if self._pending:
+            self.settle()
+        return self._n_known
+
+    @_n.setter
+    def _n(self, value: int) -> None:
+        self.settle()
+        self._n_known = self._n_upper = int(value)
+
+    @property
+    def max_id(self) -> int:
+        if self._pending:
+            self.settle()
+        return self._max_id
+
+    @max_id.setter
+    def max_id(self, value: int) -> None:
+        self.settle()
+        self._max_id = int(value)
+
+    def map_ref(self, n_exact=None) -> "L.MapRef":
+        """ovo_map_ref_t of the live buffers: the host's exact size when nothing is in flight, else "read the device state"."""
+        known = not self._pending
+        return L.MapRef(self._xyz.data_ptr(), self._ids.data_ptr(), self._ins.data_ptr(), self._rgb.data_ptr(), self._cap,
+                        self._state.data_ptr(), self._n_known if known else -1, self._max_id if known else -1)
 
     # ------------------------------------------------------------------ storage
     def _reserve(self, cap: int) -> None:
@@ -59,6 +105,9 @@ class VanillaMapper:
             ins[:self._n].copy_(self._ins[:self._n])
             rgb[:self._n].copy_(self._rgb[:self._n])
         self._xyz, self._ids, self._ins, self._rgb, self._cap = xyz, ids, ins, rgb, new_cap
+
+    def reserve(self, cap: int) -> None:
+        self._reserve(cap)
 
     @property
     def pcd(self) -> torch.Tensor:
@@ -103,36 +152,45 @@ class VanillaMapper:
 
     def map(self, frame_data: List[Any], c2w: torch.Tensor) -> None:
         """Reference: vanilla_mapper.py:46-85."""
+        self.map_launch(frame_data, c2w)
+        self.settle()
+
+    def map_launch(self, frame_data: List[Any], c2w: torch.Tensor) -> None:
+        """`map` without the host round trip (MI355X extension): queues the frame's passes; the map's size advances on the device."""
         frame_id, image, depth_in = frame_data[0], frame_data[1], frame_data[2]
         h, w = depth_in.shape
+        near, far = G.depth_range(depth_in)
+        if not far > 0:                                    # no valid depth: :60 returns early on a non-empty map, and an empty
+            return                                         # map would receive no point either
         lib = L.load()
         dev = self.device
         depth = G.to_device(depth_in, torch.float32, dev)
         rgb = G.to_device(image, torch.uint8, dev)
         pose = self._host_pose(frame_id, c2w).float().contiguous()
-        explained = None
-        if self.max_id > 0:
-            near, far = G.depth_range(depth_in)
-            if not far > 0:
-                return
-            cam = G.frame_camera(near, far, h, w, pose, self._K_host, self.match_distance_th)
-            explained = torch.empty((h, w), dtype=torch.uint8, device=dev)
-            L.check(lib.ovo_map_explained(L.ptr(self._xyz), self._n, cam, L.ptr(depth), L.ptr(explained), L.stream()))
         ds = self.downscale
         n_sub = ((h + ds - 1) // ds) * ((w + ds - 1) // ds)
-        self._reserve(self._n + n_sub)
-        nb = lib.ovo_compact_workspace_bytes(n_sub)
+        if self._n_upper + n_sub > self._cap:              # growing copies `_n` rows: needs the exact size
+            self.settle()
+            self._reserve(self._n_known + n_sub)
+        if len(self._pending) >= self._ring.slots - 1:
+            self.settle()
+        nb = lib.ovo_compact_workspace_bytes(n_sub) + 8
         ws = L.workspace(nb, depth.device)
-        cnt = torch.empty(1, dtype=torch.int64, device=dev)
-        K9 = (L.C.c_float * 9)(*self._K_host.reshape(-1).tolist())
-        T16 = (L.C.c_float * 16)(*pose.reshape(-1).tolist())
-        erode = int(self.max_id > 0 and self.k_pooling > 1)
-        L.check(lib.ovo_map_backproject(L.ptr(depth), L.ptr(rgb), L.ptr(explained), h, w, erode, ds, K9, T16, self._n,
-                                        self.max_id, L.ptr(self._xyz), L.ptr(self._ids), L.ptr(self._ins),
-                                        L.ptr(self._rgb), L.ptr(cnt), L.ptr(ws), nb, L.stream()))
-        m = int(cnt.item())
-        self._n += m
-        self.max_id += m
+        if self._explained is None or self._explained.numel() < h * w:
+            self._explained = torch.empty(h * w, dtype=torch.uint8, device=dev)
+        seq, slot = self._ring.next()
+        a = L.MapStep()
+        a.map = self.map_ref()
+        a.depth, a.rgb, a.h, a.w = depth.data_ptr(), rgb.data_ptr(), h, w
+        a.cam = G.frame_camera(near, far, h, w, pose, self._K_host, self.match_distance_th)
+        a.K = self._K9
+        a.c2w[:] = pose.reshape(-1).tolist()
+        a.ds, a.erode, a.n_upper = ds, int(self.k_pooling > 1), self._n_upper
+        a.explained, a.ws, a.ws_bytes = self._explained.data_ptr(), ws.data_ptr(), nb
+        a.result_host, a.seq = slot, seq
+        L.check(lib.ovo_map_step(L.C.byref(a), L.stream()))
+        self._pending.append(seq)
+        self._n_upper += n_sub
 
     # ------------------------------------------------------------------ map access
     def get_map(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:

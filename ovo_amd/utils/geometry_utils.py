@@ -126,20 +126,86 @@ def make_camera(frustum_corners, w2c, intrinsics, th: float, h: int, w: int) -> 
     return cam
 
 
-_frame_cam_key, _frame_cam = None, None
+_frame_cams: "dict" = {}          # (near, far, h, w, pose bytes, K bytes) -> 232-byte ovo_camera_t image with th = 0
+_FRAME_CAMS_MAX = 256
+
+
+def _cam_key(near: float, far: float, h: int, w: int, p: torch.Tensor, K: torch.Tensor):
+    return (float(near), float(far), int(h), int(w), p.numpy().tobytes(), K.numpy().tobytes())
+
+
+def _build_cameras(entries, intrinsics: torch.Tensor):
+    """ovo_camera_t images (th = 0) of SEVERAL frames in one batch of torch-CPU ops: frustum corners (geometry_utils.py:99-129), their
+    AABB (:205-215), the six planes (:163-202) and the inverse pose.  Element for element the arithmetic of the one-frame functions
+    above -- every op is elementwise over the batch, `torch.linalg.inv` factorises matrix by matrix -- so the bytes equal theirs
+    (tests/test_host_camera.py); what changes is the host time: ~40 small ops per BATCH instead of per frame (0.15 ms each)."""
+    K = _cpu32(intrinsics)
+    B = len(entries)
+    T = torch.stack([e[4] for e in entries])                       # [B, 4, 4]
+    h, w = entries[0][2], entries[0][3]
+    pxy = _corner_px.get((h, w))
+    if pxy is None:
+        pxy = _corner_px[(h, w)] = (torch.tensor(_CORNER_X * 2, dtype=torch.float32) * float(w), torch.tensor(_CORNER_Y * 2, dtype=torch.float32) * float(h))
+    z = torch.tensor([[e[0]] * 4 + [e[1]] * 4 for e in entries], dtype=torch.float32)         # [B, 8]
+    x, y = (pxy[0] - K[0, 2]) * z / K[0, 0], (pxy[1] - K[1, 2]) * z / K[1, 1]
+    Tt = T[:, :3].transpose(1, 2)                                   # [B, 4, 3]: row j = column j of the pose
+    c = (((x[..., None] * Tt[:, 0:1] + y[..., None] * Tt[:, 1:2]) + z[..., None] * Tt[:, 2:3]) + Tt[:, 3:4]).contiguous()   # [B, 8, 3]
+    a, b, e, f = _PLANE_IDX
+    n = torch.linalg.cross(c[:, a] - c[:, b], c[:, e] - c[:, f])    # [B, 6, 3]
+    p = n * c[:, :6]
+    d = -((p[..., 0] + p[..., 1]) + p[..., 2])
+    out = np.zeros((B, 58), np.float32)
+    out[:, 0:3] = c.min(dim=1).values.numpy()
+    out[:, 3:6] = c.max(dim=1).values.numpy()
+    out[:, 6:30] = torch.cat([n, d[..., None]], dim=2).reshape(B, 24).numpy()
+    out[:, 30:46] = torch.linalg.inv(T).reshape(B, 16).numpy()
+    out[:, 46:55] = K.reshape(-1).numpy()
+    hw = out.view(np.int32)
+    hw[:, 56], hw[:, 57] = h, w
+    return [out[i].tobytes() for i in range(B)]
+
+
+def prepare_frame_cameras(frames, intrinsics) -> None:
+    """Compute (and remember) the cameras of several upcoming frames in ONE batch: `frames` = [(depth, pose), ...] with depth maps whose
+    range is known without a device sync (numpy, or tagged by `tag_depth_range`).  `frame_camera` then only copies the struct."""
+    K = _cpu32(intrinsics)
+    todo, seen = [], set()
+    for depth, pose in frames:
+        if not isinstance(depth, np.ndarray) and getattr(depth, "_ovo_range", None) is None:
+            continue
+        near, far = depth_range(depth)
+        if not far > 0:
+            continue
+        h, w = depth.shape
+        p = _cpu32(pose).contiguous()
+        key = _cam_key(near, far, h, w, p, K)
+        if key not in _frame_cams and key not in seen:
+            seen.add(key)
+            todo.append((near, far, int(h), int(w), p, key))
+    for hw in {(e[2], e[3]) for e in todo}:
+        group = [e for e in todo if (e[2], e[3]) == hw]
+        for e, image in zip(group, _build_cameras(group, K)):
+            _remember_camera(e[5], image)
+
+
+def _remember_camera(key, image: bytes) -> None:
+    if len(_frame_cams) >= _FRAME_CAMS_MAX:
+        for k in list(_frame_cams)[:_FRAME_CAMS_MAX // 2]:
+            del _frame_cams[k]
+    _frame_cams[key] = image
 
 
 def frame_camera(near: float, far: float, h: int, w: int, pose: torch.Tensor, intrinsics: torch.Tensor, th: float) -> L.Camera:
-    """`make_camera` of a frame's frustum (corners from its depth range).  The frustum, its planes and the inverse pose are remembered for
-    the last frame -- the mapper and the tracker ask for the same camera within a keyframe (with their own match thresholds), and the
-    ~40 small torch-CPU ops behind it are 0.15 ms of host time per call; a caller gets its own copy of the struct with its `th`."""
-    global _frame_cam_key, _frame_cam
-    p = _cpu32(pose)
-    key = (float(near), float(far), int(h), int(w), p.numpy().tobytes(), _cpu32(intrinsics).numpy().tobytes())
-    if key != _frame_cam_key:
-        corners = frustum_corners_from_range(near, far, h, w, p, intrinsics)
-        _frame_cam, _frame_cam_key = make_camera(corners, torch.linalg.inv(p), intrinsics, 0.0, h, w), key
-    cam = L.Camera.from_buffer_copy(_frame_cam)
+    """`make_camera` of a frame's frustum (corners from its depth range).  Cameras are remembered per (range, size, pose, intrinsics):
+    the mapper and the tracker ask for the same camera within a keyframe (with their own match thresholds), and a round of keyframes
+    is prepared in one batch (`prepare_frame_cameras`); a caller gets its own copy of the struct with its `th`."""
+    p, K = _cpu32(pose).contiguous(), _cpu32(intrinsics)
+    key = _cam_key(near, far, h, w, p, K)
+    image = _frame_cams.get(key)
+    if image is None:
+        image = _build_cameras([(float(near), float(far), int(h), int(w), p, key)], K)[0]
+        _remember_camera(key, image)
+    cam = L.Camera.from_buffer_copy(image)
     cam.th = float(th)
     return cam
 

@@ -106,6 +106,102 @@ def test_tracking_golden(tag, filt):
         assert np.asarray(o.points_ids).reshape(-1).tolist() == d[f"obj{j}_points"].reshape(-1).tolist()
 
 
+@pytest.mark.parametrize("tag,filt", [("nofilter", False), ("filter", True), ("ratio", True)])
+def test_tracking_golden_device_decisions(tag, filt):
+    """The same reference goldens through the chain that takes the decisions of ovo.py:255-324 on the device (`ovo_track_step`:
+    no debug exports, so the per-instance point-id lists are not produced)."""
+    from ovo_amd.entities.ovo import OVO
+    from ovo_amd.slam.vanilla_mapper import VanillaMapper
+    d = golden(f"tracking_{tag}")
+    w = int(d["mask_w"])
+    ratio = tuple(d["ratio"].tolist())
+    ratio = (ratio[0], ratio[1], int(ratio[2])) if ratio else ()
+    K = torch.from_numpy(d["K"]).to(DEV)
+    cfg = {"match_distance_th": 0.05, "track_th": int(d["track_th"]), "depth_filter": filt, "log": False,
+           "debug_info": False, "clip": {"k_top_views": int(d["n_top_views"]), "fusion": "avg_pooling"}, "sam": {}}
+    mg = _FixedMasks()
+    ovo = OVO(cfg, None, None, K, device=DEV, clip_generator=_NoClip(), mask_generator=mg)
+    vm = VanillaMapper({"device": DEV, "mapping": {}}, K)
+    for i in range(4):
+        fd = [i, d[f"rgb{i}"], d[f"depth{i}"], d[f"c2w{i}"]]
+        vm.track_camera(fd)
+        vm.map(fd, vm.get_c2w(i))
+        assert vm.pcd.shape[0] == int(d[f"pcd_n{i}"])
+        masks = unpack(d[f"masks{i}"], w)
+        mg.next = (d[f"seg{i}"], masks)
+        updated = ovo.detect_and_track_objects([i, d[f"rgb{i}"], d[f"depth{i}"], ratio], vm.get_map(), vm.get_c2w(i))
+        assert updated.dtype == torch.int32 and np.array_equal(updated.cpu().numpy(), d[f"updated{i}"])
+        vm.update_pcd_obj_ids(updated)
+        matched, fused, _, kf = ovo.keyframes_queue[-1]
+        assert kf == i and matched == d[f"matched_ins_ids{i}"].tolist()
+        assert np.array_equal(fused.cpu().numpy(), unpack(d[f"bmaps{i}"], w))
+        assert ovo.next_ins_id == int(d[f"next_ins_id{i}"])
+    assert ovo._track_ring is not None and ovo._track_ring.seq == 4      # the device-decision chain really ran
+    assert sorted(ovo.objects) == d["obj_ids"].tolist()
+    for j, o in ovo.objects.items():
+        assert o.kfs_ids == d[f"obj{j}_kfs"].tolist()
+        assert sorted(o.top_kf) == [tuple(r) for r in d[f"obj{j}_topkf"].tolist()]
+
+
+def _run_keyframes(queued: bool, n_frames=6, top_k=2):
+    """n keyframes of the synthetic stream through mapper + tracker; `queued`: all map / tracking chains are launched back to back
+    (sizes and instance ids device-resident) and finished afterwards, else one keyframe at a time with host decisions."""
+    from ovo_amd import synthetic as syn
+    from ovo_amd.entities.ovo import OVO
+    from ovo_amd.slam.vanilla_mapper import VanillaMapper
+    scale = 0.5
+    h, w = syn.scannet_depth_hw(scale)
+    K = torch.from_numpy(syn.scannet_intrinsics(scale)).to(DEV)
+
+    class Masks:
+        def get_masks(self, image, frame_id):
+            m = syn.make_masks(h, w, grid=(3, 4), n_blobs=5, seed=frame_id)
+            return torch.from_numpy(syn.masks_to_segmap(m)).to(DEV), torch.from_numpy(m).to(DEV)
+
+    cfg = {"match_distance_th": 0.05, "track_th": 30, "depth_filter": True, "log": False, "debug_info": False, "host_decisions": not queued,
+           "clip": {"k_top_views": top_k, "fusion": "avg_pooling"}, "sam": {}}
+    ovo = OVO(cfg, None, None, K, device=DEV, clip_generator=_NoClip(), mask_generator=Masks())
+    vm = VanillaMapper({"device": DEV, "mapping": {}}, K)
+    frames = [syn.frame(t, scale=scale, seed=11) for t in range(n_frames)]
+    if queued:
+        vm.reserve(n_frames * h * w)
+        pend = []
+        for fid, rgb, depth, c2w in frames:
+            fd = [fid, rgb, depth, c2w]
+            vm.track_camera(fd)
+            vm.map_launch(fd, vm._c2w_host[fid])
+            pend.append(ovo.detect_and_track_launch([fid, rgb, depth, ()], vm, vm._c2w_host[fid]))
+        assert len(vm._pending) == n_frames and len(ovo._track_pending) == n_frames       # nothing was read back in between
+        for p in pend:
+            ovo.detect_and_track_finish(p)
+    else:
+        for fid, rgb, depth, c2w in frames:
+            fd = [fid, rgb, depth, c2w]
+            vm.track_camera(fd)
+            vm.map(fd, vm.get_c2w(fid))
+            upd = ovo.detect_and_track_objects([fid, rgb, depth, ()], vm.get_map(), vm.get_c2w(fid))
+            vm.update_pcd_obj_ids(upd)
+        assert ovo._track_ring is None                              # host decisions
+    return {"pcd": vm.pcd.cpu(), "ids": vm.pcd_ids.cpu(), "ins": vm.pcd_obj_ids.cpu(), "rgb": vm.pcd_colors.cpu(), "max_id": vm.max_id,
+            "next": ovo.next_ins_id, "objects": {i: (list(o.kfs_ids), sorted(o.top_kf), o.to_update) for i, o in ovo.objects.items()},
+            "queue": [(m, b.cpu(), kf) for m, b, _, kf in ovo.keyframes_queue]}
+
+
+def test_queued_keyframe_chains_equal_one_by_one_host_decisions():
+    """Six keyframes queued back to back on the device (map size, point ids, instance ids resident; one result block each) give the
+    map, the instance list, the heaps and the fused masks of the keyframe-at-a-time run with host decisions, bit for bit."""
+    a, b = _run_keyframes(True), _run_keyframes(False)
+    assert a["max_id"] == b["max_id"] and a["next"] == b["next"] and a["next"] > 5
+    for k in ("pcd", "ids", "ins", "rgb"):
+        assert torch.equal(a[k], b[k]), k
+    assert (a["ins"] >= 0).sum() > 1000
+    assert a["objects"] == b["objects"]
+    assert any(len(top) > 0 for _, top, _ in a["objects"].values())
+    assert len(a["queue"]) == len(b["queue"]) == 6
+    for (m1, b1, k1), (m2, b2, k2) in zip(a["queue"], b["queue"]):
+        assert m1 == m2 and k1 == k2 and torch.equal(b1, b2)
+
+
 # ------------------------------------------------------------------ oracle at full size
 def _scene(n_points, scale=1.0, t=2, seed=5):
     from ovo_amd import synthetic as syn

@@ -44,3 +44,30 @@ def test_frame_camera_is_shared_across_thresholds():
     assert abs(a.th - 0.03) < 1e-7 and abs(b.th - 0.05) < 1e-7 and list(a.planes) == list(b.planes) and list(a.w2c) == list(b.w2c)
     direct = G.make_camera(G.frustum_corners_from_range(0.5, 3.0, 480, 640, P, K), torch.linalg.inv(P), K, 0.05, 480, 640)
     assert bytes(direct) == bytes(b)
+
+
+def test_batched_cameras_equal_one_by_one():
+    """`prepare_frame_cameras` (one batch of torch-CPU ops for a round of keyframes) produces the bytes the per-frame path does."""
+    from ovo_amd.utils import geometry_utils as G
+    rng = np.random.default_rng(1)
+    K = torch.tensor([[577.6, 0, 318.9], [0, 578.7, 242.7], [0, 0, 1]], dtype=torch.float32)
+    frames, singles = [], []
+    for _ in range(24):
+        R = np.linalg.qr(rng.standard_normal((3, 3)))[0].astype(np.float32)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3], T[:3, 3] = R, (rng.standard_normal(3) * 3).astype(np.float32)
+        depth = (0.3 + 4 * rng.random((456, 616))).astype(np.float32)
+        near, far = G.depth_range(depth)
+        corners = G.frustum_corners_from_range(near, far, 456, 616, torch.from_numpy(T), K)
+        singles.append(bytes(G.make_camera(corners, torch.linalg.inv(torch.from_numpy(T)), K, 0.05, 456, 616)))
+        frames.append((depth, T))
+    G._frame_cams.clear()
+    G.prepare_frame_cameras(frames, K)
+    assert len(G._frame_cams) == 24
+    for (depth, T), ref in zip(frames, singles):
+        near, far = G.depth_range(depth)
+        assert bytes(G.frame_camera(near, far, 456, 616, torch.from_numpy(T), K, 0.05)) == ref
+    G._frame_cams.clear()
+    for (depth, T), ref in zip(frames, singles):               # and the unbatched look-up
+        near, far = G.depth_range(depth)
+        assert bytes(G.frame_camera(near, far, 456, 616, torch.from_numpy(T), K, 0.05)) == ref
