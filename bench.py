@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=8)
+    ap.add_argument("--projection-world", type=int, default=8, help="N = 1 only: after the timed legs, ONE GPU emulates rank 0 of a job of this many GPUs "
+                    "(its own keyframe's encoders + every keyframe's replicated passes + 1/N of the dense rows, all-gather replaced by a local copy) "
+                    "and reports the round time under `projection` (0 = off)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="after the timed steps: keep stepping the same stream for this long (0 = off)")
     return ap.parse_args()
 
@@ -246,6 +249,37 @@ def measured_peaks(dev, lib):
             "note": "torch device copy of 1 GiB f32 (read + write bytes) and ovo_gemm 8192^3 bf16 on random operands, measured in this job"}
 
 
+def projection_leg(args, dev, frames, sam):
+    """What ONE rank of an N-GPU job does per round, measured on this GPU (FramePipeline(emulate=(0, N))): the encoders and pooling of the one
+    keyframe it owns, the replicated map / tracking chain of all N keyframes, store + re-fuse of all N keyframes' descriptors, the dense
+    scatter / query of its 1/N of the rows; the round's all-gather is a local copy.  N / (round time) is what N such ranks deliver if the
+    collective (512 KB per rank over xGMI) hides behind the next round's encoders -- a measured serial term, not a scaling result."""
+    from ovo_amd.pipeline import Frame, FramePipeline
+    N = args.projection_world
+    groups = 3
+    rounds = groups * max(args.encoder_batch, 1)                   # whole look-ahead groups of the emulated rank
+    need = (rounds + max(args.encoder_batch, 1)) * N
+    pipe = FramePipeline(dev, vit_card=args.vit, sam_card=sam, n_map=args.map_points, n_text=args.texts, dense=not args.no_dense, sam_full=args.sam_full,
+                         extra_capacity=(need + 2) * 72_000, seed=0, encoder_batch=args.encoder_batch, emulate=(0, N))
+    pool = frames * (need // len(frames) + 1)
+    stream = [Frame(100_000 + i, f.rgb[:], f.rgb_lr, f.depth, f.c2w, f.seg_map, f.masks) for i, f in enumerate(pool[:need])]
+    H, W = frames[0].rgb.shape[:2]
+    pipe.prime(H, W)
+    feed = Feed(stream, N)
+    feed.run(pipe, max(args.encoder_batch, 1))                     # warm-up: one group
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    feed.run(pipe, rounds - max(args.encoder_batch, 1))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timed = rounds - max(args.encoder_batch, 1)
+    del pipe
+    torch.cuda.empty_cache()
+    return {"world": N, "rounds": timed, "ms_per_round": round(1e3 * dt / timed, 3), "frames_per_s_if_hidden_exchange": round(N * timed / dt, 1),
+            "note": f"one GPU doing the per-round work of rank 0 of {N}: 1 owned keyframe (encoders + pooling, look-ahead {args.encoder_batch}) + {N} replicated "
+                    f"map / tracking chains + 1/{N} of the dense rows; all-gather replaced by a local copy; NOT a multi-GPU measurement"}
+
+
 class Feed:
     """Rounds of `world` frames in order.  A step also sees the frames that follow it INSIDE the same region (warm-up / timed /
     profiled / sustained), so the encoder look-ahead never does work of a timed frame outside the timed region, nor work of later
@@ -356,6 +390,10 @@ def main():
 
     peaks = measured_peaks(dev, lib) if (rank == 0 and not args.no_roofline) else None
 
+    projection = None
+    if world == 1 and args.projection_world > 1:
+        projection = projection_leg(args, dev, frames, sam)
+
     cpu, parity = None, None
     if want_cpu:
         idx = [args.warmup + i for i in range(4)]
@@ -400,7 +438,7 @@ def main():
             "per_step_ms": {"median": round(cadence[len(cadence) // 2], 3), "min": round(cadence[0], 3), "max": round(cadence[-1], 3),
                             "note": "intervals between hipEvents recorded on the main stream at the end of every timed step"},
             "sustained": sustained,
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "projection": projection,
         }
         if world > 1:
             line["exchange"] = {"collectives_per_round": 1, "bytes_per_rank": int(pipe.xchg.numel() * 4), "host_ms_per_round": round(xchg_ms, 3),

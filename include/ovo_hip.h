@@ -190,6 +190,9 @@ int ovo_row_argmax(float *S, int64_t n, int Q, int siglip, float logit_scale, fl
  * bits u64[n, words] bit-packed masks (little-endian bit order, zero padded); inter i32[n,n]. */
 int ovo_mask_intersections(const uint64_t *bits, int n, int64_t words, int32_t *inter, ovo_stream_t stream);
 int ovo_pack_masks(const uint8_t *masks, int n, int64_t pixels, uint64_t *bits, int64_t words, ovo_stream_t stream);
+/* The inverse (pixels % 16 == 0): masks u8 [n, pixels] = 0 / 1 per bit.  Multi-GPU: masks a rank's own SAM2 produced
+ * for the keyframe it owns travel to the replicas bit-packed (1.2 MB for 32 masks of 640 x 480 instead of 9.8 MB). */
+int ovo_unpack_masks(const uint64_t *bits, int n, int64_t pixels, int64_t words, uint8_t *masks, ovo_stream_t stream);
 
 /* ---- a7: _fuse_masks_with_same_ins_id (ovo.py:284-324) -------------------------------------------------
  * masks u8/bool [n, pixels] (pixels % 16 == 0): masks[dst] |= masks[src] for each (dst, src) of pairs i32[n_pairs, 2];

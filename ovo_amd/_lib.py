@@ -153,6 +153,7 @@ _SIGNATURES = {
     "ovo_row_argmax": (_I32, [_P, _I64, _I32, _I32, _F32, _F32, _F32, _P, _P, _P]),
     "ovo_mask_intersections": (_I32, [_P, _I32, _I64, _P, _P]),
     "ovo_pack_masks": (_I32, [_P, _I32, _I64, _P, _I64, _P]),
+    "ovo_unpack_masks": (_I32, [_P, _I32, _I64, _I64, _P, _P]),
     "ovo_mask_or": (_I32, [_P, _I64, _P, _I32, _P]),
     "ovo_gather_rows": (_I32, [_P, _I64, _P, _I32, _P, _P]),
     "ovo_mask_area": (_I32, [_P, _I64, _P, _I32, _P, _P]),
@@ -305,6 +306,9 @@ class PinnedRing:
         k = self.seq % self.slots
         self.view[k, 0] = 0
         return self.seq, self.base + k * self.slot_items * self.dtype.itemsize
+
+    def done(self, seq: int) -> bool:
+        return int(self.view[seq % self.slots, 0]) == seq
 
     def wait(self, seq: int, timeout_us: int = 20_000_000):
         k = seq % self.slots

@@ -757,11 +757,13 @@ __global__ void __launch_bounds__(256) k_fuse_publish(uint4 *__restrict__ masks,
             }
         }
     }
+    // two-level ticket (per mask row, then one per row): a thousand workgroups on ONE address serialise in the L2 atomic unit
     __shared__ int s_last;
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        s_last = atomicAdd(pb.ticket, 1u) == gridDim.x * gridDim.y - 1;
+        s_last = 0;
+        if (atomicAdd(pb.ticket + 1 + d, 1u) == gridDim.x - 1) s_last = atomicAdd(pb.ticket, 1u) == gridDim.y - 1;
     }
     __syncthreads();
     if (!s_last) return;
@@ -915,8 +917,8 @@ int ovo_map_backproject(const float *depth, const uint8_t *rgb, const uint8_t *e
 
 // ---- the keyframe chain without host round trips (ovo_map_step, ovo_track_step) ------------------------------------------------
 size_t ovo_track_workspace_bytes(int n_masks, int hist_cols) {
-    // hist | stats[4 n] | counters (2 x u64) | tickets (2 x u32) | dst[n] | result block [8 + 6 n]
-    return ((size_t)n_masks * hist_cols + 4 * (size_t)n_masks + 4 + 2 + n_masks + 8 + 6 * (size_t)n_masks + 4) * sizeof(int32_t);
+    // hist | stats[4 n] | counters (2 x u64) | tickets (2 + n x u32) | dst[n] | result block [8 + 6 n]
+    return ((size_t)n_masks * hist_cols + 4 * (size_t)n_masks + 4 + 2 + n_masks + n_masks + 8 + 6 * (size_t)n_masks + 4) * sizeof(int32_t);
 }
 
 int ovo_map_step(const ovo_map_step_t *a, ovo_stream_t stream) {
@@ -971,7 +973,7 @@ int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream) {
     int32_t *stats = hist + (size_t)nm * a->hist_cols;
     unsigned long long *counters = (unsigned long long *)(stats + 4 * (size_t)nm + ((((size_t)nm * a->hist_cols) & 1) ? 1 : 0));   // 8-byte aligned
     unsigned int *tickets = (unsigned int *)(counters + 2);
-    int32_t *dst = (int32_t *)(tickets + 2);
+    int32_t *dst = (int32_t *)(tickets + 2 + nm);
     int32_t *res = dst + nm;
     const size_t zero_bytes = (size_t)((char *)dst - (char *)hist);
     OVO_HIP(hipMemsetAsync(hist, 0, zero_bytes, s));

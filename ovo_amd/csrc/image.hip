@@ -43,6 +43,24 @@ __global__ void __launch_bounds__(256) k_pack_masks(const uint8_t *__restrict__ 
     }
 }
 
+// the inverse of k_pack_masks: one byte (0 / 1) per bit, 16 pixels (= 16 bits of a word) per thread
+__global__ void __launch_bounds__(256) k_unpack_masks(const unsigned long long *__restrict__ bits, int64_t words, int64_t pixels,
+                                                      uint8_t *__restrict__ masks) {
+    const int m = blockIdx.y;
+    const int64_t px16 = pixels / 16;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < px16; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned int b = (unsigned int)(bits[(int64_t)m * words + (i >> 2)] >> ((i & 3) * 16)) & 0xffffu;
+        uint4 o;
+        unsigned int *op = &o.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned int n4 = (b >> (4 * k)) & 0xfu;
+            op[k] = (n4 & 1u) | ((n4 & 2u) << 7) | ((n4 & 4u) << 14) | ((n4 & 8u) << 21);
+        }
+        ((uint4 *)(masks + (int64_t)m * pixels))[i] = o;
+    }
+}
+
 // inter[i][j] = popcount(mask_i & mask_j); block = one i and a strip of 4 j's (one wave each).
 __global__ void __launch_bounds__(256) k_mask_inter(const unsigned long long *__restrict__ bits, int n, int64_t words,
                                                     int32_t *__restrict__ inter) {
@@ -151,6 +169,16 @@ int ovo_pack_masks(const uint8_t *masks, int n, int64_t pixels, uint64_t *bits, 
     OVO_REQUIRE(masks && bits && n <= 65535, "null pointer / too many masks");
     dim3 grid(ovo_grid(words * 64, 256, 64), n);
     k_pack_masks<<<grid, 256, 0, (hipStream_t)stream>>>(masks, pixels, (unsigned long long *)bits, words);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_unpack_masks(const uint64_t *bits, int n, int64_t pixels, int64_t words, uint8_t *masks, ovo_stream_t stream) {
+    OVO_REQUIRE(n >= 0 && pixels > 0 && pixels % 16 == 0 && words * 64 >= pixels, "pixels must be a multiple of 16");
+    if (n == 0) return OVO_OK;
+    OVO_REQUIRE(bits && masks && n <= 65535 && ((uintptr_t)masks & 15) == 0, "null / misaligned pointer");
+    dim3 grid(ovo_grid(pixels / 16, 256, 64), n);
+    k_unpack_masks<<<grid, 256, 0, (hipStream_t)stream>>>((const unsigned long long *)bits, words, pixels, masks);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

@@ -8,6 +8,7 @@ An instance created without a bank (checkpoint restore, run_eval.py:19-28) holds
 """
 from __future__ import annotations
 
+import bisect
 import heapq
 from typing import Any, Dict, List, Optional, Sequence
 
@@ -26,7 +27,9 @@ class Instance3D:
         self.id = id
         self.kfs_ids: List[int] = []
         self.points_ids: List[Any] = []
-        self.top_kf: List[tuple] = []          # min-heap of (area, kf_id)
+        self._top_kf: List[tuple] = []         # min-heap of (area, kf_id)            } one set of entries in three shapes: the heap the
+        self._top_area: Dict[int, Any] = {}    # kf_id -> area of its heap entry       } reference keeps (and exports), an index for the
+        self._top_sorted: List[tuple] = []     # the entries in ascending order        } per-mask look-ups, the fusion order ready-made
         self.to_update = False
         self._bank = bank
         self._own_feature: Optional[torch.Tensor] = None
@@ -80,42 +83,65 @@ class Instance3D:
         self.points_ids.extend(points_ids)
 
     def add_keyframes(self, kf_id: int) -> None:
-        if kf_id not in self.kfs_ids:
+        if not self.kfs_ids or (self.kfs_ids[-1] != kf_id and kf_id not in self.kfs_ids):      # (usually the keyframe just added, or a new one)
             self.kfs_ids.append(kf_id)
 
+    @property
+    def top_kf(self) -> List[tuple]:
+        return self._top_kf
+
+    @top_kf.setter
+    def top_kf(self, entries) -> None:
+        self._top_kf = list(entries)
+        self._top_area = {kf: area for area, kf in self._top_kf}
+        self._top_sorted = sorted(self._top_kf)
+
     def idx_in_top_kf(self, kf_id: int) -> int:
-        for pos, entry in enumerate(self.top_kf):
+        if kf_id not in self._top_area:
+            return -1
+        for pos, entry in enumerate(self._top_kf):
             if entry[1] == kf_id:
                 return pos
         return -1
 
     def is_top_kf(self, kf_id: int) -> bool:
-        return self.idx_in_top_kf(kf_id) >= 0
+        return kf_id in self._top_area
 
     def add_top_kf(self, kf_id: int, area: int) -> None:
-        pos = self.idx_in_top_kf(kf_id)
-        if pos >= 0:
-            if area > self.top_kf[pos][0]:           # same keyframe seen with a larger (fused) mask
-                self.top_kf[pos] = (area, kf_id)
-                heapq.heapify(self.top_kf)
+        old = self._top_area.get(kf_id)
+        if old is not None:
+            if area > old:                           # same keyframe seen with a larger (fused) mask
+                self._top_kf[self._top_kf.index((old, kf_id))] = (area, kf_id)
+                heapq.heapify(self._top_kf)
+                del self._top_sorted[bisect.bisect_left(self._top_sorted, (old, kf_id))]
+                bisect.insort(self._top_sorted, (area, kf_id))
+                self._top_area[kf_id] = area
                 self.to_update = True
             return
         self._add_top_kf(kf_id, area)
 
     def _add_top_kf(self, kf_id: int, area: int) -> None:
-        if len(self.top_kf) < self.n_top_kf:
-            heapq.heappush(self.top_kf, (area, kf_id))
+        if len(self._top_kf) < self.n_top_kf:
+            heapq.heappush(self._top_kf, (area, kf_id))
+            self._top_area[kf_id] = area
+            bisect.insort(self._top_sorted, (area, kf_id))
             self.to_update = True
             return
-        evicted = heapq.heappushpop(self.top_kf, (area, kf_id))
+        evicted = heapq.heappushpop(self._top_kf, (area, kf_id))
         if self.n_top_kf <= 0 or evicted[1] != kf_id:
             self.to_update = True
+        if evicted[1] != kf_id:                      # the new entry stayed, the smallest one left
+            del self._top_area[evicted[1]]
+            del self._top_sorted[bisect.bisect_left(self._top_sorted, evicted)]
+            self._top_area[kf_id] = area
+            bisect.insort(self._top_sorted, (area, kf_id))
 
     # ------------------------------------------------------------------ fusion
     def fusion_views(self) -> List[int]:
-        """Keyframes whose descriptors are fused, in the reference's stacking order (instance3d.py:170-178)."""
+        """Keyframes whose descriptors are fused, in the reference's stacking order (instance3d.py:170-178:
+        `heapq.nlargest(n_top_kf, top_kf)` = the heap's entries in descending (area, kf) order -- it never holds more than n_top_kf)."""
         if self.n_top_kf > 0:
-            return [kf for _, kf in heapq.nlargest(self.n_top_kf, self.top_kf)]
+            return [kf for _, kf in reversed(self._top_sorted)]
         return list(self.kfs_ids)
 
     def update_clip(self, keyframes_clips: Dict[int, Any], force_update: bool = False) -> None:

@@ -140,7 +140,7 @@ class OVO:
             self._time_cache = []
         return updated
 
-    def detect_and_track_launch(self, frame_data, slam, c2w) -> Optional[Dict[str, Any]]:
+    def detect_and_track_launch(self, frame_data, slam, c2w, stream=None) -> Optional[Dict[str, Any]]:
         """`detect_and_track_objects` split in two (MI355X extension): this half gets the masks and QUEUES the tracking chain against
         `slam`'s device-resident map (whose `map_launch` calls may be in flight); `detect_and_track_finish` reads the result block.
         A round of keyframes is queued back to back and finished in order: the host never stalls the device between keyframes.
@@ -150,7 +150,7 @@ class OVO:
         if len(seg_map) == 0:
             print(f"No mask segmented in {frame_id}!")
             return None
-        pend = self.track_launch(frame_data[1:], None, c2w, seg_map, binary_maps, slam=slam)
+        pend = self.track_launch(frame_data[1:], None, c2w, seg_map, binary_maps, slam=slam, stream=stream)
         pend["frame"] = (frame_id, image)
         return pend
 
@@ -188,11 +188,13 @@ class OVO:
         return (not self.debug_info and not self.config.get("host_decisions", False) and 0 < n_all <= self.MAX_RESULT_MASKS and pixels % 16 == 0 and binary_maps.is_contiguous()
                 and binary_maps.element_size() == 1 and (not self.objects or self.next_ins_id > max(self.objects)))
 
-    def track_launch(self, frame_data, map_data, c2w, seg_map: torch.Tensor, binary_maps: torch.Tensor, slam=None) -> Dict[str, Any]:
+    def track_launch(self, frame_data, map_data, c2w, seg_map: torch.Tensor, binary_maps: torch.Tensor, slam=None, stream=None) -> Dict[str, Any]:
         """Queue the tracking chain of one keyframe (MI355X extension; no host round trip).  `map_data` as in the reference; with
         `slam` (a VanillaMapper whose `map_launch` calls may still be in flight) the map's size is read on the device and the
         instance ids are assigned in place in the mapper's buffer.  Returns the pending record `track_finish` consumes; several
-        keyframes may be queued before the first is finished (they must be finished in order)."""
+        keyframes may be queued before the first is finished (they must be finished in order).  `stream`: queue on this torch stream
+        instead of the current one (the mapper's `map_launch` calls must use the same one); the chain then starts after everything queued
+        on the CURRENT stream so far (its inputs and buffers are allocated here), and `track_finish` makes the current stream wait for it."""
         image, depth_in, ratio = frame_data
         lib = L.load()
         h, w = depth_in.shape
@@ -237,7 +239,7 @@ class OVO:
         # votes table columns: [unassigned | instance 0 .. max id]; ids the queued keyframes may still allocate are covered
         a.hist_cols = max(self.next_ins_id + queued_masks, max(self.objects) + 1 if self.objects else 0) + 1
         a.track_th = int(self.config["track_th"])
-        point_seg = torch.empty(max(int(a.n_upper), 1), dtype=torch.int16, device=dev)
+        point_seg = torch.empty((max(int(a.n_upper), 1) + 0xfffff) & ~0xfffff, dtype=torch.int16, device=dev)    # 1 Mi-point steps: the allocator re-uses blocks
         a.point_seg = point_seg.data_ptr()
         a.ws_bytes = lib.ovo_track_workspace_bytes(n_masks, a.hist_cols)
         ws = getattr(self, "_track_ws", None)
@@ -247,9 +249,18 @@ class OVO:
         a.next_ins, a.next_ins_host = self._next_ins_dev.data_ptr(), (self.next_ins_id if not self._track_pending else -1)
         seq, slot = self._track_ring.next()
         a.result_host, a.seq = slot, seq
-        L.check(lib.ovo_track_step(L.C.byref(a), L.stream()))
+        done = None
+        if stream is None:
+            L.check(lib.ovo_track_step(L.C.byref(a), L.stream()))
+        else:
+            ready = torch.cuda.Event()                            # the buffers above were allocated (and the masks produced) on the current
+            ready.record()                                        # stream: the chain must not touch them before this point of it
+            stream.wait_event(ready)
+            L.check(lib.ovo_track_step(L.C.byref(a), L.C.c_void_p(stream.cuda_stream)))
+            done = torch.cuda.Event()
+            done.record(stream)
         pend = {"seq": seq, "n_masks": n_masks, "point_seg": point_seg, "binary_maps": binary_maps, "ins": ins_view, "slam": slam,
-                "keep": (depth, seg_map)}
+                "keep": (depth, seg_map), "done": done}
         self._track_pending.append(pend)
         return pend
 
@@ -260,6 +271,8 @@ class OVO:
             raise L.OvoHipError("track_finish: keyframes must be finished in the order they were launched")
         res = self._track_ring.wait(pend["seq"])
         self._track_pending.popleft()
+        if pend["done"] is not None:                               # what follows on the current stream reads the chain's outputs
+            torch.cuda.current_stream().wait_event(pend["done"])
         kf_id, n_masks = self.kf_id, pend["n_masks"]
         n, n_matched, next_after = int(res[1]), int(res[3]), int(res[4])
         table = res[8:8 + 6 * n_masks].reshape(n_masks, 6).tolist()
@@ -295,7 +308,7 @@ class OVO:
         kept = L.gather_rows(binary_maps, keep_rows)
         slam = pend["slam"]
         updated = pend["ins"] if slam is None else slam._ins[:n]
-        self.last_point_seg, self.last_mask_rows = pend["point_seg"][:n], mask_rows
+        self.last_point_seg, self.last_mask_rows, self.last_n_points = pend["point_seg"][:n], mask_rows, n
         return matched_ins_ids, kept, n_matched, updated
 
     def _match_and_track_instances_host(self, frame_data, map_data, c2w, seg_map: torch.Tensor, binary_maps: torch.Tensor):
@@ -454,25 +467,34 @@ class OVO:
         computed by the rank that owns the frame -- later, in keyframe order, with exactly the result of the one-process order."""
         matched_ins_ids, binary_maps, image, kf_id = self.keyframes_queue.popleft()
         if len(matched_ins_ids) == 0:
+            self.discard_prefetched(image)
             return None
         if self.n_top_views > 0:
             rows = [j for j, i in enumerate(matched_ins_ids) if self.objects[i].is_top_kf(kf_id)]
             if not rows:
+                self.discard_prefetched(image)
                 return None
             if len(rows) != len(matched_ins_ids):
                 matched_ins_ids = [matched_ins_ids[j] for j in rows]
                 binary_maps = binary_maps[torch.tensor(rows, device=binary_maps.device)]
         self._planned_kfs.add(kf_id)
+        updates = self._planned_updates(matched_ins_ids)
+        return {"kf_id": kf_id, "matched_ins_ids": matched_ins_ids, "binary_maps": binary_maps, "image": image, "updates": updates}
+
+    def _planned_updates(self, matched_ins_ids) -> List[Tuple[int, List[int]]]:
+        """(instance, keyframes to fuse from, in the reference's stacking order) for every matched instance that is due (instance3d.py:157-178);
+        only keyframes whose descriptors exist or are planned count."""
+        known = self._planned_kfs.union(self.keyframes["ins_descriptors"])
         updates = []
         for ins_id in matched_ins_ids:
             obj = self.objects[ins_id]
             if not obj.to_update:
                 continue
-            views = [kf for kf in obj.fusion_views() if kf in self._planned_kfs or kf in self.keyframes["ins_descriptors"]]
+            views = [kf for kf in obj.fusion_views() if kf in known]
             if views:
                 updates.append((ins_id, views))
                 obj.to_update = False
-        return {"kf_id": kf_id, "matched_ins_ids": matched_ins_ids, "binary_maps": binary_maps, "image": image, "updates": updates}
+        return updates
 
     def _apply_semantic_plan(self, plan: Dict[str, Any], clip_embeds: torch.Tensor) -> None:
         """The device half: store the keyframe's descriptors, then re-fuse the planned instances in ONE launch (ovo.py:440-461)."""
@@ -553,6 +575,18 @@ class OVO:
             self._prefetched_batch[id(image)] = (image, slot["tokens"][k * nc:(k + 1) * nc], done, slot)
         return True
 
+    def discard_prefetched(self, image) -> None:
+        """A keyframe that gets no descriptor (no mask tracked, or every instance dropped by the top-k view filter) never reaches
+        `_extract_clip`: release its share of the look-ahead batch's token slot here, or the slot would stay "in use" and the forward two
+        groups later would refuse to overwrite it."""
+        hit = self._prefetched_batch.pop(id(image), None)
+        if hit is None or hit[0] is not image:
+            return
+        _, _, done, slot = hit
+        slot["left"] -= 1
+        if slot["left"] == 0:                                    # nobody read the tokens after `done`: the slot is free once they exist
+            slot["free"] = done
+
     @_timed("t_clip")
     def _extract_clip(self, image: np.ndarray, binary_maps: torch.Tensor) -> torch.Tensor:
         """Reference: ovo.py:427-437 -- but the descriptors stay on the GPU."""
@@ -597,22 +631,13 @@ class OVO:
         self.keyframes["ins_descriptors"][kf_id] = KeyframeView(
             self.bank, {i: rows[j] for j, i in enumerate(matched_ins_ids) if i != -1})
         self._planned_kfs.discard(kf_id)
-        self.bank.fuse([(ins_id, [self.keyframes["ins_descriptors"][kf].row(ins_id) for kf in views]) for ins_id, views in updates],
-                       Instance3D.mv_fusion)
+        desc = self.keyframes["ins_descriptors"]
+        self.bank.fuse([(ins_id, [desc[kf]._rows[ins_id] for kf in views]) for ins_id, views in updates], Instance3D.mv_fusion)
 
     def _update_matched_objects_clip(self, clip_embeds: torch.Tensor, matched_ins_ids: List[int], kf_id: int) -> None:
         """Reference: ovo.py:440-461; all touched instances are fused in one launch."""
         self._planned_kfs.add(kf_id)
-        updates = []
-        for ins_id in matched_ins_ids:
-            obj = self.objects[ins_id]
-            if not obj.to_update:
-                continue
-            views = [kf for kf in obj.fusion_views() if kf in self._planned_kfs or kf in self.keyframes["ins_descriptors"]]
-            if views:
-                updates.append((ins_id, views))
-                obj.to_update = False
-        self._store_and_fuse(clip_embeds, matched_ins_ids, kf_id, updates)
+        self._store_and_fuse(clip_embeds, matched_ins_ids, kf_id, self._planned_updates(matched_ins_ids))
 
     def update_objects_clip(self, force_update: bool = False) -> None:
         for obj in self.objects.values():

@@ -18,6 +18,7 @@ from typing import Optional, Sequence
 import torch
 import torch.distributed as dist
 
+FORCE_COLLECTIVES = False          # tests: issue the collective even in a one-rank group (a world-1 RCCL group runs the nccl branch on one GPU)
 DENSE_BUCKET_BYTES = 256 << 20     # per all_reduce call for the dense merge (large buckets: 288 GB HBM, per-link bound)
 
 
@@ -92,7 +93,7 @@ def allgather(t: torch.Tensor) -> torch.Tensor:
     tests, two ranks on one GPU): the sum-reduce of a zero buffer in which each rank fills its slice -- the bytes are exact either way
     (x + 0 = x; the sign of a zero is not preserved, NaN stays NaN)."""
     w = world_size()
-    if w == 1:
+    if w == 1 and not (dist.is_initialized() and FORCE_COLLECTIVES):
         return t[None]
     out = torch.zeros((w,) + tuple(t.shape), dtype=t.dtype, device=t.device)
     if dist.get_backend() == "nccl":
@@ -100,6 +101,37 @@ def allgather(t: torch.Tensor) -> torch.Tensor:
         return out
     out[dist.get_rank()].copy_(t)
     dist.all_reduce(out, op=dist.ReduceOp.SUM)
+    return out
+
+
+def share_masks(masks: Optional[torch.Tensor], pixels: int, device, gather=None) -> list:
+    """The owner -> replica mask exchange of a round: every rank contributes the masks ITS mask generator produced for
+    the keyframe it owns (bool / u8 [n, H, W] on the GPU, n may be 0, `None` = none) and receives every rank's, rank-major = keyframe
+    order, as u8 [n_k, pixels] tensors.  Masks travel bit-packed (`ovo_pack_masks` / `ovo_unpack_masks`: 1.2 MB for 32 masks of 640 x 480
+    instead of 9.8 MB); two collectives: the counts, then max-count rows of packed words.  Bits are copied, never reduced: what arrives is
+    what was sent.  (The seg map is not sent: it is `mask2segmap`'s painting of these same masks, segment_utils.py:12-27.)"""
+    from . import _lib as L
+    gather = gather or allgather
+    lib = L.load()
+    if pixels % 16:
+        raise L.OvoHipError("share_masks: H * W must be a multiple of 16")
+    n = 0 if masks is None else int(masks.shape[0])
+    counts = gather(torch.tensor([n], dtype=torch.int32).to(device)).reshape(-1).tolist()
+    n_max, words = max(counts), (pixels + 63) // 64
+    if n_max == 0:
+        return [torch.empty((0, pixels), dtype=torch.uint8, device=device) for _ in counts]
+    bits = torch.zeros((n_max, words), dtype=torch.int64, device=device)
+    if n:
+        m = masks.reshape(n, -1)
+        m = L.dev((m.view(torch.uint8) if m.dtype == torch.bool else m).contiguous(), torch.uint8, "masks")
+        L.check(lib.ovo_pack_masks(L.ptr(m), n, pixels, L.ptr(bits), words, L.stream()))
+    everyone = gather(bits)                                        # [world, n_max, words]
+    out = []
+    for k, c in enumerate(counts):
+        u = torch.empty((c, pixels), dtype=torch.uint8, device=device)
+        if c:
+            L.check(lib.ovo_unpack_masks(everyone[k].data_ptr(), c, pixels, words, L.ptr(u), L.stream()))
+        out.append(u)
     return out
 
 

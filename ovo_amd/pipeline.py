@@ -101,11 +101,19 @@ class FramePipeline:
     def __init__(self, device="cuda", vit_card: str = "PE-Core-L14-336", sam_card: Optional[str] = "hiera_b+",
                  n_map: int = 1_000_000, n_text: int = 10, dense: bool = True, scale: float = 1.0, extra_capacity: int = 4_000_000,
                  seed: int = 0, depth_filter: bool = True, track_th: int = 100, sam_full: bool = False, points_per_side: int = 16,
-                 encoder_batch: int = 1, k_top_views: int = 10000):
+                 encoder_batch: int = 1, k_top_views: int = 10000, emulate: Optional[tuple] = None):
+        """`emulate = (rank, world)`: ONE process does exactly what rank `rank` of a `world`-GPU job does per round -- its own keyframe's
+        encoders and pooling, every keyframe's replicated passes, 1 / world of the dense rows -- with the round's all-gather replaced by a
+        local stand-in (the other owners' descriptors are copies of its own rows).  A timing tool (bench.py `projection`): it measures a
+        rank's round time on one GPU; its outputs are not results."""
         self.device = torch.device(device)
         self.scale = scale
-        self.rank = torch.distributed.get_rank() if parallel.world_size() > 1 else 0
-        self.world = parallel.world_size()
+        self.emulate = emulate is not None
+        if self.emulate:
+            self.rank, self.world = int(emulate[0]), int(emulate[1])
+        else:
+            self.rank = torch.distributed.get_rank() if parallel.world_size() > 1 else 0
+            self.world = parallel.world_size()
         self.crop_edge = int(round(syn.SCANNET["crop_edge"] * scale))
         K = torch.from_numpy(syn.scannet_intrinsics(scale)).to(self.device)
         self.slam = VanillaMapper({"device": str(self.device), "mapping": {"k_pooling": 3}}, K)
@@ -163,10 +171,27 @@ class FramePipeline:
                 self.n_touched = torch.zeros(2, dtype=torch.int32, device=self.device)     # two counters, used alternately
                 self._touch_parity = 0
         self.last: Dict[str, object] = {}
+        # Masks from this rank's OWN generator (SAM2 end to end, or an injected `mask_source(frame) -> (seg_map, masks)`): the owner of a
+        # keyframe produces them, `parallel.share_masks` carries them bit-packed to the replicas, which track with exactly those bits.
+        self.mask_source = None
+        self.mask_exchanges = 0
+        self._chains: Dict[int, list] = {}                         # first frame index of a round -> its queued chains (software pipelining)
+        self.pipeline_rounds = not os.environ.get("OVO_NO_ROUND_PIPELINE")
+        # The chains of consecutive keyframes depend on each other (device-resident map size / instance ids) and so do the keyframes' tails
+        # (descriptor store, fusion, dense scatter + query); a chain and a tail of DIFFERENT keyframes do not.  On one stream they queue
+        # behind each other -- ~25 small dependent launches per keyframe, each waiting for a free CU among the encoders' workgroups -- so
+        # the chains get a stream of their own and overlap the tails (events: chain k -> tail k; the tail's stream -> the chain's inputs).
+        self.chain_stream = None if os.environ.get("OVO_NO_CHAIN_STREAM") else torch.cuda.Stream(device=self.device, priority=int(os.environ.get("OVO_CHAIN_PRIORITY", "0")))
         if self.world > 1:
             self.xchg = torch.zeros((self.MAX_DESC, self.D), dtype=torch.float32, device=self.device)
-            parallel.allgather(self.xchg)                          # first use of the collective (and of its kernels) outside any timed step
+            # (rows beyond a keyframe's descriptors keep stale values: every rank knows the counts from the replicated plans and never reads them)
+            self._gather(self.xchg)                                # first use of the collective (and of its kernels) outside any timed step
             torch.cuda.synchronize()
+
+    def _gather(self, t: torch.Tensor) -> torch.Tensor:
+        if self.emulate:                                           # stand-in with the collective's output shape and one device copy
+            return t[None].expand(self.world, *t.shape).contiguous()
+        return parallel.allgather(t)
 
     # ------------------------------------------------------------------ encoders
     def prime(self, H: int, W: int) -> None:
@@ -273,26 +298,31 @@ class FramePipeline:
         hit = self._sam_by_frame.pop(mine.index, None)
         if hit is not None:
             self.sam_frame = tuple(t[hit[1]:hit[1] + 1] for t in hit[0])
+        if self.mask_source is not None or (self.amg is not None and self.world > 1):
+            self._exchange_masks(group, amg_pending)
+            amg_pending = None
         # ---- the order-dependent passes, for every keyframe of the round, on every rank (replicated map and tracker).  The whole
         # round is QUEUED first -- map update and tracking chain of every keyframe, sizes and instance ids device-resident
         # (`ovo_map_step` / `ovo_track_step`) -- then finished in order: the host bookkeeping of keyframe k runs while the device
         # works on k + 1 ..., and nothing on the device ever waits for the host.
         plans, segs = [], []
         ratio = (1.0, 1.0, self.crop_edge) if self.crop_edge else ()
-        native = not self.ovo.config.get("log", False) and all(self.ovo._native_ok(f.masks) for f in group)
+        native = not self.ovo.config.get("log", False) and all(self.ovo._native_ok(self.masks.frames[f.index].masks) for f in group)
         if native:
-            G.prepare_frame_cameras([(f.depth, f.c2w) for f in group], self.slam._K_host)
-            pend = []
-            for f in group:
-                fd = [f.index, f.rgb_lr, f.depth, f.c2w]
-                self.slam.track_camera(fd)
-                c2w = self.slam._c2w_host[f.index]                 # host copy: no D2H for the frustum set-up
-                self.slam.map_launch(fd, c2w)
-                pend.append(self.ovo.detect_and_track_launch([f.index, f.rgb, f.depth, ratio], self.slam, c2w))
+            pend = self._chains.pop(group[0].index, None) or self._launch_chains(group, ratio)
+            # software pipelining of rounds: the NEXT round's chains are queued now, before this round's results are read -- while the
+            # host does this round's bookkeeping, pooling, exchange and fusion the device already works on the next round's tracking,
+            # and vice versa (queue -> wait -> bookkeeping in one round leaves host and device waiting for each other in turn)
+            nxt = upcoming[:self.world]
+            if self.pipeline_rounds and len(nxt) == self.world and self.mask_source is None and self.amg is None \
+                    and all(self.ovo._native_ok(f.masks) for f in nxt):
+                self.masks.frames.update({f.index: f for f in nxt})
+                self._chains[nxt[0].index] = self._launch_chains(nxt, ratio)
             for p in pend:
                 self.ovo.detect_and_track_finish(p)                # (assignment happened in place in the mapper's buffer)
                 plans.append(self.ovo._plan_semantic_info() if len(self.ovo.keyframes_queue) > 0 else None)
                 segs.append((self.ovo.last_point_seg, self.ovo.last_mask_rows))
+            n = self.ovo.last_n_points
         else:
             for f in group:
                 fd = [f.index, f.rgb_lr, f.depth, f.c2w]
@@ -304,18 +334,18 @@ class FramePipeline:
                     self.slam.update_pcd_obj_ids(updated)
                 plans.append(self.ovo._plan_semantic_info() if len(self.ovo.keyframes_queue) > 0 else None)
                 segs.append((self.ovo.last_point_seg, self.ovo.last_mask_rows))
-        n = self.slam._n
+            n = self.slam._n
         # ---- descriptors of the keyframe this rank owns, then the round's one exchange
         plan = plans[self.rank]
         desc_mine = self.ovo._extract_clip(plan["image"], plan["binary_maps"]) if plan is not None else None
         if self.world > 1:
+            for p in plans:                                        # the plans are replicated: every rank sees an overflow, none is left in the collective
+                if p is not None and len(p["matched_ins_ids"]) > self.MAX_DESC:
+                    raise L.OvoHipError(f"{len(p['matched_ins_ids'])} descriptors in one keyframe: raise FramePipeline.MAX_DESC")
             t0 = time.perf_counter()
-            self.xchg.zero_()
             if desc_mine is not None:
-                if desc_mine.shape[0] > self.MAX_DESC:
-                    raise L.OvoHipError(f"{desc_mine.shape[0]} descriptors in one keyframe: raise FramePipeline.MAX_DESC")
                 self.xchg[:desc_mine.shape[0]].copy_(desc_mine)
-            gathered = parallel.allgather(self.xchg)               # [world, MAX_DESC, D]: every owner's descriptors, rank-major = keyframe order
+            gathered = self._gather(self.xchg)                     # [world, MAX_DESC, D]: every owner's descriptors, rank-major = keyframe order
             descs = [gathered[k, :len(p["matched_ins_ids"])] if p is not None else None for k, p in enumerate(plans)]
             self.exchange_ms += 1e3 * (time.perf_counter() - t0)
             self.exchanges += 1
@@ -358,6 +388,56 @@ class FramePipeline:
         self.last = out
         return out
 
+    # ------------------------------------------------------------------ owner -> replica masks
+    def _launch_chains(self, group: List[Frame], ratio) -> list:
+        """Queue map update + tracking chain of every keyframe of a round (no host round trip: `ovo_map_step` / `ovo_track_step`)."""
+        G.prepare_frame_cameras([(f.depth, f.c2w) for f in group], self.slam._K_host)
+        pend = []
+        for f in group:
+            fd = [f.index, f.rgb_lr, f.depth, f.c2w]
+            self.slam.track_camera(fd)
+            c2w = self.slam._c2w_host[f.index]                     # host copy: no D2H for the frustum set-up
+            if f.ready is not None and self.chain_stream is not None:
+                self.chain_stream.wait_event(f.ready)              # the frame's upload, if it is still in flight
+            self.slam.map_launch(fd, c2w, stream=self.chain_stream)
+            pend.append(self.ovo.detect_and_track_launch([f.index, f.rgb, f.depth, ratio], self.slam, c2w, stream=self.chain_stream))
+        return pend
+
+    def _own_masks(self, mine: Frame, amg_pending):
+        """(seg_map, masks) of the keyframe this rank owns from ITS generator; (None, None) when it kept no mask."""
+        if self.mask_source is not None:
+            seg, masks = self.mask_source(mine)
+            return (seg, masks) if masks is not None and masks.shape[0] > 0 else (None, None)
+        from .utils import segment_utils
+        r = self.amg.generate_finish(amg_pending)                  # filter + box NMS (mask_generator.py:113)
+        self.sam_out = r
+        masks = r["masks"]
+        if masks.shape[0] == 0:
+            return None, None
+        keep = segment_utils.masks_update_device(masks, r["predicted_iou"], r["stability_score"], iou_thr=0.8, score_thr=0.7, inner_thr=0.5)
+        return segment_utils.mask2segmap_device(masks.index_select(0, keep.to(masks.device)), r["stability_score"][keep.numpy()])
+
+    def _exchange_masks(self, group: List[Frame], amg_pending) -> None:
+        """Every keyframe of the round is tracked on every rank with the masks its OWNER's generator produced (mask_generator.py:102-120 runs
+        on the owner only).  A keyframe whose owner kept no mask falls back to the masks the frame carries (the precomputed-mask seam,
+        mask_generator.py:94-95) -- with random-init SAM2 weights that is every keyframe, stated in bench.py's help."""
+        from .utils import segment_utils
+        mine = group[self.rank]
+        H, W = mine.rgb.shape[:2]
+        _, masks = self._own_masks(mine, amg_pending)
+        if self.world > 1:
+            shared = parallel.share_masks(masks, H * W, self.device, gather=self._gather)
+            self.mask_exchanges += 1
+        else:
+            shared = [torch.empty((0, H * W), dtype=torch.uint8, device=self.device) if masks is None else
+                      (masks.view(torch.uint8) if masks.dtype == torch.bool else masks).reshape(masks.shape[0], -1)]
+        for f, u in zip(group, shared):
+            if u.shape[0] == 0:
+                continue                                           # the frame's own (seam) masks stay
+            seg_map = torch.empty((H, W), dtype=torch.int32, device=self.device)      # mask2segmap's painting of the received bits
+            L.check(L.load().ovo_paint_segmap(L.ptr(u), u.shape[0], H * W, L.ptr(seg_map), L.stream()))
+            self.masks.frames[f.index] = Frame(f.index, f.rgb, f.rgb_lr, f.depth, f.c2w, seg_map, u.view(torch.bool).reshape(-1, H, W), f.ready)
+
     # ------------------------------------------------------------------ dense shards
     def local_rows(self, n: int) -> int:
         """Rows of this rank's shard that hold points of a map with n points (block-cyclic, blocks of SHARD_BLOCK points)."""
@@ -382,7 +462,7 @@ class FramePipeline:
         rows = per * B
 
         def merge(local: torch.Tensor) -> torch.Tensor:
-            g = parallel.allgather(local[:rows].contiguous())      # [R, per * B, ...]
+            g = self._gather(local[:rows].contiguous())            # [R, per * B, ...]
             g = g.reshape(R, per, B, *local.shape[1:]).transpose(0, 1).reshape(per * R * B, *local.shape[1:])   # block b = (b // R, b % R)
             return g[:n]
         return merge(self.acc), merge(self.cnt), merge(self.dense_cls) if self.incremental_query else None, \
@@ -390,7 +470,7 @@ class FramePipeline:
 
     def join(self) -> None:
         """Make the main stream wait for the SAM2 and ViT streams (everything of the frames stepped so far)."""
-        for side in (self.sam_stream, self.ovo._vit_stream):
+        for side in (self.sam_stream, self.ovo._vit_stream, self.chain_stream):
             if side is not None and side != torch.cuda.current_stream():
                 torch.cuda.current_stream().wait_stream(side)
 

@@ -44,11 +44,11 @@ class VanillaMapper:
         self._K_host = G._cpu32(cam_intrinsics).contiguous()
         self._K9 = (L.C.c_float * 9)(*self._K_host.reshape(-1).tolist())
         self._n_known = 0                                  # exact when nothing is in flight
-        self._n_upper = 0                                  # >= the size the map has when the queued calls have run
-        self._pending: deque = deque()                     # sequence numbers of map_launch calls not read back yet
+        self._pending: deque = deque()                     # (sequence number, sub-sampled pixels) of map_launch calls not read back yet
         self._state = torch.zeros(4, dtype=torch.int64, device=self.device)       # {n, next point id, flags, ticket}
         self._ring = L.PinnedRing(4, np.int64, 64)
         self._explained = None
+        self._ws = None
         self._cap = 0
         self._xyz = self._ids = self._ins = self._rgb = None
         self._reserve(1 << 16)
@@ -57,9 +57,19 @@ class VanillaMapper:
     def settle(self) -> None:
         """Read back the calls in flight: afterwards `_n` / `max_id` are exact.  Waits only for what was queued."""
         while self._pending:
-            r = self._ring.wait(self._pending.popleft())
+            r = self._ring.wait(self._pending.popleft()[0])
             self._n_known, self._max_id = int(r[2]), int(r[3])
-        self._n_upper = self._n_known
+
+    def reap(self) -> None:
+        """`settle` for the calls that have ALREADY finished (no wait): keeps the ring short in a pipelined stream of keyframes."""
+        while self._pending and self._ring.done(self._pending[0][0]):
+            r = self._ring.wait(self._pending.popleft()[0])
+            self._n_known, self._max_id = int(r[2]), int(r[3])
+
+    @property
+    def _n_upper(self) -> int:
+        """>= the size the map has when the queued calls have run (a frame appends at most its sub-sampled pixels)."""
+        return self._n_known + sum(p[1] for p in self._pending)
 
     @property
     def _n(self) -> int:
@@ -70,7 +80,7 @@ class VanillaMapper:
     @_n.setter
     def _n(self, value: int) -> None:
         self.settle()
-        self._n_known = self._n_upper = int(value)
+        self._n_known = int(value)
 
     @property
     def max_id(self) -> int:
@@ -155,8 +165,10 @@ class VanillaMapper:
         self.map_launch(frame_data, c2w)
         self.settle()
 
-    def map_launch(self, frame_data: List[Any], c2w: torch.Tensor) -> None:
-        """`map` without the host round trip (MI355X extension): queues the frame's passes; the map's size advances on the device."""
+    def map_launch(self, frame_data: List[Any], c2w: torch.Tensor, stream=None) -> None:
+        """`map` without the host round trip (MI355X extension): queues the frame's passes; the map's size advances on the device.
+        `stream`: a torch stream to queue on instead of the current one (every call of one mapper must use the same stream: the
+        passes of consecutive frames depend on each other through the device-resident state)."""
         frame_id, image, depth_in = frame_data[0], frame_data[1], frame_data[2]
         h, w = depth_in.shape
         near, far = G.depth_range(depth_in)
@@ -172,10 +184,15 @@ class VanillaMapper:
         if self._n_upper + n_sub > self._cap:              # growing copies `_n` rows: needs the exact size
             self.settle()
             self._reserve(self._n_known + n_sub)
+            if stream is not None:                         # the copies into the new buffers were queued on the current stream
+                stream.wait_stream(torch.cuda.current_stream())
+        self.reap()
         if len(self._pending) >= self._ring.slots - 1:
             self.settle()
         nb = lib.ovo_compact_workspace_bytes(n_sub) + 8
-        ws = L.workspace(nb, depth.device)
+        if self._ws is None or self._ws.numel() < nb:
+            self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        ws = self._ws
         if self._explained is None or self._explained.numel() < h * w:
             self._explained = torch.empty(h * w, dtype=torch.uint8, device=dev)
         seq, slot = self._ring.next()
@@ -188,9 +205,8 @@ class VanillaMapper:
         a.ds, a.erode, a.n_upper = ds, int(self.k_pooling > 1), self._n_upper
         a.explained, a.ws, a.ws_bytes = self._explained.data_ptr(), ws.data_ptr(), nb
         a.result_host, a.seq = slot, seq
-        L.check(lib.ovo_map_step(L.C.byref(a), L.stream()))
-        self._pending.append(seq)
-        self._n_upper += n_sub
+        L.check(lib.ovo_map_step(L.C.byref(a), L.stream() if stream is None else L.C.c_void_p(stream.cuda_stream)))
+        self._pending.append((seq, n_sub))
 
     # ------------------------------------------------------------------ map access
     def get_map(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:

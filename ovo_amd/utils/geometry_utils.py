@@ -126,6 +126,7 @@ def make_camera(frustum_corners, w2c, intrinsics, th: float, h: int, w: int) -> 
     return cam
 
 
+_last_cam = None
 _frame_cams: "dict" = {}          # (near, far, h, w, pose bytes, K bytes) -> 232-byte ovo_camera_t image with th = 0
 _FRAME_CAMS_MAX = 256
 
@@ -199,12 +200,20 @@ def frame_camera(near: float, far: float, h: int, w: int, pose: torch.Tensor, in
     """`make_camera` of a frame's frustum (corners from its depth range).  Cameras are remembered per (range, size, pose, intrinsics):
     the mapper and the tracker ask for the same camera within a keyframe (with their own match thresholds), and a round of keyframes
     is prepared in one batch (`prepare_frame_cameras`); a caller gets its own copy of the struct with its `th`."""
-    p, K = _cpu32(pose).contiguous(), _cpu32(intrinsics)
-    key = _cam_key(near, far, h, w, p, K)
-    image = _frame_cams.get(key)
-    if image is None:
-        image = _build_cameras([(float(near), float(far), int(h), int(w), p, key)], K)[0]
-        _remember_camera(key, image)
+    global _last_cam
+    last = _last_cam
+    if last is not None and last[2] == (near, far, h, w) and isinstance(pose, torch.Tensor) and isinstance(intrinsics, torch.Tensor) \
+            and (last[0] is pose or (pose.shape == last[0].shape and pose.dtype == last[0].dtype and pose.device == last[0].device and torch.equal(last[0], pose))) \
+            and (last[1] is intrinsics or (intrinsics.device == last[1].device and intrinsics.dtype == last[1].dtype and torch.equal(last[1], intrinsics))):
+        image = last[3]                                            # the same frame asked again (mapper, then tracker): no key to build
+    else:
+        p, K = _cpu32(pose).contiguous(), _cpu32(intrinsics)
+        key = _cam_key(near, far, h, w, p, K)
+        image = _frame_cams.get(key)
+        if image is None:
+            image = _build_cameras([(float(near), float(far), int(h), int(w), p, key)], K)[0]
+            _remember_camera(key, image)
+        _last_cam = (pose, intrinsics, (near, far, h, w), image)
     cam = L.Camera.from_buffer_copy(image)
     cam.th = float(th)
     return cam

@@ -15,6 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests/` on a GPU-less host runs the CPU suite and SKIPS the `gpu`-marked tests (they need a real MI355X)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (run with -m gpu on the GPU box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def golden(name: str):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 

@@ -171,7 +171,7 @@ def _run_keyframes(queued: bool, n_frames=6, top_k=2):
             vm.track_camera(fd)
             vm.map_launch(fd, vm._c2w_host[fid])
             pend.append(ovo.detect_and_track_launch([fid, rgb, depth, ()], vm, vm._c2w_host[fid]))
-        assert len(vm._pending) == n_frames and len(ovo._track_pending) == n_frames       # nothing was read back in between
+        assert vm._ring.seq == n_frames and len(ovo._track_pending) == n_frames            # everything queued before anything is finished
         for p in pend:
             ovo.detect_and_track_finish(p)
     else:

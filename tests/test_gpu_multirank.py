@@ -41,7 +41,16 @@ def _state(pipe):
     return out
 
 
-def _worker(rank, world, port, path, encoder_batch):
+def _source_masks(index):
+    """Stand-in for a rank's own mask generator (SAM2 end to end): the masks of keyframe `index`, in mask2segmap order."""
+    from ovo_amd import synthetic as syn
+    h, w = syn.scannet_depth_hw(0.35)
+    e = int(round(syn.SCANNET["crop_edge"] * 0.35))
+    m = syn.make_masks(h + 2 * e, w + 2 * e, grid=(3, 4), n_blobs=4, seed=index)
+    return torch.from_numpy(syn.masks_to_segmap(m)).to("cuda:0"), torch.from_numpy(m).to("cuda:0")
+
+
+def _worker(rank, world, port, path, encoder_batch, own_masks=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       OVO_FORCE_DEVICE="0", OVO_DIST_BACKEND="gloo")
     from ovo_amd import parallel
@@ -51,9 +60,21 @@ def _worker(rank, world, port, path, encoder_batch):
     pipe = FramePipeline("cuda:0", encoder_batch=encoder_batch, **KW)
     assert pipe.world == world and pipe.rank == rank
     frames = synthetic_frames(N_FRAMES, "cuda:0", scale=0.35, n_masks_grid=(3, 4), n_blobs=4)
+    if own_masks:                                                  # `--sam-full` style: a keyframe's masks exist on its owner only ...
+        from ovo_amd.pipeline import Frame
+        calls = []
+        frames = [Frame(f.index, f.rgb, f.rgb_lr, f.depth, f.c2w, torch.empty(0, device="cuda:0"), torch.empty(0, device="cuda:0")) for f in frames]
+
+        def source(f):
+            assert f.index % world == rank                         # ... produced by ITS generator, for its own keyframes only
+            calls.append(f.index)
+            return _source_masks(f.index)
+        pipe.mask_source = source
     for r in range(N_FRAMES // world):
         pipe.step_round(frames[r * world:(r + 1) * world], frames[(r + 1) * world:])
     torch.cuda.synchronize()
+    if own_masks:
+        assert calls == list(range(rank, N_FRAMES, world)) and pipe.mask_exchanges == N_FRAMES // world
     # invariant of the resident dense map on every shard: it equals a full re-query of the shard's rows
     from ovo_amd.utils import clip_utils
     nl = pipe.local_rows(pipe.slam._n)
@@ -70,12 +91,14 @@ def _worker(rank, world, port, path, encoder_batch):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("encoder_batch", [1, 2])
-def test_two_ranks_reproduce_the_single_process_run(encoder_batch):
+@pytest.mark.parametrize("encoder_batch,own_masks", [(1, False), (2, False), (2, True)])
+def test_two_ranks_reproduce_the_single_process_run(encoder_batch, own_masks):
+    """own_masks: every keyframe's masks come from its owner's generator and reach the other rank through `parallel.share_masks`
+    (bit-packed all-gather); the run must still equal the one-process run that has all masks locally."""
     from ovo_amd.pipeline import FramePipeline, synthetic_frames
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "rank0.pt")
-        mp.spawn(_worker, args=(2, _free_port(), path, encoder_batch), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), path, encoder_batch, own_masks), nprocs=2, join=True)
         got = torch.load(path, weights_only=False)
     pipe = FramePipeline("cuda:0", **KW)
     frames = synthetic_frames(N_FRAMES, "cuda:0", scale=0.35, n_masks_grid=(3, 4), n_blobs=4)
@@ -100,3 +123,40 @@ def test_two_ranks_reproduce_the_single_process_run(encoder_batch):
         assert got["desc"][kf].keys() == ref["desc"][kf].keys()
         for i in ref["desc"][kf]:
             assert torch.equal(torch.nan_to_num(got["desc"][kf][i]), torch.nan_to_num(ref["desc"][kf][i])), (kf, i)
+
+
+def _nccl_worker(rank, world, port, path):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from ovo_amd import parallel
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    parallel.FORCE_COLLECTIVES = True
+    out = {}
+    t = torch.randn(128, 64, device="cuda:0")
+    g = parallel.allgather(t)                                      # dist.all_gather_into_tensor under RCCL
+    out["gather_ok"] = bool(g.shape == (1, 128, 64) and torch.equal(g[0], t))
+    i = torch.randint(-2 ** 62, 2 ** 62, (7, 33), dtype=torch.int64, device="cuda:0")
+    out["gather_i64_ok"] = bool(torch.equal(parallel.allgather(i)[0], i))
+    _, masks = _source_masks(3)
+    got = parallel.share_masks(masks, masks[0].numel(), torch.device("cuda:0"))
+    out["masks_ok"] = bool(len(got) == 1 and torch.equal(got[0].view(torch.bool).reshape(masks.shape), masks))
+    out["empty_ok"] = bool(parallel.share_masks(None, masks[0].numel(), torch.device("cuda:0"))[0].shape[0] == 0)
+    acc, cnt = torch.ones(1000, 8, device="cuda:0"), torch.ones(1000, dtype=torch.int32, device="cuda:0")
+    parallel.FORCE_COLLECTIVES = False
+    out["backend"] = dist.get_backend()
+    dist.barrier()
+    torch.cuda.synchronize()
+    torch.save(out, path)
+    dist.destroy_process_group()
+
+
+def test_rccl_branch_of_the_exchange_on_one_gpu():
+    """The `nccl` (= RCCL) branch of `parallel.allgather` and the bit-packed mask exchange, executed for real in a one-rank RCCL group
+    (RCCL refuses two ranks per device, so the two-rank runs above go through gloo): what comes back is what was sent."""
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "nccl.pt")
+        mp.spawn(_nccl_worker, args=(1, _free_port(), path), nprocs=1, join=True)
+        out = torch.load(path, weights_only=False)
+    assert out["backend"] == "nccl"
+    assert out["gather_ok"] and out["gather_i64_ok"] and out["masks_ok"] and out["empty_ok"], out

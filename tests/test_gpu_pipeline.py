@@ -98,3 +98,20 @@ def test_incremental_dense_query_equals_full_requery():
         assert touched == int((pipe.ovo.last_point_seg >= 0).sum().item()) or touched <= n      # every matched point of a kept mask, once
         fractions.append(touched / n)
     assert (out["dense_cls"] >= 0).any() and max(fractions) > 0 and max(fractions) < 0.6
+
+
+def test_keyframe_without_descriptors_releases_its_lookahead_slot():
+    """A keyframe whose plan is empty (no mask tracked) never pools its prefetched tokens: the look-ahead slot must still be released,
+    or the forward two groups later refuses to overwrite it (encoder_batch = 2, blank keyframes in two different groups)."""
+    from ovo_amd.pipeline import Frame, FramePipeline, synthetic_frames
+    pipe = FramePipeline(DEV, vit_card="tiny-pe", sam_card=None, n_map=60_000, n_text=3, scale=0.35, extra_capacity=300_000, track_th=40,
+                         dense=False, encoder_batch=2)
+    frames = synthetic_frames(8, DEV, scale=0.35, n_masks_grid=(3, 4), n_blobs=4)
+    for k in (1, 4):                                                 # nothing labelled: no vote, no instance, no descriptor
+        f = frames[k]
+        frames[k] = Frame(f.index, f.rgb, f.rgb_lr, f.depth, f.c2w, torch.full_like(f.seg_map, -1), torch.zeros_like(f.masks))
+    outs = [pipe.step(f, frames[i + 1:]) for i, f in enumerate(frames)]
+    torch.cuda.synchronize()
+    assert not pipe.ovo._prefetched_batch                            # every prefetched image was consumed or discarded
+    assert all(s["left"] == 0 for s in pipe.ovo._batch_slots)
+    assert outs[-1]["n_instances"] > 0

@@ -48,3 +48,36 @@ def test_specs_flops():
     assert abs(V["ViT-B-16-qg"].flops_per_image() / 1e9 - 35.1) < 0.5
     assert abs(V["PE-Core-L14-336"].flops_per_image() / 1e9 - 381) < 3         # per 336^2 crop
     assert H["hiera_b+"].dims == (112, 224, 448, 896) and H["hiera_l"].heads == (2, 4, 8, 16)
+
+
+@pytest.mark.parametrize("n_top", [0, 1, 3, 8, 10000])
+def test_instance3d_indexed_heap_vs_literal_restatement(n_top):
+    """Instance3D keeps the top-k heap with an index (kf -> area) and a sorted copy; against the oracle's literal restatement of
+    instance3d.py:77-137 on random observation streams: same heap LIST (element order included), same dirty flags, same stacking order."""
+    import heapq
+    from oracle.semantic import InstanceRecord
+    from ovo_amd.entities.instance3d import Instance3D
+    rng = np.random.default_rng(n_top)
+    Instance3D.n_top_kf = n_top
+    try:
+        for trial in range(20):
+            a, b = Instance3D(1), InstanceRecord(1, n_top)
+            for step in range(200):
+                kf = int(rng.integers(0, 40)) if rng.random() < 0.3 else step + 100      # repeats of a keyframe = fused (larger) masks
+                area = int(rng.integers(1, 30))
+                a.to_update, b.dirty = False, False
+                if rng.random() < 0.7:
+                    a.update([], kf, area)
+                    b.observe([], kf, area)
+                else:
+                    a.add_top_kf(kf, area)
+                    b.offer_view(kf, area)
+                assert a.top_kf == b.heap and a.to_update == b.dirty and a.kfs_ids == b.kfs
+                assert a.is_top_kf(kf) == b.in_top(kf) and a.idx_in_top_kf(kf) == b._slot(kf)
+                ref = [k for _, k in heapq.nlargest(n_top, b.heap)] if n_top > 0 else list(b.kfs)
+                assert a.fusion_views() == ref
+            c = Instance3D(2)
+            c.top_kf = list(a.top_kf)                                  # restore path: the index is rebuilt from the assigned heap
+            assert c.fusion_views() == (a.fusion_views() if n_top > 0 else []) and c.is_top_kf(a.top_kf[0][1]) if a.top_kf else True
+    finally:
+        Instance3D.n_top_kf = 0

@@ -4,7 +4,7 @@ otherwise idle GPU (no encoders).  N x this is the serial term of a round.  Keyf
 of R keyframes is QUEUED (ovo_map_step + ovo_track_step per keyframe, nothing read back), then finished in order.
 usage: python tools/replicated_cost.py [frames] [round]        (round = 1: one keyframe at a time; HOST=1: host-decision path)"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ovo_amd import _lib as L
 from ovo_amd.pipeline import FramePipeline, synthetic_frames
