@@ -568,6 +568,24 @@ typedef struct {
 size_t ovo_track_workspace_bytes(int n_masks, int hist_cols);
 int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream);
 
+/* A whole ROUND of keyframes -- ovo_map_step + ovo_track_step of keyframe 0, then of keyframe 1, ... -- in ONE launch of a few dozen
+ * persistent workgroups that walk through every pass, separated by grid-wide barriers.  Same passes, same results, same result
+ * blocks; what changes is how often the chain waits for the dispatcher: as separate launches a keyframe is ~12 small dependent
+ * kernels, each of which queues behind the encoders' GEMM workgroups on a busy GPU.  maps[k].depth == NULL: no map update for keyframe
+ * k; tracks[k].n_masks == 0: no tracking.  OVO_E_UNSUPPORTED (n > 16, > 1024 masks, > 131072 sub-sampled pixels): use the two calls.
+ * ctx: params_host = ovo_host_alloc(ovo_round_chain_params_bytes()); barrier = device u64[2], zero before the first call;
+ * arrivals / next_slot start at 0 and are advanced here; at most 8 rounds may be in flight.  A barrier that times out (a bug, not
+ * a load condition) sets result[6] of the tracking blocks instead of hanging the device. */
+typedef struct {
+    void *params_host;
+    uint64_t *barrier;
+    uint64_t arrivals;
+    uint32_t next_slot;
+    int32_t workgroups;      /* persistent workgroups per launch; 0 = 64 */
+} ovo_round_chain_t;
+size_t ovo_round_chain_params_bytes(void);
+int ovo_round_chain(ovo_round_chain_t *ctx, const ovo_map_step_t *maps, const ovo_track_step_t *tracks, int n, ovo_stream_t stream);
+
 /* Pinned, device-visible host memory for the result blocks, and the wait on a block's sequence word: spins (no runtime call) until
  * *flag == value, at most timeout_us microseconds (OVO_E_LAUNCH on timeout). */
 void *ovo_host_alloc(size_t bytes);

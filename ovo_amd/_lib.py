@@ -119,6 +119,11 @@ class TrackStep(C.Structure):
                 ("next_ins", _P), ("next_ins_host", C.c_int32), ("n_upper", _I64), ("result_host", _P), ("seq", C.c_int32)]
 
 
+class RoundChain(C.Structure):
+    """ovo_round_chain_t"""
+    _fields_ = [("params_host", _P), ("barrier", _P), ("arrivals", C.c_uint64), ("next_slot", C.c_uint32), ("workgroups", C.c_int32)]
+
+
 DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.uint8: 3}
 
 _SIGNATURES = {
@@ -139,6 +144,8 @@ _SIGNATURES = {
     "ovo_map_step": (_I32, [C.POINTER(MapStep), _P]),
     "ovo_track_step": (_I32, [C.POINTER(TrackStep), _P]),
     "ovo_track_workspace_bytes": (_SZ, [_I32, _I32]),
+    "ovo_round_chain_params_bytes": (_SZ, []),
+    "ovo_round_chain": (_I32, [C.POINTER(RoundChain), C.POINTER(MapStep), C.POINTER(TrackStep), _I32, _P]),
     "ovo_host_alloc": (_P, [_SZ]),
     "ovo_host_free": (None, [_P]),
     "ovo_host_wait32": (_I32, [_P, C.c_int32, _I64]),

@@ -5,8 +5,10 @@
 // half-to-even -- the exact sequence oracle/ovo_oracle.c uses, which is bit-identical to the reference's
 // torch-CPU einsum (tests/golden/geometry_*.npz).  This file is compiled with -ffp-contract=off.
 #include <limits.h>
+#include <string.h>
 
 #include "common.h"
+#include "depth_filter.h"
 
 namespace {
 
@@ -148,8 +150,7 @@ __global__ void __launch_bounds__(256) k_scan_words(const unsigned long long *__
 }
 
 // the three steps in one workgroup when the words fit one chunk (<= 131 072 items: the back-projection of a 640 x 480 frame)
-__global__ void __launch_bounds__(256) k_scan_one(const unsigned long long *__restrict__ words, long long *__restrict__ offs, int64_t n_words,
-                                                  long long *__restrict__ total_out) {
+__device__ void dev_scan_one(const unsigned long long *words, long long *offs, int64_t n_words, long long *total_out) {
     __shared__ long long sh[4];
     const int64_t w0 = (int64_t)threadIdx.x * 8;
     int pc[8];
@@ -168,6 +169,10 @@ __global__ void __launch_bounds__(256) k_scan_one(const unsigned long long *__re
     }
     if (threadIdx.x == 0 && total_out) *total_out = total;
 }
+__global__ void __launch_bounds__(256) k_scan_one(const unsigned long long *__restrict__ words, long long *__restrict__ offs, int64_t n_words,
+                                                  long long *__restrict__ total_out) {
+    dev_scan_one(words, offs, n_words, total_out);
+}
 
 // the scan of one compaction: words -> offs, *total = number of set bits
 __host__ void scan_words(const unsigned long long *words, long long *offs, long long *sums, int64_t n_words, long long *total, hipStream_t s) {
@@ -180,6 +185,11 @@ __host__ void scan_words(const unsigned long long *words, long long *offs, long 
     k_scan_bases<<<1, 256, 0, s>>>(sums, chunks, total);
     k_scan_words<<<(unsigned)chunks, 256, 0, s>>>(words, offs, n_words, sums);
 }
+
+// A workgroup's place in the grid that shares a pass: the launch's own (blockIdx, gridDim) for the one-pass kernels, the persistent
+// workgroup's (index, count) inside k_round_chain, where one launch walks through every pass of a round of keyframes.
+struct Blk { int bid, nblk; };
+__device__ __forceinline__ Blk this_block() { return Blk{(int)blockIdx.x, (int)gridDim.x}; }
 
 template <typename Load, typename Pred>
 __device__ __forceinline__ void flag_words(int64_t n, unsigned long long *words, Load load, Pred pred) {
@@ -207,11 +217,11 @@ __device__ __forceinline__ void flag_words(int64_t n, unsigned long long *words,
 }
 
 template <typename Pred>
-__device__ __forceinline__ void flag_words_idx(int64_t n, unsigned long long *words, Pred pred) {     // pred(index): small inputs
+__device__ __forceinline__ void flag_words_idx(Blk b, int64_t n, unsigned long long *words, Pred pred) {     // pred(index): small inputs
     const int lane = threadIdx.x & 63;
-    const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t waves = (int64_t)b.nblk * (blockDim.x >> 6);
     const int64_t n_words = (n + 63) >> 6;
-    for (int64_t wd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wd < n_words; wd += waves) {
+    for (int64_t wd = (int64_t)b.bid * (blockDim.x >> 6) + (threadIdx.x >> 6); wd < n_words; wd += waves) {
         const int64_t i = wd * 64 + lane;
         const bool p = i < n && pred(i);
         const unsigned long long m = __ballot(p);
@@ -220,11 +230,11 @@ __device__ __forceinline__ void flag_words_idx(int64_t n, unsigned long long *wo
 }
 
 template <typename Emit>
-__device__ __forceinline__ void emit_words(int64_t n, const unsigned long long *words, const long long *offs, Emit emit) {
+__device__ __forceinline__ void emit_words(Blk b, int64_t n, const unsigned long long *words, const long long *offs, Emit emit) {
     const int lane = threadIdx.x & 63;
-    const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t waves = (int64_t)b.nblk * (blockDim.x >> 6);
     const int64_t n_words = (n + 63) >> 6;
-    for (int64_t wd = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wd < n_words; wd += waves) {
+    for (int64_t wd = (int64_t)b.bid * (blockDim.x >> 6) + (threadIdx.x >> 6); wd < n_words; wd += waves) {
         const unsigned long long m = words[wd];
         if ((m >> lane) & 1ull) {
             const long long pos = offs[wd] + __popcll(m & ((1ull << lane) - 1ull));
@@ -241,7 +251,7 @@ __global__ void __launch_bounds__(256) k_frustum_flag(const float *__restrict__ 
 }
 __global__ void __launch_bounds__(256) k_frustum_emit(int64_t n, const unsigned long long *words, const long long *offs,
                                                       int64_t *out_idx) {
-    emit_words(n, words, offs, [&](int64_t i, long long pos) { out_idx[pos] = i; });
+    emit_words(this_block(), n, words, offs, [&](int64_t i, long long pos) { out_idx[pos] = i; });
 }
 
 // ---- a3 ----
@@ -269,7 +279,7 @@ __global__ void __launch_bounds__(256) k_match_flag(const float *__restrict__ pt
 __global__ void __launch_bounds__(256) k_match_emit(const float *__restrict__ pts, int64_t n, int stride, ovo_camera_t cam,
                                                     const unsigned long long *words, const long long *offs,
                                                     int64_t *out_idx, int32_t *out_uv) {
-    emit_words(n, words, offs, [&](int64_t i, long long pos) {
+    emit_words(this_block(), n, words, offs, [&](int64_t i, long long pos) {
         const float *p = pts + i * stride;
         float zc; int u, v;
         project(cam, p[0], p[1], p[2], stride == 4 ? p[3] : 1.0f, zc, u, v);
@@ -311,23 +321,22 @@ __device__ __forceinline__ int queue_push(bool keep, int *s_count) {
     return keep ? base + (int)__popcll(m & ((1ull << lane) - 1ull)) : -1;
 }
 
-__global__ void __launch_bounds__(256) k_track_project(const float *__restrict__ pts, const int32_t *__restrict__ point_ins,
-                                                       int64_t n, ovo_camera_t cam, const float *__restrict__ depth,
-                                                       const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
-                                                       ovo_ratio_t ratio, int16_t *__restrict__ point_seg,
-                                                       int32_t *__restrict__ hist, int n_masks, int hist_cols,
-                                                       unsigned long long *__restrict__ counters, const long long *__restrict__ n_dev) {
-    if (n_dev) n = *n_dev;                                         // device-resident map size (ovo_track_step): no host round trip
+__device__ void dev_track_project(Blk b, const float *__restrict__ pts, const int32_t *__restrict__ point_ins,
+                                  int64_t n, const ovo_camera_t &cam, const float *__restrict__ depth,
+                                  const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
+                                  ovo_ratio_t ratio, int16_t *__restrict__ point_seg,
+                                  int32_t *__restrict__ hist, int n_masks, int hist_cols,
+                                  unsigned long long *__restrict__ counters) {
     __shared__ float s_x[1024], s_y[1024], s_z[1024];
     __shared__ long long s_i[1024];
     __shared__ int s_n;
     const int lane = threadIdx.x & 63;
     long long n_in = 0, n_match = 0;
-    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    const int64_t step = (int64_t)b.nblk * blockDim.x;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     // trip: 4 points per thread (loads first: bytes in flight), the frustum test, survivors -> LDS queue; then the queue, densely
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 - threadIdx.x < n; i0 += 4 * step) {     // block-uniform trip count
+    for (int64_t i0 = (int64_t)b.bid * blockDim.x + threadIdx.x; i0 - threadIdx.x < n; i0 += 4 * step) {     // block-uniform trip count
         float px[4], py[4], pz[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -394,19 +403,32 @@ __global__ void __launch_bounds__(256) k_track_project(const float *__restrict__
     }
 }
 
+__global__ void __launch_bounds__(256) k_track_project(const float *__restrict__ pts, const int32_t *__restrict__ point_ins,
+                                                       int64_t n, ovo_camera_t cam, const float *__restrict__ depth,
+                                                       const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
+                                                       ovo_ratio_t ratio, int16_t *__restrict__ point_seg,
+                                                       int32_t *__restrict__ hist, int n_masks, int hist_cols,
+                                                       unsigned long long *__restrict__ counters, const long long *__restrict__ n_dev) {
+    if (n_dev) n = *n_dev;                                         // device-resident map size (ovo_track_step): no host round trip
+    dev_track_project(this_block(), pts, point_ins, n, cam, depth, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, counters);
+}
+
 // ---- a6: per-mask statistics ----
-__global__ void __launch_bounds__(256) k_seg_area(const int32_t *__restrict__ seg_map, int64_t pixels, int n_masks,
-                                                  int32_t *__restrict__ stats) {
-    extern __shared__ int area[];
+__device__ void dev_seg_area(Blk b, const int32_t *__restrict__ seg_map, int64_t pixels, int n_masks, int32_t *__restrict__ stats, int *area) {
     for (int i = threadIdx.x; i < n_masks; i += blockDim.x) area[i] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)b.bid * blockDim.x + threadIdx.x; i < pixels; i += (int64_t)b.nblk * blockDim.x) {
         const int s = seg_map[i];
         if (s >= 0 && s < n_masks) atomicAdd(area + s, 1);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n_masks; i += blockDim.x)
         if (area[i]) atomicAdd(stats + 4 * i + 3, area[i]);
+}
+__global__ void __launch_bounds__(256) k_seg_area(const int32_t *__restrict__ seg_map, int64_t pixels, int n_masks,
+                                                  int32_t *__restrict__ stats) {
+    extern __shared__ int area[];
+    dev_seg_area(this_block(), seg_map, pixels, n_masks, stats, area);
 }
 
 __global__ void __launch_bounds__(256) k_vote_stats(const int32_t *__restrict__ hist, int hist_cols, int32_t *__restrict__ stats) {
@@ -463,10 +485,9 @@ __global__ void __launch_bounds__(256) k_assign(const int32_t *__restrict__ poin
 }
 
 // k_assign with the targets read from the device-side decision block (row stride 6, column 4), in place
-__global__ void __launch_bounds__(256) k_assign_res(int32_t *__restrict__ point_ins, const int16_t *__restrict__ point_seg, int64_t n,
-                                                    const int32_t *__restrict__ res, int n_masks, const long long *__restrict__ n_dev) {
-    if (n_dev) n = *n_dev;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void dev_assign_res(Blk b, int32_t *__restrict__ point_ins, const int16_t *__restrict__ point_seg, int64_t n,
+                                               const int32_t *res, int n_masks) {
+    for (int64_t i = (int64_t)b.bid * blockDim.x + threadIdx.x; i < n; i += (int64_t)b.nblk * blockDim.x) {
         const int s = point_seg[i];
         if (s >= 0 && s < n_masks && point_ins[i] == -1) {
             const int tgt = res[8 + 6 * s + 4];
@@ -474,21 +495,21 @@ __global__ void __launch_bounds__(256) k_assign_res(int32_t *__restrict__ point_
         }
     }
 }
+__global__ void __launch_bounds__(256) k_assign_res(int32_t *__restrict__ point_ins, const int16_t *__restrict__ point_seg, int64_t n,
+                                                    const int32_t *__restrict__ res, int n_masks, const long long *__restrict__ n_dev) {
+    if (n_dev) n = *n_dev;
+    dev_assign_res(this_block(), point_ins, point_seg, n, res, n_masks);
+}
 
 // ---- a9 ----
-__global__ void __launch_bounds__(256) k_map_explained(const float *__restrict__ pts, int64_t n, ovo_camera_t cam,
-                                                       const float *__restrict__ depth, uint8_t *__restrict__ explained,
-                                                       const long long *__restrict__ state) {
-    if (state) {                                                   // device-resident map state {n, next point id} (ovo_map_step)
-        n = state[0];
-        if (state[1] <= 0) return;                                 // vanilla_mapper.py:56 `if self.max_id > 0`
-    }
+__device__ void dev_map_explained(Blk b, const float *__restrict__ pts, int64_t n, const ovo_camera_t &cam,
+                                  const float *__restrict__ depth, uint8_t *__restrict__ explained) {
     __shared__ float s_x[1024], s_y[1024], s_z[1024];
     __shared__ int s_n;
-    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    const int64_t step = (int64_t)b.nblk * blockDim.x;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 - threadIdx.x < n; i0 += 4 * step) {     // as k_track_project
+    for (int64_t i0 = (int64_t)b.bid * blockDim.x + threadIdx.x; i0 - threadIdx.x < n; i0 += 4 * step) {     // as k_track_project
         float px[4], py[4], pz[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -514,6 +535,16 @@ __global__ void __launch_bounds__(256) k_map_explained(const float *__restrict__
     }
 }
 
+__global__ void __launch_bounds__(256) k_map_explained(const float *__restrict__ pts, int64_t n, ovo_camera_t cam,
+                                                       const float *__restrict__ depth, uint8_t *__restrict__ explained,
+                                                       const long long *__restrict__ state) {
+    if (state) {                                                   // device-resident map state {n, next point id} (ovo_map_step)
+        n = state[0];
+        if (state[1] <= 0) return;                                 // vanilla_mapper.py:56 `if self.max_id > 0`
+    }
+    dev_map_explained(this_block(), pts, n, cam, depth, explained);
+}
+
 struct BackprojArgs {
     float K[9];
     float c2w[16];
@@ -524,14 +555,9 @@ __device__ __forceinline__ bool px_valid(const float *depth, const uint8_t *expl
     return depth[i] > 0.0f && !(explained && explained[i]);
 }
 
-__global__ void __launch_bounds__(256) k_backproj_flag(const float *__restrict__ depth, const uint8_t *__restrict__ explained,
-                                                       BackprojArgs a, int64_t n_sub, unsigned long long *words,
-                                                       const long long *__restrict__ state) {
-    if (state && state[1] <= 0) {                                  // empty map so far: no explained-pixel test, no erosion (vanilla_mapper.py:56,62)
-        explained = nullptr;
-        a.erode = 0;
-    }
-    flag_words_idx(n_sub, words, [&](int64_t k) {
+__device__ __forceinline__ void dev_backproj_flag(Blk b, const float *__restrict__ depth, const uint8_t *explained, const BackprojArgs &a,
+                                                  int64_t n_sub, unsigned long long *words) {
+    flag_words_idx(b, n_sub, words, [&](int64_t k) {
         const int y = (int)(k / a.ws_w) * a.ds, x = (int)(k % a.ws_w) * a.ds;
         if (!px_valid(depth, explained, (int64_t)y * a.w + x)) return false;
         if (a.erode) {
@@ -545,6 +571,15 @@ __global__ void __launch_bounds__(256) k_backproj_flag(const float *__restrict__
         return true;
     });
 }
+__global__ void __launch_bounds__(256) k_backproj_flag(const float *__restrict__ depth, const uint8_t *__restrict__ explained,
+                                                       BackprojArgs a, int64_t n_sub, unsigned long long *words,
+                                                       const long long *__restrict__ state) {
+    if (state && state[1] <= 0) {                                  // empty map so far: no explained-pixel test, no erosion (vanilla_mapper.py:56,62)
+        explained = nullptr;
+        a.erode = 0;
+    }
+    dev_backproj_flag(this_block(), depth, explained, a, n_sub, words);
+}
 
 // What the LAST workgroup of k_backproj_emit does for ovo_map_step: advance the device-resident map state by the number of appended
 // points and publish it to the host's pinned result block (sequence number last, after a system-scope fence).
@@ -556,22 +591,18 @@ struct MapCommit {
     long long n_host, id_host;   // the host's exact copy of the state when it has one (n_host >= 0), else read `state`
 };
 
-__global__ void __launch_bounds__(256) k_backproj_emit(const float *__restrict__ depth, const uint8_t *__restrict__ rgb, BackprojArgs a,
-                                                       int64_t n_sub, const unsigned long long *words, const long long *offs,
-                                                       int64_t base, int32_t first_id, float *xyz, int32_t *ids, int32_t *ins,
-                                                       uint8_t *out_rgb, MapCommit mc) {
-    if (mc.state) {
-        base = mc.n_host >= 0 ? mc.n_host : mc.state[0];
-        first_id = (int32_t)(mc.n_host >= 0 ? mc.id_host : mc.state[1]);
-    }
-    emit_words(n_sub, words, offs, [&](int64_t k, long long pos) {
+__device__ __forceinline__ void dev_backproj_emit(Blk b, const float *__restrict__ depth, const uint8_t *__restrict__ rgb, const BackprojArgs &a,
+                                                  int64_t n_sub, const unsigned long long *words, const long long *offs,
+                                                  int64_t base, int32_t first_id, int64_t cap, float *xyz, int32_t *ids, int32_t *ins,
+                                                  uint8_t *out_rgb) {
+    emit_words(b, n_sub, words, offs, [&](int64_t k, long long pos) {
         const int y = (int)(k / a.ws_w) * a.ds, x = (int)(k % a.ws_w) * a.ds;
         const int64_t px = (int64_t)y * a.w + x;
         const float d = depth[px];
         const float x3 = __fdiv_rn(__fmul_rn(__fsub_rn((float)x, a.K[2]), d), a.K[0]);
         const float y3 = __fdiv_rn(__fmul_rn(__fsub_rn((float)y, a.K[5]), d), a.K[4]);
         const int64_t r = base + pos;
-        if (mc.state && r >= mc.cap) return;                       // never taken: the host reserves n_upper + n_sub rows (flagged below)
+        if (r >= cap) return;                                      // never taken: the host reserves n_upper + n_sub rows (flagged by the commit)
         xyz[3 * r + 0] = dot4(a.c2w, x3, y3, d, 1.0f);
         xyz[3 * r + 1] = dot4(a.c2w + 4, x3, y3, d, 1.0f);
         xyz[3 * r + 2] = dot4(a.c2w + 8, x3, y3, d, 1.0f);
@@ -583,6 +614,17 @@ __global__ void __launch_bounds__(256) k_backproj_emit(const float *__restrict__
             out_rgb[3 * r + 2] = rgb[3 * px + 2];
         }
     });
+}
+
+__global__ void __launch_bounds__(256) k_backproj_emit(const float *__restrict__ depth, const uint8_t *__restrict__ rgb, BackprojArgs a,
+                                                       int64_t n_sub, const unsigned long long *words, const long long *offs,
+                                                       int64_t base, int32_t first_id, float *xyz, int32_t *ids, int32_t *ins,
+                                                       uint8_t *out_rgb, MapCommit mc) {
+    if (mc.state) {
+        base = mc.n_host >= 0 ? mc.n_host : mc.state[0];
+        first_id = (int32_t)(mc.n_host >= 0 ? mc.id_host : mc.state[1]);
+    }
+    dev_backproj_emit(this_block(), depth, rgb, a, n_sub, words, offs, base, first_id, mc.state ? mc.cap : LLONG_MAX, xyz, ids, ins, out_rgb);
     if (!mc.state) return;
     __shared__ int s_last;
     __syncthreads();
@@ -621,7 +663,7 @@ __device__ void decide_masks(const Decide d, const int32_t *stats) {
     __shared__ int s_scan[256];
     __shared__ int s_base;
     const int t = threadIdx.x;
-    if (t == 0) s_base = d.next_host >= 0 ? d.next_host : *d.next_ins;
+    if (t == 0) s_base = d.next_host >= 0 ? d.next_host : ld_agent(d.next_ins);
     __syncthreads();
     const int first_new = s_base;
     for (int m0 = 0; m0 < d.n_masks; m0 += 256) {
@@ -650,7 +692,7 @@ __device__ void decide_masks(const Decide d, const int32_t *stats) {
         if (t == 255) s_base += s_scan[255];
         __syncthreads();
     }
-    if (t == 0) { *d.next_ins = s_base; d.res[4] = s_base; d.res[5] = first_new; }
+    if (t == 0) { *d.next_ins = s_base; d.res[4] = s_base; d.res[5] = first_new; d.res[6] = 0; d.res[7] = 0; }
     __threadfence_block();
     __syncthreads();
     for (int m = t; m < d.n_masks; m += 256) {                      // first mask of each target (targets of new instances are unique)
@@ -663,17 +705,16 @@ __device__ void decide_masks(const Decide d, const int32_t *stats) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_vote_decide(const int32_t *__restrict__ hist, int hist_cols, int32_t *__restrict__ stats,
-                                                     unsigned int *__restrict__ ticket, Decide d) {
+// one workgroup, one mask: total, assigned, mode with smallest-id tie break (k_vote_stats), thread 0 writes the row
+__device__ void dev_vote_row(int m, const int32_t *hist, int hist_cols, int32_t *stats) {
     __shared__ long long s_cnt[256];
     __shared__ int s_best[256], s_arg[256];
-    __shared__ int s_last;
-    const int m = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
     const int32_t *row = hist + (int64_t)m * hist_cols;
     long long assigned = 0;
     int best = 0, arg = -1;
     for (int c = 1 + t; c < hist_cols; c += 256) {
-        const int v = row[c];
+        const int v = ld_agent(row + c);
         assigned += v;
         if (v > best) { best = v; arg = c - 1; }
     }
@@ -690,9 +731,18 @@ __global__ void __launch_bounds__(256) k_vote_decide(const int32_t *__restrict__
         __syncthreads();
     }
     if (t == 0) {
-        stats[4 * m + 0] = (int)(s_cnt[0] + row[0]);
+        stats[4 * m + 0] = (int)(s_cnt[0] + ld_agent(row));
         stats[4 * m + 1] = (int)s_cnt[0];
         stats[4 * m + 2] = s_arg[0];
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_vote_decide(const int32_t *__restrict__ hist, int hist_cols, int32_t *__restrict__ stats,
+                                                     unsigned int *__restrict__ ticket, Decide d) {
+    __shared__ int s_last;
+    dev_vote_row(blockIdx.x, hist, hist_cols, stats);
+    if (threadIdx.x == 0) {
         __threadfence();
         s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
@@ -718,45 +768,64 @@ __device__ __forceinline__ int nonzero_bytes(unsigned int w) {
     return __popc(w & 0x01010101u);
 }
 
+// masks[d] |= its followers, for the pixel chunk (part of parts) of row d; the row's fused area accumulates in res[d][5] (from -1)
+__device__ void dev_fuse_row(int d, int part, int parts, uint4 *masks, long long px16, int n_masks, const int32_t *dst, int32_t *res) {
+    __shared__ int s_follow[256], s_nf;
+    if (ld_agent(dst + d) != d) return;                            // workgroup-uniform
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int m = d + 1; m < n_masks; ++m)
+            if (ld_agent(dst + m) == d) { if (c < 256) s_follow[c] = m; ++c; }
+        s_nf = c;
+    }
+    __syncthreads();
+    const int n_follow = s_nf;
+    if (!n_follow) return;
+    int area = 0;
+    for (long long i = (long long)part * blockDim.x + threadIdx.x; i < px16; i += (long long)parts * blockDim.x) {
+        uint4 a = masks[d * px16 + i];
+        if (n_follow <= 256) {
+            for (int k = 0; k < n_follow; ++k) {
+                const uint4 b = masks[s_follow[k] * px16 + i];
+                a.x |= b.x; a.y |= b.y; a.z |= b.z; a.w |= b.w;
+            }
+        } else {
+            for (int m = d + 1; m < n_masks; ++m)
+                if (ld_agent(dst + m) == d) {
+                    const uint4 b = masks[m * px16 + i];
+                    a.x |= b.x; a.y |= b.y; a.z |= b.z; a.w |= b.w;
+                }
+        }
+        masks[d * px16 + i] = a;
+        area += nonzero_bytes(a.x) + nonzero_bytes(a.y) + nonzero_bytes(a.z) + nonzero_bytes(a.w);
+    }
+    for (int o = 32; o > 0; o >>= 1) area += __shfl_xor(area, o, 64);
+    if ((threadIdx.x & 63) == 0) {
+        if (part == 0 && threadIdx.x == 0) area += 1;              // the row starts at -1 ("not fused")
+        if (area) atomicAdd(res + 8 + 6 * d + 5, area);
+    }
+}
+
+// the keyframe's result block -> pinned host memory, sequence word last (one workgroup)
+__device__ void dev_publish(int32_t *res, const Publish &pb, long long n_points) {
+    if (threadIdx.x == 0) {
+        res[1] = (int32_t)n_points;
+        res[2] = (int32_t)__hip_atomic_load(pb.counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        res[3] = (int32_t)__hip_atomic_load(pb.counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!pb.host) return;
+    for (int i = 1 + threadIdx.x; i < pb.n_ints; i += 256) pb.host[i] = ld_agent(res + i);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) pb.host[0] = pb.seq;
+}
+
 __global__ void __launch_bounds__(256) k_fuse_publish(uint4 *__restrict__ masks, long long px16, int n_masks, const int32_t *__restrict__ dst,
                                                       int32_t *__restrict__ res, Publish pb) {
     const int d = blockIdx.y;
-    __shared__ int s_follow[256], s_nf;
-    if (masks && dst[d] == d) {                                    // workgroup-uniform
-        if (threadIdx.x == 0) {
-            int c = 0;
-            for (int m = d + 1; m < n_masks; ++m)
-                if (dst[m] == d) { if (c < 256) s_follow[c] = m; ++c; }
-            s_nf = c;
-        }
-        __syncthreads();
-        const int n_follow = s_nf;
-        if (n_follow) {
-            int area = 0;
-            for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < px16; i += (long long)gridDim.x * blockDim.x) {
-                uint4 a = masks[d * px16 + i];
-                if (n_follow <= 256) {
-                    for (int k = 0; k < n_follow; ++k) {
-                        const uint4 b = masks[s_follow[k] * px16 + i];
-                        a.x |= b.x; a.y |= b.y; a.z |= b.z; a.w |= b.w;
-                    }
-                } else {
-                    for (int m = d + 1; m < n_masks; ++m)
-                        if (dst[m] == d) {
-                            const uint4 b = masks[m * px16 + i];
-                            a.x |= b.x; a.y |= b.y; a.z |= b.z; a.w |= b.w;
-                        }
-                }
-                masks[d * px16 + i] = a;
-                area += nonzero_bytes(a.x) + nonzero_bytes(a.y) + nonzero_bytes(a.z) + nonzero_bytes(a.w);
-            }
-            for (int o = 32; o > 0; o >>= 1) area += __shfl_xor(area, o, 64);
-            if ((threadIdx.x & 63) == 0) {
-                if (blockIdx.x == 0 && threadIdx.x == 0) area += 1;       // the row starts at -1 ("not fused")
-                if (area) atomicAdd(res + 8 + 6 * d + 5, area);
-            }
-        }
-    }
+    if (masks) dev_fuse_row(d, blockIdx.x, gridDim.x, masks, px16, n_masks, dst, res);
     // two-level ticket (per mask row, then one per row): a thousand workgroups on ONE address serialise in the L2 atomic unit
     __shared__ int s_last;
     __syncthreads();
@@ -768,17 +837,145 @@ __global__ void __launch_bounds__(256) k_fuse_publish(uint4 *__restrict__ masks,
     __syncthreads();
     if (!s_last) return;
     __threadfence();
+    dev_publish(res, pb, pb.n_host >= 0 ? pb.n_host : *pb.n_dev);
+}
+
+// =================================================================================================
+// k_round_chain: the map + tracking chains of a whole ROUND of keyframes in ONE launch.  A few dozen persistent workgroups walk
+// through every pass of every keyframe, separated by grid-wide barriers (an atomic arrival counter, spin on an agent-scope load).
+// Why: as separate launches a chain is ~12 small DEPENDENT kernels, and on a GPU whose CUs are filled by the encoders' GEMM workgroups
+// every one of them waits for the dispatcher to get round to its queue (~45 us each: 0.6 ms per keyframe instead of 0.14 on an idle
+// GPU, the serial term of an 8-GPU round).  Here the workgroups wait for CUs once per round and then keep them.
+// The passes are the device functions the one-pass kernels above are made of (same arithmetic, same results).
+struct ChainKf {
+    // map update (vanilla_mapper.py:46-85)
+    float *xyz; int32_t *ids, *ins; uint8_t *rgb_out; long long cap; long long *state; long long n_host, id_host;
+    const float *depth; const uint8_t *rgb; ovo_camera_t cam_map; BackprojArgs bp; long long n_sub;
+    uint8_t *explained; unsigned long long *words; long long *offs; long long *total;
+    volatile long long *map_result; long long map_seq;
+    int do_map, erode;
+    // tracking (ovo.py:182-324)
+    int do_track, filter; const float *depth_t; float *depth_f; float filter_th;
+    ovo_camera_t cam; ovo_ratio_t ratio; const int32_t *seg_map; int seg_h, seg_w;
+    uint4 *masks; int n_masks; long long px16; int16_t *point_seg;
+    int32_t *hist, *stats; unsigned long long *counters; int32_t *dst, *res; long long zero_bytes; int hist_cols, track_th;
+    int32_t *next_ins; int next_host; volatile int32_t *result; int seq;
+};
+constexpr int CHAIN_MAX_KF = 16, CHAIN_MAX_MASKS = 1024, CHAIN_BARRIERS = 10;
+
+__device__ __forceinline__ void dev_depth_filter(Blk b, const float *__restrict__ depth, int h, int w, const BlurTaps &taps, float th, float *out) {
+    const int n = h * w;
+    for (int i = b.bid * 256 + threadIdx.x; i < n; i += b.nblk * 256) out[i] = depth_filter_pixel(depth, h, w, taps, th, i % w, i / w);
+}
+
+struct GridBar { unsigned long long *count; unsigned long long base; unsigned int nblk; unsigned int *abort; };
+
+__device__ __forceinline__ void grid_sync(const GridBar &g, unsigned long long &gen) {
+    __syncthreads();
     if (threadIdx.x == 0) {
-        res[1] = (int32_t)(pb.n_host >= 0 ? pb.n_host : *pb.n_dev);
-        res[2] = (int32_t)pb.counters[0];
-        res[3] = (int32_t)pb.counters[1];
+        ++gen;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(g.count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = g.base + gen * g.nblk;
+        unsigned long long spins = 0;
+        while (__hip_atomic_load(g.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1ull << 26)) { *g.abort = 1; break; }   // ~ seconds: a workgroup never arrived; leave instead of hanging the GPU
+        }
     }
     __syncthreads();
-    if (!pb.host) return;
-    for (int i = 1 + threadIdx.x; i < pb.n_ints; i += 256) pb.host[i] = ld_agent(res + i);
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) pb.host[0] = pb.seq;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // drop this CU's stale L1 lines of what the others wrote
+}
+
+__global__ void __launch_bounds__(256) k_round_chain(const ChainKf *__restrict__ params, int n_kf, GridBar gb, BlurTaps taps) {
+    __shared__ ChainKf kf;
+    __shared__ int s_area[CHAIN_MAX_MASKS];
+    const Blk b{(int)blockIdx.x, (int)gridDim.x};
+    unsigned long long gen = 0;
+    for (int k = 0; k < n_kf; ++k) {
+        if (__hip_atomic_load(gb.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;      // a barrier timed out: leave, the host sees the flag
+        __syncthreads();
+        for (int i = threadIdx.x; i < (int)(sizeof(ChainKf) / 4); i += blockDim.x) ((int32_t *)&kf)[i] = ((const int32_t *)(params + k))[i];
+        __syncthreads();
+        // ---- pass A: zero the scratch, high-pass filter of the depth (geometry_utils.py:92-96)
+        const long long n_old = kf.n_host >= 0 ? kf.n_host : __hip_atomic_load(kf.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long id_old = kf.n_host >= 0 ? kf.id_host : __hip_atomic_load(kf.state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool nonempty = id_old > 0;
+        const int hw = kf.cam_map.h * kf.cam_map.w;
+        if (kf.do_map) {
+            for (int i = b.bid * 256 + threadIdx.x; i < hw / 16; i += b.nblk * 256) ((uint4 *)kf.explained)[i] = make_uint4(0, 0, 0, 0);
+            if (b.bid == 0 && threadIdx.x < hw % 16) kf.explained[hw - 1 - threadIdx.x] = 0;
+        }
+        if (kf.do_track) {
+            for (long long i = b.bid * 256 + threadIdx.x; i < kf.zero_bytes / 4; i += b.nblk * 256) kf.hist[i] = 0;
+            if (kf.filter) dev_depth_filter(b, kf.depth_t, kf.cam.h, kf.cam.w, taps, kf.filter_th, kf.depth_f);
+        }
+        grid_sync(gb, gen);                                                                                       // 1
+        // ---- pass B: explained pixels (vanilla_mapper.py:56-61); mask areas of the seg map
+        if (kf.do_map && nonempty) dev_map_explained(b, kf.xyz, n_old, kf.cam_map, kf.depth, kf.explained);
+        if (kf.do_track) dev_seg_area(b, kf.seg_map, (int64_t)kf.seg_h * kf.seg_w, kf.n_masks, kf.stats, s_area);
+        grid_sync(gb, gen);                                                                                       // 2
+        // ---- pass C..E: erode + subsample -> ordered append (vanilla_mapper.py:62-85)
+        long long m_new = 0;
+        if (kf.do_map) {
+            BackprojArgs bp = kf.bp;
+            bp.erode = kf.erode && nonempty;
+            dev_backproj_flag(b, kf.depth, nonempty ? kf.explained : nullptr, bp, kf.n_sub, kf.words);
+        }
+        grid_sync(gb, gen);                                                                                       // 3
+        if (kf.do_map && b.bid == 0) dev_scan_one(kf.words, kf.offs, (kf.n_sub + 63) >> 6, kf.total);
+        grid_sync(gb, gen);                                                                                       // 4
+        if (kf.do_map) {
+            m_new = __hip_atomic_load(kf.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n_old + m_new > kf.cap) m_new = kf.cap - n_old;
+            dev_backproj_emit(b, kf.depth, kf.rgb, kf.bp, kf.n_sub, kf.words, kf.offs, n_old, (int32_t)id_old, kf.cap, kf.xyz, kf.ids, kf.ins, kf.rgb_out);
+        }
+        const long long n_now = n_old + m_new;
+        grid_sync(gb, gen);                                                                                       // 5
+        // ---- pass F: cull / project / depth-test / seg lookup / votes over the whole map (ovo.py:208-222)
+        if (kf.do_track && n_now > 0)
+            dev_track_project(b, kf.xyz, kf.ins, n_now, kf.cam, kf.filter ? kf.depth_f : kf.depth_t, kf.seg_map, kf.seg_h, kf.seg_w, kf.ratio,
+                              kf.point_seg, kf.hist, kf.n_masks, kf.hist_cols, kf.counters);
+        grid_sync(gb, gen);                                                                                       // 6
+        // ---- pass G: per-mask vote statistics, then the decisions in mask order (ovo.py:255-282)
+        if (kf.do_track)
+            for (int m = b.bid; m < kf.n_masks; m += b.nblk) dev_vote_row(m, kf.hist, kf.hist_cols, kf.stats);
+        grid_sync(gb, gen);                                                                                       // 7
+        if (kf.do_track && b.bid == 0) {
+            Decide d;
+            d.res = kf.res; d.dst = kf.dst; d.next_ins = kf.next_ins; d.next_host = kf.next_host; d.track_th = kf.track_th; d.n_masks = kf.n_masks;
+            decide_masks(d, kf.stats);
+        }
+        grid_sync(gb, gen);                                                                                       // 8
+        // ---- pass H: assignment in place (ovo.py:228-229,280); masks of one instance OR-ed into its first mask (ovo.py:284-309)
+        if (kf.do_track) {
+            if (n_now > 0) dev_assign_res(b, kf.ins, kf.point_seg, n_now, kf.res, kf.n_masks);
+            if (kf.masks)
+                for (int d = 0; d < kf.n_masks; ++d) dev_fuse_row(d, b.bid, b.nblk, kf.masks, kf.px16, kf.n_masks, kf.dst, kf.res);
+        }
+        grid_sync(gb, gen);                                                                                       // 9
+        // ---- pass I: commit the map state, publish both result blocks
+        if (b.bid == 0) {
+            if (kf.do_map && threadIdx.x == 0) {
+                if (n_old + __hip_atomic_load(kf.total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > kf.cap) kf.state[2] |= 1;
+                kf.state[0] = n_now;
+                kf.state[1] = id_old + m_new;
+                if (kf.map_result) {
+                    kf.map_result[1] = m_new; kf.map_result[2] = n_now; kf.map_result[3] = id_old + m_new;
+                    __threadfence_system();
+                    kf.map_result[0] = kf.map_seq;
+                }
+            }
+            if (kf.do_track) {
+                Publish pb;
+                pb.res = kf.res; pb.host = kf.result; pb.counters = kf.counters; pb.n_dev = nullptr; pb.n_host = n_now; pb.ticket = nullptr;
+                pb.seq = kf.seq; pb.n_ints = 8 + 6 * kf.n_masks;
+                if (threadIdx.x == 0) kf.res[6] = (int32_t)__hip_atomic_load(gb.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dev_publish(kf.res, pb, n_now);
+            }
+        }
+        grid_sync(gb, gen);                                                                                       // 10: the next keyframe reads the state
+    }
 }
 
 }  // namespace
@@ -1008,6 +1205,81 @@ int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream) {
     dim3 grid(a->masks ? ovo_grid(px16, 256, 32) : 1, nm);
     k_fuse_publish<<<grid, 256, 0, s>>>((uint4 *)a->masks, px16, nm, dst, res, pb);
     OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+
+// ---- a whole round of keyframes in one launch (k_round_chain) -------------------------------------------------------------------
+size_t ovo_round_chain_params_bytes(void) { return (size_t)8 * CHAIN_MAX_KF * sizeof(ChainKf); }       // a ring of 8 rounds
+
+int ovo_round_chain(ovo_round_chain_t *ctx, const ovo_map_step_t *maps, const ovo_track_step_t *tracks, int n, ovo_stream_t stream) {
+    OVO_REQUIRE(ctx && ctx->params_host && ctx->barrier && maps && tracks && n > 0, "null argument");
+    static_assert(sizeof(ChainKf) % 4 == 0, "ChainKf is copied word by word");
+    if (n > CHAIN_MAX_KF) { ovo_set_error("ovo_round_chain: more than %d keyframes", CHAIN_MAX_KF); return OVO_E_UNSUPPORTED; }
+    ChainKf *slot = (ChainKf *)ctx->params_host + (size_t)(ctx->next_slot % 8) * CHAIN_MAX_KF;
+    for (int k = 0; k < n; ++k) {
+        const ovo_map_step_t *a = maps + k;
+        const ovo_track_step_t *t = tracks + k;
+        ChainKf c;
+        memset(&c, 0, sizeof(c));
+        c.do_map = a->depth != nullptr;
+        c.do_track = t->n_masks > 0;
+        const ovo_map_ref_t &mr = c.do_map ? a->map : t->map;
+        OVO_REQUIRE(c.do_map || c.do_track, "a keyframe with neither map update nor tracking");
+        OVO_REQUIRE(mr.xyz && mr.ins && mr.state, "null map");
+        c.xyz = mr.xyz; c.ids = mr.ids; c.ins = mr.ins; c.rgb_out = mr.rgb; c.cap = mr.cap; c.state = (long long *)mr.state;
+        c.n_host = mr.n; c.id_host = mr.next_id;
+        if (c.do_map) {
+            OVO_REQUIRE(a->map.ids && a->explained && a->ws && a->h > 0 && a->w > 0 && a->ds >= 1, "bad map step");
+            const int64_t ws_w = (a->w + a->ds - 1) / a->ds;
+            c.n_sub = (int64_t)((a->h + a->ds - 1) / a->ds) * ws_w;
+            if (((c.n_sub + 63) >> 6) > SCAN_CHUNK) { ovo_set_error("ovo_round_chain: frame too large for the one-workgroup scan"); return OVO_E_UNSUPPORTED; }
+            OVO_REQUIRE(a->ws_bytes >= ovo_compact_workspace_bytes(c.n_sub) + 8, "workspace too small");
+            OVO_REQUIRE(a->map.cap >= a->n_upper + c.n_sub, "map capacity below n_upper + one frame of points");
+            c.depth = a->depth; c.rgb = a->rgb; c.cam_map = a->cam;
+            for (int i = 0; i < 9; ++i) c.bp.K[i] = a->K[i];
+            for (int i = 0; i < 16; ++i) c.bp.c2w[i] = a->c2w[i];
+            c.bp.h = a->h; c.bp.w = a->w; c.bp.ds = a->ds; c.bp.ws_w = (int)ws_w; c.bp.erode = a->erode;
+            c.erode = a->erode;
+            c.explained = a->explained;
+            c.total = (long long *)a->ws;
+            CompactWs cw = carve((char *)a->ws + 8, c.n_sub);
+            c.words = cw.words; c.offs = cw.offs;
+            c.map_result = (volatile long long *)a->result_host; c.map_seq = a->seq;
+        }
+        if (c.do_track) {
+            if (t->n_masks > CHAIN_MAX_MASKS) { ovo_set_error("ovo_round_chain: more than %d masks", CHAIN_MAX_MASKS); return OVO_E_UNSUPPORTED; }
+            OVO_REQUIRE(t->depth && t->seg_map && t->point_seg && t->ws && t->next_ins && t->hist_cols >= 1, "bad track step");
+            OVO_REQUIRE(t->ws_bytes >= ovo_track_workspace_bytes(t->n_masks, t->hist_cols), "workspace too small");
+            OVO_REQUIRE(!t->masks || (t->pixels > 0 && t->pixels % 16 == 0 && ((uintptr_t)t->masks & 15) == 0), "masks: pixels must be a multiple of 16");
+            const int nm = t->n_masks;
+            if (!c.do_map) c.cam_map = t->cam;
+            c.depth_t = t->depth;
+            c.filter = t->filter_depth; c.depth_f = t->depth_scratch; c.filter_th = 0.05f;
+            OVO_REQUIRE(!c.filter || c.depth_f, "depth_scratch needed for the depth filter");
+            c.cam = t->cam; c.ratio = t->ratio; c.seg_map = t->seg_map; c.seg_h = t->seg_h; c.seg_w = t->seg_w;
+            c.masks = (uint4 *)t->masks; c.n_masks = nm; c.px16 = t->masks ? t->pixels / 16 : 0; c.point_seg = t->point_seg;
+            c.hist = (int32_t *)t->ws;
+            c.stats = c.hist + (size_t)nm * t->hist_cols;
+            c.counters = (unsigned long long *)(c.stats + 4 * (size_t)nm + ((((size_t)nm * t->hist_cols) & 1) ? 1 : 0));
+            unsigned int *tickets = (unsigned int *)(c.counters + 2);
+            c.dst = (int32_t *)(tickets + 2 + nm);
+            c.res = c.dst + nm;
+            c.zero_bytes = (long long)((char *)c.dst - (char *)c.hist);
+            c.hist_cols = t->hist_cols; c.track_th = t->track_th;
+            c.next_ins = t->next_ins; c.next_host = t->next_ins_host;
+            c.result = (volatile int32_t *)t->result_host; c.seq = t->seq;
+        }
+        slot[k] = c;
+    }
+    const unsigned nblk = ctx->workgroups > 0 ? (unsigned)ctx->workgroups : 64u;
+    GridBar gb;
+    gb.count = (unsigned long long *)ctx->barrier; gb.abort = (unsigned int *)(ctx->barrier + 1); gb.base = ctx->arrivals; gb.nblk = nblk;
+    const BlurTaps taps = make_blur_taps(7, 2.5f);
+    k_round_chain<<<nblk, 256, 0, (hipStream_t)stream>>>(slot, n, gb, taps);
+    OVO_CHECK_LAUNCH();
+    ctx->arrivals += (uint64_t)nblk * CHAIN_BARRIERS * n;
+    ctx->next_slot += 1;
     return OVO_OK;
 }
 

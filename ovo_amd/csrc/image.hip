@@ -1,33 +1,16 @@
 // image.hip -- per-frame image-space helpers: depth high-pass filter (geometry_utils.py:92-96),
 // mask bit-packing and pairwise mask intersections for NMS (segment_utils.py:195-230).
 #include "common.h"
+#include "depth_filter.h"
 
 namespace {
-
-struct BlurTaps { float w[15 * 15]; int k; };
-
-__device__ __forceinline__ int reflect(int i, int n) {   // torch 'reflect' padding (no edge repeat)
-    if (i < 0) i = -i;
-    if (i >= n) i = 2 * n - 2 - i;
-    return i;
-}
 
 __global__ void __launch_bounds__(256) k_depth_filter(const float *__restrict__ depth, int h, int w, BlurTaps taps, float th,
                                                       float *__restrict__ out) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    const int k = taps.k, p = k >> 1;
-    float acc = 0.f;
-    for (int dy = 0; dy < k; ++dy) {
-        const int yy = reflect(y + dy - p, h);
-        for (int dx = 0; dx < k; ++dx) {
-            const int xx = reflect(x + dx - p, w);
-            acc = fmaf(taps.w[dy * k + dx], depth[(int64_t)yy * w + xx], acc);
-        }
-    }
-    const float d = depth[(int64_t)y * w + x];
-    out[(int64_t)y * w + x] = fabsf(d - acc) > th ? -1.0f : d;
+    out[(int64_t)y * w + x] = depth_filter_pixel(depth, h, w, taps, th, x, y);
 }
 
 __global__ void __launch_bounds__(256) k_pack_masks(const uint8_t *__restrict__ masks, int64_t pixels, unsigned long long *__restrict__ bits,
@@ -143,20 +126,7 @@ int ovo_depth_filter(const float *depth, int h, int w, int ksize, float sigma, f
     OVO_REQUIRE(depth && out && h > 0 && w > 0, "null / empty image");
     OVO_REQUIRE(ksize >= 1 && ksize <= 15 && (ksize & 1) && sigma > 0.f, "ksize must be odd and <= 15");
     OVO_REQUIRE(h > ksize / 2 && w > ksize / 2, "image smaller than the reflect padding");
-    BlurTaps t;
-    t.k = ksize;
-    // torchvision _get_gaussian_kernel1d: pdf at linspace(-(k-1)/2, (k-1)/2, k), normalised, in fp32
-    float k1[15], sum = 0.f;
-    const float half = (ksize - 1) * 0.5f;
-    for (int i = 0; i < ksize; ++i) {
-        const float x = ksize == 1 ? 0.f : -half + (2.f * half) * (float)i / (float)(ksize - 1);
-        const float r = x / sigma;
-        k1[i] = expf(-0.5f * r * r);
-        sum += k1[i];
-    }
-    for (int i = 0; i < ksize; ++i) k1[i] /= sum;
-    for (int a = 0; a < ksize; ++a)
-        for (int b = 0; b < ksize; ++b) t.w[a * ksize + b] = k1[a] * k1[b];
+    const BlurTaps t = make_blur_taps(ksize, sigma);
     dim3 grid((w + 63) / 64, (h + 3) / 4);
     k_depth_filter<<<grid, 256, 0, (hipStream_t)stream>>>(depth, h, w, t, th, out);
     OVO_CHECK_LAUNCH();

@@ -140,7 +140,7 @@ class OVO:
             self._time_cache = []
         return updated
 
-    def detect_and_track_launch(self, frame_data, slam, c2w, stream=None) -> Optional[Dict[str, Any]]:
+    def detect_and_track_launch(self, frame_data, slam, c2w, stream=None, defer: bool = False) -> Optional[Dict[str, Any]]:
         """`detect_and_track_objects` split in two (MI355X extension): this half gets the masks and QUEUES the tracking chain against
         `slam`'s device-resident map (whose `map_launch` calls may be in flight); `detect_and_track_finish` reads the result block.
         A round of keyframes is queued back to back and finished in order: the host never stalls the device between keyframes.
@@ -150,7 +150,7 @@ class OVO:
         if len(seg_map) == 0:
             print(f"No mask segmented in {frame_id}!")
             return None
-        pend = self.track_launch(frame_data[1:], None, c2w, seg_map, binary_maps, slam=slam, stream=stream)
+        pend = self.track_launch(frame_data[1:], None, c2w, seg_map, binary_maps, slam=slam, stream=stream, defer=defer)
         pend["frame"] = (frame_id, image)
         return pend
 
@@ -188,13 +188,16 @@ class OVO:
         return (not self.debug_info and not self.config.get("host_decisions", False) and 0 < n_all <= self.MAX_RESULT_MASKS and pixels % 16 == 0 and binary_maps.is_contiguous()
                 and binary_maps.element_size() == 1 and (not self.objects or self.next_ins_id > max(self.objects)))
 
-    def track_launch(self, frame_data, map_data, c2w, seg_map: torch.Tensor, binary_maps: torch.Tensor, slam=None, stream=None) -> Dict[str, Any]:
+    def track_launch(self, frame_data, map_data, c2w, seg_map: torch.Tensor, binary_maps: torch.Tensor, slam=None, stream=None,
+                     defer: bool = False) -> Dict[str, Any]:
         """Queue the tracking chain of one keyframe (MI355X extension; no host round trip).  `map_data` as in the reference; with
         `slam` (a VanillaMapper whose `map_launch` calls may still be in flight) the map's size is read on the device and the
         instance ids are assigned in place in the mapper's buffer.  Returns the pending record `track_finish` consumes; several
         keyframes may be queued before the first is finished (they must be finished in order).  `stream`: queue on this torch stream
         instead of the current one (the mapper's `map_launch` calls must use the same one); the chain then starts after everything queued
-        on the CURRENT stream so far (its inputs and buffers are allocated here), and `track_finish` makes the current stream wait for it."""
+        on the CURRENT stream so far (its inputs and buffers are allocated here), and `track_finish` makes the current stream wait for it.
+        `defer`: do not launch; the `ovo_track_step_t` is left in the record (`pend["step"]`) for the caller's `ovo_round_chain`, who also
+        sets `pend["done"]`."""
         image, depth_in, ratio = frame_data
         lib = L.load()
         h, w = depth_in.shape
@@ -250,7 +253,9 @@ class OVO:
         seq, slot = self._track_ring.next()
         a.result_host, a.seq = slot, seq
         done = None
-        if stream is None:
+        if defer:
+            pass
+        elif stream is None:
             L.check(lib.ovo_track_step(L.C.byref(a), L.stream()))
         else:
             ready = torch.cuda.Event()                            # the buffers above were allocated (and the masks produced) on the current
@@ -260,7 +265,7 @@ class OVO:
             done = torch.cuda.Event()
             done.record(stream)
         pend = {"seq": seq, "n_masks": n_masks, "point_seg": point_seg, "binary_maps": binary_maps, "ins": ins_view, "slam": slam,
-                "keep": (depth, seg_map), "done": done}
+                "keep": (depth, seg_map), "done": done, "step": a if defer else None}
         self._track_pending.append(pend)
         return pend
 
@@ -271,6 +276,8 @@ class OVO:
             raise L.OvoHipError("track_finish: keyframes must be finished in the order they were launched")
         res = self._track_ring.wait(pend["seq"])
         self._track_pending.popleft()
+        if int(res[6]) != 0:
+            raise L.OvoHipError("the round chain aborted on the device (a grid barrier timed out)")
         if pend["done"] is not None:                               # what follows on the current stream reads the chain's outputs
             torch.cuda.current_stream().wait_event(pend["done"])
         kf_id, n_masks = self.kf_id, pend["n_masks"]

@@ -41,6 +41,7 @@ from .encoders.hiera import SPECS as HIERA_SPECS, HipHiera
 from .encoders.vit import SPECS as VIT_SPECS, HipViT
 from .entities.clip_generator import CLIPGenerator
 from .entities.ovo import OVO
+from .entities.round_chain import RoundLauncher
 from .slam.vanilla_mapper import VanillaMapper
 from .utils import clip_utils, geometry_utils as G
 from .utils.streams import side_stream
@@ -177,6 +178,7 @@ class FramePipeline:
         self.mask_exchanges = 0
         self._chains: Dict[int, list] = {}                         # first frame index of a round -> its queued chains (software pipelining)
         self.pipeline_rounds = not os.environ.get("OVO_NO_ROUND_PIPELINE")
+        self.round_launcher = RoundLauncher(self.device)           # one persistent launch per round instead of ~12 launches per keyframe
         # The chains of consecutive keyframes depend on each other (device-resident map size / instance ids) and so do the keyframes' tails
         # (descriptor store, fusion, dense scatter + query); a chain and a tail of DIFFERENT keyframes do not.  On one stream they queue
         # behind each other -- ~25 small dependent launches per keyframe, each waiting for a free CU among the encoders' workgroups -- so
@@ -390,17 +392,37 @@ class FramePipeline:
 
     # ------------------------------------------------------------------ owner -> replica masks
     def _launch_chains(self, group: List[Frame], ratio) -> list:
-        """Queue map update + tracking chain of every keyframe of a round (no host round trip: `ovo_map_step` / `ovo_track_step`)."""
+        """Queue map update + tracking chain of every keyframe of a round -- no host round trip -- as ONE launch (`ovo_round_chain`:
+        persistent workgroups walking through all passes of all keyframes); a round that call does not cover goes keyframe by
+        keyframe (`ovo_map_step` / `ovo_track_step`)."""
         G.prepare_frame_cameras([(f.depth, f.c2w) for f in group], self.slam._K_host)
-        pend = []
+        side = self.chain_stream
+        maps, tracks, pend = [], [], []
         for f in group:
             fd = [f.index, f.rgb_lr, f.depth, f.c2w]
             self.slam.track_camera(fd)
             c2w = self.slam._c2w_host[f.index]                     # host copy: no D2H for the frustum set-up
-            if f.ready is not None and self.chain_stream is not None:
-                self.chain_stream.wait_event(f.ready)              # the frame's upload, if it is still in flight
-            self.slam.map_launch(fd, c2w, stream=self.chain_stream)
-            pend.append(self.ovo.detect_and_track_launch([f.index, f.rgb, f.depth, ratio], self.slam, c2w, stream=self.chain_stream))
+            if f.ready is not None and side is not None:
+                side.wait_event(f.ready)                           # the frame's upload, if it is still in flight
+            m = self.slam.map_launch(fd, c2w, defer=True)
+            p = self.ovo.detect_and_track_launch([f.index, f.rgb, f.depth, ratio], self.slam, c2w, defer=True)
+            pend.append(p)
+            if m is not None or p is not None:
+                maps.append(m if m is not None else L.MapStep())
+                tracks.append(p["step"] if p is not None else L.TrackStep())
+        if not maps:
+            return pend
+        if side is not None:
+            ready = torch.cuda.Event()                             # the chains' buffers (and masks) were produced on the current stream
+            ready.record()
+            side.wait_event(ready)
+        self.round_launcher.launch(maps, tracks, side)
+        if side is not None:
+            done = torch.cuda.Event()
+            done.record(side)
+            for p in pend:
+                if p is not None:
+                    p["done"] = done
         return pend
 
     def _own_masks(self, mine: Frame, amg_pending):

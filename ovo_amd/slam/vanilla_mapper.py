@@ -49,6 +49,7 @@ class VanillaMapper:
         self._ring = L.PinnedRing(4, np.int64, 64)
         self._explained = None
         self._ws = None
+        self._keep: deque = deque(maxlen=64)
         self._cap = 0
         self._xyz = self._ids = self._ins = self._rgb = None
         self._reserve(1 << 16)
@@ -165,15 +166,16 @@ class VanillaMapper:
         self.map_launch(frame_data, c2w)
         self.settle()
 
-    def map_launch(self, frame_data: List[Any], c2w: torch.Tensor, stream=None) -> None:
+    def map_launch(self, frame_data: List[Any], c2w: torch.Tensor, stream=None, defer: bool = False):
         """`map` without the host round trip (MI355X extension): queues the frame's passes; the map's size advances on the device.
         `stream`: a torch stream to queue on instead of the current one (every call of one mapper must use the same stream: the
-        passes of consecutive frames depend on each other through the device-resident state)."""
+        passes of consecutive frames depend on each other through the device-resident state).  `defer`: build and RETURN the
+        `ovo_map_step_t` (None: nothing to do for this frame) without launching -- the caller hands a round of them to `ovo_round_chain`."""
         frame_id, image, depth_in = frame_data[0], frame_data[1], frame_data[2]
         h, w = depth_in.shape
         near, far = G.depth_range(depth_in)
         if not far > 0:                                    # no valid depth: :60 returns early on a non-empty map, and an empty
-            return                                         # map would receive no point either
+            return None                                    # map would receive no point either
         lib = L.load()
         dev = self.device
         depth = G.to_device(depth_in, torch.float32, dev)
@@ -205,8 +207,12 @@ class VanillaMapper:
         a.ds, a.erode, a.n_upper = ds, int(self.k_pooling > 1), self._n_upper
         a.explained, a.ws, a.ws_bytes = self._explained.data_ptr(), ws.data_ptr(), nb
         a.result_host, a.seq = slot, seq
-        L.check(lib.ovo_map_step(L.C.byref(a), L.stream() if stream is None else L.C.c_void_p(stream.cuda_stream)))
+        self._keep.append((depth, rgb))                    # raw pointers cross the ABI (later, when deferred): keep converted copies alive
         self._pending.append((seq, n_sub))
+        if defer:
+            return a
+        L.check(lib.ovo_map_step(L.C.byref(a), L.stream() if stream is None else L.C.c_void_p(stream.cuda_stream)))
+        return None
 
     # ------------------------------------------------------------------ map access
     def get_map(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:

@@ -143,9 +143,10 @@ def test_tracking_golden_device_decisions(tag, filt):
         assert sorted(o.top_kf) == [tuple(r) for r in d[f"obj{j}_topkf"].tolist()]
 
 
-def _run_keyframes(queued: bool, n_frames=6, top_k=2):
+def _run_keyframes(queued, n_frames=6, top_k=2):
     """n keyframes of the synthetic stream through mapper + tracker; `queued`: all map / tracking chains are launched back to back
-    (sizes and instance ids device-resident) and finished afterwards, else one keyframe at a time with host decisions."""
+    (sizes and instance ids device-resident) and finished afterwards -- "chain": all of them in ONE launch of the persistent round
+    kernel (`ovo_round_chain`) -- else one keyframe at a time with host decisions."""
     from ovo_amd import synthetic as syn
     from ovo_amd.entities.ovo import OVO
     from ovo_amd.slam.vanilla_mapper import VanillaMapper
@@ -163,7 +164,22 @@ def _run_keyframes(queued: bool, n_frames=6, top_k=2):
     ovo = OVO(cfg, None, None, K, device=DEV, clip_generator=_NoClip(), mask_generator=Masks())
     vm = VanillaMapper({"device": DEV, "mapping": {}}, K)
     frames = [syn.frame(t, scale=scale, seed=11) for t in range(n_frames)]
-    if queued:
+    if queued == "chain":
+        from ovo_amd.entities.round_chain import RoundLauncher
+        vm.reserve(n_frames * h * w)
+        maps, tracks, pend = [], [], []
+        for fid, rgb, depth, c2w in frames:
+            fd = [fid, rgb, depth, c2w]
+            vm.track_camera(fd)
+            maps.append(vm.map_launch(fd, vm._c2w_host[fid], defer=True))
+            pend.append(ovo.detect_and_track_launch([fid, rgb, depth, ()], vm, vm._c2w_host[fid], defer=True))
+            tracks.append(pend[-1]["step"])
+        launcher = RoundLauncher(DEV, workgroups=48)
+        launcher.launch(maps, tracks)
+        assert launcher.launches == 1 and launcher.fallbacks == 0
+        for p in pend:
+            ovo.detect_and_track_finish(p)
+    elif queued:
         vm.reserve(n_frames * h * w)
         pend = []
         for fid, rgb, depth, c2w in frames:
@@ -187,10 +203,12 @@ def _run_keyframes(queued: bool, n_frames=6, top_k=2):
             "queue": [(m, b.cpu(), kf) for m, b, _, kf in ovo.keyframes_queue]}
 
 
-def test_queued_keyframe_chains_equal_one_by_one_host_decisions():
-    """Six keyframes queued back to back on the device (map size, point ids, instance ids resident; one result block each) give the
-    map, the instance list, the heaps and the fused masks of the keyframe-at-a-time run with host decisions, bit for bit."""
-    a, b = _run_keyframes(True), _run_keyframes(False)
+@pytest.mark.parametrize("mode", [True, "chain"])
+def test_queued_keyframe_chains_equal_one_by_one_host_decisions(mode):
+    """Six keyframes queued back to back on the device (map size, point ids, instance ids resident; one result block each) -- as
+    ~12 launches per keyframe, or all in ONE persistent launch with grid barriers -- give the map, the instance list, the heaps and
+    the fused masks of the keyframe-at-a-time run with host decisions, bit for bit."""
+    a, b = _run_keyframes(mode), _run_keyframes(False)
     assert a["max_id"] == b["max_id"] and a["next"] == b["next"] and a["next"] > 5
     for k in ("pcd", "ids", "ins", "rgb"):
         assert torch.equal(a[k], b[k]), k
