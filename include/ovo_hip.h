@@ -284,12 +284,21 @@ int ovo_im2col(const float *img, int B, int C, int H, int W, int ksz, int stride
                ovo_stream_t stream);
 
 /* Crop + resize (bilinear, align_corners = False, optional antialias exactly as torch's
- * F.interpolate(..., antialias=True)) + per-channel normalise: out[c] = (resize(src[c]) * scale - mean[c]) / std[c].
+ * F.interpolate(..., antialias=True); antialias = 2: antialiased bicubic) + per-channel normalise: out[c] = (resize(src[c]) * scale - mean[c]) / std[c].
  * src is CHW, u8 (src_dtype 3) or f32 (0), or an interleaved u8 [H, W, C] frame as the camera delivers it (src_dtype 4: no permute
  * pass before the encoders); the crop is rows [y0, y0+ch) x cols [x0, x0+cw). out f32 [C, oh, ow]. */
 int ovo_resize_normalize(const void *src, int src_dtype, int C, int H, int W, int y0, int x0, int ch, int cw,
                          float *out, int oh, int ow, int antialias, float scale, const float *mean3_host,
                          const float *std3_host, ovo_stream_t stream);
+
+/* The kept transforms of open_clip's preprocess (clip_utils.py:83-84: Resize + CenterCrop + Normalize; clip_generator.py:112-122 pushes whole
+ * frames and mask crops through them): the output [C, oh, ow] is the WINDOW (top, left, oh, ow) of the crop's resize to virt_h x virt_w --
+ * torchvision Resize(size) on the shorter side followed by CenterCrop(size) -- never materialising the part that is cropped away.
+ * filter: 0 = bilinear, 1 = antialiased bilinear, 2 = antialiased bicubic (F.interpolate(mode="bicubic", antialias=True): Keys a = -0.5;
+ * float input is not clamped, like torchvision's tensor path).  ovo_resize_normalize = this with the window covering the whole output. */
+int ovo_resize_window_normalize(const void *src, int src_dtype, int C, int H, int W, int y0, int x0, int ch, int cw, float *out,
+                                int oh, int ow, int virt_h, int virt_w, int top, int left, int filter, float scale,
+                                const float *mean3_host, const float *std3_host, ovo_stream_t stream);
 
 /* ---- a14: per-mask crops of the crop-mode descriptors (segment_utils.py:29-41 segmap2segimg, :43-94, :118-172) ----
  * ovo_mask_boxes: masks u8 [n, H, W] -> boxes i32 [n, 4] = (x, y, w, h) with the reference's w = x_max - x_min,

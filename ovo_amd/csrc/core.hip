@@ -40,7 +40,7 @@ void ovo_prof_begin(int kind, double work, hipStream_t s) {
     if (!g_prof.on || g_prof.recs.size() >= (1u << 20)) return;
     Rec r; r.kind = kind; r.work = work; r.shape[0] = r.shape[1] = r.shape[2] = 0; r.a = g_prof.get(); r.b = g_prof.get();
     if (!r.a || !r.b) return;
-    hipEventRecord(r.a, s);
+    (void)hipEventRecord(r.a, s);
     g_prof.recs.push_back(r);
 }
 void ovo_prof_shape(int a, int b, int c) {
@@ -50,7 +50,7 @@ void ovo_prof_shape(int a, int b, int c) {
 }
 void ovo_prof_end(hipStream_t s) {
     if (!g_prof.on || g_prof.recs.empty()) return;
-    hipEventRecord(g_prof.recs.back().b, s);
+    (void)hipEventRecord(g_prof.recs.back().b, s);
 }
 
 template <typename T>

@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(256) k_im2col(const float *__restrict__ img, i
 // ---- crop + resize + normalise ----
 struct ResizeArgs {
     const void *src; int src_u8, hwc; int C, H, W, y0, x0, ch, cw, oh, ow, aa;     // hwc: interleaved [H, W, C] source (a camera frame as it arrives)
+    int vh, vw, top, left;         // the output is the window (top, left, oh, ow) of a virtual vh x vw resize (Resize + CenterCrop)
     float scale, mean[4], std[4];
 };
 __device__ __forceinline__ float src_px(const ResizeArgs &a, int c, int y, int x) {
@@ -118,14 +119,23 @@ __device__ __forceinline__ float src_px(const ResizeArgs &a, int c, int y, int x
     return a.src_u8 ? (float)((const uint8_t *)a.src)[i] : ((const float *)a.src)[i];
 }
 __device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
+// Keys cubic with a = -0.5: the kernel of torch's antialiased bicubic (_upsample_bicubic2d_aa; the plain bicubic uses -0.75)
+__device__ __forceinline__ float cubic_aa(float x) {
+    x = fabsf(x);
+    if (x < 1.f) return ((1.5f * x - 2.5f) * x) * x + 1.f;
+    if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * -0.5f;
+    return 0.f;
+}
+__device__ __forceinline__ float aa_filter(int kind, float x) { return kind == 2 ? cubic_aa(x) : tri(x); }
 
 // One thread per output pixel; the tap weights do not depend on the channel, so they are computed once (the first version recomputed them,
 // divisions included, per channel and per tap: 30 us for a 1024^2 output that is 13 MB of stores) and the channels run innermost.
 #define OVO_RS_TAPS 10                                  // taps per axis held in registers: down-scaling up to ~4.5x; beyond that the generic loop
 __global__ void __launch_bounds__(256) k_resize_norm(ResizeArgs a, float *__restrict__ out) {
-    const int ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (ox >= a.ow || oy >= a.oh) return;
-    const float sy = (float)a.ch / (float)a.oh, sx = (float)a.cw / (float)a.ow;
+    const int wx_ = blockIdx.x * 64 + (threadIdx.x & 63), wy_ = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (wx_ >= a.ow || wy_ >= a.oh) return;
+    const int ox = wx_ + a.left, oy = wy_ + a.top;     // position in the virtual vh x vw output
+    const float sy = (float)a.ch / (float)a.vh, sx = (float)a.cw / (float)a.vw;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (!a.aa) {                                        // torch upsample_bilinear2d, align_corners = False
         float fy = sy * ((float)oy + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
@@ -136,8 +146,9 @@ __global__ void __launch_bounds__(256) k_resize_norm(ResizeArgs a, float *__rest
         for (int c = 0; c < a.C; ++c)
             v[c] = (1.f - ly) * ((1.f - lx) * src_px(a, c, y0, x0) + lx * src_px(a, c, y0, x1)) +
                    ly * ((1.f - lx) * src_px(a, c, y1, x0) + lx * src_px(a, c, y1, x1));
-    } else {                                            // torch _upsample_bilinear2d_aa (separable triangle filter)
-        const float supy = sy >= 1.f ? sy : 1.f, supx = sx >= 1.f ? sx : 1.f;
+    } else {                                            // torch _upsample_bilinear2d_aa / _upsample_bicubic2d_aa (separable triangle / cubic filter)
+        const float half = a.aa == 2 ? 2.f : 1.f;       // interp_size / 2
+        const float supy = (sy >= 1.f ? sy : 1.f) * half, supx = (sx >= 1.f ? sx : 1.f) * half;
         const float ivy = sy >= 1.f ? 1.f / sy : 1.f, ivx = sx >= 1.f ? 1.f / sx : 1.f;
         const float cy = sy * ((float)oy + 0.5f), cx = sx * ((float)ox + 0.5f);
         int ymin = (int)(cy - supy + 0.5f); ymin = ymin < 0 ? 0 : ymin;
@@ -145,15 +156,15 @@ __global__ void __launch_bounds__(256) k_resize_norm(ResizeArgs a, float *__rest
         int xmin = (int)(cx - supx + 0.5f); xmin = xmin < 0 ? 0 : xmin;
         int xmax = (int)(cx + supx + 0.5f); xmax = xmax > a.cw ? a.cw : xmax;
         float wy_tot = 0.f, wx_tot = 0.f;
-        for (int y = ymin; y < ymax; ++y) wy_tot += tri(((float)y - cy + 0.5f) * ivy);
-        for (int x = xmin; x < xmax; ++x) wx_tot += tri(((float)x - cx + 0.5f) * ivx);
+        for (int y = ymin; y < ymax; ++y) wy_tot += aa_filter(a.aa, ((float)y - cy + 0.5f) * ivy);
+        for (int x = xmin; x < xmax; ++x) wx_tot += aa_filter(a.aa, ((float)x - cx + 0.5f) * ivx);
         const int ny = ymax - ymin, nx = xmax - xmin;
         if (ny <= OVO_RS_TAPS && nx <= OVO_RS_TAPS) {
             float wy[OVO_RS_TAPS], wx[OVO_RS_TAPS];
 #pragma unroll
             for (int i = 0; i < OVO_RS_TAPS; ++i) {
-                wy[i] = i < ny ? tri(((float)(ymin + i) - cy + 0.5f) * ivy) / wy_tot : 0.f;
-                wx[i] = i < nx ? tri(((float)(xmin + i) - cx + 0.5f) * ivx) / wx_tot : 0.f;
+                wy[i] = i < ny ? aa_filter(a.aa, ((float)(ymin + i) - cy + 0.5f) * ivy) / wy_tot : 0.f;
+                wx[i] = i < nx ? aa_filter(a.aa, ((float)(xmin + i) - cx + 0.5f) * ivx) / wx_tot : 0.f;
             }
 #pragma unroll
             for (int iy = 0; iy < OVO_RS_TAPS; ++iy) {
@@ -170,16 +181,16 @@ __global__ void __launch_bounds__(256) k_resize_norm(ResizeArgs a, float *__rest
             for (int c = 0; c < a.C; ++c) {
                 float acc = 0.f;
                 for (int y = ymin; y < ymax; ++y) {
-                    const float wyy = tri(((float)y - cy + 0.5f) * ivy) / wy_tot;
+                    const float wyy = aa_filter(a.aa, ((float)y - cy + 0.5f) * ivy) / wy_tot;
                     float rowacc = 0.f;
-                    for (int x = xmin; x < xmax; ++x) rowacc += (tri(((float)x - cx + 0.5f) * ivx) / wx_tot) * src_px(a, c, y, x);
+                    for (int x = xmin; x < xmax; ++x) rowacc += (aa_filter(a.aa, ((float)x - cx + 0.5f) * ivx) / wx_tot) * src_px(a, c, y, x);
                     acc += wyy * rowacc;
                 }
                 v[c] = acc;
             }
         }
     }
-    for (int c = 0; c < a.C; ++c) out[((long long)c * a.oh + oy) * a.ow + ox] = (v[c] * a.scale - a.mean[c]) / a.std[c];
+    for (int c = 0; c < a.C; ++c) out[((long long)c * a.oh + wy_) * a.ow + wx_] = (v[c] * a.scale - a.mean[c]) / a.std[c];
 }
 
 // ---- a14: per-mask crops for the crop-mode descriptors (segment_utils.py:29-41, 118-170) ----
@@ -481,20 +492,30 @@ int ovo_im2col(const float *img, int B, int C, int H, int W, int ksz, int stride
     return OVO_OK;
 }
 
-int ovo_resize_normalize(const void *src, int src_dtype, int C, int H, int W, int y0, int x0, int ch, int cw, float *out,
-                         int oh, int ow, int antialias, float scale, const float *mean3_host, const float *std3_host,
-                         ovo_stream_t stream) {
+int ovo_resize_window_normalize(const void *src, int src_dtype, int C, int H, int W, int y0, int x0, int ch, int cw, float *out,
+                                int oh, int ow, int virt_h, int virt_w, int top, int left, int filter, float scale,
+                                const float *mean3_host, const float *std3_host, ovo_stream_t stream) {
     OVO_REQUIRE(src && out && (src_dtype == 0 || src_dtype == 3 || src_dtype == 4), "src_dtype: 0 = f32 [C,H,W], 3 = u8 [C,H,W], 4 = u8 [H,W,C]");
     OVO_REQUIRE(C >= 1 && C <= 4 && ch > 0 && cw > 0 && oh > 0 && ow > 0, "bad shape");
     OVO_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + ch <= H && x0 + cw <= W, "crop outside the image");
+    OVO_REQUIRE(top >= 0 && left >= 0 && top + oh <= virt_h && left + ow <= virt_w, "window outside the resized image");
+    OVO_REQUIRE(filter >= 0 && filter <= 2, "filter: 0 = bilinear, 1 = antialiased bilinear, 2 = antialiased bicubic");
     ResizeArgs a;
     a.src = src; a.src_u8 = src_dtype >= 3; a.hwc = src_dtype == 4; a.C = C; a.H = H; a.W = W; a.y0 = y0; a.x0 = x0; a.ch = ch; a.cw = cw;
-    a.oh = oh; a.ow = ow; a.aa = antialias; a.scale = scale;
+    a.oh = oh; a.ow = ow; a.aa = filter; a.scale = scale;
+    a.vh = virt_h; a.vw = virt_w; a.top = top; a.left = left;
     for (int c = 0; c < 4; ++c) { a.mean[c] = mean3_host && c < C ? mean3_host[c] : 0.f; a.std[c] = std3_host && c < C ? std3_host[c] : 1.f; }
     dim3 grid((ow + 63) / 64, (oh + 3) / 4);
     k_resize_norm<<<grid, 256, 0, (hipStream_t)stream>>>(a, out);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
+}
+
+int ovo_resize_normalize(const void *src, int src_dtype, int C, int H, int W, int y0, int x0, int ch, int cw, float *out,
+                         int oh, int ow, int antialias, float scale, const float *mean3_host, const float *std3_host,
+                         ovo_stream_t stream) {
+    return ovo_resize_window_normalize(src, src_dtype, C, H, W, y0, x0, ch, cw, out, oh, ow, oh, ow, 0, 0, antialias, scale, mean3_host,
+                                       std3_host, stream);
 }
 
 int ovo_mask_boxes(const uint8_t *masks, int n, int H, int W, int32_t *boxes_xywh, ovo_stream_t stream) {

@@ -43,6 +43,11 @@ class ViTSpec:
     attn_pool_heads: int = 0          # > 0: PE attention-pool head (only W_v / W_o / proj are used by TextRegion)
     map_pool: bool = False            # SigLIP: timm AttentionPoolLatent head instead of class token + proj
     patch_bias: bool = False          # conv1 has a bias (timm / SigLIP patch embedding)
+    # the card's open_clip preprocess (open_clip 2.32 `image_transform`, of which clip_utils.py:83-84 keeps Resize / CenterCrop /
+    # Normalize): "shortest" = Resize(size) on the shorter side + CenterCrop(size) (OpenAI / LAION / DFN cards), "squash" =
+    # Resize((size, size)) (the timm-hub cards: SigLIP, PE); torchvision 0.20 resizes tensors antialiased
+    resize_mode: str = "shortest"
+    interpolation: str = "bicubic"
 
     @property
     def grid(self) -> int:
@@ -75,23 +80,23 @@ SPECS: Dict[str, ViTSpec] = {
     "ViT-H-14": ViTSpec("ViT-H-14", 224, 14, 1280, 32, 16, 5120, 1024),
     "ViT-H-14-qg": ViTSpec("ViT-H-14-qg", 224, 14, 1280, 32, 16, 5120, 1024, act="quick_gelu"),
     "PE-Core-L14-336": ViTSpec("PE-Core-L14-336", 336, 14, 1024, 24, 16, 4096, 1024, use_rope=True,
-                               mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), attn_pool_heads=8),
+                               mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), attn_pool_heads=8, resize_mode="squash", interpolation="bilinear"),
     "ViT-H-14-378qg": ViTSpec("ViT-H-14-378qg", 378, 14, 1280, 32, 16, 5120, 1024, act="quick_gelu"),
     # SigLIP so400m towers (open_clip "ViT-SO400M-14-SigLIP[-384]", clip_utils.py:62-75): no class token, no ln_pre,
     # tanh-GELU, LayerNorm eps 1e-6, attention-pool head, no output projection
     "SigLIP": ViTSpec("SigLIP", 224, 14, 1152, 27, 16, 4304, 1152, act="gelu_tanh", pre_ln=False, cls_token=False, ln_eps=1e-6,
-                      mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), map_pool=True, patch_bias=True),
+                      mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), map_pool=True, patch_bias=True, resize_mode="squash"),
     "SigLIP-384": ViTSpec("SigLIP-384", 384, 14, 1152, 27, 16, 4304, 1152, act="gelu_tanh", pre_ln=False, cls_token=False,
-                          ln_eps=1e-6, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), map_pool=True, patch_bias=True),   # 27x27 patches: the
+                          ln_eps=1e-6, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), map_pool=True, patch_bias=True, resize_mode="squash"),   # 27x27 patches: the
                                                                                      # stride-14 conv ignores the last 6 rows / columns
     "SigLIP2-384": ViTSpec("SigLIP2-384", 384, 16, 1152, 27, 16, 4304, 1152, act="gelu_tanh", pre_ln=False, cls_token=False,
-                           ln_eps=1e-6, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), map_pool=True, patch_bias=True),
+                           ln_eps=1e-6, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), map_pool=True, patch_bias=True, resize_mode="squash"),
     # reduced shapes for tests
     "tiny-siglip": ViTSpec("tiny-siglip", 56, 14, 128, 2, 4, 432, 128, act="gelu_tanh", pre_ln=False, cls_token=False, ln_eps=1e-6,
-                           mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), map_pool=True, patch_bias=True),
+                           mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), map_pool=True, patch_bias=True, resize_mode="squash"),
     "tiny-clip": ViTSpec("tiny-clip", 64, 16, 128, 2, 4, 512, 64, act="quick_gelu"),
     "tiny-pe": ViTSpec("tiny-pe", 84, 14, 128, 2, 4, 512, 128, use_rope=True, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5),
-                       attn_pool_heads=4),
+                       attn_pool_heads=4, resize_mode="squash", interpolation="bilinear"),
 }
 
 
@@ -276,6 +281,35 @@ class HipViT:
         for i, (y0, x0, ch, cw) in enumerate(crops):
             L.check(lib.ovo_resize_normalize(L.ptr(img), code, 3, h, w, y0, x0, ch, cw, L.ptr(out[i]),
                                              s.image_size, s.image_size, int(antialias), float(scale), mean, std, L.stream()))
+        return out
+
+    def clip_window(self, h: int, w: int) -> Tuple[int, int, int, int]:
+        """(virt_h, virt_w, top, left) of the card's open_clip transform on an h x w image: torchvision `Resize(S)` puts the shorter side
+        at S and the longer at int(S * long / short); `CenterCrop(S)` starts at int(round((size - S) / 2)).  "squash": (S, S, 0, 0)."""
+        S = self.spec.image_size
+        if self.spec.resize_mode == "squash":
+            return S, S, 0, 0
+        vh, vw = (int(S * h / w), S) if w <= h else (S, int(S * w / h))
+        return vh, vw, int(round((vh - S) / 2.0)), int(round((vw - S) / 2.0))
+
+    def preprocess_clip(self, images: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The reference's `self.preprocess` (clip_generator.py:119, clip_utils.py:83-84) for a batch [B, 3, h, w] (u8 or f32): the card's
+        Resize (antialiased bicubic / bilinear, shorter side or squash) + CenterCrop + Normalize, one launch per image, writing only the
+        kept window."""
+        s = self.spec
+        x = L.dev(images, images.dtype, "images")
+        if x.dtype not in (torch.uint8, torch.float32):
+            raise L.OvoHipError("images must be u8 or f32")
+        b, _, h, w = x.shape
+        if out is None:
+            out = torch.empty((b, 3, s.image_size, s.image_size), dtype=torch.float32, device=x.device)
+        vh, vw, top, left = self.clip_window(h, w)
+        filt = 2 if s.interpolation == "bicubic" else 1
+        mean, std = (C.c_float * 3)(*s.mean), (C.c_float * 3)(*s.std)
+        lib = L.load()
+        for i in range(b):
+            L.check(lib.ovo_resize_window_normalize(L.ptr(x[i]), L.DTYPE_CODE[x.dtype], 3, h, w, 0, 0, h, w, L.ptr(out[i]), s.image_size, s.image_size,
+                                                    vh, vw, top, left, filt, float(scale), mean, std, L.stream()))
         return out
 
     # ---------------------------------------------------------------- forward

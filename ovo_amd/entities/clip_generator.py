@@ -109,15 +109,12 @@ class CLIPGenerator:
     # ------------------------------------------------------------------ image side
     @torch.no_grad()
     def encode_image(self, input: torch.Tensor) -> torch.Tensor:
-        """Reference: clip_generator.py:112-122.  [B, 3, h, w] (or [3, h, w]) in [0, 1] -> [B, D]."""
+        """Reference: clip_generator.py:112-122.  [B, 3, h, w] (or [3, h, w]) in [0, 1] -> [B, D]: the card's kept open_clip transforms
+        (Resize on the shorter side / squash, antialiased bicubic / bilinear, CenterCrop, Normalize; clip_utils.py:83-84), then the tower."""
         if input.dim() == 3:
             input = input[None]
         x = L.dev(input.float().contiguous(), torch.float32, "input")
-        s = self.model.spec
-        batch = torch.empty((x.shape[0], 3, s.image_size, s.image_size), dtype=torch.float32, device=x.device)
-        for i in range(x.shape[0]):
-            self.model.preprocess(x[i], out=batch[i:i + 1])
-        return self.model.forward(batch)
+        return self.model.forward(self.model.preprocess_clip(x))
 
     @torch.no_grad()
     def extract_clip(self, image: torch.Tensor, binary_maps: torch.Tensor, return_all: bool = False) -> torch.Tensor:

@@ -333,6 +333,32 @@ def test_resize_normalize_vs_torch(aa, src, crop, out):
     assert torch.equal(got, got_hwc)
 
 
+@pytest.mark.parametrize("card,src", [("ViT-B-16-qg", (480, 640)), ("ViT-B-16-qg", (640, 480)), ("ViT-B-16-qg", (384, 384)), ("ViT-H-14-378qg", (480, 640)),
+                                      ("SigLIP-384", (480, 640)), ("SigLIP", (150, 200)), ("PE-Core-L14-336", (480, 640)), ("tiny-clip", (150, 200)),
+                                      ("ViT-L-14-qg", (97, 1300))])
+def test_clip_preprocess_vs_torch(card, src):
+    """The kept open_clip transforms (clip_utils.py:83-84): Resize on the shorter side (antialiased bicubic) + CenterCrop for the OpenAI / DFN
+    cards -- a 640 x 480 frame becomes 298 x 224 and loses 37 columns on either side -- squash for the timm-hub cards; against torch's own
+    antialiased interpolate, which is what torchvision's tensor Resize calls.  Only the kept window is computed."""
+    from oracle import vit as OV
+    from ovo_amd.encoders.vit import SPECS, HipViT
+    spec = SPECS[card]
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(3, *src, generator=g)
+    vit = object.__new__(HipViT)
+    vit.spec, vit.device = spec, torch.device(DEV)
+    got = HipViT.preprocess_clip(vit, img[None].to(DEV))[0].cpu()
+    ref = OV.open_clip_preprocess(img, spec.image_size, spec.mean, spec.std, spec.resize_mode, spec.interpolation)
+    assert got.shape == ref.shape == (3, spec.image_size, spec.image_size)
+    torch.testing.assert_close(got, ref, atol=2e-5, rtol=1e-5)
+    if card == "ViT-B-16-qg" and src == (480, 640):
+        assert vit.clip_window(480, 640) == (224, 298, 0, 37)
+    u8 = (img * 255).to(torch.uint8)
+    got8 = HipViT.preprocess_clip(vit, u8[None].to(DEV), scale=1 / 255.0)[0].cpu()
+    ref8 = OV.open_clip_preprocess(u8.float() / 255.0, spec.image_size, spec.mean, spec.std, spec.resize_mode, spec.interpolation)
+    torch.testing.assert_close(got8, ref8, atol=3e-5, rtol=1e-5)
+
+
 def test_vit_forward_vs_hf_golden():
     """HIP bf16 forward vs HuggingFace CLIP (fp32) on the golden weights/input: width 64, 2 layers, 10 tokens."""
     from oracle import vit as OV

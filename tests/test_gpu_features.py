@@ -229,7 +229,8 @@ def test_extract_clip_crop_modes_vs_oracle(mode, card):
     got = gen.extract_clip(_t(img), _t(masks)).cpu().numpy()
 
     def encode(x01):                                     # encode_image: preprocess to the model size, pooled + projected
-        b = torch.stack([OV.resize_normalize(torch.from_numpy(np.ascontiguousarray(im)), spec.image_size, spec.mean, spec.std, None, scale=1.0) for im in x01])
+        b = torch.stack([OV.open_clip_preprocess(torch.from_numpy(np.ascontiguousarray(im)), spec.image_size, spec.mean, spec.std, spec.resize_mode,
+                                                 spec.interpolation) for im in x01])
         if spec.map_pool:
             t = OV.vit_forward(sd, b, patch=spec.patch, heads=spec.heads, act=spec.act, pre_ln=False, cls_token=False, eps=spec.ln_eps, tokens=True)
             f = OV.map_pool(sd, t, spec.heads, act=spec.act, eps=spec.ln_eps).numpy()
