@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--projection-world", type=int, default=8, help="N = 1 only: after the timed legs, ONE GPU emulates rank 0 of a job of this many GPUs "
                     "(its own keyframe's encoders + every keyframe's replicated passes + 1/N of the dense rows, all-gather replaced by a local copy) "
                     "and reports the round time under `projection` (0 = off)")
+    ap.add_argument("--no-online", action="store_true", help="skip the `online` leg (the same workload with no encoder look-ahead)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="after the timed steps: keep stepping the same stream for this long (0 = off)")
     return ap.parse_args()
 
@@ -77,7 +78,7 @@ def cpu_frame(pipe_args, frame_np, map_xyz, texts):
     from ovo_amd.encoders import hiera as EH, vit as EV
     spec = EV.SPECS[pipe_args.vit]
     sd = EV.random_state(spec, 0)
-    rope = EV.rope_tables(spec) if spec.use_rope else None
+    rope = OV.rope_for(spec)
     K = syn.scannet_intrinsics(1.0)
     rgb, rgb_lr, depth, c2w, seg, masks = frame_np
     t0 = time.time()
@@ -249,6 +250,28 @@ def measured_peaks(dev, lib):
             "note": "torch device copy of 1 GiB f32 (read + write bytes) and ovo_gemm 8192^3 bf16 on random operands, measured in this job"}
 
 
+def online_leg(args, dev, frames, sam):
+    """The same workload with NO look-ahead (encoder_batch 1): keyframe t's encoders start when keyframe t arrives -- what an online
+    mapper whose masks come from SAM2 can do (ovo.py:121-166); the headline's look-ahead needs the next keyframes of a recorded stream."""
+    from ovo_amd.pipeline import Frame, FramePipeline
+    steps, warm = 48, 6
+    pipe = FramePipeline(dev, vit_card=args.vit, sam_card=sam, n_map=args.map_points, n_text=args.texts, dense=not args.no_dense, sam_full=args.sam_full,
+                         extra_capacity=(steps + warm + 2) * 72_000, seed=0, encoder_batch=1)
+    pool = frames * ((steps + warm) // len(frames) + 1)
+    stream = [Frame(200_000 + i, f.rgb[:], f.rgb_lr, f.depth, f.c2w, f.seg_map, f.masks) for i, f in enumerate(pool[:steps + warm])]
+    feed = Feed(stream, 1)
+    feed.run(pipe, warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    feed.run(pipe, steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del pipe
+    torch.cuda.empty_cache()
+    return {"encoder_batch": 1, "steps": steps, "frames_per_s": round(steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3),
+            "note": "same workload, no encoder look-ahead: the encoders of keyframe t are launched when it arrives (overlap with the previous keyframe's tail only)"}
+
+
 def projection_leg(args, dev, frames, sam):
     """What ONE rank of an N-GPU job does per round, measured on this GPU (FramePipeline(emulate=(0, N))): the encoders and pooling of the one
     keyframe it owns, the replicated map / tracking chain of all N keyframes, store + re-fuse of all N keyframes' descriptors, the dense
@@ -338,12 +361,14 @@ def main():
     stamps = []
     first = torch.cuda.Event(enable_timing=True)
     first.record()
+    L.check(lib.ovo_marker(1, L.stream()))                         # a kernel trace of this command is cut at these two markers
     t0 = time.perf_counter()
     x0, n0 = pipe.exchange_ms, pipe.exchanges
     feed.run(pipe, args.steps, stamps)
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    L.check(lib.ovo_marker(2, L.stream()))
     xchg_ms = (pipe.exchange_ms - x0) / max(pipe.exchanges - n0, 1)
     cadence = sorted(a.elapsed_time(b) for a, b in zip([first] + stamps[:-1], stamps))
 
@@ -393,6 +418,7 @@ def main():
     projection = None
     if world == 1 and args.projection_world > 1:
         projection = projection_leg(args, dev, frames, sam)
+    online = online_leg(args, dev, frames, sam) if (world == 1 and args.encoder_batch > 1 and not args.no_online) else None
 
     cpu, parity = None, None
     if want_cpu:
@@ -438,7 +464,7 @@ def main():
             "per_step_ms": {"median": round(cadence[len(cadence) // 2], 3), "min": round(cadence[0], 3), "max": round(cadence[-1], 3),
                             "note": "intervals between hipEvents recorded on the main stream at the end of every timed step"},
             "sustained": sustained,
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "projection": projection,
+            "online": online, "roofline": roof, "cpu_baseline": cpu, "parity": parity, "projection": projection,
         }
         if world > 1:
             line["exchange"] = {"collectives_per_round": 1, "bytes_per_rank": int(pipe.xchg.numel() * 4), "host_ms_per_round": round(xchg_ms, 3),

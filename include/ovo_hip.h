@@ -41,6 +41,9 @@ int ovo_hip_abi_version(void); /* bumped when a signature changes */
  * 2 = fused point-map tracking pass (bytes), 4..7 = MFMA GEMM with tile 128x128 / 128x64 / 64x128 / 64x64, 3 / 0 = the 256x256 /
  * 256x128 ping-pong GEMM, 8 = the weights-resident streaming GEMM (flops).
  * stop synchronises the device and returns, per kind, total milliseconds, total work and launch count. */
+/* An empty one-thread kernel (`k_marker`): bench.py brackets its timed region with two of them so that a rocprofv3 kernel trace of the
+ * same command can be cut to exactly that region (tools/kstats_region.py). */
+int ovo_marker(int id, ovo_stream_t stream);
 int ovo_profile_start(void);
 int ovo_profile_stop(double *ms, double *work, int64_t *launches, int n_kinds);
 

@@ -129,6 +129,7 @@ DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.uint8
 _SIGNATURES = {
     "ovo_hip_last_error": (C.c_char_p, []),
     "ovo_hip_abi_version": (_I32, []),
+    "ovo_marker": (_I32, [_I32, _P]),
     "ovo_profile_start": (_I32, []),
     "ovo_profile_stop": (_I32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
     "ovo_compact_workspace_bytes": (_SZ, [_I64]),

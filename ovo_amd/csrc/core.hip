@@ -69,7 +69,14 @@ static int host_wait(const T *flag, T value, int64_t timeout_us) {
     }
 }
 
+__global__ void k_marker(int id, int *sink) { if (sink && id < 0) *sink = id; }
+
 extern "C" {
+int ovo_marker(int id, ovo_stream_t stream) {
+    k_marker<<<1, 1, 0, (hipStream_t)stream>>>(id, nullptr);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
 const char *ovo_hip_last_error(void) { return g_err; }
 int ovo_hip_abi_version(void) { return 6; }
 

@@ -48,6 +48,10 @@ class ViTSpec:
     # Resize((size, size)) (the timm-hub cards: SigLIP, PE); torchvision 0.20 resizes tensors antialiased
     resize_mode: str = "shortest"
     interpolation: str = "bicubic"
+    # Rope2D conventions (perception_models core/vision_encoder/rope.py, not available offline -- see `rope_tables`): the two switches a
+    # maintainer with the upstream package flips if `tools/check_rope.py` shows a mismatch
+    rope_cls_offset: int = 1          # patch positions start at 1 when there is a class token ("leave space for the cls token to be (0, 0)")
+    rope_axis_order: str = "xy"       # first half of a head's channels rotates with the COLUMN (x), second half with the ROW (y)
 
     @property
     def grid(self) -> int:
@@ -142,21 +146,32 @@ def random_state(spec: ViTSpec, seed: int = 0) -> Dict[str, torch.Tensor]:
     return sd
 
 
-def rope_tables(spec: ViTSpec, theta: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
-    """cos / sin f32 [T, head_dim] of a 2-D axial rotary embedding in interleaved-pair form.
+def rope_tables(spec: ViTSpec, theta: float = 10000.0, cls_offset: Optional[int] = None, axis_order: Optional[str] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cos / sin f32 [T, head_dim] of PE's 2-D axial rotary embedding in interleaved-pair form.
 
-    perception_models' Rope2D is not available offline ([upstream-knowledge]): this follows
-    its published design -- half of each head's channels rotate with the patch row, half with the column,
-    frequencies theta^(-2i/(hd/2)), pairs (2i, 2i+1) share an angle, the class token is not rotated."""
+    perception_models is not vendored in the reference (.gitmodules) and not available offline, so this restates
+    `core/vision_encoder/rope.py::Rope2D.update_grid` from its published source as best recalled [upstream-knowledge, UNPINNED]:
+      * one 1-D rotary table of head_dim / 2 channels per axis: frequency i = theta^(-i / (head_dim / 4)), i = 0 .. head_dim/4 - 1, each
+        shared by the adjacent channel pair (2i, 2i+1), which rotates as (x0, x1) -> (x0 cos - x1 sin, x1 cos + x0 sin);
+      * with a class token the grid coordinates are `arange(G) + 1` ("+1 to leave space for the cls token to be (0, 0)")  -> cls_offset 1;
+      * `freq = cat([freqs_x, freqs_y], -1)`: the first half of a head rotates with the column, the second with the row       -> axis_order "xy";
+      * the class token's row is all zeros (identity rotation).
+    Round 1-2 of this build used cls_offset 0 / axis_order "yx"; both conventions are parameters (ViTSpec.rope_cls_offset /
+    rope_axis_order), all four combinations are tested HIP-vs-oracle, and `tools/check_rope.py` writes all four for a maintainer to diff
+    against the real package."""
+    off = spec.rope_cls_offset if cls_offset is None else int(cls_offset)
+    order = spec.rope_axis_order if axis_order is None else axis_order
+    if order not in ("xy", "yx"):
+        raise ValueError("axis_order must be 'xy' or 'yx'")
     hd = spec.width // spec.heads
     quarter = hd // 4
     freqs = theta ** (-torch.arange(quarter, dtype=torch.float32) / quarter)
-    pos = torch.arange(spec.grid, dtype=torch.float32)
+    pos = torch.arange(spec.grid, dtype=torch.float32) + float(off if spec.cls_token else 0)
     ang = pos[:, None] * freqs[None, :]                                   # [G, hd/4]
     ang = ang.repeat_interleave(2, dim=1)                                 # pairs share the angle -> [G, hd/2]
-    ay = ang[:, None, :].expand(spec.grid, spec.grid, hd // 2)
-    ax = ang[None, :, :].expand(spec.grid, spec.grid, hd // 2)
-    full = torch.cat([ay, ax], dim=-1).reshape(spec.grid * spec.grid, hd)
+    ay = ang[:, None, :].expand(spec.grid, spec.grid, hd // 2)            # varies with the row
+    ax = ang[None, :, :].expand(spec.grid, spec.grid, hd // 2)            # varies with the column
+    full = torch.cat([ax, ay] if order == "xy" else [ay, ax], dim=-1).reshape(spec.grid * spec.grid, hd)
     if spec.cls_token:
         full = torch.cat([torch.zeros(1, hd), full], dim=0)
     return full.cos().contiguous(), full.sin().contiguous()

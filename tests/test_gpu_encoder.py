@@ -383,13 +383,13 @@ def test_vit_forward_vs_oracle_full_size(card, batch):
     """Unit-normalised descriptor error vs the fp32 oracle: north_star bound 1e-3 (features) on every card of clip_utils.py:53-63
     (ViT-B/16, ViT-L/14, ViT-H/14 at 224 and 378, PE-L/14-336)."""
     from oracle import vit as OV
-    from ovo_amd.encoders.vit import SPECS, HipViT, random_state, rope_tables
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state
     spec = SPECS[card]
     sd = random_state(spec, seed=11)
     vit = HipViT(spec, sd, device=DEV)
     g = torch.Generator().manual_seed(2)
     x = torch.randn(batch, 3, spec.image_size, spec.image_size, generator=g)
-    rope = rope_tables(spec) if spec.use_rope else None
+    rope = OV.rope_for(spec)
     torch.set_num_threads(max(1, torch.get_num_threads()))
     ref = OV.vit_forward(sd, x, patch=spec.patch, heads=spec.heads, act=spec.act, rope=rope)
     out = vit.forward(x.to(DEV)).cpu()
@@ -449,7 +449,7 @@ def test_textregion_predict_vs_oracle(hw):
     """Full region-descriptor path (crops -> ViT tokens -> mask resample -> stitch -> masked-mean pooling -> proj -> L2)."""
     from oracle import features as OF, vit as OV
     from ovo_amd import synthetic as syn
-    from ovo_amd.encoders.vit import SPECS, HipViT, random_state, rope_tables
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state
     from ovo_amd.entities.textregion import PETextRegion
     spec = SPECS["tiny-pe"]
     sd = random_state(spec, seed=4)
@@ -463,7 +463,7 @@ def test_textregion_predict_vs_oracle(hw):
     # oracle pipeline in fp32
     crops = tr._crops(H, W)
     batch = torch.stack([OV.resize_normalize(img, spec.image_size, spec.mean, spec.std, c, scale=1 / 255.0) for c in crops])
-    tok = OV.vit_forward(sd, batch, patch=spec.patch, heads=spec.heads, act=spec.act, rope=rope_tables(spec), tokens=True)
+    tok = OV.vit_forward(sd, batch, patch=spec.patch, heads=spec.heads, act=spec.act, rope=OV.rope_for(spec), tokens=True)
     P, nh, nw = spec.grid, tr.crop_num_h, tr.crop_num_w
     x = OF.stitch_tokens(tok[:, 1:].numpy(), P, P * nh, P * nw, nh, nw)
     fm = OF.feature_masks(masks, P * nh, P * nw)
@@ -481,12 +481,37 @@ def test_textregion_predict_vs_oracle(hw):
     np.testing.assert_allclose(np.linalg.norm(out[~empty], axis=1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("cls_offset,axis_order", [(1, "xy"), (0, "xy"), (1, "yx"), (0, "yx")])
+def test_rope_conventions_hip_vs_oracle(cls_offset, axis_order):
+    """PE's Rope2D is unpinned upstream knowledge: its two conventions are switches (ViTSpec.rope_cls_offset / rope_axis_order).  For all four
+    combinations the HIP forward (tables from ovo_amd.encoders.vit.rope_tables, rotation in the QKV GEMM epilogue) must follow the oracle's
+    independently written tables (oracle/vit.py:rope2d_tables) -- and the combinations must really differ."""
+    import dataclasses
+    from oracle import vit as OV
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state, rope_tables
+    spec = dataclasses.replace(SPECS["tiny-pe"], rope_cls_offset=cls_offset, rope_axis_order=axis_order)
+    sd = random_state(spec, seed=21)
+    cos, sin = rope_tables(spec)
+    ocos, osin = OV.rope_for(spec)
+    torch.testing.assert_close(cos, ocos, atol=2e-6, rtol=0)
+    torch.testing.assert_close(sin, osin, atol=2e-6, rtol=0)
+    x = torch.randn(2, 3, spec.image_size, spec.image_size, generator=torch.Generator().manual_seed(4))
+    ref = OV.vit_forward(sd, x, patch=spec.patch, heads=spec.heads, act=spec.act, rope=(ocos, osin), tokens=True)
+    out = HipViT(spec, sd, device=DEV).forward(x.to(DEV), tokens=True).cpu()
+    nr, no = torch.nn.functional.normalize(ref, dim=-1), torch.nn.functional.normalize(out, dim=-1)
+    assert (nr - no).abs().max().item() < 3e-3
+    other = dataclasses.replace(spec, rope_cls_offset=1 - cls_offset)
+    ref2 = OV.vit_forward(sd, x, patch=spec.patch, heads=spec.heads, act=spec.act, rope=OV.rope_for(other), tokens=True)
+    assert (torch.nn.functional.normalize(ref2, dim=-1) - nr).abs().max().item() > 1e-2     # the switch is not a no-op
+    assert SPECS["PE-Core-L14-336"].rope_cls_offset == 1 and SPECS["PE-Core-L14-336"].rope_axis_order == "xy"
+
+
 @pytest.mark.parametrize("th", [0.02, 0.07])
 def test_textregion_remove_global_patch_vs_oracle(th):
     """a18 (textregion.py:31-50): the folded two-GEMM score must clear the same token columns as the literal T x T form."""
     from oracle import features as OF, vit as OV
     from ovo_amd import synthetic as syn
-    from ovo_amd.encoders.vit import SPECS, HipViT, random_state, rope_tables
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state
     from ovo_amd.entities.textregion import PETextRegion
     spec = SPECS["tiny-pe"]
     sd = random_state(spec, seed=4)
@@ -585,7 +610,7 @@ def test_textregion_full_size_640x480_vs_oracle():
     |unit-descriptor error| <= 1e-3 (north_star), i.e. what bench.py's `parity.max_abs_desc_err` reports, as a test."""
     from oracle import features as OF, vit as OV
     from ovo_amd import synthetic as syn
-    from ovo_amd.encoders.vit import SPECS, HipViT, random_state, rope_tables
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state
     from ovo_amd.entities.textregion import PETextRegion
     spec = SPECS["PE-Core-L14-336"]
     sd = random_state(spec, seed=0)
@@ -601,7 +626,7 @@ def test_textregion_full_size_640x480_vs_oracle():
     ch, cw = -(-H // nh), -(-W // nw)
     crops = [(0, 0, H, W)] + [(max(min(i * ch + ch, H) - ch, 0), max(min(j * cw + cw, W) - cw, 0), ch, cw) for i in range(nh) for j in range(nw)]
     batch = torch.stack([OV.resize_normalize(img, spec.image_size, spec.mean, spec.std, c, 1 / 255.0) for c in crops])
-    tok = OV.vit_forward(sd, batch, patch=spec.patch, heads=spec.heads, act=spec.act, rope=rope_tables(spec), tokens=True)
+    tok = OV.vit_forward(sd, batch, patch=spec.patch, heads=spec.heads, act=spec.act, rope=OV.rope_for(spec), tokens=True)
     P = spec.grid
     xs = OF.stitch_tokens(tok[:, 1:].numpy(), P, P * nh, P * nw, nh, nw)
     fm = OF.feature_masks(masks, P * nh, P * nw)
