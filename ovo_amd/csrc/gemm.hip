@@ -305,6 +305,10 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
     if (const char *force = getenv("OVO_GEMM_TILE")) {           // tuning knob (tools/gemm_bench.py): "128x128", "64x128", "256x256", ...
         int fm = 0, fn = 0;
         if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm == 64 || fm == 128) && (fn == 64 || fn == 128)) { bm = fm; bn = fn; }
+        if (!strcmp(force, "256x128p")) {                          // the persistent form (gemm8q.hip)
+            const int rc = gemm8q_launch(g, std::is_same<VT, bf16x8>::value ? 2 : 1, s);
+            if (rc != OVO_E_UNSUPPORTED) return rc;
+        }
         if (fm == 256 && (fn == 256 || fn == 128) && k64) return gemm8p_launch(g, fn, std::is_same<VT, bf16x8>::value ? 2 : 1, s);
     }
     if (bm == 128 && bn == 128) return k64 ? launch<128, 128, 64, VT, 8, 3>(g, s) : launch<128, 128, 32, VT, 8, 3>(g, s);

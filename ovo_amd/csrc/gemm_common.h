@@ -189,6 +189,8 @@ __device__ __forceinline__ void finish_best(const GemmArgs &g, int m, int fq, fl
 
 // launch of the 256-row ping-pong kernels (gemm8p.hip); bn in {128, 256}; returns OVO_E_UNSUPPORTED when the shape does not fit
 int gemm8p_launch(const GemmArgs &g, int bn, int in_dtype, hipStream_t s);
+// the persistent 256 x 128 form (gemm8q.hip: one DMA ring across a workgroup's tiles, epilogue of tile j behind the K-loop of tile j + 1)
+int gemm8q_launch(const GemmArgs &g, int in_dtype, hipStream_t s);
 // the weights-resident streaming form for tall short-K products (gemm_stream.hip); OVO_E_UNSUPPORTED when the shape has no instantiation
 int gemm_stream_launch(const GemmArgs &g, int in_dtype, hipStream_t s);
 

@@ -1,6 +1,6 @@
 """GEMM micro-benchmark over the shapes of the ViT-L/14-336 and hiera_b+ forwards (tile override via OVO_GEMM_TILE)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ovo_amd import _lib as L
 dev = torch.device("cuda", 0)
