@@ -55,7 +55,12 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, gemm_debug: bool = False) -> str:
+    """`gemm_debug` (tools/ only: python -m ovo_amd.build --force --gemm-debug): the GEMM kernels' early exits / time stamps / ablation knobs
+    (OVO_8P_DEBUG, OVO_8P_STAMPS, OVO_8P_DELAY, OVO_8Q_DEBUG) are compiled in; a production build has none of them."""
+    if gemm_debug:
+        for f in ("gemm8p.hip", "gemm8q.hip"):
+            EXTRA[f] = EXTRA.get(f, []) + ["-DOVO_GEMM_DEBUG"]
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = sources()
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
@@ -71,4 +76,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, gemm_debug="--gemm-debug" in sys.argv)

@@ -79,13 +79,17 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int fr = lane & 15, fq = lane >> 4;
+#ifdef OVO_GEMM_DEBUG        // tools/ builds only (python -m ovo_amd.build --gemm-debug): early exits, per-phase time stamps, de-phased starts
     if (g.dbg & 1) return;
     auto stamp = [&](int k) { if (g.stamps && tid == 0) g.stamps[(long long)tile * 4 + k] = __builtin_amdgcn_s_memrealtime(); };
     stamp(0);
-    if ((g.dbg >> 8) && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {      // tools/ only (OVO_8P_DELAY us): de-phase every other CU's tile sequence
+    if ((g.dbg >> 8) && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {      // OVO_8P_DELAY us: de-phase every other CU's tile sequence
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), ticks = (unsigned long long)(g.dbg >> 8) * 100;
         while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
     }
+#else
+    auto stamp = [&](int) {};
+#endif
 
     // ---- DMA sources: half h, piece (it * 8 + wave) = local rows [8 * piece, +8), lane -> (row, swizzled 16-byte chunk).
     // 32-bit byte offsets from the (wave-uniform) operand base: the launch checks that both operands span < 4 GB.
@@ -174,7 +178,9 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     OVO_VMCNT(2 * NA + 2 * NB);                           // Ah0(0), Bh0(0) landed (this wave's pieces)
     OVO_BARRIER();
     stamp(1);
+#ifdef OVO_GEMM_DEBUG
     if (g.dbg & 2) { OVO_VMCNT(0); return; }
+#endif
     if (group == 1) OVO_BARRIER();                        // group 1 runs one barrier behind group 0 from here on
 
     // One K-tile = four phases.  The counted wait of a phase leaves exactly the stages of the last four phases in flight
@@ -222,7 +228,9 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     if (t < nt) body(I0{}, t);
     OVO_VMCNT(0);
     stamp(2);
+#ifdef OVO_GEMM_DEBUG
     if (g.dbg & 4) { if (acc[0][0][0] == 12345.678f) *(float *)g.C = 1.f; return; }
+#endif
 
     if constexpr (STAGED) {
         // ---- epilogue through LDS.  Stored straight from the accumulators a wave instruction writes 16 rows x 32-64 bytes; with 16-32
@@ -339,8 +347,13 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
 template <int BM, int BN, int WARPS_M, typename VT, bool STAGED>
 int launch8p_(const GemmArgs &g0, hipStream_t s) {
     GemmArgs g = g0;
+    g.dbg = 0; g.stamps = nullptr;
+#ifdef OVO_GEMM_DEBUG        // the stamp buffer's ADDRESS comes from the environment: never in a production build
     g.dbg = (getenv("OVO_8P_DEBUG") ? atoi(getenv("OVO_8P_DEBUG")) : 0) | ((getenv("OVO_8P_DELAY") ? atoi(getenv("OVO_8P_DELAY")) : 0) << 8);
     g.stamps = getenv("OVO_8P_STAMPS") ? (unsigned long long *)strtoull(getenv("OVO_8P_STAMPS"), nullptr, 0) : nullptr;
+#endif
+    static const bool no_chunk = getenv("OVO_GEMM_NO_CHUNK") != nullptr;        // tuning knobs: read once
+    static const int strip_env = getenv("OVO_GEMM_STRIP") ? atoi(getenv("OVO_GEMM_STRIP")) : -1;
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;
     constexpr size_t ring = 2 * (size_t)(BM + BN) * 128;                                  // two K-tile buffers
@@ -355,10 +368,10 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     const bool prof = ovo_prof_enabled();
     if (prof) { ovo_prof_begin(BN == 256 ? 3 : 0, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); }     // kinds 3 / 0: 256x256 / 256x128
     g.tiles = nbm * g.nbn;
-    g.chunk = (g.M > g.N || g.nbn % 8 != 0) && !getenv("OVO_GEMM_NO_CHUNK") ? (g.tiles + 7) / 8 : 0;
+    g.chunk = (g.M > g.N || g.nbn % 8 != 0) && !no_chunk ? (g.tiles + 7) / 8 : 0;
     // tile order: measured to matter little (the K-loop is bound by the L2->LDS arrival rate, not by L2 misses); column strips of 8 n-tiles
     // gain ~5% on the widest products (N/BN >= 16: the per-XCD working set of a round drops under the 4 MB L2), nothing elsewhere
-    g.strip = getenv("OVO_GEMM_STRIP") ? atoi(getenv("OVO_GEMM_STRIP")) : (g.nbn >= 16 ? 8 : 0);
+    g.strip = strip_env >= 0 ? strip_env : (g.nbn >= 16 ? 8 : 0);
     if (g.strip > 0) g.chunk = (g.tiles + 7) / 8;
     const int grid = g.chunk > 0 ? g.chunk * 8 : g.tiles;
     k_gemm8p<BM, BN, WARPS_M, VT, STAGED><<<grid, 512, lds, s>>>(g);

@@ -209,7 +209,9 @@ __global__ void __launch_bounds__(512) k_gemm8q(PArgs p) {
             default: break;
         }
         float v[4] = {t[0], t[1], t[2], t[3]};
-        if (g.dbg & 1) return make_uint2(__float_as_uint(t[0]) ^ bias_v[e].x, __float_as_uint(t[1]));      // tools/ only: no epilogue arithmetic
+#ifdef OVO_GEMM_DEBUG
+        if (g.dbg & 1) return make_uint2(__float_as_uint(t[0]) ^ bias_v[e].x, __float_as_uint(t[1]));      // tools/ builds only: no epilogue arithmetic
+#endif
         const u32x4 b = bias_v[e];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
@@ -235,7 +237,10 @@ __global__ void __launch_bounds__(512) k_gemm8q(PArgs p) {
         const auto s0 = __builtin_amdgcn_permlane16_swap(pk0.x, pk1.x, false, false), s1 = __builtin_amdgcn_permlane16_swap(pk0.y, pk1.y, false, false);
         const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
         const int m = row_of(step), n8 = dn0 + wc * WTN + (2 * (step & 1) + (fq & 1)) * 16 + (fq >> 1) * 8;
-        const bool ok = active && m < g.M && n8 < g.N && !(g.dbg & 2);       // N % 16 == 0: a column tile is all in or all out  (dbg 2, tools/ only: no store leaves)
+        bool ok = active && m < g.M && n8 < g.N;                             // N % 16 == 0: a column tile is all in or all out
+#ifdef OVO_GEMM_DEBUG
+        ok = ok && !(g.dbg & 2);                                             // tools/ builds only: no store leaves
+#endif
         const unsigned off = ok ? (unsigned)(((long long)m * g.ldc + n8) * 2) : 0xfffffff0u;
         __builtin_amdgcn_raw_buffer_store_b128(out, __builtin_amdgcn_make_buffer_rsrc(g.C, 0, p.c_bytes, 0x00020000), off, 0, 0);
     };
@@ -371,8 +376,11 @@ int launch8q(const GemmArgs &g0, hipStream_t s) {
     PArgs p;
     p.g = g0;
     GemmArgs &g = p.g;
+    g.dbg = 0; g.stamps = nullptr;
+#ifdef OVO_GEMM_DEBUG
     static const int dbg = getenv("OVO_8Q_DEBUG") ? atoi(getenv("OVO_8Q_DEBUG")) : 0;
-    g.dbg = dbg; g.stamps = nullptr;
+    g.dbg = dbg;
+#endif
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;
     constexpr size_t lds = 2 * (size_t)BUF;

@@ -304,21 +304,61 @@ __device__ __forceinline__ void wave_hist_add(int32_t *hist, int cell, bool acti
     }
 }
 
-// A workgroup's survivors of the cheap frustum test are compacted through LDS before the expensive part runs.  PMC at 10 M points
-// (profiles/r02_geom_sq_counters.txt): with every lane walking the whole chain the pass issued 4.5x the VALU instructions of the plain
-// frustum flag pass -- nearly every wave holds a few in-frustum lanes, so the projection (five IEEE divisions, strict-rounding FMA
-// chains) ran for all of them at ~8 % lane use, and the pass sat at 1.7 TB/s VALU-bound.  Compacted, that chain runs on full waves.
-struct Survivor { float x, y, z; int i_lo, i_hi; };
+// The survivors of the cheap frustum test are compacted before the expensive part runs.  PMC at 10 M points (profiles/r02_geom_sq_counters.txt):
+// with every lane walking the whole chain the pass issued 4.5x the VALU instructions of the plain frustum flag pass -- nearly every wave
+// holds a few in-frustum lanes, so the projection (five IEEE divisions, strict-rounding FMA chains) ran for all of them at ~8 % lane use.
+// Round 2 compacted per WORKGROUP (LDS queue, an LDS atomic per wave, four __syncthreads per 1024 points): VALU halved, but the waves
+// then waited (SQ_ACTIVE_INST_ANY 18 % of SQ_WAVE_CYCLES).  Round 3: per WAVE -- a wave owns a private LDS ring, a lane's slot is
+// tail + mbcnt(ballot), no atomic and no workgroup barrier anywhere in the loop; whenever 64 survivors are queued the wave runs the
+// chain on them with all lanes active.
+struct WaveQueue {                      // one per wave: 256 slots (a trip adds at most 4 x 64, a full batch of 64 leaves first)
+    float x[256], y[256], z[256];
+    int i[256];
+};
 
-__device__ __forceinline__ int queue_push(bool keep, int *s_count) {
-    // wave-aggregated append: one LDS atomic per wave; returns this lane's slot (-1 if it does not push)
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void wq_push(WaveQueue &q, int &tail, bool keep, float x, float y, float z, int i) {
     const unsigned long long m = __ballot(keep);
-    if (!m) return -1;
-    int base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(s_count, (int)__popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1, 64);
-    return keep ? base + (int)__popcll(m & ((1ull << lane) - 1ull)) : -1;
+    if (keep) {
+        const int slot = (tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & 255;
+        q.x[slot] = x; q.y[slot] = y; q.z[slot] = z; q.i[slot] = i;
+    }
+    tail += (int)__popcll(m);
+}
+
+// The chain of one batch of survivors (lane < count active): project, depth-test, colour-frame remap, seg lookup, vote.
+__device__ __forceinline__ void track_batch(const WaveQueue &q, int head, int count, const ovo_camera_t &cam, const float *__restrict__ depth,
+                                            const int32_t *__restrict__ point_ins, const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
+                                            const ovo_ratio_t &ratio, int16_t *__restrict__ point_seg, int32_t *__restrict__ hist, int n_masks,
+                                            int hist_cols, long long &n_match) {
+    const int lane = threadIdx.x & 63;
+    int cell = 0;
+    bool vote = false;
+    if (lane < count) {
+        const int slot = (head + lane) & 255;
+        const float x = q.x[slot], y = q.y[slot], z = q.z[slot];
+        const int64_t i = q.i[slot];
+        int seg = -2;
+        float zc; int u, v;
+        project(cam, x, y, z, 1.0f, zc, u, v);
+        if (depth_match(cam, depth, zc, u, v)) {
+            ++n_match;
+            if (ratio.enabled) {
+                u = f2i(__fmul_rn((float)(u + ratio.crop_edge), ratio.r_w));
+                v = f2i(__fmul_rn((float)(v + ratio.crop_edge), ratio.r_h));
+            }
+            seg = -1;
+            if (u >= 0 && v >= 0 && u < seg_w && v < seg_h) seg = seg_map[(int64_t)v * seg_w + u];
+            if (seg >= n_masks) seg = -1;
+            if (seg >= 0) {
+                int ins = point_ins[i];
+                if (ins + 1 >= hist_cols) ins = -1;   // never taken: the host sizes hist_cols > max id + 1
+                cell = seg * hist_cols + (ins < 0 ? 0 : ins + 1);
+                vote = true;
+            }
+        }
+        point_seg[i] = (int16_t)seg;
+    }
+    wave_hist_add(hist, cell, vote);
 }
 
 __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const int32_t *__restrict__ point_ins,
@@ -327,16 +367,14 @@ __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const in
                                   ovo_ratio_t ratio, int16_t *__restrict__ point_seg,
                                   int32_t *__restrict__ hist, int n_masks, int hist_cols,
                                   unsigned long long *__restrict__ counters) {
-    __shared__ float s_x[1024], s_y[1024], s_z[1024];
-    __shared__ long long s_i[1024];
-    __shared__ int s_n;
-    const int lane = threadIdx.x & 63;
+    __shared__ WaveQueue s_q[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    WaveQueue &q = s_q[wave];
     long long n_in = 0, n_match = 0;
+    int head = 0, tail = 0;                                         // wave-uniform ring positions (mod 256 at use)
     const int64_t step = (int64_t)b.nblk * blockDim.x;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    // trip: 4 points per thread (loads first: bytes in flight), the frustum test, survivors -> LDS queue; then the queue, densely
-    for (int64_t i0 = (int64_t)b.bid * blockDim.x + threadIdx.x; i0 - threadIdx.x < n; i0 += 4 * step) {     // block-uniform trip count
+    // trip: 4 points per lane (loads first: bytes in flight), the frustum test, survivors -> the wave's ring; full batches of 64 run the chain
+    for (int64_t i0 = (int64_t)b.bid * blockDim.x + threadIdx.x; i0 - lane < n; i0 += 4 * step) {     // wave-uniform trip count
         float px[4], py[4], pz[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -348,45 +386,18 @@ __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const in
             const int64_t i = i0 + k * step;
             const bool in = i < n && in_frustum(cam, px[k], py[k], pz[k]);
             if (i < n && !in) point_seg[i] = (int16_t)-2;
-            const int slot = queue_push(in, &s_n);
-            if (slot >= 0) { s_x[slot] = px[k]; s_y[slot] = py[k]; s_z[slot] = pz[k]; s_i[slot] = i; }
-        }
-        __syncthreads();
-        const int q = s_n;
-        n_in += (threadIdx.x < q) + (threadIdx.x + 256 < q) + (threadIdx.x + 512 < q) + (threadIdx.x + 768 < q);
-        for (int e0 = 0; e0 < q; e0 += 256) {                      // whole waves stay in the loop (ballots inside)
-            const int e = e0 + threadIdx.x;
-            int seg = -2;
-            int cell = 0;
-            bool vote = false;
-            if (e < q) {
-                const float x = s_x[e], y = s_y[e], z = s_z[e];
-                const int64_t i = s_i[e];
-                float zc; int u, v;
-                project(cam, x, y, z, 1.0f, zc, u, v);
-                if (depth_match(cam, depth, zc, u, v)) {
-                    ++n_match;
-                    if (ratio.enabled) {
-                        u = f2i(__fmul_rn((float)(u + ratio.crop_edge), ratio.r_w));
-                        v = f2i(__fmul_rn((float)(v + ratio.crop_edge), ratio.r_h));
-                    }
-                    seg = -1;
-                    if (u >= 0 && v >= 0 && u < seg_w && v < seg_h) seg = seg_map[(int64_t)v * seg_w + u];
-                    if (seg >= n_masks) seg = -1;
-                    if (seg >= 0) {
-                        int ins = point_ins[i];
-                        if (ins + 1 >= hist_cols) ins = -1;   // never taken: the host sizes hist_cols > max id + 1
-                        cell = seg * hist_cols + (ins < 0 ? 0 : ins + 1);
-                        vote = true;
-                    }
-                }
-                point_seg[i] = (int16_t)seg;
+            wq_push(q, tail, in, px[k], py[k], pz[k], (int)i);
+            __builtin_amdgcn_wave_barrier();                        // the ring is private to the wave: LDS operations of one wave stay in order
+            if (tail - head >= 64) {                                // at most 63 + 64 queued: the 256-slot ring never wraps onto live entries
+                track_batch(q, head, 64, cam, depth, point_ins, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, n_match);
+                head += 64; n_in += 1;
+                __builtin_amdgcn_wave_barrier();
             }
-            if (e0 + (threadIdx.x & ~63) < q) wave_hist_add(hist, cell, vote);     // wave-uniform condition
         }
-        __syncthreads();
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
+    }
+    if (tail - head > 0) {
+        n_in += lane < tail - head;
+        track_batch(q, head, tail - head, cam, depth, point_ins, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, n_match);
     }
     // the two counters: wave reduction, then across the workgroup's waves through LDS -> one atomic pair per workgroup
     // (every wave of the grid adding to the same two addresses serialises in the L2 atomic unit: 16k same-address atomics)
@@ -395,12 +406,13 @@ __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const in
         n_match += __shfl_xor(n_match, o, 64);
     }
     __shared__ long long s_cnt[2][4];
-    if (lane == 0) { s_cnt[0][threadIdx.x >> 6] = n_in; s_cnt[1][threadIdx.x >> 6] = n_match; }
+    if (lane == 0) { s_cnt[0][wave] = n_in; s_cnt[1][wave] = n_match; }
     __syncthreads();
     if (threadIdx.x < 2) {
         const long long t = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
         if (t) atomicAdd(counters + threadIdx.x, (unsigned long long)t);
     }
+    __syncthreads();
 }
 
 __global__ void __launch_bounds__(256) k_track_project(const float *__restrict__ pts, const int32_t *__restrict__ point_ins,
@@ -504,12 +516,20 @@ __global__ void __launch_bounds__(256) k_assign_res(int32_t *__restrict__ point_
 // ---- a9 ----
 __device__ void dev_map_explained(Blk b, const float *__restrict__ pts, int64_t n, const ovo_camera_t &cam,
                                   const float *__restrict__ depth, uint8_t *__restrict__ explained) {
-    __shared__ float s_x[1024], s_y[1024], s_z[1024];
-    __shared__ int s_n;
+    __shared__ WaveQueue s_q[4];
+    const int lane = threadIdx.x & 63;
+    WaveQueue &q = s_q[threadIdx.x >> 6];
+    int head = 0, tail = 0;
     const int64_t step = (int64_t)b.nblk * blockDim.x;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    for (int64_t i0 = (int64_t)b.bid * blockDim.x + threadIdx.x; i0 - threadIdx.x < n; i0 += 4 * step) {     // as k_track_project
+    auto batch = [&](int count) {
+        if (lane < count) {
+            const int slot = (head + lane) & 255;
+            float zc; int u, v;
+            project(cam, q.x[slot], q.y[slot], q.z[slot], 1.0f, zc, u, v);
+            if (depth_match(cam, depth, zc, u, v)) explained[(int64_t)v * cam.w + u] = 1;
+        }
+    };
+    for (int64_t i0 = (int64_t)b.bid * blockDim.x + threadIdx.x; i0 - lane < n; i0 += 4 * step) {     // as dev_track_project
         float px[4], py[4], pz[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -519,20 +539,13 @@ __device__ void dev_map_explained(Blk b, const float *__restrict__ pts, int64_t 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int64_t i = i0 + k * step;
-            const int slot = queue_push(i < n && in_frustum(cam, px[k], py[k], pz[k]), &s_n);
-            if (slot >= 0) { s_x[slot] = px[k]; s_y[slot] = py[k]; s_z[slot] = pz[k]; }
+            wq_push(q, tail, i < n && in_frustum(cam, px[k], py[k], pz[k]), px[k], py[k], pz[k], 0);
+            __builtin_amdgcn_wave_barrier();
+            if (tail - head >= 64) { batch(64); head += 64; __builtin_amdgcn_wave_barrier(); }
         }
-        __syncthreads();
-        const int q = s_n;
-        for (int e = threadIdx.x; e < q; e += 256) {
-            float zc; int u, v;
-            project(cam, s_x[e], s_y[e], s_z[e], 1.0f, zc, u, v);
-            if (depth_match(cam, depth, zc, u, v)) explained[(int64_t)v * cam.w + u] = 1;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
     }
+    if (tail - head > 0) batch(tail - head);
+    __syncthreads();
 }
 
 __global__ void __launch_bounds__(256) k_map_explained(const float *__restrict__ pts, int64_t n, ovo_camera_t cam,

@@ -40,3 +40,20 @@ if os.environ.get("OVO_PROF_DUMP"):
     for (k, a, b, c), (cnt, t, w) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
         print(f"kind {k} shape {(a, b, c)!s:26s} x{cnt:3d} {1e3 * t / cnt:9.1f} us  total {t:7.3f} ms  {w / t / 1e9:7.0f} TF")
     print("gemm+attn ms:", sum(ms))
+# ---- where generate_device's time goes: launch half (encoder + decoder + statistics, device) vs finish half (host filters,
+# box NMS, binarise), at the candidate counts the thresholds let through
+import numpy as np
+for thr in ((0.5, 0.5), (0.0, 0.0)):
+    amg.pred_iou_thresh, amg.stability_score_thresh = thr
+    t = {}
+    for rep in range(6):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        h = amg.generate_launch(img)
+        t1 = time.perf_counter()
+        h["done"].synchronize(); t2 = time.perf_counter()
+        r = amg.generate_finish(h)
+        t3 = time.perf_counter(); torch.cuda.synchronize(); t4 = time.perf_counter()
+        if rep:
+            for k, v in (("launch (host)", t1 - t0), ("wait for device", t2 - t1), ("finish (host: filter + box NMS + binarise launch)", t3 - t2), ("binarise (device tail)", t4 - t3)):
+                t[k] = t.get(k, 0.0) + v / 5
+    print(f"thresholds {thr}: kept {r['masks'].shape[0]:4d}  " + "  ".join(f"{k} {1e3 * v:.2f} ms" for k, v in t.items()))

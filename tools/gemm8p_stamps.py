@@ -1,4 +1,5 @@
-"""Timeline of one launch of the 256-row ping-pong GEMM: s_memrealtime (100 MHz) per workgroup at start / K-loop entry / epilogue
+"""(needs a debug build: python -m ovo_amd.build --force --gemm-debug)
+Timeline of one launch of the 256-row ping-pong GEMM: s_memrealtime (100 MHz) per workgroup at start / K-loop entry / epilogue
 entry / end (OVO_8P_STAMPS).  usage: python tools/gemm8p_stamps.py M N K [tile]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.getcwd())
