@@ -16,6 +16,16 @@ def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
     return ((a - b).abs().max() / b.pow(2).mean().sqrt()).item()
 
 
+def _rel_rms(a: torch.Tensor, b: torch.Tensor) -> float:
+    return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+
+# Measured on MI355X (profiles/r03*_pytest_gpu.txt): per card, max |error| / rms over the three FPN levels and rms(error) / rms.  The maximum
+# over 1-4 M elements of a bf16-operand pipeline sits 5-6 sigma out (rms error 4-7e-3: ~2^-9 per GEMM operand through 12-48 blocks), so the
+# MAX bound is a statistic of the tail, the RMS bound is the one that moves when a kernel loses precision.  Bounds = 1.5 x measured.
+_HIERA_BOUNDS = {"hiera_test": (0.06, 0.012), "hiera_b+": (0.06, 0.012), "hiera_t": (0.06, 0.012), "hiera_l": (0.075, 0.015)}
+
+
 def test_hiera_vs_hf_golden():
     from oracle import hiera as OH
     from ovo_amd.encoders.hiera import HieraSpec, HipHiera
@@ -50,10 +60,11 @@ def test_hiera_vs_oracle(card, batch):
     out = enc.forward(x.to(DEV))
     for i, (f, r) in enumerate(zip(out, ref)):
         assert f.shape == r.shape, (f.shape, r.shape)
-        e = _rel(f.cpu(), r)
+        e, er = _rel(f.cpu(), r), _rel_rms(f.cpu(), r)
         cos = torch.nn.functional.cosine_similarity(f.cpu().flatten(), r.flatten(), dim=0).item()
-        print(f"{card} level {i} {tuple(f.shape)}: max err / rms = {e:.3e}, cosine = {cos:.6f}")
-        assert e < 0.1 and cos > 0.9995
+        print(f"{card} level {i} {tuple(f.shape)}: max err / rms = {e:.3e}, rms err / rms = {er:.3e}, cosine = {cos:.6f}")
+        b_max, b_rms = _HIERA_BOUNDS[card]
+        assert e < b_max and er < b_rms and cos > 0.9999
 
 
 def test_hiera_preprocess_matches_torch():
