@@ -324,6 +324,119 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
     }
 }
 
+// ---- tiny problems: Tq <= 64 and Tk <= 64 (Hiera's 8 x 8 / 4 x 4 windows and pooled blocks: tens of thousands of (window, head) pairs of
+// 4-64 tokens).  The tiled kernel above gives each of them a whole 4-wave workgroup and a 64-key tile: 4-16 TFLOP/s, at half the HBM rate
+// of their q / k / v / o stream.  Here ONE WAVE owns a (batch, head) pair: it stages its K / V rows in a private LDS slab sized for the
+// (16-rounded) key count -- no workgroup barrier anywhere -- walks its 1-4 query tiles of 16, and the softmax is a single pass (one key
+// tile: no running maximum).  Same MFMA operand scheme, same rounding points as k_attention (P in bf16, fp32 accumulation).
+template <int HD>
+__global__ void __launch_bounds__(256) k_attention_tiny(AttnArgs a, int krows) {
+    constexpr int KROW = HD + 8, VB = HD / 16 + 1, CH = HD / 8;
+    extern __shared__ __attribute__((aligned(16))) uint16_t tsm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+    const long long bh = (long long)blockIdx.x * 4 + wave;
+    if (bh >= (long long)a.B * a.H) return;
+    const int per_wave = krows * KROW + (krows / 4) * VB * 64;
+    uint16_t *sK = tsm + wave * per_wave, *sV = sK + krows * KROW;
+    const int b = (int)(bh / a.H), h = (int)(bh % a.H);
+    const uint16_t *qp = a.q + b * a.q_sb + h * a.q_sh;
+    const uint16_t *kp = a.k + b * a.k_sb + h * a.k_sh;
+    const uint16_t *vp = a.v + b * a.v_sb + h * a.v_sh;
+    // K row-major (padded rows), V in [4 keys][16 d] blocks read back transposed (as k_attention::commit)
+    for (int id = lane; id < krows * CH; id += 64) {
+        const int row = id / CH, c = id % CH;
+        uint4 kr = make_uint4(0, 0, 0, 0), vr = make_uint4(0, 0, 0, 0);
+        if (row < a.Tk && c * 8 < a.hd) {
+            kr = *(const uint4 *)(kp + (long long)row * a.k_st + c * 8);
+            vr = *(const uint4 *)(vp + (long long)row * a.v_st + c * 8);
+        }
+        *(uint4 *)(sK + row * KROW + c * 8) = kr;
+        *(uint4 *)(sV + ((row >> 2) * VB + (c >> 1)) * 64 + (row & 3) * 16 + (c & 1) * 8) = vr;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int nkt = krows >> 4;                                     // 16-key sub-tiles (1..4)
+    for (int q0 = 0; q0 < a.Tq; q0 += 16) {
+        const int q_row = q0 + fr;
+        bf16x8 qf[HD / 32];
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            const int d0 = ks * 32 + fq * 8;
+            if (q_row < a.Tq && d0 < a.hd) raw = *(const uint4 *)(qp + (long long)q_row * a.q_st + d0);
+            qf[ks] = *(bf16x8 *)&raw;
+        }
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt) {
+#pragma unroll
+                for (int ks = 0; ks < HD / 32; ++ks) {
+                    const bf16x8 kf = *(const bf16x8 *)(sK + (kt * 16 + fr) * KROW + ks * 32 + fq * 8);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (kt * 16 + fq * 4 + r >= a.Tk || (a.causal && kt * 16 + fq * 4 + r > q_row)) s[kt][r] = -3.0e38f;
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+        mx = max_xor16_32(mx);
+        const float m = fmaxf(-1.0e30f, mx * a.scale_log2e);         // (k_attention's first tile: running max starts at -1e30)
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], a.scale_log2e, -m));
+                    s[kt][r] = p;
+                    ps += p;
+                }
+            } else s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        ps = sum_xor16_32(ps);
+        bf16x8 pf[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint32_t tmp[4];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) tmp[e >> 1] = pack2(s[kk * 2 + (e >> 2)][e & 3], s[kk * 2 + (e >> 2)][(e & 3) + 1]);
+            pf[kk] = *(bf16x8 *)tmp;
+        }
+        const float inv = 1.0f / ps;
+        uint16_t *op = a.o + b * a.o_sb + h * a.o_sh + (long long)q_row * a.o_st;
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (kk * 2 >= nkt) continue;
+                const bool hi_ok = kk * 2 + 1 < nkt;                  // the slab holds only `krows` keys
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4 *)(sV + (((kk * 2) * 4 + fq) * VB + dt) * 64 + fr * 4));
+                s16x4 hi = s16x4{0, 0, 0, 0};
+                if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4 *)(sV + (((kk * 2 + 1) * 4 + fq) * VB + dt) * 64 + fr * 4));
+                const uint2 l2 = *(const uint2 *)&lo, h2 = *(const uint2 *)&hi;
+                uint4 raw = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8 *)&raw, pf[kk], o, 0, 0, 0);
+            }
+            const int d0 = dt * 16 + fq * 4;
+            if (q_row < a.Tq && d0 < a.hd) {
+                uint2 pk;
+                pk.x = pack2(o[0] * inv, o[1] * inv);
+                pk.y = pack2(o[2] * inv, o[3] * inv);
+                *(uint2 *)(op + d0) = pk;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
@@ -351,8 +464,11 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     // 64-query form, and with several frames per launch there are always enough workgroups; tools/attn_bench.py, round 2:
     // 8 x 16 heads x 577^2 (four keyframes' ViT crops) 59.8 us wide vs 37.4 narrow, 4 x 8 x 4096^2 x 56 394 vs 292, while
     // 8 x 16 x 2048^2 x 128 stays 703 wide vs 849 narrow
+    // -- and for Hiera's 14 x 14 windows (196 queries and keys): two 128-query workgroups per (window, head) stage K / V twice instead of
+    // four times (64 + 64 + 64 + 4 queries): 12 frames' stage-3 windows 118 -> 104 us (tools/attn_bench.py, round 3)
     const bool wide = (getenv("OVO_ATTN_WIDE") != nullptr) ||
-                      (p->hd > 64 && p->Tq >= 512 && (long long)((p->Tq + 127) / 128) * p->B * p->H >= 512 && !getenv("OVO_ATTN_NARROW"));
+                      (!getenv("OVO_ATTN_NARROW") && ((p->hd > 64 && p->Tq >= 512 && (long long)((p->Tq + 127) / 128) * p->B * p->H >= 512) ||
+                                                      (p->Tq > 128 && p->Tq <= 256 && p->Tk <= 256 && (long long)p->B * p->H >= 512)));
     const int qpb = wide ? 128 : 64;
     dim3 grid((p->Tq + qpb - 1) / qpb, p->B * p->H);
     a.q_tiles = (int)grid.x; a.chunk = 0;
@@ -365,11 +481,23 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     const bool prof = ovo_prof_enabled();
     if (prof) { ovo_prof_begin(1, 4.0 * p->B * p->H * (double)p->Tq * p->Tk * p->hd, s); ovo_prof_shape(p->B * p->H, p->Tq, p->Tk); }
     struct Done { bool on; hipStream_t s; ~Done() { if (on) ovo_prof_end(s); } } done{prof, s};
+    // tiny problems (one key tile, at most four query tiles): one wave per (batch, head) pair
+    // (tools/attn_bench.py, 12 frames of hiera_b+: 16 x 16 windows 165 -> 79 us = 4.5 TB/s of q/k/v/o, pooled 4 x 16 blocks 321 -> 89 us;
+    //  with 2-4 query tiles per pair -- 64 x 64, 49 x 49 -- the tiled kernel's four waves per pair are ahead: 180 vs 201 us, 33 vs 37)
+    if (p->hd <= 64 && p->Tk <= 64 && p->Tq <= 16 && !getenv("OVO_ATTN_NO_TINY")) {
+        const int krows = (p->Tk + 15) & ~15;
+        const size_t lds = 4 * (size_t)(krows * (64 + 8) + (krows / 4) * (64 / 16 + 1) * 64) * 2;
+        const long long nb = ((long long)p->B * p->H + 3) / 4;
+        k_attention_tiny<64><<<(unsigned)nb, 256, lds, s>>>(a, krows);
+        OVO_CHECK_LAUNCH();
+        return OVO_OK;
+    }
 #define GO(HD)                                                       \
     do {                                                             \
         if (wide) k_attention<HD, 2><<<grid, 256, 0, s>>>(a);        \
         else k_attention<HD, 1><<<grid, 256, 0, s>>>(a);             \
     } while (0)
+    // (the trimmed form for a LAST tile that is mostly padding -- 196 keys = 3 tiles + 4 keys -- measured no gain: 117 vs 118 us)
     if (p->hd <= 64 && p->Tk <= 64 && !wide) k_attention<64, 1, true><<<grid, 256, 0, s>>>(a);     // one ragged key tile: the trimmed form
     else if (p->hd <= 64) GO(64);
     else if (p->hd <= 96) GO(96);

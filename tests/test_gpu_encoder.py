@@ -266,7 +266,9 @@ def test_gemm_rope_epilogue_vs_rope_kernel_and_torch(b, t, heads, hd):
 
 @pytest.mark.parametrize("B,H,Tq,Tk,hd", [(2, 16, 577, 577, 64), (1, 4, 197, 197, 64), (64, 2, 16, 64, 56), (3, 1, 49, 196, 96),
                                           (2, 2, 1, 1, 8), (1, 2, 130, 70, 72), (1, 1, 4096, 4096, 56), (2, 8, 257, 257, 128),
-                                          (64, 4, 16, 16, 56), (32, 8, 4, 16, 56), (8, 2, 64, 64, 56), (5, 3, 70, 50, 64), (3, 2, 17, 33, 40)])   # Tk <= 64: the trimmed instantiation
+                                          (64, 4, 16, 16, 56), (32, 8, 4, 16, 56), (8, 2, 64, 64, 56), (5, 3, 70, 50, 64), (3, 2, 17, 33, 40),   # Tk <= 64: trimmed / tiny forms
+                                          (7, 3, 49, 49, 64), (9, 1, 33, 17, 24), (1, 1, 1, 64, 64), (130, 2, 16, 64, 56), (3, 2, 64, 1, 8),    # one wave per (batch, head) pair
+                                          (6, 2, 196, 196, 56), (2, 2, 196, 200, 64), (2, 1, 300, 280, 64)])                                  # last key tile mostly padding
 def test_attention_vs_torch(B, H, Tq, Tk, hd):
     from ovo_amd import _lib as L
     g = torch.Generator().manual_seed(B + H + Tq + Tk + hd)

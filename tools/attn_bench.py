@@ -1,10 +1,12 @@
-"""Attention micro-benchmark over the ViT-L/14-336 and hiera_b+ shapes."""
+"""Attention micro-benchmark over the ViT-L/14-336 and hiera_b+ shapes (12 frames per launch, as the bench's look-ahead groups):
+auto = what ovo_attention picks; notiny = OVO_ATTN_NO_TINY (the tiled kernel for the <= 64-token problems); narrow / wide = forced
+64 / 128-query workgroups.  GB/s = the q / k / v / o bytes of the launch."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ovo_amd import _lib as L
 dev = torch.device("cuda", 0); lib = L.load()
-def run(B, H, Tq, Tk, hd, iters=50):
+def run(B, H, Tq, Tk, hd, iters=30):
     D = H * hd; T = max(Tq, Tk)
     qkv = torch.randn(B, T, 3, H, hd, device=dev).to(torch.bfloat16)
     out = torch.zeros(B, Tq, D, dtype=torch.bfloat16, device=dev)
@@ -19,14 +21,16 @@ def run(B, H, Tq, Tk, hd, iters=50):
     for _ in range(iters): L.check(lib.ovo_attention(C.byref(a), L.stream()))
     e1.record(); torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / iters
-    return us, 4.0 * B * H * Tq * Tk * hd / us / 1e6
-shapes = [(8, 16, 577, 577, 64), (16, 16, 577, 577, 64), (4, 8, 4096, 4096, 56), (8, 8, 4096, 4096, 56), (100, 8, 196, 196, 56), (200, 8, 196, 196, 56), (8192, 2, 64, 64, 56), (8192, 4, 16, 64, 56), (8192, 4, 16, 16, 56), (8192, 8, 4, 16, 56), (8, 16, 2048, 2048, 128)]
+    return us, 4.0 * B * H * Tq * Tk * hd / us / 1e6, 2.0 * B * H * hd * (2 * Tq + 2 * Tk) / us / 1e3
+shapes = [(24, 16, 577, 577, 64), (12, 8, 4096, 4096, 56), (300, 8, 196, 196, 56), (12288, 2, 64, 64, 56), (12288, 4, 16, 64, 56), (12288, 4, 16, 16, 56),
+          (12288, 8, 4, 16, 56), (300, 16, 49, 196, 56), (300, 16, 49, 49, 56), (8, 16, 2048, 2048, 128)]
 for shape in shapes:
     row = "%-28s" % str(shape)
-    for mode in ("auto", "narrow", "wide"):
-        os.environ.pop("OVO_ATTN_NARROW", None); os.environ.pop("OVO_ATTN_WIDE", None)
+    for mode in ("auto", "notiny", "narrow", "wide"):
+        for k in ("OVO_ATTN_NARROW", "OVO_ATTN_WIDE", "OVO_ATTN_NO_TINY"): os.environ.pop(k, None)
         if mode == "narrow": os.environ["OVO_ATTN_NARROW"] = "1"
         if mode == "wide": os.environ["OVO_ATTN_WIDE"] = "1"
-        us, tf = run(*shape)
-        row += "  %s %8.1fus %6.0fTF" % (mode, us, tf)
+        if mode == "notiny": os.environ["OVO_ATTN_NO_TINY"] = "1"
+        us, tf, gbs = run(*shape)
+        row += "  %s %8.1fus %5.0fTF %5.0fGB/s" % (mode, us, tf, gbs)
     print(row)
