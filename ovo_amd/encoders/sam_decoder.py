@@ -289,6 +289,9 @@ class HipSamDecoder:
         c, ci, H, s = spec.hidden, spec.hidden // 2, spec.heads, spec.embed_size
         S, P, T = s * s, self.P, self.T
         dev = self.device
+        # the per-prompt keys live as bf16 only where the fused out-projection + norm kernel exists (hidden 256 / 128, samfuse.hip); at any
+        # other width the unfused chain needs the f32 stream as its residual operand (`force_unfused`: tests)
+        res16_on = RES16 and c in (256, 128) and not getattr(self, "force_unfused", False)
         emb = L.dev(image_embed.reshape(S, c), torch.float32, "image_embed")
         f1 = L.dev(feat_s1.reshape(4 * S, c // 4), torch.float32, "feat_s1")
         f0 = L.dev(feat_s0.reshape(16 * S, c // 8), torch.float32, "feat_s0")
@@ -373,25 +376,26 @@ class HipSamDecoder:
             # does not cover run the product and the row pass separately
             last = i == spec.depth - 1
             if shared:                                            # the prompts diverge here: materialise per-prompt keys
-                keys = None if last or RES16 else torch.empty((P * S, c), dtype=f32, device=dev)
+                keys = None if last or res16_on else torch.empty((P * S, c), dtype=f32, device=dev)
                 k16 = torch.empty((P * S, c), dtype=bf, device=dev)
                 kpe16 = None                                      # (keys + pe) is never formed per prompt: see `fuse` in __init__
                 res, res16, res_rows = keys0, None, S
-            elif RES16:
+            elif res16_on:
                 res, res16, res_rows, k16 = None, k16, P * S, torch.empty((P * S, c), dtype=bf, device=dev)
             else:
                 res, res16, res_rows = keys, None, P * S
             y32 = None if last else keys                          # the f32 residual stream is not read after the last layer
-            rc = lib.ovo_sam_proj_ln(L.ptr(oi), L.ptr(self.w[a + "out_proj.w"]), L.ptr(self.w[a + "out_proj.b"]), L.ptr(res), L.ptr(res16), res_rows,
-                                     L.ptr(self.w[b + "norm4.g"]), L.ptr(self.w[b + "norm4.b"]), 1e-5, L.ptr(key_pe), S, L.ptr(y32), L.ptr(k16),
-                                     L.ptr(kpe16), P * S, c, ci, L.stream())
-            if rc == L.E_UNSUPPORTED:
+            rc = L.E_UNSUPPORTED if getattr(self, "force_unfused", False) else \
+                lib.ovo_sam_proj_ln(L.ptr(oi), L.ptr(self.w[a + "out_proj.w"]), L.ptr(self.w[a + "out_proj.b"]), L.ptr(res), L.ptr(res16), res_rows,
+                                    L.ptr(self.w[b + "norm4.g"]), L.ptr(self.w[b + "norm4.b"]), 1e-5, L.ptr(key_pe), S, L.ptr(y32), L.ptr(k16),
+                                    L.ptr(kpe16), P * S, c, ci, L.stream())
+            if rc == L.E_UNSUPPORTED:                             # product and row pass separately (f32 stream: res16_on is off at these widths)
                 if shared:
                     x = self._gemm(oi, a + "out_proj", f32)
                     self._rows(x, P * S, c, base=keys0, base_rows=S, norm=b + "norm4", pe=key_pe, pe_rows=S, y=y32, y16=k16, ype16=kpe16)
                 else:
                     self._gemm(oi, a + "out_proj", f32, add=keys, out=keys)
-                    self._rows(keys, P * S, c, norm=b + "norm4", pe=key_pe, pe_rows=S, y=y32, y16=k16, ype16=kpe16)
+                    self._rows(keys, P * S, c, norm=b + "norm4", pe=key_pe, pe_rows=S, y=None if last else keys, y16=k16, ype16=kpe16)
             else:
                 L.check(rc)
             shared = False

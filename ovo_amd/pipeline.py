@@ -17,7 +17,8 @@ Several GPUs (one process each): a ROUND is `world` consec
   * the order-dependent integer passes -- back-projection append (vanilla_mapper.py:81-85), cull / project / vote / instance-id
     allocation (ovo.py:255-282) -- run on EVERY rank for EVERY keyframe of the round in keyframe order against a replicated map: they
     are deterministic, so all replicas stay bit-identical with no message at all (what they need of a foreign frame is its depth, pose
-    and masks: inputs every rank receives; masks produced by a rank's own SAM2 are exchanged bit-packed, `share_masks`);
+    and masks: inputs every rank receives; masks produced by a rank's OWN generator (SAM2 end to end, or `mask_source`) reach the other ranks
+    bit-packed through `parallel.share_masks` before the round is tracked, `_exchange_masks`);
   * the ONE exchange of a round: an all-gather of the owners' descriptors f32[<= 128, D] (KBs over xGMI / RCCL); every rank then stores and
     re-fuses them in keyframe order (`OVO._apply_semantic_plan`), so the instance tables are identical too;
   * the dense per-point accumulators are SHARDED by point (block-cyclic): each rank applies every keyframe's descriptors to its own

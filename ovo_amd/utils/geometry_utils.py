@@ -34,8 +34,8 @@ def to_device(arr, dtype: torch.dtype, device) -> torch.Tensor:
     if isinstance(arr, torch.Tensor):
         t = arr if arr.dtype == dtype else arr.to(dtype)
         out = (t if t.is_cuda else t.to(device, non_blocking=True)).contiguous()
-        if out is not arr and hasattr(arr, "_ovo_range"):
-            out._ovo_range = arr._ovo_range
+        if out is not arr and hasattr(arr, "_ovo_range") and getattr(arr, "_ovo_range_version", arr._version) == arr._version:
+            out._ovo_range, out._ovo_range_version = arr._ovo_range, out._version
         return out
     np_dtype = {torch.float32: np.float32, torch.uint8: np.uint8, torch.int32: np.int32}[dtype]
     return torch.from_numpy(np.ascontiguousarray(arr, dtype=np_dtype)).to(device, non_blocking=True)
@@ -52,18 +52,18 @@ def depth_range(depth) -> Tuple[float, float]:
             return float("inf"), 0.0
         return float(v.min()), float(v.max())
     cached = getattr(depth, "_ovo_range", None)
-    if cached is not None:
-        return cached
+    if cached is not None and getattr(depth, "_ovo_range_version", depth._version) == depth._version:
+        return cached                                  # (a buffer rewritten in place -- buf.copy_(next_depth) -- has a new version: recompute)
     big = torch.where(depth > 0, depth, torch.full_like(depth, float("inf"))).min()
     top = depth.max()
     lo, hi = torch.stack([big, top]).tolist()
-    depth._ovo_range = (lo, hi)
+    depth._ovo_range, depth._ovo_range_version = (lo, hi), depth._version
     return lo, hi
 
 
 def tag_depth_range(depth_dev: torch.Tensor, depth_host: np.ndarray) -> torch.Tensor:
     """Attach the (min valid, max) range of a depth map, computed from its HOST copy, to the device tensor of the same frame."""
-    depth_dev._ovo_range = depth_range(np.asarray(depth_host))
+    depth_dev._ovo_range, depth_dev._ovo_range_version = depth_range(np.asarray(depth_host)), depth_dev._version
     return depth_dev
 
 

@@ -45,6 +45,26 @@ def test_mask_decoder_vs_oracle(card, n_side):
     assert (iou.cpu() - ri).abs().max().item() < 2e-2
 
 
+def test_mask_decoder_unfused_chain_equals_fused_kernels():
+    """The chain the decoder takes at hidden widths the fused out-projection + norm kernel does not cover (ovo_sam_proj_ln returns
+    OVO_E_UNSUPPORTED: product, then the row pass, over an f32 residual stream) -- forced here at a covered width -- against the fused path:
+    same masks up to the bf16 rounding of the per-prompt keys the fused path keeps (and the unfused one does not)."""
+    from ovo_amd.encoders.sam_decoder import SPECS, HipSamDecoder, random_state
+    spec = SPECS["sam2_test"]
+    sd = random_state(spec, seed=7)
+    emb, f1, f0 = (t.to(DEV) for t in _inputs(spec, seed=1))
+    outs = []
+    for unfused in (False, True):
+        dec = HipSamDecoder(spec, sd, device=DEV)
+        dec.force_unfused = unfused
+        dec.set_point_grid(3)
+        outs.append(dec.forward(emb, f1, f0))
+    (m0, i0), (m1, i1) = outs
+    rms = m0.pow(2).mean().sqrt().item()
+    assert torch.isfinite(m1).all() and (m0 - m1).abs().max().item() / rms < 0.05
+    assert ((m0 > 0) == (m1 > 0)).float().mean().item() > 0.995 and (i0 - i1).abs().max().item() < 1e-2
+
+
 def test_mask_decoder_batch_invariance():
     """The generator decodes all clicks in one batch where the reference uses batches of 64: a click's masks must not depend
     on which other clicks share its batch (full-size decoder, 64 clicks at once vs 4 x 16)."""

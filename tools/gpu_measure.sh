@@ -9,23 +9,25 @@ R=$GRAFT_REPO_ROOT
 timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
 timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 600 python bench.py --sam hiera_l --no-cpu-baseline --sustain-seconds 0 > $OUT/bench_hiera_l.json 2> $OUT/bench_hiera_l.err
-timeout 600 python bench.py --sam-full --no-cpu-baseline --sustain-seconds 0 > $OUT/bench_sam_full.json 2> $OUT/bench_sam_full.err
-timeout 300 python tools/query_bench.py > $OUT/query_bench.log 2>&1
+timeout 600 python bench.py --sam hiera_l --no-cpu-baseline --sustain-seconds 0 --projection-world 0 --no-online > $OUT/bench_hiera_l.json 2> $OUT/bench_hiera_l.err
+timeout 600 python bench.py --sam-full --no-cpu-baseline --sustain-seconds 0 --projection-world 0 --no-online > $OUT/bench_sam_full.json 2> $OUT/bench_sam_full.err
+(timeout 300 python tools/query_bench.py; timeout 300 python tools/query_bench.py 1250000) > $OUT/query_bench.log 2>&1
 timeout 300 python tools/amg_bench.py 16 > $OUT/amg_bench.log 2>&1
 timeout 300 python tools/geom_bench.py > $OUT/geom_bench.txt 2>&1
 TILES="auto,ring,256x256,256x128" SHAPES="13848,3072,1024;13848,1024,1024;13848,4096,1024;13848,1024,4096;49152,1792,448;49152,448,1792;58800,1344,448;9232,3072,1024;9232,4096,1024;4616,3072,1024;4616,4096,1024;4096,4096,4096;8192,8192,8192" timeout 600 python tools/gemm_bench.py > $OUT/gemm_sweep.txt 2>&1
-(python tools/gemm8p_stamps.py 13848 3072 1024 256x256; python tools/gemm8p_stamps.py 13848 4096 1024 256x256; python tools/gemm8p_stamps.py 4096 4096 4096 256x256) > $OUT/gemm8p_timeline.txt 2>&1
 (python tools/enc_table.py vit 12; python tools/enc_table.py sam 12) > $OUT/enc_tables_b12.txt 2>&1
 (export TILES="tiled,stream" ROUNDS=3 ITERS=30
  echo "== bf16 out, bias"; BIAS=1 SHAPES="524288,336,128;524288,448,128;524288,672,128;131072,896,256;131072,672,256;131072,1344,256;131072,448,256;524288,32,256;131072,64,256" python tools/gemm_bench.py
  echo "== bf16 out, bias + GELU"; BIAS=1 ACT=1 SHAPES="524288,448,128;131072,896,256" python tools/gemm_bench.py
  echo "== f32 out, bias + in-place residual"; BIAS=1 ADD=1 INPLACE=1 OUT=f32 SHAPES="524288,112,128;131072,224,256;524288,256,128;524288,224,128;131072,256,256;65536,112,192" python tools/gemm_bench.py) > $OUT/gemm_stream.txt 2>&1
-timeout 300 python tools/replicated_cost.py 32 > $OUT/replicated_cost.txt 2>&1
+timeout 300 python tools/replicated_cost.py 64 8 > $OUT/replicated_cost.txt 2>&1
+(for w in 1 2 4 8; do echo "world $w"; timeout 300 python tools/round_emulation.py $w; done) > $OUT/round_emulation.txt 2>&1
+timeout 600 python tools/vit_bench.py > $OUT/vit_bench.txt 2>&1
+timeout 300 python tools/attn_bench.py > $OUT/attn_bench.txt 2>&1
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $R/bench.py --no-cpu-baseline --steps 12 --sustain-seconds 0 > $OUT/prof_bench.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 > $OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $R/bench.py --no-cpu-baseline --steps 24 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- python $R/tools/pmc_calib.py > $OUT/calib_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- python $R/tools/pmc_calib.py > $OUT/calib_write.log 2>&1
 DEC_ONLY=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/amg_prof -- python $R/tools/amg_bench.py 16 > $OUT/amg_prof.log 2>&1
@@ -38,6 +40,7 @@ python tools/pmc_traffic.py --fetch-dir $OUT/pmc_fetch --write-dir $OUT/pmc_writ
 python tools/pmc_traffic.py --fetch-dir $OUT/geom_fetch --write-dir $OUT/geom_write --out $OUT/geom_10m_pmc_traffic.json > $OUT/geom_pmc.log 2>&1
 python tools/sq_counters.py $OUT/geom_sq > $OUT/geom_10m_sq_counters.txt 2>&1
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_n1_kernel_stats.csv
+python tools/kstats_region.py $OUT/prof $OUT/bench_n1_timed_region_kernel_stats.csv > $OUT/kstats_region.log 2>&1
 cp $(find $OUT/geom_stats -name "*kernel_stats.csv" | head -1) $OUT/geom_10m_kernel_stats.csv
 cp $(find $OUT/amg_prof -name "*kernel_stats.csv" | head -1) $OUT/sam_decoder_kernel_stats.csv
 # keep the merge-back small: drop the per-dispatch traces, keep stats + reduced PMC
