@@ -468,7 +468,8 @@ def main():
         }
         if world > 1:
             line["exchange"] = {"collectives_per_round": 1, "bytes_per_rank": int(pipe.xchg.numel() * 4), "host_ms_per_round": round(xchg_ms, 3),
-                                "note": "all-gather of the round's descriptors (RCCL), issued inside the timed step"}
+                                "backend": torch.distributed.get_backend(),
+                                "note": "all-gather of the round's descriptors, issued inside the timed step"}
         print(json.dumps(line))
     parallel.barrier()
 

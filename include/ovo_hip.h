@@ -146,6 +146,12 @@ int ovo_map_backproject(const float *depth, const uint8_t *rgb, const uint8_t *e
 int ovo_fuse_views(const float *store, int D, const int32_t *csr_off, const int32_t *csr_rows, int n_updates,
                    int mode, float *table, const int32_t *table_rows, int32_t *out_view, ovo_stream_t stream);
 
+/* avg_pooling as a running sum: update k adds the views csr_rows[csr_off[k] .. csr_off[k+1]) (NEW ones only) to sums f32[cap,D] row table_rows[k]
+ * -- starting it when before[k] == 0 -- and writes table row = sum / (before[k] + new) (a single view is stored as it is).  The mean over all
+ * of an instance's views without re-reading them on every update. */
+int ovo_fuse_views_add(const float *store, int D, const int32_t *csr_off, const int32_t *csr_rows, const int32_t *before, int n_updates,
+                       float *sums, float *table, const int32_t *table_rows, ovo_stream_t stream);
+
 /* ---- dense ("voxel") fusion, BASELINE.json configs 3-4 -----------------------------------------
  * For every point with point_seg = m >= 0 and mask_row[m] >= 0:
  *   acc[i,:] += desc[mask_row[m],:]; cnt[i] += 1.      acc f32[n,D], cnt i32[n], desc f32[*,D]. */
@@ -579,6 +585,11 @@ typedef struct {
 } ovo_track_step_t;
 size_t ovo_track_workspace_bytes(int n_masks, int hist_cols);
 int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream);
+
+/* Both halves of ONE keyframe with their independent passes merged into shared launches (7 launches instead of 13; the map's size after
+ * the append is read on the device by the tracking half in any case): same passes, same results, same two result blocks.  The map step
+ * and the tracking step must describe the same map (`map.state` shared).  Shapes the merged launches do not cover fall back to the two calls. */
+int ovo_keyframe_step(const ovo_map_step_t *map_step, const ovo_track_step_t *track_step, ovo_stream_t stream);
 
 /* A whole ROUND of keyframes -- ovo_map_step + ovo_track_step of keyframe 0, then of keyframe 1, ... -- in ONE launch of a few dozen
  * persistent workgroups that walk through every pass, separated by grid-wide barriers.  Same passes, same results, same result

@@ -145,6 +145,7 @@ _SIGNATURES = {
     "ovo_map_step": (_I32, [C.POINTER(MapStep), _P]),
     "ovo_track_step": (_I32, [C.POINTER(TrackStep), _P]),
     "ovo_track_workspace_bytes": (_SZ, [_I32, _I32]),
+    "ovo_keyframe_step": (_I32, [C.POINTER(MapStep), C.POINTER(TrackStep), _P]),
     "ovo_round_chain_params_bytes": (_SZ, []),
     "ovo_round_chain": (_I32, [C.POINTER(RoundChain), C.POINTER(MapStep), C.POINTER(TrackStep), _I32, _P]),
     "ovo_host_alloc": (_P, [_SZ]),
@@ -152,6 +153,7 @@ _SIGNATURES = {
     "ovo_host_wait32": (_I32, [_P, C.c_int32, _I64]),
     "ovo_host_wait64": (_I32, [_P, _I64, _I64]),
     "ovo_fuse_views": (_I32, [_P, _I32, _P, _P, _I32, _I32, _P, _P, _P, _P]),
+    "ovo_fuse_views_add": (_I32, [_P, _I32, _P, _P, _P, _I32, _P, _P, _P, _P]),
     "ovo_scatter_accum": (_I32, [_P, _I64, _P, _I32, _P, _I32, _P, _P, _P]),
     "ovo_similarity": (_I32, [_P, _I32, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P, _P]),
     "ovo_similarity_rows": (_I32, [_P, _I32, _P, _P, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P]),

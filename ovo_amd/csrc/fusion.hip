@@ -63,6 +63,25 @@ __global__ void __launch_bounds__(256) k_fuse_views(const float *__restrict__ st
     if (t == 0 && out_view) out_view[k] = s_arg;
 }
 
+// avg_pooling kept as a RUNNING SUM per instance: an update adds the instance's NEW views (csr rows) to sums[slot] (or, with before[k] = 0, starts
+// it) and writes table[slot] = sum / (before + new); a single view is stored as it is, like k_fuse_views.  The mean of all views
+// (instance3d.py:9-21 `avg_pooling`, :170-178) without re-reading every view on every update -- with k_top_views = 10000 (ovo.yaml:49) an instance's
+// view list, and the CSR the host had to build for it per keyframe, grows with the length of the sequence.
+__global__ void __launch_bounds__(256) k_fuse_views_add(const float *__restrict__ store, int D, const int32_t *__restrict__ csr_off,
+                                                        const int32_t *__restrict__ csr_rows, const int32_t *__restrict__ before,
+                                                        float *__restrict__ sums, float *__restrict__ table, const int32_t *__restrict__ table_rows) {
+    const int k = blockIdx.x, t = threadIdx.x;
+    const int lo = csr_off[k], V = csr_off[k + 1] - lo, nb = before[k];
+    if (V <= 0) return;
+    float *acc = sums + (int64_t)table_rows[k] * D, *dst = table + (int64_t)table_rows[k] * D;
+    for (int d = t; d < D; d += 256) {
+        float s = nb > 0 ? acc[d] : 0.f;
+        for (int v = 0; v < V; ++v) s += store[(int64_t)csr_rows[lo + v] * D + d];
+        acc[d] = s;
+        dst[d] = nb + V == 1 ? s : s / (float)(nb + V);
+    }
+}
+
 // Dense fusion: one wave per point slot; lanes stride the descriptor with float4.
 // HBM traffic per matched point: D*4 read-modify-write of acc (desc rows stay in L2).
 __global__ void __launch_bounds__(256) k_scatter_accum(const int16_t *__restrict__ point_seg, int64_t n,
@@ -151,6 +170,16 @@ int ovo_scatter_accum_touched(const int16_t *point_seg, int64_t n, const int32_t
     k_scatter_accum<<<ovo_grid((n + 63) / 64 * 64, 256), 256, 0, (hipStream_t)stream>>>(point_seg, n, mask_row, n_masks,
                                                                                        desc, D, acc, cnt, touched, n_touched, n_next,
                                                                                        shard_rank, shard_count, block_log2);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+int ovo_fuse_views_add(const float *store, int D, const int32_t *csr_off, const int32_t *csr_rows, const int32_t *before, int n_updates,
+                       float *sums, float *table, const int32_t *table_rows, ovo_stream_t stream) {
+    OVO_REQUIRE(n_updates >= 0 && D > 0, "bad shape");
+    if (n_updates == 0) return OVO_OK;
+    OVO_REQUIRE(store && csr_off && csr_rows && before && sums && table && table_rows, "null pointer");
+    k_fuse_views_add<<<n_updates, 256, 0, (hipStream_t)stream>>>(store, D, csr_off, csr_rows, before, sums, table, table_rows);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

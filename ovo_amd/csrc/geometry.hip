@@ -854,6 +854,133 @@ __global__ void __launch_bounds__(256) k_fuse_publish(uint4 *__restrict__ masks,
 }
 
 // =================================================================================================
+// ovo_keyframe_step: the two halves of a keyframe's chain with their independent passes MERGED into shared launches -- 7 launches instead
+// of 13.  On a GPU whose CUs are filled by the encoders' GEMM workgroups every dependent launch of the chain waits for the dispatcher
+// (~45 us each, profiles/r03_round_emulation.txt); the passes themselves are the device functions above, so results do not change.
+//   k_kf_zero      explained[h w] and the tracking scratch (votes, statistics, counters, tickets)
+//   k_kf_phase1    workgroup ranges: explained-pixel pass over the map | depth high-pass filter | mask areas of the seg map
+//   k_backproj_flag
+//   k_kf_emit      every workgroup rebuilds the (<= 2048-word) scan in LDS, emits its words; the last one commits the map state
+//   k_track_project
+//   k_vote_decide
+//   k_kf_finish    workgroup ranges: in-place assignment | mask fusion; the last one publishes the result block
+constexpr int CHAIN_MAX_MASKS_V = 1024;
+struct KfZero { uint4 *a; long long a16; uint4 *b; long long b16; };
+__global__ void __launch_bounds__(256) k_kf_zero(KfZero z) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+    for (long long i = i0; i < z.a16; i += step) z.a[i] = make_uint4(0, 0, 0, 0);
+    for (long long i = i0; i < z.b16; i += step) z.b[i] = make_uint4(0, 0, 0, 0);
+}
+
+struct KfPhase1 {
+    int g_expl, g_filt, g_area;
+    const float *xyz; long long n_host; const long long *state; ovo_camera_t cam_map; const float *depth_map; uint8_t *explained;
+    const float *depth_t; int fh, fw; float filter_th; float *depth_f;
+    const int32_t *seg_map; long long seg_pixels; int n_masks; int32_t *stats;
+};
+__global__ void __launch_bounds__(256) k_kf_phase1(KfPhase1 a, BlurTaps taps) {
+    __shared__ int s_area[CHAIN_MAX_MASKS_V];
+    int bid = blockIdx.x;
+    if (bid < a.g_expl) {
+        long long n = a.n_host;
+        if (n < 0) { n = a.state[0]; if (a.state[1] <= 0) return; }
+        dev_map_explained(Blk{bid, a.g_expl}, a.xyz, n, a.cam_map, a.depth_map, a.explained);
+        return;
+    }
+    bid -= a.g_expl;
+    if (bid < a.g_filt) {
+        const int n = a.fh * a.fw;
+        for (int i = bid * 256 + threadIdx.x; i < n; i += a.g_filt * 256) a.depth_f[i] = depth_filter_pixel(a.depth_t, a.fh, a.fw, taps, a.filter_th, i % a.fw, i / a.fw);
+        return;
+    }
+    bid -= a.g_filt;
+    dev_seg_area(Blk{bid, a.g_area}, a.seg_map, a.seg_pixels, a.n_masks, a.stats, s_area);
+}
+
+__global__ void __launch_bounds__(256) k_kf_emit(const float *__restrict__ depth, const uint8_t *__restrict__ rgb, BackprojArgs a, int64_t n_sub,
+                                                 const unsigned long long *words, float *xyz, int32_t *ids, int32_t *ins, uint8_t *out_rgb, MapCommit mc) {
+    __shared__ int s_offs[SCAN_CHUNK + 1];
+    __shared__ long long sh[4];
+    const int n_words = (int)((n_sub + 63) >> 6);
+    // the whole scan, in every workgroup: <= 2048 words (16 KB from L2) cost less than a launch boundary
+    const int w0 = threadIdx.x * 8;
+    int pc[8];
+    long long c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { pc[k] = w0 + k < n_words ? __popcll(words[w0 + k]) : 0; c += pc[k]; }
+    long long total;
+    long long run = block_exclusive_scan(c, sh, total);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { if (w0 + k < n_words) s_offs[w0 + k] = (int)run; run += pc[k]; }
+    __syncthreads();
+    const long long base = mc.n_host >= 0 ? mc.n_host : mc.state[0];
+    const int32_t first_id = (int32_t)(mc.n_host >= 0 ? mc.id_host : mc.state[1]);
+    const int lane = threadIdx.x & 63;
+    for (int wd = blockIdx.x * 4 + (threadIdx.x >> 6); wd < n_words; wd += gridDim.x * 4) {
+        const unsigned long long m = words[wd];
+        if ((m >> lane) & 1ull) {
+            const long long pos = s_offs[wd] + __popcll(m & ((1ull << lane) - 1ull));
+            const int64_t k = (int64_t)wd * 64 + lane;
+            const int y = (int)(k / a.ws_w) * a.ds, x = (int)(k % a.ws_w) * a.ds;
+            const int64_t px = (int64_t)y * a.w + x;
+            const float d = depth[px];
+            const float x3 = __fdiv_rn(__fmul_rn(__fsub_rn((float)x, a.K[2]), d), a.K[0]);
+            const float y3 = __fdiv_rn(__fmul_rn(__fsub_rn((float)y, a.K[5]), d), a.K[4]);
+            const int64_t r = base + pos;
+            if (r < mc.cap) {
+                xyz[3 * r + 0] = dot4(a.c2w, x3, y3, d, 1.0f);
+                xyz[3 * r + 1] = dot4(a.c2w + 4, x3, y3, d, 1.0f);
+                xyz[3 * r + 2] = dot4(a.c2w + 8, x3, y3, d, 1.0f);
+                ids[r] = first_id + (int32_t)pos;
+                ins[r] = -1;
+                if (rgb) { out_rgb[3 * r + 0] = rgb[3 * px + 0]; out_rgb[3 * r + 1] = rgb[3 * px + 1]; out_rgb[3 * r + 2] = rgb[3 * px + 2]; }
+            }
+        }
+    }
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd((unsigned long long *)(mc.state + 3), 1ull) == (unsigned long long)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    long long m = total;
+    if (base + m > mc.cap) { m = mc.cap - base; mc.state[2] |= 1; }
+    mc.state[0] = base + m;
+    mc.state[1] = (long long)first_id + m;
+    mc.state[3] = 0;
+    if (mc.result) {
+        mc.result[1] = m; mc.result[2] = base + m; mc.result[3] = (long long)first_id + m;
+        __threadfence_system();
+        mc.result[0] = mc.seq;
+    }
+}
+
+struct KfFinish { int g_assign, gx; int32_t *ins; const int16_t *point_seg; long long n_host; const long long *n_dev; uint4 *masks; long long px16; int n_masks;
+                  const int32_t *dst; int32_t *res; };
+__global__ void __launch_bounds__(256) k_kf_finish(KfFinish a, Publish pb) {
+    int bid = blockIdx.x;
+    if (bid < a.g_assign) {
+        const long long n = a.n_host >= 0 ? a.n_host : *a.n_dev;
+        dev_assign_res(Blk{bid, a.g_assign}, a.ins, a.point_seg, n, a.res, a.n_masks);
+    } else if (a.masks) {
+        bid -= a.g_assign;
+        dev_fuse_row(bid / a.gx, bid % a.gx, a.gx, a.masks, a.px16, a.n_masks, a.dst, a.res);
+    }
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(pb.ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    dev_publish(a.res, pb, pb.n_host >= 0 ? pb.n_host : *pb.n_dev);
+}
+
+// =================================================================================================
 // k_round_chain: the map + tracking chains of a whole ROUND of keyframes in ONE launch.  A few dozen persistent workgroups walk
 // through every pass of every keyframe, separated by grid-wide barriers (an atomic arrival counter, spin on an agent-scope load).
 // Why: as separate launches a chain is ~12 small DEPENDENT kernels, and on a GPU whose CUs are filled by the encoders' GEMM workgroups
@@ -1293,6 +1420,87 @@ int ovo_round_chain(ovo_round_chain_t *ctx, const ovo_map_step_t *maps, const ov
     OVO_CHECK_LAUNCH();
     ctx->arrivals += (uint64_t)nblk * CHAIN_BARRIERS * n;
     ctx->next_slot += 1;
+    return OVO_OK;
+}
+
+
+int ovo_keyframe_step(const ovo_map_step_t *a, const ovo_track_step_t *t, ovo_stream_t stream) {
+    OVO_REQUIRE(a && t && a->depth && t->depth && t->n_masks > 0, "both halves are needed (use ovo_map_step / ovo_track_step for one)");
+    const int64_t ws_w = (a->w + a->ds - 1) / a->ds;
+    const int64_t n_sub = (int64_t)((a->h + a->ds - 1) / a->ds) * ws_w;
+    if (((n_sub + 63) >> 6) > SCAN_CHUNK || t->n_masks > CHAIN_MAX_MASKS_V || ((size_t)a->h * a->w) % 16 != 0) {      // shapes the merged launches do not cover
+        const int rc = ovo_map_step(a, stream);
+        return rc != OVO_OK ? rc : ovo_track_step(t, stream);
+    }
+    OVO_REQUIRE(a->map.xyz && a->map.ids && a->map.ins && a->map.state && a->explained && a->ws && t->seg_map && t->point_seg && t->ws && t->next_ins, "null argument");
+    OVO_REQUIRE(a->h > 0 && a->w > 0 && a->ds >= 1 && a->n_upper >= 0 && t->hist_cols >= 1, "bad shape");
+    OVO_REQUIRE(a->ws_bytes >= ovo_compact_workspace_bytes(n_sub) + 8 && t->ws_bytes >= ovo_track_workspace_bytes(t->n_masks, t->hist_cols), "workspace too small");
+    OVO_REQUIRE(a->map.cap >= a->n_upper + n_sub, "map capacity below n_upper + one frame of points");
+    OVO_REQUIRE(!t->masks || (t->pixels > 0 && t->pixels % 16 == 0 && ((uintptr_t)t->masks & 15) == 0), "masks: pixels must be a multiple of 16");
+    OVO_REQUIRE(!t->filter_depth || t->depth_scratch, "depth_scratch needed for the depth filter");
+    OVO_REQUIRE(((uintptr_t)a->explained & 15) == 0 && ((uintptr_t)t->ws & 15) == 0, "misaligned scratch");
+    hipStream_t s = (hipStream_t)stream;
+    const int nm = t->n_masks;
+    int32_t *hist = (int32_t *)t->ws;
+    int32_t *stats = hist + (size_t)nm * t->hist_cols;
+    unsigned long long *counters = (unsigned long long *)(stats + 4 * (size_t)nm + ((((size_t)nm * t->hist_cols) & 1) ? 1 : 0));
+    unsigned int *tickets = (unsigned int *)(counters + 2);
+    int32_t *dst = (int32_t *)(tickets + 2 + nm);
+    int32_t *res = dst + nm;
+    const size_t zero_bytes = ((size_t)((char *)dst - (char *)hist) + 15) & ~(size_t)15;        // (dst / res are rewritten by the decisions anyway)
+    // ---- 1: zero
+    KfZero z;
+    z.a = (uint4 *)a->explained; z.a16 = (long long)((size_t)a->h * a->w / 16); z.b = (uint4 *)hist; z.b16 = (long long)(zero_bytes / 16);
+    k_kf_zero<<<64, 256, 0, s>>>(z);
+    // ---- 2: the three independent first passes
+    const bool known = a->map.n >= 0;
+    const bool maybe_nonempty = known ? a->map.next_id > 0 : true;
+    KfPhase1 p1;
+    memset(&p1, 0, sizeof(p1));
+    p1.g_expl = (maybe_nonempty && a->n_upper > 0) ? ovo_grid(known ? a->map.n : a->n_upper, 256) : 0;
+    p1.g_filt = t->filter_depth ? ovo_grid((int64_t)t->cam.h * t->cam.w, 256, 512) : 0;
+    const int64_t seg_pixels = (int64_t)t->seg_h * t->seg_w;
+    p1.g_area = ovo_grid(seg_pixels, 256, 256);
+    p1.xyz = a->map.xyz; p1.n_host = known ? a->map.n : -1; p1.state = (const long long *)a->map.state; p1.cam_map = a->cam; p1.depth_map = a->depth;
+    p1.explained = a->explained;
+    p1.depth_t = t->depth; p1.fh = t->cam.h; p1.fw = t->cam.w; p1.filter_th = 0.05f; p1.depth_f = t->depth_scratch;
+    p1.seg_map = t->seg_map; p1.seg_pixels = seg_pixels; p1.n_masks = nm; p1.stats = stats;
+    k_kf_phase1<<<p1.g_expl + p1.g_filt + p1.g_area, 256, 0, s>>>(p1, make_blur_taps(7, 2.5f));
+    // ---- 3, 4: erode + subsample -> ordered append, state commit
+    BackprojArgs b;
+    for (int i = 0; i < 9; ++i) b.K[i] = a->K[i];
+    for (int i = 0; i < 16; ++i) b.c2w[i] = a->c2w[i];
+    b.h = a->h; b.w = a->w; b.ds = a->ds; b.ws_w = (int)ws_w;
+    b.erode = a->erode && maybe_nonempty;
+    CompactWs c = carve((char *)a->ws + 8, n_sub);
+    const int g = ovo_grid(n_sub, 256);
+    k_backproj_flag<<<g, 256, 0, s>>>(a->depth, maybe_nonempty ? a->explained : nullptr, b, n_sub, c.words, known ? nullptr : (const long long *)a->map.state);
+    MapCommit mc;
+    mc.state = (long long *)a->map.state; mc.total = nullptr; mc.result = (volatile long long *)a->result_host; mc.seq = a->seq;
+    mc.cap = a->map.cap; mc.n_host = known ? a->map.n : -1; mc.id_host = a->map.next_id;
+    k_kf_emit<<<g, 256, 0, s>>>(a->depth, a->rgb, b, n_sub, c.words, a->map.xyz, a->map.ids, a->map.ins, a->map.rgb, mc);
+    // ---- 5: the tracking pass (the map's size after the append is device-resident in any case)
+    const float *depth = t->filter_depth ? t->depth_scratch : t->depth;
+    const int64_t n_grid = a->n_upper + n_sub;
+    const bool prof = ovo_prof_enabled();
+    if (prof) ovo_prof_begin(2, 14.0 * (double)n_grid, s);
+    k_track_project<<<ovo_grid(n_grid, 256), 256, 0, s>>>(t->map.xyz, t->map.ins, 0, t->cam, depth, t->seg_map, t->seg_h, t->seg_w, t->ratio, t->point_seg, hist, nm,
+                                                       t->hist_cols, counters, (const long long *)t->map.state);
+    if (prof) ovo_prof_end(s);
+    // ---- 6: vote statistics + decisions
+    Decide d;
+    d.res = res; d.dst = dst; d.next_ins = t->next_ins; d.next_host = t->next_ins_host; d.track_th = t->track_th; d.n_masks = nm;
+    k_vote_decide<<<nm, 256, 0, s>>>(hist, t->hist_cols, stats, tickets, d);
+    // ---- 7: assignment | mask fusion, publish
+    KfFinish f;
+    f.g_assign = ovo_grid(n_grid, 256, 1024); f.gx = t->masks ? ovo_grid(t->pixels / 16, 256, 32) : 1;
+    f.ins = t->map.ins; f.point_seg = t->point_seg; f.n_host = -1; f.n_dev = (const long long *)t->map.state;
+    f.masks = (uint4 *)t->masks; f.px16 = t->masks ? t->pixels / 16 : 0; f.n_masks = nm; f.dst = dst; f.res = res;
+    Publish pb;
+    pb.res = res; pb.host = (volatile int32_t *)t->result_host; pb.counters = counters; pb.n_dev = (const long long *)t->map.state; pb.n_host = -1;
+    pb.ticket = tickets + 1; pb.seq = t->seq; pb.n_ints = 8 + 6 * nm;
+    k_kf_finish<<<f.g_assign + (t->masks ? f.gx * nm : 0), 256, 0, s>>>(f, pb);
+    OVO_CHECK_LAUNCH();
     return OVO_OK;
 }
 

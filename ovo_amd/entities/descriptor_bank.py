@@ -90,6 +90,7 @@ class DescriptorBank:
         self.dim, self.device = int(dim), device
         self.store = torch.empty((rows, self.dim), dtype=torch.float32, device=device)
         self.table = torch.zeros((slots, self.dim), dtype=torch.float32, device=device)
+        self.sums: Optional[torch.Tensor] = None   # running sums of avg_pooling (fuse_add), same shape as table, allocated on first use
         self.n_rows = 0
         self.slot_of: Dict[int, int] = {}
         self.views_of: Dict[int, int] = {}       # slot -> number of views used by the last fusion
@@ -115,6 +116,10 @@ class DescriptorBank:
             if s >= self.table.shape[0]:
                 grown = torch.zeros((2 * self.table.shape[0], self.dim), dtype=torch.float32, device=self.device)
                 grown[:self.table.shape[0]].copy_(self.table)
+                if self.sums is not None:
+                    g2 = torch.zeros_like(grown)
+                    g2[:self.table.shape[0]].copy_(self.sums)
+                    self.sums = g2
                 self.table = grown
             self.slot_of[ins_id] = s
         return s
@@ -165,6 +170,33 @@ class DescriptorBank:
             dict.__setitem__(self.medoid_of, s, kf)
             dict.__setitem__(result, ins_id, kf)
         return result
+
+    def fuse_add(self, updates: Sequence[Tuple[int, Sequence[int], int]]) -> None:
+        """avg_pooling as a running sum (`ovo_fuse_views_add`).  updates: (ins_id, store rows of the NEW views, views already in the sum --
+        0 starts the sum over).  One kernel launch; the CSR holds only the new rows."""
+        updates = [(i, list(r), int(b)) for i, r, b in updates if len(r) > 0]
+        if not updates:
+            return
+        off, rows, slots, before = [0], [], [], []
+        for ins_id, r, b in updates:
+            rows.extend(r)
+            off.append(len(rows))
+            slots.append(self.slot(ins_id))
+            before.append(b)
+        if self.sums is None or self.sums.shape[0] < self.table.shape[0]:
+            grown = torch.zeros_like(self.table)
+            if self.sums is not None:
+                grown[:self.sums.shape[0]].copy_(self.sums)
+            self.sums = grown
+        n = len(updates)
+        meta = torch.tensor(off + rows + slots + before, dtype=torch.int32).to(self.device, non_blocking=True)
+        csr_off, csr_rows = meta[:n + 1], meta[n + 1:n + 1 + len(rows)]
+        t_rows, d_before = meta[n + 1 + len(rows):n + 1 + len(rows) + n], meta[n + 1 + len(rows) + n:]
+        L.check(L.load().ovo_fuse_views_add(L.ptr(self.store), self.dim, L.ptr(csr_off), L.ptr(csr_rows), L.ptr(d_before), n, L.ptr(self.sums),
+                                            L.ptr(self.table), L.ptr(t_rows), L.stream()))
+        for (ins_id, r, b), s in zip(updates, slots):
+            self.views_of[s] = b + len(r)
+            dict.__setitem__(self.medoid_of, s, 0 if b + len(r) == 1 else None)
 
     def gather(self, ins_ids: Iterable[int]) -> torch.Tensor:
         """f32[N, D] fused descriptors in the given order (the resident replacement of ovo.py:513-527)."""

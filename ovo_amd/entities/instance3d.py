@@ -31,6 +31,11 @@ class Instance3D:
         self._top_area: Dict[int, Any] = {}    # kf_id -> area of its heap entry       } reference keeps (and exports), an index for the
         self._top_sorted: List[tuple] = []     # the entries in ascending order        } per-mask look-ups, the fusion order ready-made
         self.to_update = False
+        # running-sum fusion (avg_pooling, OVO._planned_updates): the keyframes already in the sum, those pushed since the last plan, and whether
+        # the sum has to be rebuilt (nothing summed yet, a summed view left the heap, or the descriptor was fused the full way in between)
+        self._inc_kfs: set = set()
+        self._pending_kfs: List[int] = []
+        self._needs_full = True
         self._bank = bank
         self._own_feature: Optional[torch.Tensor] = None
         self._own_feature_kf = None
@@ -85,6 +90,8 @@ class Instance3D:
     def add_keyframes(self, kf_id: int) -> None:
         if not self.kfs_ids or (self.kfs_ids[-1] != kf_id and kf_id not in self.kfs_ids):      # (usually the keyframe just added, or a new one)
             self.kfs_ids.append(kf_id)
+            if self.n_top_kf <= 0:
+                self._pending_kfs.append(kf_id)
 
     @property
     def top_kf(self) -> List[tuple]:
@@ -92,6 +99,7 @@ class Instance3D:
 
     @top_kf.setter
     def top_kf(self, entries) -> None:
+        self._needs_full = True
         self._top_kf = list(entries)
         self._top_area = {kf: area for area, kf in self._top_kf}
         self._top_sorted = sorted(self._top_kf)
@@ -125,6 +133,7 @@ class Instance3D:
             heapq.heappush(self._top_kf, (area, kf_id))
             self._top_area[kf_id] = area
             bisect.insort(self._top_sorted, (area, kf_id))
+            self._pending_kfs.append(kf_id)
             self.to_update = True
             return
         evicted = heapq.heappushpop(self._top_kf, (area, kf_id))
@@ -135,6 +144,9 @@ class Instance3D:
             del self._top_sorted[bisect.bisect_left(self._top_sorted, evicted)]
             self._top_area[kf_id] = area
             bisect.insort(self._top_sorted, (area, kf_id))
+            self._pending_kfs.append(kf_id)
+            if evicted[1] in self._inc_kfs:
+                self._needs_full = True
 
     # ------------------------------------------------------------------ fusion
     def fusion_views(self) -> List[int]:
@@ -164,6 +176,7 @@ class Instance3D:
             return
         self._own_feature = None
         self._require_bank(None).fuse([(self.id, rows)], Instance3D.mv_fusion)
+        self._needs_full = True                      # (fused the full way: a later running-sum update starts over)
         self.to_update = False
 
     def _require_bank(self, like) -> DescriptorBank:

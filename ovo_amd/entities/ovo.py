@@ -278,8 +278,11 @@ class OVO:
         self._track_pending.popleft()
         if int(res[6]) != 0:
             raise L.OvoHipError("the round chain aborted on the device (a grid barrier timed out)")
-        if pend["done"] is not None:                               # what follows on the current stream reads the chain's outputs
-            torch.cuda.current_stream().wait_event(pend["done"])
+        if pend["done"] is not None:                               # what follows on the current stream reads the chain's outputs, which were
+            cur = torch.cuda.current_stream()                      # allocated on the chain's stream: tell the allocator about the second user
+            cur.wait_event(pend["done"])
+            pend["point_seg"].record_stream(cur)
+            pend["binary_maps"].record_stream(cur)
         kf_id, n_masks = self.kf_id, pend["n_masks"]
         n, n_matched, next_after = int(res[1]), int(res[3]), int(res[4])
         table = res[8:8 + 6 * n_masks].reshape(n_masks, 6).tolist()
@@ -488,19 +491,42 @@ class OVO:
         updates = self._planned_updates(matched_ins_ids)
         return {"kf_id": kf_id, "matched_ins_ids": matched_ins_ids, "binary_maps": binary_maps, "image": image, "updates": updates}
 
-    def _planned_updates(self, matched_ins_ids) -> List[Tuple[int, List[int]]]:
-        """(instance, keyframes to fuse from, in the reference's stacking order) for every matched instance that is due (instance3d.py:157-178);
-        only keyframes whose descriptors exist or are planned count."""
+    def _planned_updates(self, matched_ins_ids) -> List[tuple]:
+        """(instance, keyframes to fuse from, in the reference's stacking order[, views already summed]) for every matched instance that is due
+        (instance3d.py:157-178); only keyframes whose descriptors exist or are planned count.
+        avg_pooling (the configured fusion, ovo.yaml:50) is kept as a RUNNING SUM per instance: the tuple then names only the views that are new
+        since the instance's last fusion plus the number already in the sum (0 = start over: first fusion, a summed view evicted from the top-k
+        heap, or a full re-fusion in between) -- the mean of all views, without walking an instance's whole view list (which grows with the
+        sequence at k_top_views = 10000) on every keyframe it is seen in."""
         known = self._planned_kfs.union(self.keyframes["ins_descriptors"])
+        incremental = Instance3D.mv_fusion == "avg_pooling" and not self.config.get("full_refusion", False)
         updates = []
         for ins_id in matched_ins_ids:
             obj = self.objects[ins_id]
             if not obj.to_update:
                 continue
-            views = [kf for kf in obj.fusion_views() if kf in known]
+            if not incremental:
+                views = [kf for kf in obj.fusion_views() if kf in known]
+                if views:
+                    updates.append((ins_id, views))
+                    obj.to_update = False
+                continue
+            if obj._needs_full:
+                views = [kf for kf in obj.fusion_views() if kf in known]
+                if not views:
+                    continue
+                obj._inc_kfs, before = set(views), 0
+                obj._pending_kfs = [kf for kf in obj._pending_kfs if kf not in obj._inc_kfs]
+                obj._needs_full = False
+            else:
+                in_views = obj.is_top_kf if obj.n_top_kf > 0 else obj.kfs_ids.__contains__
+                views = [kf for kf in obj._pending_kfs if kf in known and kf not in obj._inc_kfs and in_views(kf)]
+                obj._pending_kfs = [kf for kf in obj._pending_kfs if kf not in known and in_views(kf)]
+                before = len(obj._inc_kfs)
+                obj._inc_kfs.update(views)
+            obj.to_update = False
             if views:
-                updates.append((ins_id, views))
-                obj.to_update = False
+                updates.append((ins_id, views, before))
         return updates
 
     def _apply_semantic_plan(self, plan: Dict[str, Any], clip_embeds: torch.Tensor) -> None:
@@ -639,7 +665,10 @@ class OVO:
             self.bank, {i: rows[j] for j, i in enumerate(matched_ins_ids) if i != -1})
         self._planned_kfs.discard(kf_id)
         desc = self.keyframes["ins_descriptors"]
-        self.bank.fuse([(ins_id, [desc[kf]._rows[ins_id] for kf in views]) for ins_id, views in updates], Instance3D.mv_fusion)
+        full = [(u[0], [desc[kf]._rows[u[0]] for kf in u[1]]) for u in updates if len(u) == 2]
+        add = [(u[0], [desc[kf]._rows[u[0]] for kf in u[1]], u[2]) for u in updates if len(u) == 3]
+        self.bank.fuse(full, Instance3D.mv_fusion)
+        self.bank.fuse_add(add)
 
     def _update_matched_objects_clip(self, clip_embeds: torch.Tensor, matched_ins_ids: List[int], kf_id: int) -> None:
         """Reference: ovo.py:440-461; all touched instances are fused in one launch."""

@@ -22,6 +22,7 @@ class RoundLauncher:
         # so the one-launch form is opt-in (OVO_ROUND_CHAIN=1) until its passes keep more loads in flight.
         self.enabled = bool(os.environ.get("OVO_ROUND_CHAIN")) if workgroups is None else True
         self.workgroups = int(os.environ.get("OVO_CHAIN_WORKGROUPS", "0")) if workgroups is None else int(workgroups)
+        self.merged = not os.environ.get("OVO_NO_KEYFRAME_STEP")
         self._ctx = None
         self.launches = 0                # rounds that went through ovo_round_chain
         self.fallbacks = 0               # rounds that went keyframe by keyframe
@@ -45,6 +46,9 @@ class RoundLauncher:
         if rc == L.E_UNSUPPORTED:                                  # shapes the one-launch form does not cover: the two calls per keyframe
             self.fallbacks += 1
             for m, t in zip(maps, tracks):
+                if m.depth and t.n_masks > 0 and self.merged:         # both halves: their independent passes share launches
+                    L.check(lib.ovo_keyframe_step(L.C.byref(m), L.C.byref(t), handle))
+                    continue
                 if m.depth:
                     L.check(lib.ovo_map_step(L.C.byref(m), handle))
                 if t.n_masks > 0:

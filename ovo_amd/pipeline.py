@@ -28,6 +28,7 @@ tests/test_gpu_multirank.py runs two ranks on one GPU and asserts equality with 
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import time
 from dataclasses import dataclass, field
@@ -399,31 +400,30 @@ class FramePipeline:
         G.prepare_frame_cameras([(f.depth, f.c2w) for f in group], self.slam._K_host)
         side = self.chain_stream
         maps, tracks, pend = [], [], []
-        for f in group:
-            fd = [f.index, f.rgb_lr, f.depth, f.c2w]
-            self.slam.track_camera(fd)
-            c2w = self.slam._c2w_host[f.index]                     # host copy: no D2H for the frustum set-up
-            if f.ready is not None and side is not None:
-                side.wait_event(f.ready)                           # the frame's upload, if it is still in flight
-            m = self.slam.map_launch(fd, c2w, defer=True)
-            p = self.ovo.detect_and_track_launch([f.index, f.rgb, f.depth, ratio], self.slam, c2w, defer=True)
-            pend.append(p)
-            if m is not None or p is not None:
-                maps.append(m if m is not None else L.MapStep())
-                tracks.append(p["step"] if p is not None else L.TrackStep())
-        if not maps:
-            return pend
-        if side is not None:
-            ready = torch.cuda.Event()                             # the chains' buffers (and masks) were produced on the current stream
-            ready.record()
-            side.wait_event(ready)
-        self.round_launcher.launch(maps, tracks, side)
-        if side is not None:
-            done = torch.cuda.Event()
-            done.record(side)
-            for p in pend:
-                if p is not None:
-                    p["done"] = done
+        # Everything the chains touch is produced ON their stream (the masks' working copy, the per-keyframe buffers): nothing of the chain
+        # waits for the main stream, whose queue holds the previous rounds' tails (with a main -> chain dependency the two streams took turns:
+        # tail(r - 1) -> chains(r + 1) -> tail(r + 1) ..., 4.5 ms per round).  The other direction is an event: chain k -> tail k.
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            for f in group:
+                fd = [f.index, f.rgb_lr, f.depth, f.c2w]
+                self.slam.track_camera(fd)
+                c2w = self.slam._c2w_host[f.index]                 # host copy: no D2H for the frustum set-up
+                if f.ready is not None and side is not None:
+                    side.wait_event(f.ready)                       # the frame's upload, if it is still in flight
+                m = self.slam.map_launch(fd, c2w, defer=True)
+                p = self.ovo.detect_and_track_launch([f.index, f.rgb, f.depth, ratio], self.slam, c2w, defer=True)
+                pend.append(p)
+                if m is not None or p is not None:
+                    maps.append(m if m is not None else L.MapStep())
+                    tracks.append(p["step"] if p is not None else L.TrackStep())
+            if maps:
+                self.round_launcher.launch(maps, tracks, None)     # (the current stream IS the chain stream here)
+                if side is not None:
+                    done = torch.cuda.Event()
+                    done.record(side)
+                    for p in pend:
+                        if p is not None:
+                            p["done"] = done
         return pend
 
     def _own_masks(self, mine: Frame, amg_pending):

@@ -164,7 +164,7 @@ def _run_keyframes(queued, n_frames=6, top_k=2):
     ovo = OVO(cfg, None, None, K, device=DEV, clip_generator=_NoClip(), mask_generator=Masks())
     vm = VanillaMapper({"device": DEV, "mapping": {}}, K)
     frames = [syn.frame(t, scale=scale, seed=11) for t in range(n_frames)]
-    if queued == "chain":
+    if queued in ("chain", "merged"):
         from ovo_amd.entities.round_chain import RoundLauncher
         vm.reserve(n_frames * h * w)
         maps, tracks, pend = [], [], []
@@ -175,8 +175,10 @@ def _run_keyframes(queued, n_frames=6, top_k=2):
             pend.append(ovo.detect_and_track_launch([fid, rgb, depth, ()], vm, vm._c2w_host[fid], defer=True))
             tracks.append(pend[-1]["step"])
         launcher = RoundLauncher(DEV, workgroups=48)
+        if queued == "merged":                                       # ovo_keyframe_step: 7 launches per keyframe, independent passes share launches
+            launcher.enabled = False
         launcher.launch(maps, tracks)
-        assert launcher.launches == 1 and launcher.fallbacks == 0
+        assert (launcher.launches, launcher.fallbacks) == ((0, 1) if queued == "merged" else (1, 0))
         for p in pend:
             ovo.detect_and_track_finish(p)
     elif queued:
@@ -203,10 +205,10 @@ def _run_keyframes(queued, n_frames=6, top_k=2):
             "queue": [(m, b.cpu(), kf) for m, b, _, kf in ovo.keyframes_queue]}
 
 
-@pytest.mark.parametrize("mode", [True, "chain"])
+@pytest.mark.parametrize("mode", [True, "merged", "chain"])
 def test_queued_keyframe_chains_equal_one_by_one_host_decisions(mode):
     """Six keyframes queued back to back on the device (map size, point ids, instance ids resident; one result block each) -- as
-    ~12 launches per keyframe, or all in ONE persistent launch with grid barriers -- give the map, the instance list, the heaps and
+    ~13 launches per keyframe, as 7 (independent passes merged, `ovo_keyframe_step`), or all in ONE persistent launch with grid barriers -- give the map, the instance list, the heaps and
     the fused masks of the keyframe-at-a-time run with host decisions, bit for bit."""
     a, b = _run_keyframes(mode), _run_keyframes(False)
     assert a["max_id"] == b["max_id"] and a["next"] == b["next"] and a["next"] > 5

@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_encoder.py tests/test_gpu_hiera.py -x -q -k "attention or hiera_vs" > gpurun_out/t1.log 2>&1; tail -3 gpurun_out/t1.log
-(python tools/enc_table.py sam 12 | grep -i "attn\|total") > gpurun_out/enc_attn.txt 2>&1; cat gpurun_out/enc_attn.txt
-timeout 600 python bench.py --no-cpu-baseline --projection-world 0 --no-online > gpurun_out/bench_b.json 2> gpurun_out/bench_b.err; python -c "
-import json; d=json.load(open('gpurun_out/bench_b.json')); print(d['value'], d['ms_per_step'], d['sustained']['frames_per_s'], d['roofline']['isolated']['attention_ms_per_frame'], d['roofline']['attention_ms_per_frame'])"
+timeout 1500 python -m pytest tests/test_gpu_geometry.py tests/test_gpu_pipeline.py tests/test_gpu_e2e.py tests/test_gpu_multirank.py tests/test_gpu_features.py tests/test_gpu_loopclose.py -x -q > gpurun_out/t1.log 2>&1; tail -8 gpurun_out/t1.log
+(echo "running-sum fusion"; python tools/round_emulation.py 8; python tools/round_emulation.py 4; python tools/round_emulation.py 1
+python tools/replicated_cost.py 64 8
+python tools/round_profile.py 8 24 | head -12) > gpurun_out/round_emulation.txt 2>&1
+grep -v amdgpu.ids gpurun_out/round_emulation.txt | cut -c1-150
