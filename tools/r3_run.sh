@@ -1,6 +1,17 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_geometry.py tests/test_gpu_pipeline.py tests/test_gpu_e2e.py tests/test_gpu_multirank.py tests/test_gpu_features.py tests/test_gpu_loopclose.py -x -q > gpurun_out/t1.log 2>&1; tail -8 gpurun_out/t1.log
-(echo "running-sum fusion"; python tools/round_emulation.py 8; python tools/round_emulation.py 4; python tools/round_emulation.py 1
-python tools/replicated_cost.py 64 8
-python tools/round_profile.py 8 24 | head -12) > gpurun_out/round_emulation.txt 2>&1
-grep -v amdgpu.ids gpurun_out/round_emulation.txt | cut -c1-150
+#!/bin/bash
+# scratch driver of one gpurun call (round 3): encoder batch sweep
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+{
+for B in 10 12 14 16; do timeout 300 python tools/enc_only.py vit $B 10; done
+for B in 8 12 14 16; do timeout 300 python tools/enc_only.py sam $B 6; done
+} > gpurun_out/enc_sweep.txt 2>&1
+for B in 12 14 16; do
+  timeout 600 python bench.py --encoder-batch $B --steps $((4*B)) --warmup $B --no-cpu-baseline --no-roofline --no-online --projection-world 0 --sustain-seconds 0 2>&1 | grep '^{' > gpurun_out/bench_b$B.json
+done
+tail -n 20 gpurun_out/enc_sweep.txt
+for B in 12 14 16; do python - <<PY
+import json
+d=json.loads(open("gpurun_out/bench_b$B.json").read().strip().splitlines()[-1])
+print($B, d["value"], d["ms_per_step"])
+PY
+done
