@@ -60,6 +60,44 @@ __device__ __forceinline__ float sum_xor16_32(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// Online-softmax update for one query tile over one 64-key tile.  In: s = raw scores (lane: query lane & 15, keys 16 kt + 4 fq + r; masked
+// entries -3e38).  Out: s = the probabilities exp2(score * scale_log2e - m_new) in fp32 (one FMA in front of v_exp_f32), m_run / l_run
+// updated; returns the factor the caller's accumulators are rescaled by.  The running maximum is taken over the SCALED scores: a product
+// is a canonical float, so the maxima compile to a v_max3_f32 chain -- on raw MFMA results every fmaxf operand was first quieted by a
+// `v_max_f32 x, x, x` (96 extra VALU instructions per three q-tiles, a fifth of the softmax).  Products, FMAs and partial sums are packed
+// (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two floats per lane and instruction).
+template <bool TAIL>
+__device__ __forceinline__ float softmax_tile(f32x4 (&s)[4], int nkt, float scale_log2e, float &m_run, float &l_run) {
+    const f32x4 sc = f32x4{scale_log2e, scale_log2e, scale_log2e, scale_log2e};
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        const f32x4 x = s[kt] * sc;
+        mx = fmaxf(fmaxf(mx, x[0]), x[1]);                             // v_max3_f32
+        mx = fmaxf(fmaxf(mx, x[2]), x[3]);
+    }
+    mx = max_xor16_32(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const f32x4 nm = f32x4{-m_new, -m_new, -m_new, -m_new};
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        if (!TAIL || kt < nkt) {
+            s[kt] = __builtin_elementwise_fma(s[kt], sc, nm);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r]);     // v_exp_f32
+            acc = acc + s[kt];
+        } else {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};                     // sub-tile past the last key: p = +0 exactly, nothing exponentiated
+        }
+    }
+    const float ps = sum_xor16_32((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    return alpha;
+}
+
 #ifdef OVO_ATTN_TRACE
 __device__ unsigned long long g_attn_trace[256];
 #define ATTN_STAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 1 && threadIdx.x == 0 && (i) < 256) g_attn_trace[i] = __builtin_readcyclecounter(); } while (0)
@@ -197,29 +235,7 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
                     for (int r = 0; r < 4; ++r)
                         if (k0 + kt * 16 + fq * 4 + r > q_row[t]) s[kt][r] = -3.0e38f;
             }
-            float mx = -3.0e38f;                                    // max of the RAW scores (scale > 0 commutes with max)
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
-            mx = max_xor16_32(mx);
-            const float m_new = fmaxf(m_run[t], mx * a.scale_log2e);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
-            float ps = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                if (!TAIL || kt < nkt) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], a.scale_log2e, -m_new));   // v_exp_f32, one FMA in front
-                        s[kt][r] = p;
-                        ps += p;
-                    }
-                } else {
-                    s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};            // masked sub-tile: p = exp2(-huge) = +0 exactly
-                }
-            }
-            ps = sum_xor16_32(ps);
-            l_run[t] = l_run[t] * alpha + ps;
-            m_run[t] = m_new;
+            const float alpha = softmax_tile<TAIL>(s, nkt, a.scale_log2e, m_run[t], l_run[t]);
             if (__any(alpha != 1.0f)) {                             // the running max settles after a few tiles
 #pragma unroll
                 for (int i = 0; i < HD / 16; ++i) {
@@ -437,6 +453,196 @@ __global__ void __launch_bounds__(256) k_attention_tiny(AttnArgs a, int krows) {
     }
 }
 
+
+// ---- whole-head-resident form: Tk <= 592 keys of head_dim <= 64 (the ViT-L/14-336 blocks: 577 tokens; Hiera's 14 x 14 windows: 196).
+// k_attention gives every 64 queries a workgroup that walks K / V in tiles -- fetch into registers, commit to LDS, one barrier per tile,
+// one q-tile per wave (every K / V^T fragment read from LDS feeds ONE MFMA: the LDS pipe is as busy as the matrix pipe) -- and measured
+// ~1600 cycles per (16 queries x 64 keys) on a SIMD whose MFMAs need 256.  Here K and V of one (batch, head) pair are copied into LDS
+// ONCE (K: 128-byte rows, 16-byte chunk index XORed with (row >> 1) & 7; V: the [4 keys][16 d] blocks of k_attention with the block's
+// d-group XORed with the key group & 3 -- no padding, 2 x 74 KB at 577 keys), one barrier, and then every wave walks all key tiles for
+// its OWN 2-3 q-tiles out of read-only LDS with no further synchronisation: a fragment feeds 2-3 MFMAs, nothing is handed over between
+// tiles, and the two waves of a SIMD cover each other's softmax with MFMAs.  A workgroup takes a contiguous range of a head's q-tiles
+// (`splits` ranges per head: 577 queries = 37 q-tiles = 19 + 18, eight waves x (3, 3, 3, 2, 2, 2, 2, 2) / (3, 3, 2, ...)); the same
+// arithmetic in the same order as k_attention -- bit-identical results (test_attention_resident_kernel_equals_tiled_kernel).
+typedef __attribute__((address_space(3))) char lds_char;
+
+// S^T of QT q-tiles against one 64-key tile (TAIL: the last, ragged one -- sub-tiles past the last key are not multiplied, keys past it masked)
+template <int QT, bool TAIL>
+__device__ __forceinline__ void resident_qk(const AttnArgs &a, const lds_char *sKt, int k0, const int (&kb)[2], const bf16x8 (&qf)[QT][2],
+                                            f32x4 (&s)[QT][4], int fq) {
+    const int nkt = TAIL ? (a.Tk - k0 + 15) >> 4 : 4;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) s[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!TAIL || kt < nkt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kf = *(const __attribute__((address_space(3))) bf16x8 *)(sKt + kt * (16 * 128) + kb[ks]);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[t][kt], 0, 0, 0);
+            }
+        }
+    }
+    if (TAIL) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + kt * 16 + fq * 4 + r >= a.Tk) s[t][kt][r] = -3.0e38f;
+    }
+}
+
+// online softmax of those scores and O^T += V^T P^T
+template <int QT, bool TAIL>
+__device__ __forceinline__ void resident_pv(const AttnArgs &a, const lds_char *sVt, int k0, const int (&vb)[4], f32x4 (&s)[QT][4],
+                                            f32x4 (&oacc)[QT][4], float (&m_run)[QT], float (&l_run)[QT]) {
+    const int nkt = TAIL ? (a.Tk - k0 + 15) >> 4 : 4;
+    bf16x8 pf[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const float alpha = softmax_tile<TAIL>(s[t], nkt, a.scale_log2e, m_run[t], l_run[t]);
+        if (__any(alpha != 1.0f)) {                                 // the running max settles after a few tiles
+#pragma unroll
+            for (int i = 0; i < 4; ++i) oacc[t][i] = oacc[t][i] * alpha;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint32_t tmp[4];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) tmp[e >> 1] = pack2(s[t][kk * 2 + (e >> 2)][e & 3], s[t][kk * 2 + (e >> 2)][(e & 3) + 1]);
+            pf[t][kk] = *(bf16x8 *)tmp;
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (TAIL && kk * 2 >= nkt) continue;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(sVt + (kk * 2) * (4 * 512) + vb[dt]));
+            s16x4 hi = s16x4{0, 0, 0, 0};
+            if (!TAIL || kk * 2 + 1 < nkt)
+                hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(sVt + (kk * 2 + 1) * (4 * 512) + vb[dt]));
+            const uint2 l2 = *(const uint2 *)&lo, h2 = *(const uint2 *)&hi;
+            uint4 raw = make_uint4(l2.x, l2.y, h2.x, h2.y);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8 *)&raw, pf[t][kk], oacc[t][dt], 0, 0, 0);
+        }
+    }
+}
+
+// One wave, QT q-tiles from q-tile qt0, all key tiles out of the resident K / V.
+template <int QT>
+__device__ __forceinline__ void resident_wave(const AttnArgs &a, const lds_char *sK, const lds_char *sV, const uint16_t *qp, uint16_t *obase, int qt0, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    int q_row[QT];
+    bf16x8 qf[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        q_row[t] = (qt0 + t) * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            const int d0 = ks * 32 + fq * 8;
+            if (q_row[t] < a.Tq && d0 < a.hd) raw = *(const uint4 *)(qp + (long long)q_row[t] * a.q_st + d0);
+            qf[t][ks] = *(bf16x8 *)&raw;
+        }
+    }
+    f32x4 oacc[QT][4];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = -1.0e30f; l_run[t] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oacc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // lane parts of the fragment addresses (bytes): K row (16 kt + fr) chunk (4 ks + fq) ^ (fr >> 1); V block (key group 4 x + fq, d-group dt ^ fq) + 8 fr
+    int kb[2], vb[4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) kb[ks] = fr * 128 + (((ks * 4 + fq) ^ (fr >> 1)) << 4);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vb[dt] = (fq * 4 + (dt ^ fq)) * 128 + fr * 8;
+    const int full = a.Tk >> 6;
+    for (int tile = 0; tile < full; ++tile) {
+        f32x4 s[QT][4];
+        resident_qk<QT, false>(a, sK + tile * (64 * 128), tile * 64, kb, qf, s, fq);
+        resident_pv<QT, false>(a, sV + tile * (16 * 512), tile * 64, vb, s, oacc, m_run, l_run);
+    }
+    if (a.Tk & 63) {
+        f32x4 s[QT][4];
+        resident_qk<QT, true>(a, sK + full * (64 * 128), full * 64, kb, qf, s, fq);
+        resident_pv<QT, true>(a, sV + full * (16 * 512), full * 64, vb, s, oacc, m_run, l_run);
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        if (q_row[t] >= a.Tq) continue;
+        const float inv = 1.0f / l_run[t];
+        uint16_t *op = obase + (long long)q_row[t] * a.o_st;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int d0 = dt * 16 + fq * 4;
+            if (d0 < a.hd) {
+                uint2 p;
+                p.x = pack2(oacc[t][dt][0] * inv, oacc[t][dt][1] * inv);
+                p.y = pack2(oacc[t][dt][2] * inv, oacc[t][dt][3] * inv);
+                *(uint2 *)(op + d0) = p;
+            }
+        }
+    }
+}
+
+// a.q_tiles = q-tiles (of 16) per head, a.chunk = work items per XCD (work item = (head, split)); `splits` ranges of q-tiles per head
+__global__ void __launch_bounds__(512) k_attention_resident(AttnArgs a, int splits, int krows) {
+    extern __shared__ __attribute__((aligned(16))) char rsm[];
+    lds_char *sK = (lds_char *)rsm, *sV = sK + krows * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int work = (blockIdx.x & 7) * a.chunk + (blockIdx.x >> 3);          // items of one head next to each other on ONE XCD (its L2 serves K / V twice)
+    if (work >= a.B * a.H * splits) return;
+    const int bh = work / splits, split = work - bh * splits;
+    const int b = bh / a.H, h = bh % a.H;
+    const uint16_t *qp = a.q + b * a.q_sb + h * a.q_sh;
+    const uint16_t *kp = a.k + b * a.k_sb + h * a.k_sh;
+    const uint16_t *vp = a.v + b * a.v_sb + h * a.v_sh;
+    // (measured alternatives, tools/attn_bench.py, 24 x 16 heads x 577^2: this copy through registers 81 us; the same image brought in by
+    // LDS-DMA in tile order and consumed behind counted waits + one barrier per key tile 100 us -- waves in lock-step multiply and
+    // exponentiate at the same time, the drift between them IS the overlap; DMA with one wait 85 us)
+    const int pieces = krows * 8;
+    for (int id0 = tid; id0 < pieces; id0 += 4 * blockDim.x) {                 // four 16-byte pieces of K and of V in flight per thread
+        uint4 kr[4], vr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = id0 + u * blockDim.x, row = id >> 3, c = id & 7;
+            kr[u] = make_uint4(0, 0, 0, 0); vr[u] = make_uint4(0, 0, 0, 0);
+            if (id < pieces && row < a.Tk && c * 8 < a.hd) {
+                kr[u] = *(const uint4 *)(kp + (long long)row * a.k_st + c * 8);
+                vr[u] = *(const uint4 *)(vp + (long long)row * a.v_st + c * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = id0 + u * blockDim.x, row = id >> 3, c = id & 7, kg = row >> 2;
+            if (id < pieces) {
+                *(uint4 *)(rsm + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kr[u];
+                *(uint4 *)(rsm + krows * 128 + (kg * 4 + ((c >> 1) ^ (kg & 3))) * 128 + (row & 3) * 32 + (c & 1) * 16) = vr[u];
+            }
+        }
+    }
+    __syncthreads();
+    // this workgroup's q-tiles [t0, t0 + nt), dealt to the waves as contiguous runs of 2-3 (the first `rem` waves take one more)
+    const int per = a.q_tiles / splits, extra = a.q_tiles % splits;
+    const int t0 = split * per + (split < extra ? split : extra), nt = per + (split < extra ? 1 : 0);
+    const int base = nt / n_waves, rem = nt % n_waves;
+    int mine = base + (wave < rem ? 1 : 0), first = t0 + wave * base + (wave < rem ? wave : rem);
+    uint16_t *obase = a.o + b * a.o_sb + h * a.o_sh;
+    while (mine > 0) {                                                          // (more than 3 only when a split holds more than 3 q-tiles per wave)
+        if (mine >= 3) { resident_wave<3>(a, sK, sV, qp, obase, first, lane); first += 3; mine -= 3; }
+        else if (mine == 2) { resident_wave<2>(a, sK, sV, qp, obase, first, lane); first += 2; mine -= 2; }
+        else { resident_wave<1>(a, sK, sV, qp, obase, first, lane); first += 1; mine -= 1; }
+    }
+}
+
 }  // namespace
 
 extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
@@ -468,7 +674,10 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     // four times (64 + 64 + 64 + 4 queries): 12 frames' stage-3 windows 118 -> 104 us (tools/attn_bench.py, round 3)
     const bool wide = (getenv("OVO_ATTN_WIDE") != nullptr) ||
                       (!getenv("OVO_ATTN_NARROW") && ((p->hd > 64 && p->Tq >= 512 && (long long)((p->Tq + 127) / 128) * p->B * p->H >= 512) ||
-                                                      (p->Tq > 128 && p->Tq <= 256 && p->Tk <= 256 && (long long)p->B * p->H >= 512)));
+                                                      (p->Tq > 128 && p->Tq <= 256 && p->Tk <= 256 && (long long)p->B * p->H >= 512) ||
+                                                      // head_dim <= 64, long sequences: 12 frames' Hiera global blocks (96 x 4096^2 x 56) 730 us wide vs 772 narrow,
+                                                      // four frames' (32 pairs: 1024 wide workgroups) 394 vs 292 -- wide from ten 128-query workgroups per CU
+                                                      (p->hd <= 64 && p->Tq >= 2048 && (long long)((p->Tq + 127) / 128) * p->B * p->H >= 2560)));
     const int qpb = wide ? 128 : 64;
     dim3 grid((p->Tq + qpb - 1) / qpb, p->B * p->H);
     a.q_tiles = (int)grid.x; a.chunk = 0;
@@ -481,6 +690,29 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     const bool prof = ovo_prof_enabled();
     if (prof) { ovo_prof_begin(1, 4.0 * p->B * p->H * (double)p->Tq * p->Tk * p->hd, s); ovo_prof_shape(p->B * p->H, p->Tq, p->Tk); }
     struct Done { bool on; hipStream_t s; ~Done() { if (on) ovo_prof_end(s); } } done{prof, s};
+    // 65-592 keys of head_dim <= 64, not causal: K / V of a head resident in LDS (k_attention_resident)
+    if (p->hd <= 64 && p->Tk > 64 && p->Tk <= 592 && !p->causal && !getenv("OVO_ATTN_NO_RESIDENT")) {
+        const int krows = (p->Tk + 15) & ~15, nq = (p->Tq + 15) / 16;
+        const size_t lds = (size_t)krows * 256;
+        // one 8-wave workgroup per CU above half the LDS; below it 4-wave workgroups, so that one loads while another multiplies
+        const int threads = lds > 80 * 1024 ? 512 : 256, waves = threads / 64;
+        int splits = (nq + 3 * waves - 1) / (3 * waves);                  // at most 3 q-tiles per wave ...
+        const long long heads = (long long)p->B * p->H;
+        while (heads * splits < 768 && (splits + 1) * 2 * waves <= nq) ++splits;   // ... and 3+ workgroups per CU while every wave keeps 2 q-tiles
+        static bool attr_done = false;
+        if (heads * splits < 192) goto tiled;                             // too few workgroups for the chip (one frame's two crops: 32 heads): the 64-query tiled form has 10x more
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_attention_resident, hipFuncAttributeMaxDynamicSharedMemorySize, 592 * 256);
+            if (e != hipSuccess) { ovo_set_error("ovo_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
+            attr_done = true;
+        }
+        const long long items = heads * splits;
+        a.q_tiles = nq; a.chunk = (int)((items + 7) / 8);
+        k_attention_resident<<<(unsigned)(a.chunk * 8), threads, lds, s>>>(a, splits, krows);
+        OVO_CHECK_LAUNCH();
+        return OVO_OK;
+    }
+tiled:
     // tiny problems (one key tile, at most four query tiles): one wave per (batch, head) pair
     // (tools/attn_bench.py, 12 frames of hiera_b+: 16 x 16 windows 165 -> 79 us = 4.5 TB/s of q/k/v/o, pooled 4 x 16 blocks 321 -> 89 us;
     //  with 2-4 query tiles per pair -- 64 x 64, 49 x 49 -- the tiled kernel's four waves per pair are ahead: 180 vs 201 us, 33 vs 37)

@@ -268,7 +268,8 @@ def test_gemm_rope_epilogue_vs_rope_kernel_and_torch(b, t, heads, hd):
                                           (2, 2, 1, 1, 8), (1, 2, 130, 70, 72), (1, 1, 4096, 4096, 56), (2, 8, 257, 257, 128),
                                           (64, 4, 16, 16, 56), (32, 8, 4, 16, 56), (8, 2, 64, 64, 56), (5, 3, 70, 50, 64), (3, 2, 17, 33, 40),   # Tk <= 64: trimmed / tiny forms
                                           (7, 3, 49, 49, 64), (9, 1, 33, 17, 24), (1, 1, 1, 64, 64), (130, 2, 16, 64, 56), (3, 2, 64, 1, 8),    # one wave per (batch, head) pair
-                                          (6, 2, 196, 196, 56), (2, 2, 196, 200, 64), (2, 1, 300, 280, 64)])                                  # last key tile mostly padding
+                                          (6, 2, 196, 196, 56), (2, 2, 196, 200, 64), (2, 1, 300, 280, 64),                                   # last key tile mostly padding
+                                          (40, 16, 577, 577, 64), (1, 1, 577, 592, 64), (2, 3, 100, 65, 48), (3, 2, 900, 128, 64), (1, 2, 31, 593, 64)])   # K / V resident in LDS (65..592 keys)
 def test_attention_vs_torch(B, H, Tq, Tk, hd):
     from ovo_amd import _lib as L
     g = torch.Generator().manual_seed(B + H + Tq + Tk + hd)
@@ -292,6 +293,37 @@ def test_attention_vs_torch(B, H, Tq, Tk, hd):
     # P is rounded to bf16 before P.V (rel 2^-9) and O is stored in bf16
     torch.testing.assert_close(out.float(), ref, atol=2e-2, rtol=2e-2)
     assert (out.float() - ref).abs().mean() < 2e-3
+
+
+def _attention_call(qkv, B, H, Tq, Tk, hd):
+    from ovo_amd import _lib as L
+    D, T = H * hd, qkv.shape[1]
+    out = torch.zeros(B, Tq, D, dtype=torch.bfloat16, device=DEV)
+    a = L.Attention()
+    base = qkv.data_ptr()
+    a.q, a.k, a.v, a.o = base, base + D * 2, base + 2 * D * 2, out.data_ptr()
+    a.q_sb = a.k_sb = a.v_sb = T * 3 * D
+    a.q_sh = a.k_sh = a.v_sh = hd
+    a.q_st = a.k_st = a.v_st = 3 * D
+    a.o_sb, a.o_sh, a.o_st = Tq * D, hd, D
+    a.B, a.H, a.Tq, a.Tk, a.hd, a.scale = B, H, Tq, Tk, hd, hd ** -0.5
+    L.check(L.load().ovo_attention(C.byref(a), L.stream()))
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,hd", [(24, 16, 577, 577, 64), (30, 8, 196, 196, 56), (10, 16, 49, 196, 56), (2, 4, 100, 300, 64), (1, 2, 577, 592, 64),
+                                          (3, 1, 33, 65, 40), (2, 2, 1200, 128, 64), (1, 1, 16, 80, 8), (300, 2, 197, 197, 64)])
+def test_attention_resident_kernel_equals_tiled_kernel(B, H, Tq, Tk, hd, monkeypatch):
+    """k_attention_resident (K / V of a head copied to LDS once, 2-3 q-tiles per wave, no barrier per tile) does k_attention's arithmetic in
+    k_attention's order: the outputs are the same bits."""
+    g = torch.Generator().manual_seed(B * 7 + H + Tq + Tk + hd)
+    qkv = torch.randn(B, max(Tq, Tk), 3, H, hd, generator=g).to(DEV, torch.bfloat16)
+    qkv[:, :, 0] *= 2.0
+    new = _attention_call(qkv, B, H, Tq, Tk, hd)
+    monkeypatch.setenv("OVO_ATTN_NO_RESIDENT", "1")
+    old = _attention_call(qkv, B, H, Tq, Tk, hd)
+    assert torch.equal(new, old)
 
 
 def test_layernorm_embed_im2col_rope():

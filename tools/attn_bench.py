@@ -1,6 +1,6 @@
 """Attention micro-benchmark over the ViT-L/14-336 and hiera_b+ shapes (12 frames per launch, as the bench's look-ahead groups):
-auto = what ovo_attention picks; notiny = OVO_ATTN_NO_TINY (the tiled kernel for the <= 64-token problems); narrow / wide = forced
-64 / 128-query workgroups.  GB/s = the q / k / v / o bytes of the launch."""
+auto = what ovo_attention picks; notiny = OVO_ATTN_NO_TINY (the tiled kernel for the <= 64-token problems); narrow / wide = the tiled
+kernel with forced 64 / 128-query workgroups (and OVO_ATTN_NO_RESIDENT: not the K / V-resident kernel of the 65..592-key problems).  GB/s = the q / k / v / o bytes of the launch."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,14 +22,14 @@ def run(B, H, Tq, Tk, hd, iters=30):
     e1.record(); torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / iters
     return us, 4.0 * B * H * Tq * Tk * hd / us / 1e6, 2.0 * B * H * hd * (2 * Tq + 2 * Tk) / us / 1e3
-shapes = [(24, 16, 577, 577, 64), (12, 8, 4096, 4096, 56), (300, 8, 196, 196, 56), (12288, 2, 64, 64, 56), (12288, 4, 16, 64, 56), (12288, 4, 16, 16, 56),
+shapes = [(24, 16, 577, 577, 64), (2, 16, 577, 577, 64), (12, 8, 4096, 4096, 56), (300, 8, 196, 196, 56), (12288, 2, 64, 64, 56), (12288, 4, 16, 64, 56), (12288, 4, 16, 16, 56),
           (12288, 8, 4, 16, 56), (300, 16, 49, 196, 56), (300, 16, 49, 49, 56), (8, 16, 2048, 2048, 128)]
 for shape in shapes:
     row = "%-28s" % str(shape)
     for mode in ("auto", "notiny", "narrow", "wide"):
-        for k in ("OVO_ATTN_NARROW", "OVO_ATTN_WIDE", "OVO_ATTN_NO_TINY"): os.environ.pop(k, None)
-        if mode == "narrow": os.environ["OVO_ATTN_NARROW"] = "1"
-        if mode == "wide": os.environ["OVO_ATTN_WIDE"] = "1"
+        for k in ("OVO_ATTN_NARROW", "OVO_ATTN_WIDE", "OVO_ATTN_NO_TINY", "OVO_ATTN_NO_RESIDENT"): os.environ.pop(k, None)
+        if mode == "narrow": os.environ["OVO_ATTN_NARROW"] = "1"; os.environ["OVO_ATTN_NO_RESIDENT"] = "1"
+        if mode == "wide": os.environ["OVO_ATTN_WIDE"] = "1"; os.environ["OVO_ATTN_NO_RESIDENT"] = "1"
         if mode == "notiny": os.environ["OVO_ATTN_NO_TINY"] = "1"
         us, tf, gbs = run(*shape)
         row += "  %s %8.1fus %5.0fTF %5.0fGB/s" % (mode, us, tf, gbs)

@@ -1,17 +1,11 @@
 #!/bin/bash
-# scratch driver of one gpurun call (round 3): encoder batch sweep
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-{
-for B in 10 12 14 16; do timeout 300 python tools/enc_only.py vit $B 10; done
-for B in 8 12 14 16; do timeout 300 python tools/enc_only.py sam $B 6; done
-} > gpurun_out/enc_sweep.txt 2>&1
-for B in 12 14 16; do
-  timeout 600 python bench.py --encoder-batch $B --steps $((4*B)) --warmup $B --no-cpu-baseline --no-roofline --no-online --projection-world 0 --sustain-seconds 0 2>&1 | grep '^{' > gpurun_out/bench_b$B.json
-done
-tail -n 20 gpurun_out/enc_sweep.txt
-for B in 12 14 16; do python - <<PY
+timeout 900 python -m pytest tests/test_gpu_encoder.py tests/test_gpu_hiera.py -x -q -m gpu 2>&1 | tail -5 > gpurun_out/t1.log
+timeout 600 python tools/attn_bench.py > gpurun_out/attn_bench.txt 2>&1
+timeout 600 python bench.py --no-cpu-baseline --no-online --projection-world 0 --sustain-seconds 0 2>&1 | grep '^{' > gpurun_out/bench_n1.json
+cat gpurun_out/t1.log; grep -v amdgpu gpurun_out/attn_bench.txt | cut -c1-150
+python - <<PY
 import json
-d=json.loads(open("gpurun_out/bench_b$B.json").read().strip().splitlines()[-1])
-print($B, d["value"], d["ms_per_step"])
+d=json.loads(open("gpurun_out/bench_n1.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d.get("roofline"))
 PY
-done
