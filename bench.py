@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--projection-world", type=int, default=8, help="N = 1 only: after the timed legs, ONE GPU emulates rank 0 of a job of this many GPUs "
                     "(its own keyframe's encoders + every keyframe's replicated passes + 1/N of the dense rows, all-gather replaced by a local copy) "
                     "and reports the round time under `projection` (0 = off)")
+    ap.add_argument("--no-shared-crops", action="store_true", help="skip the `shared_crops` leg (identical TextRegion crops encoded once; not the headline)")
     ap.add_argument("--no-online", action="store_true", help="skip the `online` leg (the same workload with no encoder look-ahead)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="after the timed steps: keep stepping the same stream for this long (0 = off)")
     return ap.parse_args()
@@ -250,6 +251,32 @@ def measured_peaks(dev, lib):
             "note": "torch device copy of 1 GiB f32 (read + write bytes) and ovo_gemm 8192^3 bf16 on random operands, measured in this job"}
 
 
+def shared_crops_leg(args, dev, frames, sam):
+    """NOT the headline workload: the same stream with `share_identical_crops` -- a 640 x 480 frame tiles into one 336-pixel tile that IS the
+    global image (textregion.py:104-143), so the reference encodes the same pixels twice; this leg encodes them once (same descriptor bits,
+    test_textregion_shared_crops_equal_separate_forwards).  Off by default everywhere; reported so that the cost of the duplicate is on record."""
+    from ovo_amd.pipeline import Frame, FramePipeline
+    eb = max(args.encoder_batch, 1)
+    steps, warm = 4 * eb, eb
+    pipe = FramePipeline(dev, vit_card=args.vit, sam_card=sam, n_map=args.map_points, n_text=args.texts, dense=not args.no_dense, sam_full=args.sam_full,
+                         extra_capacity=(steps + warm + 2) * 72_000, seed=0, encoder_batch=eb, share_crops=True)
+    pool = frames * ((steps + warm) // len(frames) + 1)
+    stream = [Frame(300_000 + i, f.rgb[:], f.rgb_lr, f.depth, f.c2w, f.seg_map, f.masks) for i, f in enumerate(pool[:steps + warm])]
+    if eb > 1:
+        pipe.prime(*stream[0].rgb.shape[:2])
+    feed = Feed(stream, 1)
+    feed.run(pipe, warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    feed.run(pipe, steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del pipe
+    torch.cuda.empty_cache()
+    return {"encoder_batch": eb, "steps": steps, "frames_per_s": round(steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 3),
+            "note": "NOT `value`: identical TextRegion crops (global image = the single tile at 640 x 480) encoded once instead of twice; same descriptors"}
+
+
 def online_leg(args, dev, frames, sam):
     """The same workload with NO look-ahead (encoder_batch 1): keyframe t's encoders start when keyframe t arrives -- what an online
     mapper whose masks come from SAM2 can do (ovo.py:121-166); the headline's look-ahead needs the next keyframes of a recorded stream."""
@@ -419,6 +446,7 @@ def main():
     if world == 1 and args.projection_world > 1:
         projection = projection_leg(args, dev, frames, sam)
     online = online_leg(args, dev, frames, sam) if (world == 1 and args.encoder_batch > 1 and not args.no_online) else None
+    shared = shared_crops_leg(args, dev, frames, sam) if (world == 1 and not args.no_shared_crops) else None
 
     cpu, parity = None, None
     if want_cpu:
@@ -464,7 +492,7 @@ def main():
             "per_step_ms": {"median": round(cadence[len(cadence) // 2], 3), "min": round(cadence[0], 3), "max": round(cadence[-1], 3),
                             "note": "intervals between hipEvents recorded on the main stream at the end of every timed step"},
             "sustained": sustained,
-            "online": online, "roofline": roof, "cpu_baseline": cpu, "parity": parity, "projection": projection,
+            "online": online, "shared_crops": shared, "roofline": roof, "cpu_baseline": cpu, "parity": parity, "projection": projection,
         }
         if world > 1:
             line["exchange"] = {"collectives_per_round": 1, "bytes_per_rank": int(pipe.xchg.numel() * 4), "host_ms_per_round": round(xchg_ms, 3),

@@ -68,7 +68,8 @@ class CLIPGenerator:
             self.textregion = PETextRegion(encoder, model_card="PE" if not card.startswith("PE") else card,
                                            resize_method=config.get("resize_method", "multi_resolution"),
                                            remove_global_patch=config.get("remove_global_patch", False),
-                                           project_and_normalize=config.get("project_and_normalize", True))
+                                           project_and_normalize=config.get("project_and_normalize", True),
+                                           share_identical_crops=config.get("share_identical_crops"))
             self.clip_dim = self.textregion.out_dim
         if text_encoder is None and config.get("vocab_path"):
             # the real text side (clip_generator.py:161-173): tokenizer file + text tower of the same card

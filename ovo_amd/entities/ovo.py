@@ -585,7 +585,7 @@ class OVO:
         if slot["left"] > 0:
             raise L.OvoHipError("prefetch_image_features_batch: the batch before the previous one still has unconsumed images")
         _, h, w = images[0].permute(2, 0, 1).shape
-        crops = tr._crops(h, w)
+        crops = tr.forward_crops(h, w)
         nc, spec = len(crops), tr.vlm.spec
         n = len(images) * nc
         if slot["batch"] is None or slot["batch"].shape[0] < n:

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -39,8 +41,15 @@ class PETextRegion(torch.nn.Module):
     def __init__(self, model: HipViT, model_card: str = "PE-Core-L14-336", preprocess=None,
                  resize_method: str = "multi_resolution", remove_global_patch: bool = True,
                  global_patch_threshold: float = 0.07, crop_size: Optional[int] = None, upsample_times: int = 1,
-                 mask_type: str = "soft", dtype: str = "bf16", device=None, project_and_normalize: bool = True):
+                 mask_type: str = "soft", dtype: str = "bf16", device=None, project_and_normalize: bool = True,
+                 share_identical_crops: Optional[bool] = None):
         super().__init__()
+        # MI355X extension, OFF by default (the reference forwards every crop): on frames smaller than two crop sizes per side -- 640 x 480
+        # with 336-pixel crops -- the tiling's one tile IS the global image (textregion.py:104-143: crops = [whole, whole]), and the
+        # reference pushes the same pixels through the ViT twice.  With this switch identical crop rectangles are encoded once and their
+        # tokens used for both; the descriptors are the same bits (test_textregion_shared_crops_equal_separate_forwards).
+        self.share_identical_crops = bool(int(os.environ.get("OVO_SHARE_CROPS", "0"))) if share_identical_crops is None else bool(share_identical_crops)
+        self._uniq, self._crop_index = [0], [0]
         if not model_card.startswith("PE"):
             raise NotImplementedError("Current TextRegion implementaion supports only PE models.")
         self.remove_global_patch = bool(remove_global_patch)
@@ -75,6 +84,7 @@ class PETextRegion(torch.nn.Module):
         if self.resize_method != "multi_resolution":
             self.crop_num_h = self.crop_num_w = 1
             self.points_per_h = self.points_per_w = self.crop_size // self.patch_size
+            self._uniq, self._crop_index = [0], [0]
             return [(0, 0, h, w)]
         nh, nw = max(h // self.crop_size, 1), max(w // self.crop_size, 1)
         self.crop_num_h, self.crop_num_w = nh, nw
@@ -87,12 +97,23 @@ class PETextRegion(torch.nn.Module):
                 y2, x2 = min(i * ch + ch, h), min(j * cw + cw, w)
                 y1, x1 = max(y2 - ch, 0), max(x2 - cw, 0)
                 crops.append((y1, x1, y2 - y1, x2 - x1))
+        self._uniq, self._crop_index = [], []                    # crop k uses the tokens of forwarded crop _crop_index[k] (= k without sharing)
+        for k, c in enumerate(crops):
+            first = crops.index(c) if getattr(self, "share_identical_crops", False) else k
+            if first == k:
+                self._uniq.append(k)
+            self._crop_index.append(self._uniq.index(first))
         return crops
+
+    def forward_crops(self, h: int, w: int) -> List[Tuple[int, int, int, int]]:
+        """The crops that go through the encoder: all of `_crops` -- or, with `share_identical_crops`, each distinct rectangle once."""
+        crops = self._crops(h, w)
+        return [crops[k] for k in self._uniq]
 
     def get_img_features(self, image: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
         """image [3, H, W] (f32 in [0,1], or u8 with scale = 1/255) -> f32 [crops, 1 + P*P, width] after ln_post."""
         _, h, w = image.shape
-        batch = self.vlm.preprocess(image, self._crops(h, w), scale=scale)
+        batch = self.vlm.preprocess(image, self.forward_crops(h, w), scale=scale)
         return self.vlm.forward(batch, tokens=True)
 
     def get_features_mask(self, region_masks: torch.Tensor):
@@ -112,6 +133,8 @@ class PETextRegion(torch.nn.Module):
     def pe_value_with_sam2_attn(self, feature_masks, input_feature: torch.Tensor) -> torch.Tensor:
         weights, cnt = feature_masks
         tok = L.dev(input_feature, torch.float32, "input_feature")
+        if tok.shape[0] == len(self._uniq) and len(self._uniq) != len(self._crop_index):     # shared crops: one token block serves several crops
+            tok = tok.index_select(0, torch.tensor(self._crop_index, dtype=torch.int64).to(tok.device, non_blocking=True))
         ncrop, tpc, d = tok.shape
         p = self.crop_size // self.patch_size
         t0 = 1 if self.vlm.spec.cls_token else 0

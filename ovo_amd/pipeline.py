@@ -104,7 +104,7 @@ class FramePipeline:
     def __init__(self, device="cuda", vit_card: str = "PE-Core-L14-336", sam_card: Optional[str] = "hiera_b+",
                  n_map: int = 1_000_000, n_text: int = 10, dense: bool = True, scale: float = 1.0, extra_capacity: int = 4_000_000,
                  seed: int = 0, depth_filter: bool = True, track_th: int = 100, sam_full: bool = False, points_per_side: int = 16,
-                 encoder_batch: int = 1, k_top_views: int = 10000, emulate: Optional[tuple] = None):
+                 encoder_batch: int = 1, k_top_views: int = 10000, emulate: Optional[tuple] = None, share_crops: bool = False):
         """`emulate = (rank, world)`: ONE process does exactly what rank `rank` of a `world`-GPU job does per round -- its own keyframe's
         encoders and pooling, every keyframe's replicated passes, 1 / world of the dense rows -- with the round's all-gather replaced by a
         local stand-in (the other owners' descriptors are copies of its own rows).  A timing tool (bench.py `projection`): it measures a
@@ -127,7 +127,8 @@ class FramePipeline:
                                     "color": torch.zeros((n_map, 3), dtype=torch.uint8)})
         self.slam._reserve(n_map + extra_capacity)
         self.masks = ResidentMasks()
-        clip_cfg = {"embed_type": "TextRegion", "model_card": vit_card, "k_top_views": k_top_views, "fusion": "avg_pooling", "seed": seed}
+        clip_cfg = {"embed_type": "TextRegion", "model_card": vit_card, "k_top_views": k_top_views, "fusion": "avg_pooling", "seed": seed,
+                    "share_identical_crops": bool(share_crops)}
         self.clip = CLIPGenerator(clip_cfg, device=str(self.device), encoder=HipViT(VIT_SPECS[vit_card], None, self.device, seed))
         cfg = {"match_distance_th": 0.05, "track_th": track_th, "depth_filter": depth_filter, "log": False, "kf_queue_delay": 0,
                "debug_info": False, "clip": clip_cfg, "sam": {"precomputed": True}}

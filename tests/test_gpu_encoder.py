@@ -546,6 +546,26 @@ def test_textregion_predict_vs_oracle(hw):
     np.testing.assert_allclose(np.linalg.norm(out[~empty], axis=1), 1.0, atol=1e-5)
 
 
+def test_textregion_shared_crops_equal_separate_forwards():
+    """`share_identical_crops` (off by default): a frame smaller than two crop sizes per side tiles into ONE tile = the global image
+    (crops = [whole, whole], textregion.py:104-143); encoding it once and using the tokens for both crops gives the same bits as the
+    reference's two forwards.  A frame with distinct tiles is untouched by the switch."""
+    from ovo_amd import synthetic as syn
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state
+    from ovo_amd.entities.textregion import PETextRegion
+    spec = SPECS["tiny-pe"]
+    vit = HipViT(spec, random_state(spec, seed=4), device=DEV)
+    both = PETextRegion(vit, "PE-tiny-084", remove_global_patch=True, share_identical_crops=False)
+    once = PETextRegion(vit, "PE-tiny-084", remove_global_patch=True, share_identical_crops=True)
+    g = torch.Generator().manual_seed(3)
+    for (H, W), n_fwd in (((100, 150), 1), ((170, 260), 7), ((90, 200), 3)):
+        img = (torch.rand(3, H, W, generator=g) * 255).to(torch.uint8).to(DEV)
+        masks = torch.from_numpy(syn.make_masks(H, W, grid=(2, 3), n_blobs=3, seed=6)).to(DEV)
+        assert len(once.forward_crops(H, W)) == n_fwd and len(both.forward_crops(H, W)) == len(both._crops(H, W))
+        a, b = both.predict(img, masks, scale=1 / 255.0), once.predict(img, masks, scale=1 / 255.0)
+        assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
+
+
 @pytest.mark.parametrize("cls_offset,axis_order", [(1, "xy"), (0, "xy"), (1, "yx"), (0, "yx")])
 def test_rope_conventions_hip_vs_oracle(cls_offset, axis_order):
     """PE's Rope2D is unpinned upstream knowledge: its two conventions are switches (ViTSpec.rope_cls_offset / rope_axis_order).  For all four

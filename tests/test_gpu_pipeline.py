@@ -79,6 +79,30 @@ def test_encoder_lookahead_batching_does_not_change_results():
     _check(ref, got, pipe)
 
 
+def test_shared_identical_crops_do_not_change_results():
+    """`share_crops` (opt-in): frames so small that the TextRegion tiling is [whole, whole] -- the look-ahead forward then carries ONE crop per
+    keyframe instead of two, and every descriptor / class is the same bits as with the reference's duplicate forward."""
+    from ovo_amd.pipeline import FramePipeline, synthetic_frames
+    frames = synthetic_frames(6, DEV, scale=0.25, n_masks_grid=(3, 4), n_blobs=4)
+    runs = []
+    for share in (False, True):
+        pipe = FramePipeline(DEV, vit_card="tiny-pe", sam_card=None, n_map=60_000, n_text=7, scale=0.25, extra_capacity=200_000, track_th=40,
+                             encoder_batch=2, share_crops=share)
+        tr = pipe.clip.textregion
+        assert len(tr._crops(*frames[0].rgb.shape[:2])) == 2 and len(tr.forward_crops(*frames[0].rgb.shape[:2])) == (1 if share else 2)
+        trace = []
+        for i, f in enumerate(frames):
+            out = pipe.step(f, frames[i + 1:])
+            trace.append((out["n_instances"], None if out.get("sim") is None else out["sim"].clone(), pipe.ovo.last_clip_embeds, out["dense_cls"].clone()))
+        torch.cuda.synchronize()
+        runs.append(trace)
+    assert any(d is not None and d.shape[0] > 0 for _, _, d, _ in runs[0]), "fixture produced no descriptors"
+    for (na, sa, da, ca), (nb, sb, db, cb) in zip(*runs):
+        assert na == nb and torch.equal(ca, cb)
+        assert (sa is None and sb is None) or torch.equal(sa, sb)
+        assert (da is None and db is None) or torch.equal(torch.nan_to_num(da, nan=7.0), torch.nan_to_num(db, nan=7.0))
+
+
 def test_incremental_dense_query_equals_full_requery():
     """The resident dense class / confidence map, patched only for the rows a keyframe's scatter pass touched (ovo_scatter_accum_touched
     -> ovo_similarity_rows), against a full re-query of every row after every keyframe: equal bit for bit, and the touched set is a
