@@ -289,12 +289,17 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
         const double flop = 2.0 * g.M * (double)g.N * g.K, kt = g.K / 64;
         const double bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (double)g.M * g.N * (g.out_dtype == 0 ? 4.0 : 2.0) * (g.add ? 2.0 : 1.0);
         const double t_mem = bytes / 4.0e6;                                            // us at 4 TB/s
-        const double t_ring = flop / 650.0e6 + 4.0;
+        // (the ring kernels' rate falls with K: 650 TFLOP/s from 16 K-tiles, ~560 at 7 (K = 448), ~400 at 4 (K = 256): profiles/r03c_gemm_variants.txt)
+        const double t_ring = flop / (kt <= 4 ? 400.0e6 : (kt <= 8 ? 560.0e6 : 650.0e6)) + 4.0;
         const double r256 = (double)((blocks(256, 256) + 255) / 256), r128 = (double)((blocks(256, 128) + 255) / 256);
         // per-K-tile cost of the 256x128 form rises once every CU holds a tile and stays in its K-loop (measured: 0.62 us with <= 192 tiles
         // in flight, ~0.70 on a full chip with short K-loops whose phases interleave, 0.86 at K >= 3072: every CU in its K-loop at once)
         const double s128 = blocks(256, 128) <= 192 ? 0.62 : (kt >= 48 ? 0.86 : 0.70);
-        double t256 = r256 * (8.0 + 1.5 * kt), t128 = r128 * (9.0 + s128 * kt);
+        // short K-loops over many rounds (Hiera stage 3: K = 448, 6-10 rounds): the rounds of different CUs drift apart and the 256 x 128 form's
+        // shorter tiles overlap each other's prologues and epilogues (11 us per round measured instead of 14), the 256 x 256 form's do not (20.5):
+        // (58800, 1344, 448) 126 us on the ring kernel -> 112; (196608, 1344, 256) 352 -> 300
+        const double fix256 = (kt <= 8 && r256 >= 4) ? 10.0 : 8.0, fix128 = (kt <= 8 && r128 >= 4) ? 6.5 : 9.0;
+        double t256 = r256 * (fix256 + 1.5 * kt), t128 = r128 * (fix128 + s128 * kt);
         t256 = t256 > t_mem ? t256 : t_mem; t128 = t128 > t_mem ? t128 : t_mem;
         const double t8 = t256 < t128 ? t256 : t128;
         if (t8 < 0.93 * (t_ring > t_mem ? t_ring : t_mem)) {
