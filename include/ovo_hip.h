@@ -254,6 +254,16 @@ typedef struct {
     int32_t B, H, W, wh, ww;
 } ovo_window_t;
 int ovo_gemm_unwindow(const ovo_gemm_t *g, const ovo_window_t *win, ovo_stream_t stream);
+/* ovo_gemm whose A operand is the f32 residual stream itself (Hiera stages 1-2 inside SAM2AutomaticMaskGenerator.generate,
+ * mask_generator.py:113; no reference counterpart -- there LayerNorm and the linear layer are two modules): g->A is ignored,
+ * product row m reads x[src(m), 0..d) -- src(m) = m, or with `win` the SPATIAL token of window-major row m (a padding row
+ * of the window grid reads zeros) -- through LayerNorm(gamma, beta, eps) (mode 1) or a plain cast to bf16 (mode 2) while the
+ * operand is loaded; columns [d, K) are zeros; C is written in product order (g->add must be NULL).  The normalised bf16
+ * copy of the stream is never written.  Only shapes the weights-resident streaming kernel covers (M >= 16384, K <= 256,
+ * bf16, a handful of column-group widths): returns OVO_E_UNSUPPORTED otherwise, nothing launched -- the caller then
+ * normalises into a buffer and calls ovo_gemm (ovo_hiera_forward does exactly that). */
+int ovo_gemm_f32a(const ovo_gemm_t *g, const ovo_window_t *win, const float *x, int d, const float *gamma, const float *beta,
+                  float eps, int mode, ovo_stream_t stream);
 /* The large-vocabulary query (BASELINE.json config 5) with the argmax FUSED into the GEMM epilogue: per row and wave one
  * 64-bit atomicMax on (order-preserving bits of the score << 32 | ~column) into best u64[M] (ZERO on entry; columns >=
  * n_valid -- vocabulary padding -- never win).  store_scores = 0 never writes the score matrix at all (g->C may be NULL).

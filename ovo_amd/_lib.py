@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libovo_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 E_UNSUPPORTED = -3          # OVO_E_UNSUPPORTED: the entry point does not cover this shape; the caller takes its general path
 
 
@@ -172,6 +172,7 @@ _SIGNATURES = {
     "ovo_gemm_rope": (_I32, [C.POINTER(Gemm), C.POINTER(Rope), _P]),
     "ovo_gemm_periodic": (_I32, [C.POINTER(Gemm), _I64, _P]),
     "ovo_gemm_unwindow": (_I32, [C.POINTER(Gemm), C.POINTER(Window), _P]),
+    "ovo_gemm_f32a": (_I32, [C.POINTER(Gemm), C.POINTER(Window), _P, C.c_int, _P, _P, C.c_float, C.c_int, _P]),
     "ovo_decode_best": (_I32, [_P, _I64, _F32, _P, _P, _P]),
     "ovo_attention": (_I32, [C.POINTER(Attention), _P]),
     "ovo_layernorm": (_I32, [_P, _I64, _I64, _I32, _P, _P, _F32, _P, _I64, _I32, _P]),

@@ -30,6 +30,12 @@ struct GemmArgs {
     const float *rope_cos, *rope_sin;   // ovo_gemm_rope: rotary embedding of columns [0, rope_cols) in the epilogue, or NULL
     int rope_T, rope_hd, rope_cols, rope_t0;
     int win_per, win_ww, win_wh, win_nww, win_nwin, win_H, win_W;   // ovo_gemm_unwindow: win_per > 0 remaps C / add rows (see row_dest)
+    // gemm_stream.hip, Hiera stages 1-2: A = LayerNorm (ln_mode 1) or plain cast (2) of the f32 rows of `ln_x` [*, ln_d], taken while the operand is
+    // loaded -- product row m reads source row row_dest(m) (the win_* fields then describe the A side: window order -> spatial token, -1 = a
+    // padding row of zeros) and C is written in product order; columns [ln_d, K) are zeros
+    const float *ln_x, *ln_g, *ln_b;
+    float ln_eps;
+    int ln_d, ln_mode;
     int dbg;                   // tools/ only (OVO_8P_DEBUG): 1 = leave before anything, 2 = leave after the prologue, 4 = no epilogue
     unsigned long long *stamps;   // tools/ only (OVO_8P_STAMPS = address of u64[tiles][4]): s_memrealtime at start / K-loop / epilogue / end
 };
@@ -193,5 +199,9 @@ int gemm8p_launch(const GemmArgs &g, int bn, int in_dtype, hipStream_t s);
 int gemm8q_launch(const GemmArgs &g, int in_dtype, hipStream_t s);
 // the weights-resident streaming form for tall short-K products (gemm_stream.hip); OVO_E_UNSUPPORTED when the shape has no instantiation
 int gemm_stream_launch(const GemmArgs &g, int in_dtype, hipStream_t s);
+// the same kernel with the A operand taken from an f32 tensor through LayerNorm (mode 1) or a cast (mode 2) -- hiera.hip's way around
+// k_ln_window / k_cast_pad for the layers the streaming form covers; OVO_E_UNSUPPORTED otherwise (nothing launched)
+int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *x, int d, const float *gamma, const float *beta, float eps, int mode,
+                     ovo_stream_t stream);
 
 }  // namespace ovo_gemm_detail

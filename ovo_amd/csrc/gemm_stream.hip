@@ -15,17 +15,28 @@ using namespace ovo_gemm_detail;
 
 namespace {
 
-template <int KS, int NT, typename VT, int NTHREADS>
+// F32A: the A operand is the f32 residual stream itself -- LayerNorm (g.ln_mode 1) or a plain cast (2) of source row row_dest(m) is taken while
+// the fragments are loaded (a row of K <= 256 values lives in the 4 lanes (fr, 0..3): in-lane sums + two xor shuffles give its statistics), so the
+// normalised bf16 copy of the stream is never written or read: k_ln_window / k_cast_pad and their 6 bytes per element of HBM traffic disappear for
+// the layers this kernel runs (Hiera stages 1-2, the FPN laterals of those stages, conv_s0 / conv_s1).
+template <int KS, int NT, typename VT, int NTHREADS, bool F32A = false>
 __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_groups) {
     constexpr int K = KS * 32, NG = NT * 16;
     using S = ovo_skinny::Skinny<K, NG, VT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *cs = (float *)(smem + S::W_BYTES);
+    float *lg = cs + NG, *lb = lg + K;                               // F32A: LayerNorm weight / bias of the K (padded) input channels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int group = blockIdx.x % n_groups, slot = blockIdx.x / n_groups, slots = gridDim.x / n_groups;
     const int n0 = group * NG;
     S::load_w(smem, (const uint16_t *)g.W + (long long)n0 * g.ldw, g.ldw, tid, NTHREADS);
     for (int i = tid; i < NG; i += NTHREADS) cs[i] = g.bias ? g.bias[n0 + i] : 0.f;
+    if (F32A) {
+        for (int i = tid; i < K; i += NTHREADS) {
+            lg[i] = (g.ln_mode == 1 && i < g.ln_d) ? g.ln_g[i] : 0.f;
+            lb[i] = (g.ln_mode == 1 && i < g.ln_d) ? g.ln_b[i] : 0.f;
+        }
+    }
     __syncthreads();
     const float *cl = cs + fq * 4;
     const int blocks = (g.M + 15) / 16;
@@ -33,12 +44,62 @@ __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_grou
     for (int b = slot * WPB + wave; b < blocks; b += slots * WPB) {
         const int m = b * 16 + fr, mc = m < g.M ? m : g.M - 1;
         VT af[KS];
-        S::load_a(af, (const uint16_t *)g.A, g.lda, mc, fq);
+        if (F32A) {
+            // this lane's 8 KS values of source row `src` (spatial token of product row mc; -1: a padding row of the window grid = zeros)
+            const long long src = row_dest(g, mc);
+            const float *xp = g.ln_x + (src < 0 ? 0 : src) * g.ln_d;
+            float xv[KS][8];
+            float sum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int d0 = (ks * 4 + fq) * 8;
+                float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+                if (src >= 0 && d0 < g.ln_d) { lo = *(const float4 *)(xp + d0); hi = *(const float4 *)(xp + d0 + 4); }
+                xv[ks][0] = lo.x; xv[ks][1] = lo.y; xv[ks][2] = lo.z; xv[ks][3] = lo.w;
+                xv[ks][4] = hi.x; xv[ks][5] = hi.y; xv[ks][6] = hi.z; xv[ks][7] = hi.w;
+                sum += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+            }
+            float mean = 0.f, rstd = 1.f;
+            if (g.ln_mode == 1) {                                     // two-pass statistics, as k_ln_window (columns >= ln_d hold zeros and are left out)
+                sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+                mean = sum / (float)g.ln_d;
+                float q = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if ((ks * 4 + fq) * 8 < g.ln_d) {
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const float a0 = xv[ks][e] - mean, a1 = xv[ks][e + 1] - mean;
+                            q += a0 * a0 + a1 * a1;
+                        }
+                    }
+                }
+                q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+                rstd = rsqrtf(q / (float)g.ln_d + g.ln_eps);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int d0 = (ks * 4 + fq) * 8;
+                uint32_t pk[4];
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    float y0 = xv[ks][e], y1 = xv[ks][e + 1];
+                    if (g.ln_mode == 1) {
+                        y0 = (y0 - mean) * rstd * lg[d0 + e] + lb[d0 + e];
+                        y1 = (y1 - mean) * rstd * lg[d0 + e + 1] + lb[d0 + e + 1];
+                    }
+                    pk[e >> 1] = (src >= 0 && d0 < g.ln_d) ? pack_bf16(y0, y1) : 0u;
+                }
+                af[ks] = *(const VT *)pk;
+            }
+        } else {
+            S::load_a(af, (const uint16_t *)g.A, g.lda, mc, fq);
+        }
         f32x4 acc[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         S::mma(acc, af, smem, fr, fq);
-        const long long md = m < g.M ? row_dest(g, m) : -1;          // window-major product row -> spatial row (ovo_gemm_unwindow), -1 = padding
+        const long long md = m < g.M ? (F32A ? (long long)m : row_dest(g, m)) : -1;   // window-major product row -> spatial row (ovo_gemm_unwindow), -1 = padding
         if (md < 0) continue;
         const float *ap = g.add ? g.add + add_row(g, m, md) * g.ld_add + n0 + fq * 4 : nullptr;
         auto finish = [&](int j, float (&v)[4]) {
@@ -91,16 +152,17 @@ __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_grou
     }
 }
 
-template <int KS, int NT, typename VT>
+template <int KS, int NT, typename VT, bool F32A = false>
 int launch_stream(const GemmArgs &g, hipStream_t s) {
     constexpr int K = KS * 32, NG = NT * 16;
-    constexpr size_t lds = (size_t)NG * K * 2 + NG * sizeof(float);
+    constexpr size_t lds = (size_t)NG * K * 2 + NG * sizeof(float) + (F32A ? 2 * K * sizeof(float) : 0);
     // > half the LDS: one workgroup per CU -- 16 waves (128 VGPRs each), or 12 when the accumulators of a wide group need more; else two or more of 8 waves
-    constexpr int NTHREADS = lds > 80 * 1024 ? (NT > 16 ? 768 : 1024) : 512;
+    // (the f32 A path holds a row's 8 KS floats next to the fragments: one step fewer waves, or the accumulators spill)
+    constexpr int NTHREADS = lds > 80 * 1024 ? (F32A ? ((NT > 16 || KS >= 8) ? 512 : 768) : (NT > 16 ? 768 : 1024)) : 512;
     constexpr int PER_CU = lds > 80 * 1024 ? 1 : (lds > 52 * 1024 ? 2 : (lds > 39 * 1024 ? 3 : 4));
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_gemm_stream<KS, NT, VT, NTHREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_gemm_stream<KS, NT, VT, NTHREADS, F32A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { ovo_set_error("ovo_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
         attr_done = true;
     }
@@ -111,7 +173,7 @@ int launch_stream(const GemmArgs &g, hipStream_t s) {
     if (slots < 1) slots = 1;
     const bool prof = ovo_prof_enabled();
     if (prof) { ovo_prof_begin(8, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); }
-    k_gemm_stream<KS, NT, VT, NTHREADS><<<slots * n_groups, NTHREADS, lds, s>>>(g, n_groups);
+    k_gemm_stream<KS, NT, VT, NTHREADS, F32A><<<slots * n_groups, NTHREADS, lds, s>>>(g, n_groups);
     if (prof) ovo_prof_end(s);
     return OVO_OK;
 }
@@ -134,6 +196,14 @@ int gemm_stream_launch(const GemmArgs &g, int in_dtype, hipStream_t s) {
     // measured (tools/gemm_bench.py, profiles/r02c_gemm_stream.txt): no gain over the tiled kernels with 6+ column groups (A re-read per group)
     // or for the narrow f32-residual product (524288, 112, 128), which both forms run at the HBM rate of its in-place C traffic
     if (g.N / (ng ? ng : 1) >= 6 || (g.K == 128 && g.N == 112 && g.out_dtype == 0)) return OVO_E_UNSUPPORTED;
+    if (g.ln_mode) {                                                 // f32 A with LayerNorm / cast in the load: the shapes Hiera's stages 1-2 and FPN use
+#define GO(KK, NGG) if (g.K == KK && ng == NGG) return launch_stream<KK / 32, NGG / 16, bf16x8, true>(g, s);
+        GO(128, 336) GO(128, 256) GO(128, 224)
+        GO(192, 288) GO(192, 256) GO(192, 144)
+        GO(256, 256) GO(256, 224) GO(256, 64) GO(256, 32)
+#undef GO
+        return OVO_E_UNSUPPORTED;
+    }
 #define GO(KK, NGG) if (g.K == KK && ng == NGG) return launch_stream<KK / 32, NGG / 16, bf16x8>(g, s);
     GO(128, 336) GO(128, 256) GO(128, 224) GO(128, 112) GO(128, 64)
     GO(192, 288) GO(192, 256) GO(192, 144) GO(192, 112)
@@ -142,4 +212,38 @@ int gemm_stream_launch(const GemmArgs &g, int in_dtype, hipStream_t s) {
     return OVO_E_UNSUPPORTED;
 }
 
+// hiera.hip's entry: `p` as for ovo_gemm with A unused; A = LayerNorm (mode 1) / cast (mode 2) of x[source row, :d] (f32), source row of product
+// row m = its spatial token when `win` describes a window partition (padding rows = zeros), m itself without.  OVO_E_UNSUPPORTED: no
+// instantiation for the shape (the caller normalises / casts into a buffer and calls ovo_gemm).
+int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *x, int d, const float *gamma, const float *beta, float eps, int mode,
+                     ovo_stream_t stream) {
+    if (!p || !x || p->in_dtype != 2 || p->M < 16384 || p->K > 256 || d <= 0 || d % 8 != 0 || d > p->K || (mode != 1 && mode != 2) ||
+        (mode == 1 && (!gamma || !beta)) || ((uintptr_t)x & 15) != 0 || getenv("OVO_GEMM_NO_STREAM") || getenv("OVO_GEMM_TILE") || getenv("OVO_NO_LN_FOLD"))
+        return OVO_E_UNSUPPORTED;
+    if (p->ldw % 8 != 0 || ((uintptr_t)p->W & 15) != 0 || (p->bias && ((uintptr_t)p->bias & 15) != 0) || p->add || p->N % 4 != 0 || p->K % 32 != 0)
+        return OVO_E_UNSUPPORTED;
+    GemmArgs g = {};
+    g.A = nullptr; g.lda = 0; g.W = (const char *)p->W; g.ldw = p->ldw; g.bias = p->bias;
+    g.C = p->C; g.ldc = p->ldc; g.add = nullptr; g.ld_add = 0;
+    g.M = p->M; g.N = p->N; g.K = p->K; g.out_dtype = p->out_dtype; g.act = p->act; g.alpha = p->alpha;
+    g.store = 1; g.rope_T = 1; g.rope_hd = 4;
+    g.win_per = 0; g.win_ww = g.win_wh = g.win_nww = g.win_nwin = 1;
+    if (win) {
+        const int nwh = (win->H + win->wh - 1) / win->wh, nww = (win->W + win->ww - 1) / win->ww;
+        if ((long long)win->B * nwh * nww * win->wh * win->ww != p->M) return OVO_E_UNSUPPORTED;
+        g.win_per = win->wh * win->ww; g.win_ww = win->ww; g.win_wh = win->wh; g.win_nww = nww; g.win_nwin = nwh * nww; g.win_H = win->H; g.win_W = win->W;
+    }
+    g.ln_x = x; g.ln_g = gamma; g.ln_b = beta; g.ln_eps = eps; g.ln_d = d; g.ln_mode = mode;
+    const int rc = gemm_stream_launch(g, 2, (hipStream_t)stream);
+    if (rc != OVO_OK) return rc;
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
 }  // namespace ovo_gemm_detail
+
+extern "C" int ovo_gemm_f32a(const ovo_gemm_t *g, const ovo_window_t *win, const float *x, int d, const float *gamma, const float *beta, float eps,
+                             int mode, ovo_stream_t stream) {
+    OVO_REQUIRE(g && x && g->W && g->C, "null pointer");
+    return ovo_gemm_detail::gemm_f32a_stream(g, win, x, d, gamma, beta, eps, mode, stream);
+}

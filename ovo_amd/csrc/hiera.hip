@@ -9,7 +9,7 @@
 //   (epilogue of that GEMM, ovo_gemm_unwindow)  window order -> spatial order, + residual (the pooled projected skip at stage changes)
 //   k_ln_window(identity) -> FC1 GEMM(+GELU) -> FC2 GEMM(+bias, += x)
 // All GEMM operands have K padded to a multiple of 64 with zeros (dims 112 / 224 of hiera_b+, 144 / 288 of hiera_l; the 7x7x3 patch: 192).
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -261,6 +261,24 @@ int gemm(const void *A, long long lda, const void *W, long long ldw, const float
     return ovo_gemm(&g, s);
 }
 
+// C = act(LN-or-cast(x rows) . W^T + bias) through the streaming GEMM's f32 A path when it covers the shape; otherwise the two-pass form:
+// normalise / cast into `h` (window order when g.ws > 0), then ovo_gemm.  `h_done`: a previous call already filled `h` for this x.
+int gemm_from_f32(const float *x, const Grid &g, int d, int kp, const float *gamma, const float *beta, float eps, int mode, uint16_t *h, bool &h_done,
+                  const void *W, const float *bias, void *C, long long ldc, int out_dtype, int N, int act, ovo_stream_t s) {
+    ovo_gemm_t q;
+    q.A = h; q.lda = kp; q.W = W; q.ldw = kp; q.bias = bias; q.C = C; q.ldc = ldc; q.add = nullptr; q.ld_add = 0;
+    q.M = (int)g.rows; q.N = N; q.K = kp; q.in_dtype = 2; q.out_dtype = out_dtype; q.act = act; q.alpha = 1.0f;
+    if (!h_done) {
+        const ovo_window_t w = {g.B, g.H, g.W, g.wh, g.ww};
+        const int rc = ovo_gemm_detail::gemm_f32a_stream(&q, g.ws > 0 ? &w : nullptr, x, d, gamma, beta, eps, mode, s);
+        if (rc != OVO_E_UNSUPPORTED) return rc;
+        if (mode == 1) launch_ln_window(x, g, d, kp, gamma, beta, eps, h, (hipStream_t)s);
+        else k_cast_pad<<<ovo_grid(g.rows * kp, 256), 256, 0, (hipStream_t)s>>>(x, g.rows, d, kp, h);
+        h_done = true;
+    }
+    return ovo_gemm(&q, s);
+}
+
 }  // namespace
 
 #define TRY(call)                        \
@@ -311,15 +329,16 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         OVO_REQUIRE(!p.pool[i] || (g.wh % 2 == 0 && H % 2 == 0), "query pooling needs even windows");
         const long long tok_out = (long long)B * Ho * Ho;
 
-        launch_ln_window(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, k.h, hs);
+        // LayerNorm 1 happens inside the A-operand load of its consumers where the streaming GEMM runs them (stages 1-2), else as a pass into k.h
+        bool h_done = false;
         const float *residual = x;
         if (din != dout) {                                   // skip = maxpool(proj(LN(x)))
             OVO_REQUIRE(L.res_w && L.res_b && p.pool[i], "stage-change block without projection weights");
-            TRY(gemm(k.h, kin, L.res_w, kin, L.res_b, k.tmp, dout, 0, nullptr, 0, g.rows, dout, kin, 0, stream));
+            TRY(gemm_from_f32(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, 1, k.h, h_done, L.res_w, L.res_b, k.tmp, dout, 0, dout, 0, stream));
             k_pool_unwindow<<<ovo_grid(tok_out * dout, 256), 256, 0, hs>>>(k.tmp, g, dout, spare);
             residual = spare;
         }
-        TRY(gemm(k.h, kin, L.qkv_w, kin, L.qkv_b, k.qkv, 3 * dout, 2, nullptr, 0, g.rows, 3 * dout, kin, 0, stream));
+        TRY(gemm_from_f32(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, 1, k.h, h_done, L.qkv_w, L.qkv_b, k.qkv, 3 * dout, 2, 3 * dout, 0, stream));
         const long long n_win = (long long)B * g.nwh * g.nww;
         const int tk = g.wh * g.ww, tq = p.pool[i] ? tk / 4 : tk;
         ovo_attention_t a = {};
@@ -349,16 +368,17 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         }
         // MLP
         const Grid gi = make_grid(B, Ho, Ho, 0);
-        launch_ln_window(x, gi, dout, kout, L.ln2_g, L.ln2_b, c.ln_eps, k.h, hs);
-        TRY(gemm(k.h, kout, L.fc1_w, kout, L.fc1_b, k.u, 4 * dout, 2, nullptr, 0, tok_out, 4 * dout, kout, 1, stream));
+        h_done = false;
+        TRY(gemm_from_f32(x, gi, dout, kout, L.ln2_g, L.ln2_b, c.ln_eps, 1, k.h, h_done, L.fc1_w, L.fc1_b, k.u, 4 * dout, 2, 4 * dout, 1, stream));
         TRY(gemm(k.u, 4 * dout, L.fc2_w, 4 * dout, L.fc2_b, x, dout, 0, x, dout, tok_out, dout, 4 * dout, 0, stream));
         LAUNCHED();
 
         if (p.stage_end[i] >= 0) {                           // FPN lateral 1x1 conv of this stage's output
             const int s = p.stage_end[i];
             OVO_REQUIRE(w->neck_w[s] && w->neck_b[s], "missing neck weights");
-            k_cast_pad<<<ovo_grid(tok_out * kout, 256), 256, 0, hs>>>(x, tok_out, dout, kout, k.cast);
-            TRY(gemm(k.cast, kout, w->neck_w[s], kout, w->neck_b[s], k.lat[s], c.fpn_dim, 0, nullptr, 0, tok_out, c.fpn_dim, kout, 0, stream));
+            bool cast_done = false;
+            TRY(gemm_from_f32(x, gi, dout, kout, nullptr, nullptr, 0.f, 2, k.cast, cast_done, w->neck_w[s], w->neck_b[s], k.lat[s], c.fpn_dim, 0,
+                              c.fpn_dim, 0, stream));
         }
     }
     // top-down on the coarse levels: level 2 += up(level 3); levels 0 and 1 are laterals only
@@ -369,10 +389,11 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
     const long long t0 = (long long)B * T0, t1 = t0 / 4;
     if (c.hi_res) {
         OVO_REQUIRE(w->s0_w && w->s0_b && w->s1_w && w->s1_b, "missing conv_s0 / conv_s1 weights");
-        k_cast_pad<<<ovo_grid(t0 * c.fpn_dim, 256), 256, 0, hs>>>(k.lat[0], t0, c.fpn_dim, c.fpn_dim, k.cast);
-        TRY(gemm(k.cast, c.fpn_dim, w->s0_w, c.fpn_dim, w->s0_b, feat0, 32, 0, nullptr, 0, t0, 32, c.fpn_dim, 0, stream));
-        k_cast_pad<<<ovo_grid(t1 * c.fpn_dim, 256), 256, 0, hs>>>(k.lat[1], t1, c.fpn_dim, c.fpn_dim, k.cast);
-        TRY(gemm(k.cast, c.fpn_dim, w->s1_w, c.fpn_dim, w->s1_b, feat1, 64, 0, nullptr, 0, t1, 64, c.fpn_dim, 0, stream));
+        bool cast_done = false;
+        const Grid g0 = make_grid(B, S4, S4, 0), g1 = make_grid(B, S4 / 2, S4 / 2, 0);
+        TRY(gemm_from_f32(k.lat[0], g0, c.fpn_dim, c.fpn_dim, nullptr, nullptr, 0.f, 2, k.cast, cast_done, w->s0_w, w->s0_b, feat0, 32, 0, 32, 0, stream));
+        cast_done = false;
+        TRY(gemm_from_f32(k.lat[1], g1, c.fpn_dim, c.fpn_dim, nullptr, nullptr, 0.f, 2, k.cast, cast_done, w->s1_w, w->s1_b, feat1, 64, 0, 64, 0, stream));
     } else {
         OVO_HIP(hipMemcpyAsync(feat0, k.lat[0], (size_t)t0 * c.fpn_dim * 4, hipMemcpyDeviceToDevice, hs));
         OVO_HIP(hipMemcpyAsync(feat1, k.lat[1], (size_t)t1 * c.fpn_dim * 4, hipMemcpyDeviceToDevice, hs));

@@ -326,6 +326,79 @@ def test_attention_resident_kernel_equals_tiled_kernel(B, H, Tq, Tk, hd, monkeyp
     assert torch.equal(new, old)
 
 
+@pytest.mark.parametrize("M,N,K,d,win,mode,act,out", [
+    (65536, 336, 128, 112, (1, 256, 256, 8, 8), 1, 0, torch.bfloat16),      # hiera_b+ stage-1 QKV: LayerNorm + window partition in the operand load
+    (65536, 448, 128, 112, None, 1, 1, torch.bfloat16),                      # stage-1 FC1 + GELU
+    (17424, 672, 256, 224, (1, 130, 130, 4, 4), 1, 0, torch.bfloat16),       # windows that do not tile the grid: padding rows read zeros
+    (16384, 896, 256, 224, None, 1, 1, torch.bfloat16),
+    (65536, 432, 192, 144, (1, 256, 256, 8, 8), 1, 0, torch.bfloat16),       # hiera_l stage 1
+    (65536, 256, 128, 112, None, 2, 0, torch.float32),                       # FPN lateral: cast only
+    (65536, 32, 256, 256, None, 2, 0, torch.float32)])                       # conv_s0
+def test_gemm_with_layernorm_in_the_operand_load(M, N, K, d, win, mode, act, out):
+    """ovo_gemm_f32a (gemm_stream.hip, F32A) against the two-pass form it replaces -- LayerNorm / cast of the f32 rows in torch (same formula:
+    two-pass statistics, (x - mean) * rstd * gamma + beta, bf16 RNE), then ovo_gemm on the bf16 copy.  The cast-only mode is bit-equal; with
+    LayerNorm the row statistics are summed in another order, so a few normalised values round the other way: the outputs then differ by one
+    operand ulp in a dot product of d terms -- at most one ulp of the stored bf16 output, on a fraction of a percent of the elements."""
+    from ovo_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    if win is None:
+        rows_src = M
+        src = torch.arange(M)
+    else:
+        B, H, W, wh, ww = win
+        nwh, nww = -(-H // wh), -(-W // ww)
+        assert B * nwh * nww * wh * ww == M
+        rows_src = B * H * W
+        m = torch.arange(M)
+        w_, p_ = m // (wh * ww), m % (wh * ww)
+        b_, wr = w_ // (nwh * nww), w_ % (nwh * nww)
+        y, x_ = (wr // nww) * wh + p_ // ww, (wr % nww) * ww + p_ % ww
+        src = torch.where((y < H) & (x_ < W), (b_ * H + y) * W + x_, torch.full_like(m, -1))
+    x = (torch.randn(rows_src, d, generator=g) * 2 + 0.5).to(DEV)
+    gamma, beta = (torch.randn(d, generator=g) * 0.5 + 1).to(DEV), (torch.randn(d, generator=g) * 0.1).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, torch.bfloat16)
+    w[:, d:] = 0
+    bias = torch.randn(N, generator=g).to(DEV)
+    # the two-pass form
+    xs = x[src.clamp(min=0).to(DEV)]
+    if mode == 1:
+        mean = xs.mean(1, keepdim=True)
+        rstd = torch.rsqrt(((xs - mean) ** 2).mean(1, keepdim=True) + 1e-6)
+        xs = (xs - mean) * rstd * gamma + beta
+    a = torch.zeros(M, K, dtype=torch.bfloat16, device=DEV)
+    a[:, :d] = xs.to(torch.bfloat16)
+    a[(src < 0).to(DEV)] = 0
+    ref = _gemm(a, w, bias, out_dtype=out, act=act)
+    got = torch.empty(M, N, dtype=out, device=DEV)
+    q = L.Gemm()
+    q.A, q.lda, q.W, q.ldw, q.bias, q.C, q.ldc, q.add, q.ld_add = None, K, w.data_ptr(), K, bias.data_ptr(), got.data_ptr(), N, None, 0
+    q.M, q.N, q.K, q.in_dtype, q.out_dtype, q.act, q.alpha = M, N, K, 2, 0 if out == torch.float32 else 2, act, 1.0
+    wd = None
+    if win is not None:
+        wd = L.Window(); wd.B, wd.H, wd.W, wd.wh, wd.ww = win
+    L.check(lib.ovo_gemm_f32a(C.byref(q), C.byref(wd) if wd is not None else None, x.data_ptr(), d, gamma.data_ptr(), beta.data_ptr(), 1e-6, mode,
+                              L.stream()))
+    torch.cuda.synchronize()
+    if mode == 2:
+        assert torch.equal(got, ref)
+        return
+    rms = ref.float().pow(2).mean().sqrt()
+    diff = (got.float() - ref.float()).abs()
+    print(f"({M},{N},{K}) fused LayerNorm: max {diff.max().item() / rms.item():.2e} rms {(diff.pow(2).mean().sqrt() / rms).item():.2e} of the output rms, "
+          f"{(got != ref).float().mean().item():.2%} of the elements differ")
+    # (measured: 0.01 % of the outputs differ, each by ONE bf16 ulp of its own magnitude -- 2^-7 relative; rms 3e-5 of the output rms)
+    assert diff.max() <= ref.float().abs().max() * 2.0 ** -7 and diff.pow(2).mean().sqrt() < 2e-4 * rms and (got != ref).float().mean() < 2e-3
+    if win is not None:
+        pad = (src < 0).to(DEV)
+        if pad.any():                                                # a padding row: zeros . W + bias
+            exp = bias if act == 0 else torch.nn.functional.gelu(bias)
+            torch.testing.assert_close(got[pad].float(), exp.expand(int(pad.sum()), N).to(out).float(), atol=0, rtol=0)
+    small = L.Gemm.from_buffer_copy(q)
+    small.M = 1024                                                   # below the streaming kernel's range: nothing launched
+    assert lib.ovo_gemm_f32a(C.byref(small), None, x.data_ptr(), d, gamma.data_ptr(), beta.data_ptr(), 1e-6, mode, L.stream()) == L.E_UNSUPPORTED
+
+
 def test_layernorm_embed_im2col_rope():
     from ovo_amd import _lib as L
     lib = L.load()
