@@ -261,9 +261,12 @@ int ovo_gemm_unwindow(const ovo_gemm_t *g, const ovo_window_t *win, ovo_stream_t
  * operand is loaded; columns [d, K) are zeros; C is written in product order (g->add must be NULL).  The normalised bf16
  * copy of the stream is never written.  Only shapes the weights-resident streaming kernel covers (M >= 16384, K <= 256,
  * bf16, a handful of column-group widths): returns OVO_E_UNSUPPORTED otherwise, nothing launched -- the caller then
- * normalises into a buffer and calls ovo_gemm (ovo_hiera_forward does exactly that). */
+ * normalises into a buffer and calls ovo_gemm (ovo_hiera_forward does exactly that).
+ * pool2x2 = 1 (Hiera's stage-change skip path maxpool(proj(LN(x))); needs `win` with even windows of width 2 / 4 / 8 that
+ * tile the grid exactly, f32 output): the 2 x 2 max-pool over a window's tokens is taken in the epilogue and C holds the
+ * B x H/2 x W/2 pooled tokens in SPATIAL order -- the projection of every single token is never written. */
 int ovo_gemm_f32a(const ovo_gemm_t *g, const ovo_window_t *win, const float *x, int d, const float *gamma, const float *beta,
-                  float eps, int mode, ovo_stream_t stream);
+                  float eps, int mode, int pool2x2, ovo_stream_t stream);
 /* The large-vocabulary query (BASELINE.json config 5) with the argmax FUSED into the GEMM epilogue: per row and wave one
  * 64-bit atomicMax on (order-preserving bits of the score << 32 | ~column) into best u64[M] (ZERO on entry; columns >=
  * n_valid -- vocabulary padding -- never win).  store_scores = 0 never writes the score matrix at all (g->C may be NULL).

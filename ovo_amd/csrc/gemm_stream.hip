@@ -112,7 +112,28 @@ __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_grou
                 v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
             }
         };
-        if (g.out_dtype == 0) {
+        if (F32A && g.pool_ww > 0) {
+            // Hiera's stage-change skip path, maxpool2x2(proj(LN(x))): a 16-row block of window-major rows holds whole 2-row strips of a window
+            // (16 % (2 ww) == 0), so the four tokens of a pooled position sit in the lanes fr, fr ^ 1, fr ^ ww, fr ^ (ww + 1) of one column group:
+            // two xor shuffles take their maximum and the lane of the even / even token stores the pooled SPATIAL row -- the f32 projection of
+            // every token (704 MB at 12 frames of stage 1) is never written.  (max is exact: the same bits as k_pool_unwindow's.)
+            const long long src = row_dest(g, mc);                    // (b H + y) W + x of this lane's token; no padding rows here (checked at launch)
+            const int x = (int)(src % g.win_W), y = (int)((src / g.win_W) % g.win_H), bb = (int)(src / ((long long)g.win_W * g.win_H));
+            const long long dest = ((long long)bb * (g.win_H >> 1) + (y >> 1)) * (g.win_W >> 1) + (x >> 1);
+            const bool writer = ((fr & 1) | (fr & g.pool_ww)) == 0;
+            float *cp = (float *)g.C + dest * g.ldc + n0 + fq * 4;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float v[4];
+                finish(j, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = fmaxf(v[r], __shfl_xor(v[r], 1, 64));
+                    v[r] = fmaxf(v[r], __shfl_xor(v[r], g.pool_ww, 64));
+                }
+                if (writer) *(float4 *)(cp + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else if (g.out_dtype == 0) {
             float *cp = (float *)g.C + md * g.ldc + n0 + fq * 4;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -216,7 +237,7 @@ int gemm_stream_launch(const GemmArgs &g, int in_dtype, hipStream_t s) {
 // row m = its spatial token when `win` describes a window partition (padding rows = zeros), m itself without.  OVO_E_UNSUPPORTED: no
 // instantiation for the shape (the caller normalises / casts into a buffer and calls ovo_gemm).
 int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *x, int d, const float *gamma, const float *beta, float eps, int mode,
-                     ovo_stream_t stream) {
+                     int pool2x2, ovo_stream_t stream) {
     if (!p || !x || p->in_dtype != 2 || p->M < 16384 || p->K > 256 || d <= 0 || d % 8 != 0 || d > p->K || (mode != 1 && mode != 2) ||
         (mode == 1 && (!gamma || !beta)) || ((uintptr_t)x & 15) != 0 || getenv("OVO_GEMM_NO_STREAM") || getenv("OVO_GEMM_TILE") || getenv("OVO_NO_LN_FOLD"))
         return OVO_E_UNSUPPORTED;
@@ -234,6 +255,12 @@ int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *
         g.win_per = win->wh * win->ww; g.win_ww = win->ww; g.win_wh = win->wh; g.win_nww = nww; g.win_nwin = nwh * nww; g.win_H = win->H; g.win_W = win->W;
     }
     g.ln_x = x; g.ln_g = gamma; g.ln_b = beta; g.ln_eps = eps; g.ln_d = d; g.ln_mode = mode;
+    if (pool2x2) {      // whole even windows of width 2 / 4 / 8 tiling the grid exactly, f32 output, no activation between projection and pool
+        if (!win || p->out_dtype != 0 || win->H % win->wh != 0 || win->W % win->ww != 0 || win->wh % 2 != 0 || (win->ww != 2 && win->ww != 4 && win->ww != 8) ||
+            p->M % 16 != 0)
+            return OVO_E_UNSUPPORTED;
+        g.pool_ww = win->ww;
+    }
     const int rc = gemm_stream_launch(g, 2, (hipStream_t)stream);
     if (rc != OVO_OK) return rc;
     OVO_CHECK_LAUNCH();
@@ -243,7 +270,7 @@ int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *
 }  // namespace ovo_gemm_detail
 
 extern "C" int ovo_gemm_f32a(const ovo_gemm_t *g, const ovo_window_t *win, const float *x, int d, const float *gamma, const float *beta, float eps,
-                             int mode, ovo_stream_t stream) {
+                             int mode, int pool2x2, ovo_stream_t stream) {
     OVO_REQUIRE(g && x && g->W && g->C, "null pointer");
-    return ovo_gemm_detail::gemm_f32a_stream(g, win, x, d, gamma, beta, eps, mode, stream);
+    return ovo_gemm_detail::gemm_f32a_stream(g, win, x, d, gamma, beta, eps, mode, pool2x2, stream);
 }

@@ -270,7 +270,7 @@ int gemm_from_f32(const float *x, const Grid &g, int d, int kp, const float *gam
     q.M = (int)g.rows; q.N = N; q.K = kp; q.in_dtype = 2; q.out_dtype = out_dtype; q.act = act; q.alpha = 1.0f;
     if (!h_done) {
         const ovo_window_t w = {g.B, g.H, g.W, g.wh, g.ww};
-        const int rc = ovo_gemm_detail::gemm_f32a_stream(&q, g.ws > 0 ? &w : nullptr, x, d, gamma, beta, eps, mode, s);
+        const int rc = ovo_gemm_detail::gemm_f32a_stream(&q, g.ws > 0 ? &w : nullptr, x, d, gamma, beta, eps, mode, 0, s);
         if (rc != OVO_E_UNSUPPORTED) return rc;
         if (mode == 1) launch_ln_window(x, g, d, kp, gamma, beta, eps, h, (hipStream_t)s);
         else k_cast_pad<<<ovo_grid(g.rows * kp, 256), 256, 0, (hipStream_t)s>>>(x, g.rows, d, kp, h);
@@ -334,8 +334,18 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         const float *residual = x;
         if (din != dout) {                                   // skip = maxpool(proj(LN(x)))
             OVO_REQUIRE(L.res_w && L.res_b && p.pool[i], "stage-change block without projection weights");
-            TRY(gemm_from_f32(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, 1, k.h, h_done, L.res_w, L.res_b, k.tmp, dout, 0, dout, 0, stream));
-            k_pool_unwindow<<<ovo_grid(tok_out * dout, 256), 256, 0, hs>>>(k.tmp, g, dout, spare);
+            // projection + 2 x 2 max-pool in one launch where the streaming GEMM covers it (pooled rows straight into `spare`) ...
+            ovo_gemm_t q;
+            q.A = nullptr; q.lda = kin; q.W = L.res_w; q.ldw = kin; q.bias = L.res_b; q.C = spare; q.ldc = dout; q.add = nullptr; q.ld_add = 0;
+            q.M = (int)g.rows; q.N = dout; q.K = kin; q.in_dtype = 2; q.out_dtype = 0; q.act = 0; q.alpha = 1.0f;
+            const ovo_window_t wd = {g.B, g.H, g.W, g.wh, g.ww};
+            const int rc = g.ws > 0 ? ovo_gemm_detail::gemm_f32a_stream(&q, &wd, x, din, L.ln1_g, L.ln1_b, c.ln_eps, 1, 1, stream) : OVO_E_UNSUPPORTED;
+            if (rc == OVO_E_UNSUPPORTED) {                   // ... else every token's projection into k.tmp, then the pool pass
+                TRY(gemm_from_f32(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, 1, k.h, h_done, L.res_w, L.res_b, k.tmp, dout, 0, dout, 0, stream));
+                k_pool_unwindow<<<ovo_grid(tok_out * dout, 256), 256, 0, hs>>>(k.tmp, g, dout, spare);
+            } else if (rc != OVO_OK) {
+                return rc;
+            }
             residual = spare;
         }
         TRY(gemm_from_f32(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, 1, k.h, h_done, L.qkv_w, L.qkv_b, k.qkv, 3 * dout, 2, 3 * dout, 0, stream));

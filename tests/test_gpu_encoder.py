@@ -333,7 +333,10 @@ def test_attention_resident_kernel_equals_tiled_kernel(B, H, Tq, Tk, hd, monkeyp
     (16384, 896, 256, 224, None, 1, 1, torch.bfloat16),
     (65536, 432, 192, 144, (1, 256, 256, 8, 8), 1, 0, torch.bfloat16),       # hiera_l stage 1
     (65536, 256, 128, 112, None, 2, 0, torch.float32),                       # FPN lateral: cast only
-    (65536, 32, 256, 256, None, 2, 0, torch.float32)])                       # conv_s0
+    (65536, 32, 256, 256, None, 2, 0, torch.float32),                        # conv_s0
+    (65536, 224, 128, 112, (1, 256, 256, 8, 8), 2, 0, "pool"),               # stage-change skip path: projection + 2 x 2 max-pool in the epilogue (bit-equal)
+    (65536, 224, 128, 112, (1, 256, 256, 8, 8), 1, 0, "pool"),
+    (32768, 448, 256, 224, (2, 128, 128, 4, 4), 1, 0, "pool")])
 def test_gemm_with_layernorm_in_the_operand_load(M, N, K, d, win, mode, act, out):
     """ovo_gemm_f32a (gemm_stream.hip, F32A) against the two-pass form it replaces -- LayerNorm / cast of the f32 rows in torch (same formula:
     two-pass statistics, (x - mean) * rstd * gamma + beta, bf16 RNE), then ovo_gemm on the bf16 copy.  The cast-only mode is bit-equal; with
@@ -341,6 +344,8 @@ def test_gemm_with_layernorm_in_the_operand_load(M, N, K, d, win, mode, act, out
     operand ulp in a dot product of d terms -- at most one ulp of the stored bf16 output, on a fraction of a percent of the elements."""
     from ovo_amd import _lib as L
     lib = L.load()
+    pool = out == "pool"
+    out = torch.float32 if pool else out
     g = torch.Generator().manual_seed(M + N + K)
     if win is None:
         rows_src = M
@@ -370,7 +375,12 @@ def test_gemm_with_layernorm_in_the_operand_load(M, N, K, d, win, mode, act, out
     a[:, :d] = xs.to(torch.bfloat16)
     a[(src < 0).to(DEV)] = 0
     ref = _gemm(a, w, bias, out_dtype=out, act=act)
-    got = torch.empty(M, N, dtype=out, device=DEV)
+    if pool:                                                         # window order -> spatial grid -> 2 x 2 max-pool (hieradet.py do_pool; k_pool_unwindow)
+        B, H, W = win[:3]
+        grid = torch.empty(B * H * W, N, device=DEV)
+        grid[src.to(DEV)] = ref
+        ref = torch.nn.functional.max_pool2d(grid.reshape(B, H, W, N).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).reshape(-1, N).contiguous()
+    got = torch.empty(ref.shape[0], N, dtype=out, device=DEV)
     q = L.Gemm()
     q.A, q.lda, q.W, q.ldw, q.bias, q.C, q.ldc, q.add, q.ld_add = None, K, w.data_ptr(), K, bias.data_ptr(), got.data_ptr(), N, None, 0
     q.M, q.N, q.K, q.in_dtype, q.out_dtype, q.act, q.alpha = M, N, K, 2, 0 if out == torch.float32 else 2, act, 1.0
@@ -378,7 +388,7 @@ def test_gemm_with_layernorm_in_the_operand_load(M, N, K, d, win, mode, act, out
     if win is not None:
         wd = L.Window(); wd.B, wd.H, wd.W, wd.wh, wd.ww = win
     L.check(lib.ovo_gemm_f32a(C.byref(q), C.byref(wd) if wd is not None else None, x.data_ptr(), d, gamma.data_ptr(), beta.data_ptr(), 1e-6, mode,
-                              L.stream()))
+                              int(pool), L.stream()))
     torch.cuda.synchronize()
     if mode == 2:
         assert torch.equal(got, ref)
@@ -388,6 +398,9 @@ def test_gemm_with_layernorm_in_the_operand_load(M, N, K, d, win, mode, act, out
     print(f"({M},{N},{K}) fused LayerNorm: max {diff.max().item() / rms.item():.2e} rms {(diff.pow(2).mean().sqrt() / rms).item():.2e} of the output rms, "
           f"{(got != ref).float().mean().item():.2%} of the elements differ")
     # (measured: 0.01 % of the outputs differ, each by ONE bf16 ulp of its own magnitude -- 2^-7 relative; rms 3e-5 of the output rms)
+    if pool:                                                         # f32 outputs: a flipped bf16 operand moves a dot product by ~2^-8 |a w|, not by an output ulp
+        assert diff.max() < 2e-2 * rms and diff.pow(2).mean().sqrt() < 2e-4 * rms
+        return
     assert diff.max() <= ref.float().abs().max() * 2.0 ** -7 and diff.pow(2).mean().sqrt() < 2e-4 * rms and (got != ref).float().mean() < 2e-3
     if win is not None:
         pad = (src < 0).to(DEV)
@@ -396,7 +409,7 @@ def test_gemm_with_layernorm_in_the_operand_load(M, N, K, d, win, mode, act, out
             torch.testing.assert_close(got[pad].float(), exp.expand(int(pad.sum()), N).to(out).float(), atol=0, rtol=0)
     small = L.Gemm.from_buffer_copy(q)
     small.M = 1024                                                   # below the streaming kernel's range: nothing launched
-    assert lib.ovo_gemm_f32a(C.byref(small), None, x.data_ptr(), d, gamma.data_ptr(), beta.data_ptr(), 1e-6, mode, L.stream()) == L.E_UNSUPPORTED
+    assert lib.ovo_gemm_f32a(C.byref(small), None, x.data_ptr(), d, gamma.data_ptr(), beta.data_ptr(), 1e-6, mode, 0, L.stream()) == L.E_UNSUPPORTED
 
 
 def test_layernorm_embed_im2col_rope():
