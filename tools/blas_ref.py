@@ -2,7 +2,9 @@
 import torch
 dev = "cuda"
 shapes = [(1154, 3072, 1024), (1154, 1024, 1024), (1154, 4096, 1024), (1154, 1024, 4096), (4096, 1792, 448), (4096, 448, 1792), (4096, 1344, 448),
-          (65536, 448, 128), (65536, 112, 448), (16384, 896, 224), (1250000, 1000, 768)]
+          (65536, 448, 128), (65536, 112, 448), (16384, 896, 224), (1250000, 1000, 768),
+          (13848, 3072, 1024), (13848, 1024, 1024), (13848, 4096, 1024), (13848, 1024, 4096), (49152, 1792, 448), (49152, 448, 1792), (58800, 1344, 448),   # 12 frames per launch
+          (4096, 4096, 4096), (8192, 8192, 8192)]
 for m, n, k in shapes:
     a = torch.randn(m, k, device=dev, dtype=torch.bfloat16); w = torch.randn(n, k, device=dev, dtype=torch.bfloat16)
     for _ in range(5): torch.nn.functional.linear(a, w)

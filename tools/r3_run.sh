@@ -1,8 +1,12 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 1800 python -m pytest tests/test_gpu_encoder.py tests/test_gpu_hiera.py tests/test_gpu_sam_decoder.py -x -q -m gpu -s -k "operand_load or hiera or generator" 2>&1 | grep -v amdgpu | grep "fused\|passed\|failed\|Error\|assert" | tail -30 > gpurun_out/t1.log
-for v in 0 1 0 1; do
-  if [ $v = 1 ]; then export OVO_NO_LN_FOLD=1; else unset OVO_NO_LN_FOLD; fi
-  timeout 600 python bench.py --no-cpu-baseline --no-online --projection-world 0 --sustain-seconds 0 --no-roofline --no-shared-crops 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('NO_LN_FOLD=$v', d['value'], d['ms_per_step'])"
-done > gpurun_out/ab.txt
-cat gpurun_out/t1.log gpurun_out/ab.txt
+cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_blas -- python $R/tools/blas_ref.py > $R/gpurun_out/prof_blas.log 2>&1
+f=$(find $R/gpurun_out/prof_blas -name "*kernel_stats.csv" | head -1)
+python - <<PY
+import csv
+for r in csv.DictReader(open("$f")):
+    if "Cijk" in r["Name"] or "gemm" in r["Name"].lower():
+        print(r["Calls"], "%.1f" % (float(r["AverageNs"])/1e3), r["Name"][:400])
+PY
+find $R/gpurun_out/prof_blas -name "*kernel_trace.csv" -delete
