@@ -535,6 +535,37 @@ class OVO:
         self.last_clip_embeds, self.last_clip_ins_ids, self.last_clip_kf = clip_embeds, matched_ins_ids, kf_id
         self._store_and_fuse(clip_embeds, matched_ins_ids, kf_id, plan["updates"])
 
+    def _apply_semantic_plans(self, items) -> None:
+        """`_apply_semantic_plan` for the keyframes of one multi-GPU round, in keyframe order (MI355X extension): every keyframe's descriptors are
+        stored as they are, but the running-sum fusions of the whole round go down as ONE launch -- an instance seen in several keyframes of
+        the round gets their rows added in keyframe order, the additions a keyframe-by-keyframe replay would do (nothing reads the instance
+        table between the keyframes of a round).  A plan with a full re-fusion (a view left a top-k heap) or a restarted sum sends the round
+        through the one-by-one path."""
+        items = list(items)
+        if len(items) <= 1 or any(len(u) == 2 for p, _ in items for u in p["updates"]):
+            for plan, clip in items:
+                self._apply_semantic_plan(plan, clip)
+            return
+        merged: Dict[int, list] = {}
+        desc = self.keyframes["ins_descriptors"]
+        for plan, clip in items:
+            kf_id, matched = plan["kf_id"], plan["matched_ins_ids"]
+            self.last_clip_embeds, self.last_clip_ins_ids, self.last_clip_kf = clip, matched, kf_id
+            rows = self.bank.append(clip)
+            desc[kf_id] = KeyframeView(self.bank, {i: rows[j] for j, i in enumerate(matched) if i != -1})
+            self._planned_kfs.discard(kf_id)
+            for ins_id, kfs, before in plan["updates"]:
+                new = [desc[kf]._rows[ins_id] for kf in kfs]
+                cur = merged.get(ins_id)
+                if cur is None:
+                    merged[ins_id] = [new, before]
+                elif before == cur[1] + len(cur[0]):
+                    cur[0].extend(new)
+                else:                                              # the sum restarts inside the round: keep the order, launch what is pending
+                    self.bank.fuse_add([(i, r, b) for i, (r, b) in merged.items()])
+                    merged = {ins_id: [new, before]}
+        self.bank.fuse_add([(i, r, b) for i, (r, b) in merged.items()])
+
     def prefetch_image_features(self, image, image_ready=None) -> bool:
         """MI355X extension (no counterpart in the reference): start the mask-independent half of `_extract_clip` -- the
         TextRegion crops' ViT forward (textregion.py:141-142 via :197-199) -- for `image` NOW, on a side HIP stream, so that

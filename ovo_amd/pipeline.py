@@ -357,12 +357,17 @@ class FramePipeline:
         else:
             descs = [desc_mine]
         # ---- every rank: store + re-fuse in keyframe order (identical instance tables), dense accumulate on its own rows
-        for p, d, (point_seg, mask_rows) in zip(plans, descs, segs):
+        # (the instance table is read after the round only: the round's running-sum fusions are one launch, the mask-row lists one upload)
+        self.ovo._apply_semantic_plans([(p, d) for p, d in zip(plans, descs) if p is not None])
+        live = [k for k, (p, d) in enumerate(zip(plans, descs)) if p is not None and self.dense and d.shape[0] > 0]
+        all_rows = torch.tensor([r for k in live for r in segs[k][1]], dtype=torch.int32).to(self.device, non_blocking=True) if live else None
+        row_off = 0
+        for k, (p, d, (point_seg, mask_rows)) in enumerate(zip(plans, descs, segs)):
             if p is None:
                 continue
-            self.ovo._apply_semantic_plan(p, d)
             if self.dense and d.shape[0] > 0:
-                rows = torch.tensor(mask_rows, dtype=torch.int32).to(self.device, non_blocking=True)
+                rows = all_rows[row_off:row_off + len(mask_rows)]
+                row_off += len(mask_rows)
                 touched, n_cur, n_nxt = None, None, None
                 if self.incremental_query:
                     k = self._touch_parity

@@ -1,12 +1,6 @@
 #!/bin/bash
-cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_blas -- python $R/tools/blas_ref.py > $R/gpurun_out/prof_blas.log 2>&1
-f=$(find $R/gpurun_out/prof_blas -name "*kernel_stats.csv" | head -1)
-python - <<PY
-import csv
-for r in csv.DictReader(open("$f")):
-    if "Cijk" in r["Name"] or "gemm" in r["Name"].lower():
-        print(r["Calls"], "%.1f" % (float(r["AverageNs"])/1e3), r["Name"][:400])
-PY
-find $R/gpurun_out/prof_blas -name "*kernel_trace.csv" -delete
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 1800 python -m pytest tests/test_gpu_multirank.py tests/test_gpu_pipeline.py tests/test_gpu_e2e.py -x -q -m gpu 2>&1 | grep -v amdgpu | tail -4 > gpurun_out/t1.log
+(for w in 1 8; do echo "world $w"; timeout 300 python tools/round_emulation.py $w; done) 2>&1 | grep -v amdgpu | cut -c1-110 > gpurun_out/round_emulation.txt
+timeout 300 python tools/replicated_cost.py 64 8 2>&1 | grep -v amdgpu | tail -3 >> gpurun_out/round_emulation.txt
+cat gpurun_out/t1.log gpurun_out/round_emulation.txt
