@@ -30,7 +30,37 @@ __device__ __forceinline__ int reflect_index(int i, int n) {   // torch 'reflect
     return i;
 }
 
+// the reference's 7 x 7 kernel with the loops unrolled (tap weights become scalar operands) and no reflection arithmetic away from the border:
+// the same fmaf chain in the same (dy, dx) order -- same bits -- at a third of the time of the run-time loops below (25 -> 8 us on 640 x 480)
+template <int K>
+__device__ __forceinline__ float depth_filter_pixel_k(const float *__restrict__ depth, int h, int w, const BlurTaps &taps, float th, int x, int y) {
+    constexpr int P = K >> 1;
+    float acc = 0.f;
+    if (x >= P && x < w - P && y >= P && y < h - P) {
+        const float *c = depth + (int64_t)(y - P) * w + (x - P);
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) acc = fmaf(taps.w[dy * K + dx], c[dy * w + dx], acc);
+    } else {
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy) {
+            int yy = y + dy - P;
+            yy = yy < 0 ? -yy : yy; yy = yy >= h ? 2 * h - 2 - yy : yy;
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                int xx = x + dx - P;
+                xx = xx < 0 ? -xx : xx; xx = xx >= w ? 2 * w - 2 - xx : xx;
+                acc = fmaf(taps.w[dy * K + dx], depth[(int64_t)yy * w + xx], acc);
+            }
+        }
+    }
+    const float d = depth[(int64_t)y * w + x];
+    return fabsf(d - acc) > th ? -1.0f : d;
+}
+
 __device__ __forceinline__ float depth_filter_pixel(const float *__restrict__ depth, int h, int w, const BlurTaps &taps, float th, int x, int y) {
+    if (taps.k == 7 && h > 7 && w > 7) return depth_filter_pixel_k<7>(depth, h, w, taps, th, x, y);
     const int k = taps.k, p = k >> 1;
     float acc = 0.f;
     for (int dy = 0; dy < k; ++dy) {
