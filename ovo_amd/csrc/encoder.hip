@@ -130,6 +130,28 @@ __device__ __forceinline__ float aa_filter(int kind, float x) { return kind == 2
 
 // One thread per output pixel; the tap weights do not depend on the channel, so they are computed once (the first version recomputed them,
 // divisions included, per channel and per tap: 30 us for a 1024^2 output that is 13 MB of stores) and the channels run innermost.
+template <int T>
+__device__ __forceinline__ void aa_taps(const ResizeArgs &a, int ymin, int xmin, int ny, int nx, float cy, float cx, float ivy, float ivx, float wy_tot,
+                                        float wx_tot, float (&v)[4]) {
+    float wy[T], wx[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        wy[i] = i < ny ? aa_filter(a.aa, ((float)(ymin + i) - cy + 0.5f) * ivy) / wy_tot : 0.f;
+        wx[i] = i < nx ? aa_filter(a.aa, ((float)(xmin + i) - cx + 0.5f) * ivx) / wx_tot : 0.f;
+    }
+#pragma unroll
+    for (int iy = 0; iy < T; ++iy) {
+        if (iy >= ny) break;
+        float rowacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ix = 0; ix < T; ++ix) {
+            if (ix >= nx) break;
+            for (int c = 0; c < a.C; ++c) rowacc[c] += wx[ix] * src_px(a, c, ymin + iy, xmin + ix);
+        }
+        for (int c = 0; c < a.C; ++c) v[c] += wy[iy] * rowacc[c];
+    }
+}
+
 #define OVO_RS_TAPS 10                                  // taps per axis held in registers: down-scaling up to ~4.5x; beyond that the generic loop
 __global__ void __launch_bounds__(256) k_resize_norm(ResizeArgs a, float *__restrict__ out) {
     const int wx_ = blockIdx.x * 64 + (threadIdx.x & 63), wy_ = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -159,24 +181,14 @@ __global__ void __launch_bounds__(256) k_resize_norm(ResizeArgs a, float *__rest
         for (int y = ymin; y < ymax; ++y) wy_tot += aa_filter(a.aa, ((float)y - cy + 0.5f) * ivy);
         for (int x = xmin; x < xmax; ++x) wx_tot += aa_filter(a.aa, ((float)x - cx + 0.5f) * ivx);
         const int ny = ymax - ymin, nx = xmax - xmin;
-        if (ny <= OVO_RS_TAPS && nx <= OVO_RS_TAPS) {
-            float wy[OVO_RS_TAPS], wx[OVO_RS_TAPS];
-#pragma unroll
-            for (int i = 0; i < OVO_RS_TAPS; ++i) {
-                wy[i] = i < ny ? aa_filter(a.aa, ((float)(ymin + i) - cy + 0.5f) * ivy) / wy_tot : 0.f;
-                wx[i] = i < nx ? aa_filter(a.aa, ((float)(xmin + i) - cx + 0.5f) * ivx) / wx_tot : 0.f;
-            }
-#pragma unroll
-            for (int iy = 0; iy < OVO_RS_TAPS; ++iy) {
-                if (iy >= ny) break;
-                float rowacc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ix = 0; ix < OVO_RS_TAPS; ++ix) {
-                    if (ix >= nx) break;
-                    for (int c = 0; c < a.C; ++c) rowacc[c] += wx[ix] * src_px(a, c, ymin + iy, xmin + ix);
-                }
-                for (int c = 0; c < a.C; ++c) v[c] += wy[iy] * rowacc[c];
-            }
+        // taps held in registers: 3 per axis when up-scaling (support 1: a 640 x 480 frame to SAM2's 1024^2 -- the 10-tap form spent most of its
+        // time on taps that do not exist: 60 -> 20 us), 6 up to ~2.5x down-scaling (the 336^2 ViT crops of that frame), 10 up to ~4.5x; the bound
+        // comes from the scale factors, so a launch takes one branch.  Same weights, same accumulation order in every form.
+        const int bound = (int)(2.f * (supy > supx ? supy : supx)) + 1;
+        if (bound <= 3 && ny <= 3 && nx <= 3) aa_taps<3>(a, ymin, xmin, ny, nx, cy, cx, ivy, ivx, wy_tot, wx_tot, v);
+        else if (bound <= 6 && ny <= 6 && nx <= 6) aa_taps<6>(a, ymin, xmin, ny, nx, cy, cx, ivy, ivx, wy_tot, wx_tot, v);
+        else if (ny <= OVO_RS_TAPS && nx <= OVO_RS_TAPS) {
+            aa_taps<OVO_RS_TAPS>(a, ymin, xmin, ny, nx, cy, cx, ivy, ivx, wy_tot, wx_tot, v);
         } else {
             for (int c = 0; c < a.C; ++c) {
                 float acc = 0.f;

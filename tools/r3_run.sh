@@ -1,6 +1,8 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 1800 python -m pytest tests/test_gpu_geometry.py tests/test_gpu_multirank.py tests/test_gpu_pipeline.py -x -q -m gpu 2>&1 | grep -v amdgpu | tail -4 > gpurun_out/t1.log
-(for w in 1 8; do echo "world $w"; timeout 300 python tools/round_emulation.py $w; done) 2>&1 | grep -v amdgpu | cut -c1-110 > gpurun_out/round_emulation.txt
-timeout 300 python tools/replicated_cost.py 64 8 2>&1 | grep -v amdgpu | tail -3 >> gpurun_out/round_emulation.txt
-cat gpurun_out/t1.log gpurun_out/round_emulation.txt
+cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $R/bench.py --no-cpu-baseline --steps 24 --sustain-seconds 0 --projection-world 0 --no-online --no-shared-crops > $OUT/prof_bench.log 2>&1
+cd $R
+python tools/kstats_region.py $OUT/prof $OUT/bench_n1_timed_region_kernel_stats.csv > $OUT/kstats_region.log 2>&1
+find $OUT -name "*kernel_trace.csv" -delete
+cat $OUT/kstats_region.log; grep "resize\|im2col\|depth_filter\|kf_phase1" $OUT/bench_n1_timed_region_kernel_stats.csv | cut -c1-160
+for i in 1 2; do timeout 600 python bench.py --no-cpu-baseline --no-online --projection-world 0 --sustain-seconds 0 --no-roofline --no-shared-crops 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; done

@@ -1,6 +1,6 @@
 """ovo_resize_normalize on the bench's three per-frame calls: 640x480 HWC u8 -> 1024^2 (SAM2) and two 480x320 crops -> 336^2 (ViT)."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ovo_amd.encoders.hiera import SPECS as HS, HipHiera
 from ovo_amd.encoders.vit import SPECS as VS, HipViT
