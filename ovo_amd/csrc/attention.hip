@@ -695,10 +695,15 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
         const int krows = (p->Tk + 15) & ~15, nq = (p->Tq + 15) / 16;
         const size_t lds = (size_t)krows * 256;
         // one 8-wave workgroup per CU above half the LDS; below it 4-wave workgroups, so that one loads while another multiplies
-        const int threads = lds > 80 * 1024 ? 512 : 256, waves = threads / 64;
-        int splits = (nq + 3 * waves - 1) / (3 * waves);                  // at most 3 q-tiles per wave ...
+        static const int force_threads = getenv("OVO_ATTN_RES_THREADS") ? atoi(getenv("OVO_ATTN_RES_THREADS")) : 0;    // tools/attn_bench.py
+        static const int force_splits = getenv("OVO_ATTN_RES_SPLITS") ? atoi(getenv("OVO_ATTN_RES_SPLITS")) : 0;
+        const int threads = force_threads ? force_threads : (lds > 80 * 1024 ? 512 : 256), waves = threads / 64;
+        // at most 4 q-tiles per wave (a pass of 3 and one of 1: the 13 q-tiles of a 14 x 14 window on four waves, K / V staged once -- 84 us
+        // against 94 as two workgroups of 7 + 6; tools/attn_variants.py) ...
+        int splits = (nq + 4 * waves - 1) / (4 * waves);
         const long long heads = (long long)p->B * p->H;
         while (heads * splits < 768 && (splits + 1) * 2 * waves <= nq) ++splits;   // ... and 3+ workgroups per CU while every wave keeps 2 q-tiles
+        if (force_splits) splits = force_splits;
         static bool attr_done = false;
         if (heads * splits < 192) goto tiled;                             // too few workgroups for the chip (one frame's two crops: 32 heads): the 64-query tiled form has 10x more
         if (!attr_done) {
