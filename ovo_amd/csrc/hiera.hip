@@ -321,6 +321,8 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
                  c.dims[0], T0, c.dims[0], 192, 0, stream));
 
     float *x = k.x, *spare = k.xr;
+    long long att_rows = -1;
+    int att_kout = 0;
     for (int i = 0; i < p.n_blocks; ++i) {
         const ovo_hiera_block_t &L = w->blocks[i];
         const int din = p.dim_in[i], dout = p.dim_out[i], H = p.Hin[i], Ho = p.pool[i] ? H / 2 : H;
@@ -360,7 +362,14 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         } else {
             a.q = k.qkv; a.q_sb = a.k_sb; a.q_sh = hd; a.q_st = 3 * dout;
         }
-        if (kout != dout) OVO_HIP(hipMemsetAsync(k.att, 0, (size_t)n_win * tq * kout * 2, hs));      // K-padding columns stay zero
+        // K-padding columns of the attention output must be zero; the attention kernel only writes the real ones, so they STAY zero from block to
+        // block while rows x row width do not change (the blocks of one stage): one fill per layout instead of one per block (3 of 5 for hiera_b+)
+        if (kout != dout && (att_rows != (long long)n_win * tq || att_kout != kout)) {
+            OVO_HIP(hipMemsetAsync(k.att, 0, (size_t)n_win * tq * kout * 2, hs));
+            att_rows = (long long)n_win * tq; att_kout = kout;
+        } else if (kout == dout) {
+            att_rows = -1;                                       // every column written: the next padded layout starts from a fresh fill
+        }
         a.o_sb = (int64_t)tq * kout; a.o_sh = hd; a.o_st = kout;
         a.B = (int)n_win; a.H = p.heads[i]; a.Tq = tq; a.Tk = tk; a.hd = hd; a.scale = 1.0f / sqrtf((float)hd);
         TRY(ovo_attention(&a, stream));

@@ -1,6 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-OVO_DIST_BACKEND=gloo OVO_FORCE_DEVICE=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 12 --warmup 3 > gpurun_out/bench_2rank.json 2> gpurun_out/bench_2rank.err
-echo "rc $?"; grep '^{' gpurun_out/bench_2rank.json | cut -c1-900; tail -3 gpurun_out/bench_2rank.err | cut -c1-300
-OVO_DIST_BACKEND=gloo OVO_FORCE_DEVICE=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --steps 6 --warmup 2 --sam-full > gpurun_out/bench_2rank_samfull.json 2> gpurun_out/bench_2rank_samfull.err
-echo "rc $?"; grep '^{' gpurun_out/bench_2rank_samfull.json | cut -c1-400; tail -2 gpurun_out/bench_2rank_samfull.err | cut -c1-300
+timeout 1800 python -m pytest tests/test_gpu_hiera.py tests/test_gpu_sam_decoder.py tests/test_gpu_pipeline.py -x -q -m gpu 2>&1 | grep -v amdgpu | tail -3
+for i in 1 2; do timeout 600 python bench.py --no-cpu-baseline --no-online --projection-world 0 --sustain-seconds 0 --no-roofline --no-shared-crops 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; done
