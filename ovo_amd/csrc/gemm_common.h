@@ -36,6 +36,8 @@ struct GemmArgs {
     const float *ln_x, *ln_g, *ln_b;
     float ln_eps;
     int ln_d, ln_mode;
+    uint16_t *qpool_out;       // with ln_mode, a window map and bf16 output: columns [0, qpool_cols) are NOT stored to C but 2 x 2 max-pooled over the
+    int qpool_cols;            // window's tokens into qpool_out[pooled window-major row, qpool_cols] (Hiera's pooled queries, k_qpool)
     int pool_ww;               // with ln_mode and f32 output: > 0 = 2 x 2 max-pool of the window's tokens in the epilogue (window width), C rows = pooled spatial tokens
     int dbg;                   // tools/ only (OVO_8P_DEBUG): 1 = leave before anything, 2 = leave after the prologue, 4 = no epilogue
     unsigned long long *stamps;   // tools/ only (OVO_8P_STAMPS = address of u64[tiles][4]): s_memrealtime at start / K-loop / epilogue / end
@@ -203,6 +205,6 @@ int gemm_stream_launch(const GemmArgs &g, int in_dtype, hipStream_t s);
 // the same kernel with the A operand taken from an f32 tensor through LayerNorm (mode 1) or a cast (mode 2) -- hiera.hip's way around
 // k_ln_window / k_cast_pad for the layers the streaming form covers; OVO_E_UNSUPPORTED otherwise (nothing launched)
 int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *x, int d, const float *gamma, const float *beta, float eps, int mode,
-                     int pool2x2, ovo_stream_t stream);
+                     int pool2x2, ovo_stream_t stream, uint16_t *qpool_out = nullptr, int qpool_cols = 0);
 
 }  // namespace ovo_gemm_detail

@@ -133,6 +133,26 @@ __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_grou
                 }
                 if (writer) *(float4 *)(cp + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
             }
+        } else if (F32A && g.qpool_cols > 0 && n0 < g.qpool_cols) {
+            // Hiera's query pooling at a stage change (hieradet.py: q = do_pool(q)): the q columns of the QKV product are max-pooled 2 x 2 over the
+            // window's tokens here (the four tokens of a pooled position sit in lanes fr, fr ^ 1, fr ^ ww, fr ^ (ww + 1), as in the skip path above)
+            // and only the pooled rows are stored, in pooled window-major order -- k_qpool's read of every token's q and the store of it go away
+            // (max commutes with the bf16 rounding: the same bits as pooling the stored values).
+            const int win = mc / g.win_per, pw = mc - win * g.win_per, ly = pw / g.win_ww, lx = pw - ly * g.win_ww;
+            const long long prow = (long long)win * (g.win_per >> 2) + (long long)(ly >> 1) * (g.win_ww >> 1) + (lx >> 1);
+            const bool writer = ((fr & 1) | (fr & g.win_ww)) == 0;
+            uint16_t *qp = g.qpool_out + prow * g.qpool_cols + n0 + fq * 4;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float v[4];
+                finish(j, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = fmaxf(v[r], __shfl_xor(v[r], 1, 64));
+                    v[r] = fmaxf(v[r], __shfl_xor(v[r], g.win_ww, 64));
+                }
+                if (writer) *(uint2 *)(qp + j * 16) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+            }
         } else if (g.out_dtype == 0) {
             float *cp = (float *)g.C + md * g.ldc + n0 + fq * 4;
 #pragma unroll
@@ -237,7 +257,7 @@ int gemm_stream_launch(const GemmArgs &g, int in_dtype, hipStream_t s) {
 // row m = its spatial token when `win` describes a window partition (padding rows = zeros), m itself without.  OVO_E_UNSUPPORTED: no
 // instantiation for the shape (the caller normalises / casts into a buffer and calls ovo_gemm).
 int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *x, int d, const float *gamma, const float *beta, float eps, int mode,
-                     int pool2x2, ovo_stream_t stream) {
+                     int pool2x2, ovo_stream_t stream, uint16_t *qpool_out, int qpool_cols) {
     if (!p || !x || p->in_dtype != 2 || p->M < 16384 || p->K > 256 || d <= 0 || d % 8 != 0 || d > p->K || (mode != 1 && mode != 2) ||
         (mode == 1 && (!gamma || !beta)) || ((uintptr_t)x & 15) != 0 || getenv("OVO_GEMM_NO_STREAM") || getenv("OVO_GEMM_TILE") || getenv("OVO_NO_LN_FOLD"))
         return OVO_E_UNSUPPORTED;
@@ -260,6 +280,18 @@ int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *
             p->M % 16 != 0)
             return OVO_E_UNSUPPORTED;
         g.pool_ww = win->ww;
+    }
+    if (qpool_out) {    // pooled q: the same window conditions, bf16 output, the q columns a whole number of column groups, rows 8-byte aligned
+        if (!win || p->out_dtype != 2 || win->H % win->wh != 0 || win->W % win->ww != 0 || win->wh % 2 != 0 || (win->ww != 2 && win->ww != 4 && win->ww != 8) ||
+            p->M % 16 != 0 || qpool_cols <= 0 || qpool_cols % 4 != 0 || ((uintptr_t)qpool_out & 7) != 0 || pool2x2)
+            return OVO_E_UNSUPPORTED;
+        int ng = 0;                                                  // (the column-group width gemm_stream_launch will pick)
+        for (int c : {256, 224, 112, 64, 32})
+            if (p->N % c == 0) { ng = c; break; }
+        if (p->K == 192 && p->N % 144 == 0 && p->N % 256 != 0) ng = p->N % 288 == 0 ? 288 : 144;
+        if (p->K == 128 && p->N == 336) ng = 336;
+        if (!ng || qpool_cols % ng != 0) return OVO_E_UNSUPPORTED;
+        g.qpool_out = qpool_out; g.qpool_cols = qpool_cols;
     }
     const int rc = gemm_stream_launch(g, 2, (hipStream_t)stream);
     if (rc != OVO_OK) return rc;

@@ -350,14 +350,26 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
             }
             residual = spare;
         }
-        TRY(gemm_from_f32(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, 1, k.h, h_done, L.qkv_w, L.qkv_b, k.qkv, 3 * dout, 2, 3 * dout, 0, stream));
+        // QKV; at a stage change the q columns are pooled 2 x 2 in the product's epilogue where the streaming GEMM runs it (else k_qpool below)
+        bool q_pooled = false;
+        if (p.pool[i] && g.ws > 0 && !h_done) {
+            ovo_gemm_t q;
+            q.A = nullptr; q.lda = kin; q.W = L.qkv_w; q.ldw = kin; q.bias = L.qkv_b; q.C = k.qkv; q.ldc = 3 * dout; q.add = nullptr; q.ld_add = 0;
+            q.M = (int)g.rows; q.N = 3 * dout; q.K = kin; q.in_dtype = 2; q.out_dtype = 2; q.act = 0; q.alpha = 1.0f;
+            const ovo_window_t wd = {g.B, g.H, g.W, g.wh, g.ww};
+            const int rc = ovo_gemm_detail::gemm_f32a_stream(&q, &wd, x, din, L.ln1_g, L.ln1_b, c.ln_eps, 1, 0, stream, k.qp, dout);
+            if (rc == OVO_OK) q_pooled = true;
+            else if (rc != OVO_E_UNSUPPORTED) return rc;
+        }
+        if (!q_pooled)
+            TRY(gemm_from_f32(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, 1, k.h, h_done, L.qkv_w, L.qkv_b, k.qkv, 3 * dout, 2, 3 * dout, 0, stream));
         const long long n_win = (long long)B * g.nwh * g.nww;
         const int tk = g.wh * g.ww, tq = p.pool[i] ? tk / 4 : tk;
         ovo_attention_t a = {};
         a.k = k.qkv + dout; a.v = k.qkv + 2 * dout; a.o = k.att;
         a.k_sb = a.v_sb = (int64_t)tk * 3 * dout; a.k_sh = a.v_sh = hd; a.k_st = a.v_st = 3 * dout;
         if (p.pool[i]) {
-            k_qpool<<<ovo_grid(n_win * tq * dout, 256), 256, 0, hs>>>(k.qkv, n_win, g.wh, g.ww, dout, k.qp);
+            if (!q_pooled) k_qpool<<<ovo_grid(n_win * tq * dout, 256), 256, 0, hs>>>(k.qkv, n_win, g.wh, g.ww, dout, k.qp);
             a.q = k.qp; a.q_sb = (int64_t)tq * dout; a.q_sh = hd; a.q_st = dout;
         } else {
             a.q = k.qkv; a.q_sb = a.k_sb; a.q_sh = hd; a.q_st = 3 * dout;
