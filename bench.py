@@ -405,7 +405,11 @@ def main():
         torch.cuda.synchronize()
         if args.encoder_batch > 1 or world > 1:
             pipe.serial = True                                                 # one stream: every kernel has the chip to itself
+            torch.cuda.synchronize()
+            L.check(lib.ovo_marker(3, L.stream()))                             # markers 3 / 4 of a kernel trace: the `isolated` pass (tools/kstats_region.py)
             iso = profile_pass(pipe, feed, prof_rounds, lib)
+            torch.cuda.synchronize()
+            L.check(lib.ovo_marker(4, L.stream()))
             pipe.serial = False
         else:
             streams = (pipe.sam_stream, pipe.prefetch)

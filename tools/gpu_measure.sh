@@ -40,7 +40,7 @@ python tools/pmc_traffic.py --fetch-dir $OUT/pmc_fetch --write-dir $OUT/pmc_writ
 python tools/pmc_traffic.py --fetch-dir $OUT/geom_fetch --write-dir $OUT/geom_write --out $OUT/geom_10m_pmc_traffic.json > $OUT/geom_pmc.log 2>&1
 python tools/sq_counters.py $OUT/geom_sq > $OUT/geom_10m_sq_counters.txt 2>&1
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_n1_kernel_stats.csv
-python tools/kstats_region.py $OUT/prof $OUT/bench_n1_timed_region_kernel_stats.csv > $OUT/kstats_region.log 2>&1
+python tools/kstats_region.py $OUT/prof $OUT/bench_n1_timed_region_kernel_stats.csv $OUT/bench_n1_isolated_pass_kernel_stats.csv > $OUT/kstats_region.log 2>&1
 cp $(find $OUT/geom_stats -name "*kernel_stats.csv" | head -1) $OUT/geom_10m_kernel_stats.csv
 cp $(find $OUT/amg_prof -name "*kernel_stats.csv" | head -1) $OUT/sam_decoder_kernel_stats.csv
 # keep the merge-back small: drop the per-dispatch traces, keep stats + reduced PMC

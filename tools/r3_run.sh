@@ -1,12 +1,9 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-cp ovo_amd/lib/libovo_hip.so /tmp/new.so; cp ovo_amd/lib/libovo_hip_prev.so /tmp/old.so
-for v in old new old new; do
-  cp /tmp/$v.so ovo_amd/lib/libovo_hip.so
-  echo "== $v"
-  (ROPE=1 BIAS=1 TILES="auto" SHAPES="13848,3072,1024" python tools/gemm_bench.py | tail -1
-   BIAS=1 ADD=1 INPLACE=1 OUT=f32 TILES="auto" SHAPES="13848,1024,1024;13848,1024,4096;49152,448,1792" python tools/gemm_bench.py | tail -3) 2>&1 | grep -v amdgpu
-  timeout 300 python tools/enc_only.py vit 12 10 2>&1 | grep -v amdgpu
-  timeout 600 python bench.py --no-cpu-baseline --no-online --projection-world 0 --sustain-seconds 0 --no-roofline --no-shared-crops 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench', d['value'], d['ms_per_step'])"
-done 2>&1 | tee gpurun_out/ab_epi.txt
-cp /tmp/new.so ovo_amd/lib/libovo_hip.so
+cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $R/bench.py --no-cpu-baseline --steps 24 --sustain-seconds 0 --projection-world 0 --no-online --no-shared-crops > $OUT/prof_bench.log 2>&1
+cd $R
+python tools/kstats_region.py $OUT/prof $OUT/bench_n1_timed_region_kernel_stats.csv $OUT/bench_n1_isolated_pass_kernel_stats.csv > $OUT/kstats_region.log 2>&1
+cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_n1_kernel_stats.csv
+find $OUT -name "*kernel_trace.csv" -delete
+cat $OUT/kstats_region.log; head -4 $OUT/bench_n1_isolated_pass_kernel_stats.csv | cut -c1-160
+grep '^{' $OUT/prof_bench.log | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(d['value'], r['avg_launch_us'], r['isolated']['avg_launch_us'], r['isolated']['achieved'])"
