@@ -415,6 +415,11 @@ __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const in
     __syncthreads();
 }
 
+// Grid of the tracking pass: 1024 workgroups, not the usual 2048.  Every workgroup ends with one atomic pair on the same two counters and a
+// ragged last batch of its waves' rings; with twice the workgroups those fixed costs outweigh the extra waves in flight (tools/geom_bench.py,
+// 1 M / 5 M / 10 M points: 33.4 / 47.0 / 62.3 us at 2048, 23.0 / 38.4 / 54.1 at 1024, 22.1 / 49.9 / 81.3 at 512; without the counter atomics 4096
+// workgroups would take 48.7 us at 10 M -- the same-address atomics cost ~3 ns each).
+constexpr int TRACK_GRID_CAP = 1024;
 __global__ void __launch_bounds__(256) k_track_project(const float *__restrict__ pts, const int32_t *__restrict__ point_ins,
                                                        int64_t n, ovo_camera_t cam, const float *__restrict__ depth,
                                                        const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
@@ -1182,7 +1187,7 @@ int ovo_track_project(const float *pts, const int32_t *point_ins, int64_t n, con
     OVO_REQUIRE(pts && point_ins && point_seg, "null pointer");
     const bool prof = ovo_prof_enabled();
     if (prof) ovo_prof_begin(2, 14.0 * (double)n, s);          // 12 B xyz read + 2 B mask id written per map point
-    k_track_project<<<ovo_grid(n, 256), 256, 0, s>>>(pts, point_ins, n, *cam, depth, seg_map, seg_h, seg_w, ratio,
+    k_track_project<<<ovo_grid(n, 256, TRACK_GRID_CAP), 256, 0, s>>>(pts, point_ins, n, *cam, depth, seg_map, seg_h, seg_w, ratio,
                                                       point_seg, hist, n_masks, hist_cols,
                                                       (unsigned long long *)counters, nullptr);
     if (prof) ovo_prof_end(s);
@@ -1327,7 +1332,7 @@ int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream) {
     if (n_grid > 0) {
         const bool prof = ovo_prof_enabled();
         if (prof) ovo_prof_begin(2, 14.0 * (double)n_grid, s);
-        k_track_project<<<ovo_grid(n_grid, 256), 256, 0, s>>>(a->map.xyz, a->map.ins, known ? a->map.n : 0, a->cam, depth, a->seg_map, a->seg_h,
+        k_track_project<<<ovo_grid(n_grid, 256, TRACK_GRID_CAP), 256, 0, s>>>(a->map.xyz, a->map.ins, known ? a->map.n : 0, a->cam, depth, a->seg_map, a->seg_h,
                                                            a->seg_w, a->ratio, a->point_seg, hist, nm, a->hist_cols, counters, n_dev);
         if (prof) ovo_prof_end(s);
     }
@@ -1484,7 +1489,7 @@ int ovo_keyframe_step(const ovo_map_step_t *a, const ovo_track_step_t *t, ovo_st
     const int64_t n_grid = a->n_upper + n_sub;
     const bool prof = ovo_prof_enabled();
     if (prof) ovo_prof_begin(2, 14.0 * (double)n_grid, s);
-    k_track_project<<<ovo_grid(n_grid, 256), 256, 0, s>>>(t->map.xyz, t->map.ins, 0, t->cam, depth, t->seg_map, t->seg_h, t->seg_w, t->ratio, t->point_seg, hist, nm,
+    k_track_project<<<ovo_grid(n_grid, 256, TRACK_GRID_CAP), 256, 0, s>>>(t->map.xyz, t->map.ins, 0, t->cam, depth, t->seg_map, t->seg_h, t->seg_w, t->ratio, t->point_seg, hist, nm,
                                                        t->hist_cols, counters, (const long long *)t->map.state);
     if (prof) ovo_prof_end(s);
     // ---- 6: vote statistics + decisions
