@@ -1361,12 +1361,12 @@ int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream) {
     d.res = res; d.dst = dst; d.next_ins = a->next_ins; d.next_host = a->next_ins_host; d.track_th = a->track_th; d.n_masks = nm;
     k_vote_decide<<<nm, 256, 0, s>>>(hist, a->hist_cols, stats, tickets, d);
     if (n_grid > 0)
-        k_assign_res<<<ovo_grid(n_grid, 256), 256, 0, s>>>(a->map.ins, a->point_seg, known ? a->map.n : 0, res, nm, n_dev);
+        k_assign_res<<<ovo_grid(n_grid, 256, 256), 256, 0, s>>>(a->map.ins, a->point_seg, known ? a->map.n : 0, res, nm, n_dev);
     Publish pb;
     pb.res = res; pb.host = (volatile int32_t *)a->result_host; pb.counters = counters; pb.n_dev = (const long long *)a->map.state;
     pb.n_host = known ? a->map.n : -1; pb.ticket = tickets + 1; pb.seq = a->seq; pb.n_ints = 8 + 6 * nm;
     const long long px16 = a->masks ? a->pixels / 16 : 0;
-    dim3 grid(a->masks ? ovo_grid(px16, 256, 32) : 1, nm);
+    dim3 grid(a->masks ? ovo_grid(px16, 256, 8) : 1, nm);              // (few, fat workgroups: see k_kf_finish's launch)
     k_fuse_publish<<<grid, 256, 0, s>>>((uint4 *)a->masks, px16, nm, dst, res, pb);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
@@ -1518,7 +1518,10 @@ int ovo_keyframe_step(const ovo_map_step_t *a, const ovo_track_step_t *t, ovo_st
     k_vote_decide<<<nm, 256, 0, s>>>(hist, t->hist_cols, stats, tickets, d);
     // ---- 7: assignment | mask fusion, publish
     KfFinish f;
-    f.g_assign = ovo_grid(n_grid, 256, 1024); f.gx = t->masks ? ovo_grid(t->pixels / 16, 256, 32) : 1;
+    // few, fat workgroups: every one of them pays a fixed chain of dependent loads (map size, targets / dst), a fence and its ticket, and beyond the
+    // resident capacity they queue behind each other -- 1 M points, 32 masks of 640 x 480, idle GPU: 1024 + 32 x 32 workgroups 50.5 us, 256 + 32 x 8
+    // 21.8, 128 + 32 x 4 22.9, 4096 + 32 x 32 118 (rocprofv3 over tools/round_profile.py with NOSAM=1)
+    f.g_assign = ovo_grid(n_grid, 256, 256); f.gx = t->masks ? ovo_grid(t->pixels / 16, 256, 8) : 1;
     f.ins = t->map.ins; f.point_seg = t->point_seg; f.n_host = -1; f.n_dev = (const long long *)t->map.state;
     f.masks = (uint4 *)t->masks; f.px16 = t->masks ? t->pixels / 16 : 0; f.n_masks = nm; f.dst = dst; f.res = res;
     Publish pb;
