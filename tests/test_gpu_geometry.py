@@ -143,7 +143,7 @@ def test_tracking_golden_device_decisions(tag, filt):
         assert sorted(o.top_kf) == [tuple(r) for r in d[f"obj{j}_topkf"].tolist()]
 
 
-def _run_keyframes(queued, n_frames=6, top_k=2):
+def _run_keyframes(queued, n_frames=6, top_k=2, mask_grid=(3, 4), n_blobs=5, track_th=30):
     """n keyframes of the synthetic stream through mapper + tracker; `queued`: all map / tracking chains are launched back to back
     (sizes and instance ids device-resident) and finished afterwards -- "chain": all of them in ONE launch of the persistent round
     kernel (`ovo_round_chain`) -- else one keyframe at a time with host decisions."""
@@ -156,10 +156,10 @@ def _run_keyframes(queued, n_frames=6, top_k=2):
 
     class Masks:
         def get_masks(self, image, frame_id):
-            m = syn.make_masks(h, w, grid=(3, 4), n_blobs=5, seed=frame_id)
+            m = syn.make_masks(h, w, grid=mask_grid, n_blobs=n_blobs, seed=frame_id)
             return torch.from_numpy(syn.masks_to_segmap(m)).to(DEV), torch.from_numpy(m).to(DEV)
 
-    cfg = {"match_distance_th": 0.05, "track_th": 30, "depth_filter": True, "log": False, "debug_info": False, "host_decisions": not queued,
+    cfg = {"match_distance_th": 0.05, "track_th": track_th, "depth_filter": True, "log": False, "debug_info": False, "host_decisions": not queued,
            "clip": {"k_top_views": top_k, "fusion": "avg_pooling"}, "sam": {}}
     ovo = OVO(cfg, None, None, K, device=DEV, clip_generator=_NoClip(), mask_generator=Masks())
     vm = VanillaMapper({"device": DEV, "mapping": {}}, K)
@@ -220,6 +220,25 @@ def test_queued_keyframe_chains_equal_one_by_one_host_decisions(mode):
     assert len(a["queue"]) == len(b["queue"]) == 6
     for (m1, b1, k1), (m2, b2, k2) in zip(a["queue"], b["queue"]):
         assert m1 == m2 and k1 == k2 and torch.equal(b1, b2)
+
+
+@pytest.mark.parametrize("mode", [True, "merged"])
+def test_many_masks_per_keyframe_device_vs_host_decisions(mode):
+    """168 masks per keyframe (a 9 x 12 grid + 60 blobs that overlap it), low track threshold: several masks vote for the same instance, their
+    indices more than 64 apart -- the ballot walk of the mask fusion takes several steps, the decision scan several masks per thread -- and the
+    device decisions, fused masks and heaps still equal the host-decision run bit for bit."""
+    kw = dict(n_frames=4, mask_grid=(9, 12), n_blobs=60, track_th=6)
+    a, b = _run_keyframes(mode, **kw), _run_keyframes(False, **kw)
+    assert a["max_id"] == b["max_id"] and a["next"] == b["next"] and a["next"] > 60
+    for k in ("pcd", "ids", "ins", "rgb"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["objects"] == b["objects"]
+    fused = 0
+    for (m1, b1, k1), (m2, b2, k2) in zip(a["queue"], b["queue"]):
+        assert m1 == m2 and k1 == k2 and torch.equal(b1, b2)
+        fused += len(m1) - len(set(m1)) if isinstance(m1, (list, tuple)) else 0
+    n_masks = [len(m) for m, _, _ in a["queue"]]
+    assert max(n_masks) > 64, n_masks
 
 
 # ------------------------------------------------------------------ oracle at full size
