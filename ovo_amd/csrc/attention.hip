@@ -60,43 +60,84 @@ __device__ __forceinline__ float sum_xor16_32(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// Online-softmax update for one query tile over one 64-key tile.  In: s = raw scores (lane: query lane & 15, keys 16 kt + 4 fq + r; masked
-// entries -3e38).  Out: s = the probabilities exp2(score * scale_log2e - m_new) in fp32 (one FMA in front of v_exp_f32), m_run / l_run
-// updated; returns the factor the caller's accumulators are rescaled by.  The running maximum is taken over the SCALED scores: a product
-// is a canonical float, so the maxima compile to a v_max3_f32 chain -- on raw MFMA results every fmaxf operand was first quieted by a
-// `v_max_f32 x, x, x` (96 extra VALU instructions per three q-tiles, a fifth of the softmax).  Products, FMAs and partial sums are packed
-// (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two floats per lane and instruction).
-template <bool TAIL>
-__device__ __forceinline__ float softmax_tile(f32x4 (&s)[4], int nkt, float scale_log2e, float &m_run, float &l_run) {
-    const f32x4 sc = f32x4{scale_log2e, scale_log2e, scale_log2e, scale_log2e};
-    float mx = -3.0e38f;
+// ---- online softmax, restated for the instruction mix of gfx950 (tools/ubench.hip: a lone wave issues one VALU instruction per ~8 cycles, two waves of
+// a SIMD one per ~4; v_exp_f32 ~9; beside a stream of MFMAs every VALU instruction still costs 1-4 cycles of the SIMD).  Round 3's form spent ~80 VALU
+// instructions per (16 queries x 64 keys) on a tile whose 16 MFMAs need 264 cycles.  Here:
+//   * the scale (1/sqrt(hd) * log2 e) is folded into Q once (`prescale_q`; the encoders fold it into the q rows of the QKV weights instead and
+//     pass scale_log2e == 1), so a score leaves the MFMA in log2 units;
+//   * the running reference maximum m of a query enters the QK^T product as its C operand (`negm` = four copies of -m, re-used by every first
+//     k-step of the tile -- srcC and vdst of an MFMA are separate registers), so the MFMA delivers S' = S - m: no subtraction pass;
+//   * FAST PATH (every tile after the first, unless some score of the wave outgrew the reference by more than THR): p = exp2(S') straight from the
+//     accumulators -- per 16 scores of a lane 8 v_max3 + one compare/branch, 16 v_exp, 8 packed adds (row sum, kept PER LANE: the cross-lane sum
+//     happens once, after the last tile), 8 v_cvt_pk.  No cross-lane operation at all;
+//   * SLOW PATH (first tile; or a lane saw S' > THR): the classic update -- row maximum across the four lanes of a query, d = max(rowmax', 0)
+//     (first tile: d = rowmax'), S' -= d, m += d, O and the row sum scaled by exp2(-d).  Probabilities stay <= 2^THR between rescales (bf16 /
+//     f32 have the exponent range; the relative rounding of P does not depend on its scale).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+constexpr float ATTN_THR = 6.0f;
+
+__device__ __forceinline__ float lane_max16(const f32x4 (&s)[4]) {           // 8 v_max3_f32 (MFMA results: no canonicalising v_max needed)
+    float m = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+    m = fmaxf(fmaxf(m, s[0][3]), s[1][0]);
+    m = fmaxf(fmaxf(m, s[1][1]), s[1][2]);
+    m = fmaxf(fmaxf(m, s[1][3]), s[2][0]);
+    m = fmaxf(fmaxf(m, s[2][1]), s[2][2]);
+    m = fmaxf(fmaxf(m, s[2][3]), s[3][0]);
+    m = fmaxf(fmaxf(m, s[3][1]), s[3][2]);
+    return fmaxf(m, s[3][3]);
+}
+
+// Q fragment times scale * log2(e), rounded to bf16 again (callers that folded the factor into the projection pass 1 and skip this)
+__device__ __forceinline__ bf16x8 prescale_q(bf16x8 q, float c) {
+    bf16x8 r;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        const f32x4 x = s[kt] * sc;
-        mx = fmaxf(fmaxf(mx, x[0]), x[1]);                             // v_max3_f32
-        mx = fmaxf(fmaxf(mx, x[2]), x[3]);
+    for (int e = 0; e < 8; e += 2) {
+        const bf16x2 h = __builtin_convertvector(f32x2{(float)q[e] * c, (float)q[e + 1] * c}, bf16x2);
+        r[e] = h[0]; r[e + 1] = h[1];
     }
-    mx = max_xor16_32(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    const f32x4 nm = f32x4{-m_new, -m_new, -m_new, -m_new};
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    return r;
+}
+
+// slow path of one q-tile: s = S - m_old of this tile (masked entries -3e38), lm = the lane's maximum of them
+template <bool FIRST, int NO>
+__device__ __forceinline__ void softmax_rescale(f32x4 (&s)[4], float lm, f32x4 &negm, f32x4 &lsum, f32x4 (&oacc)[NO]) {
+    const float rm = max_xor16_32(lm);
+    const float d = FIRST ? rm : fmaxf(rm, 0.f);
+    const f32x4 d4 = f32x4{d, d, d, d};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) s[kt] = s[kt] - d4;
+    negm = negm - d4;
+    if (!FIRST) {
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        lsum = lsum * alpha;
+#pragma unroll
+        for (int i = 0; i < NO; ++i) oacc[i] = oacc[i] * alpha;
+    }
+}
+
+// p = exp2(s) in place, row-sum partials, packed bf16 P fragments (element e of fragment kk <-> key (kk*2 + e/4)*16 + fq*4 + e%4)
+template <bool TAIL>
+__device__ __forceinline__ void softmax_exp(f32x4 (&s)[4], int nkt, f32x4 &lsum, bf16x8 (&pf)[2]) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
         if (!TAIL || kt < nkt) {
-            s[kt] = __builtin_elementwise_fma(s[kt], sc, nm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r]);     // v_exp_f32
-            acc = acc + s[kt];
+            lsum = lsum + s[kt];
         } else {
             s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};                     // sub-tile past the last key: p = +0 exactly, nothing exponentiated
         }
     }
-    const float ps = sum_xor16_32((acc[0] + acc[1]) + (acc[2] + acc[3]));
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
-    return alpha;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        uint32_t tmp[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) tmp[e >> 1] = pack2(s[kk * 2 + (e >> 2)][e & 3], s[kk * 2 + (e >> 2)][(e & 3) + 1]);
+        pf[kk] = *(bf16x8 *)tmp;
+    }
 }
+
+__device__ __forceinline__ float row_total(const f32x4 &lsum) { return sum_xor16_32((lsum[0] + lsum[1]) + (lsum[2] + lsum[3])); }
 
 #ifdef OVO_ATTN_TRACE
 __device__ unsigned long long g_attn_trace[256];
@@ -106,7 +147,7 @@ __device__ unsigned long long g_attn_trace[256];
 #endif
 
 template <int HD, int QT, bool TRIM = false>
-__global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
+__global__ void __launch_bounds__(256, (HD <= 64 && QT == 2) ? 2 : 1) k_attention(AttnArgs a) {
     constexpr int KT = 64;                 // keys per tile
     constexpr int KROW = HD + 8;           // padded K-tile row (elements)
     constexpr int VB = HD / 16 + 1;        // V blocks per key group (+1 block of padding: bank spread)
@@ -147,14 +188,15 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
             const int d0 = ks * 32 + fq * 8;
             if (q_row[t] < a.Tq && d0 < a.hd) raw = *(const uint4 *)(qp + (long long)q_row[t] * a.q_st + d0);
             qf[t][ks] = *(bf16x8 *)&raw;
+            if (a.scale_log2e != 1.0f) qf[t][ks] = prescale_q(qf[t][ks], a.scale_log2e);
         }
     }
 
     f32x4 oacc[QT][HD / 16];
-    float m_run[QT], l_run[QT];
+    f32x4 negm[QT], lsum[QT];                 // -m (four copies: the C operand of the first k-step) and the lane's part of the row sum
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        m_run[t] = -1.0e30f; l_run[t] = 0.f;
+        negm[t] = f32x4{0.f, 0.f, 0.f, 0.f}; lsum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < HD / 16; ++i) oacc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -206,11 +248,11 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
         const int nkt = TAIL ? (a.Tk - k0 + 15) >> 4 : 4;           // 16-key sub-tiles of this tile that hold a key
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            // ---- S^T = K Q^T : 4 tiles of 16 keys ----
+            // ---- S^T - m = K Q^T - m : 4 tiles of 16 keys, the reference maximum as the C operand of the first k-step ----
             f32x4 s[4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s[kt] = negm[t];
                 if (!TAIL || kt < nkt) {
 #pragma unroll
                     for (int ks = 0; ks < HD / 32; ++ks) {
@@ -235,23 +277,12 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
                     for (int r = 0; r < 4; ++r)
                         if (k0 + kt * 16 + fq * 4 + r > q_row[t]) s[kt][r] = -3.0e38f;
             }
-            const float alpha = softmax_tile<TAIL>(s, nkt, a.scale_log2e, m_run[t], l_run[t]);
-            if (__any(alpha != 1.0f)) {                             // the running max settles after a few tiles
-#pragma unroll
-                for (int i = 0; i < HD / 16; ++i) {
-                    oacc[t][i][0] *= alpha; oacc[t][i][1] *= alpha; oacc[t][i][2] *= alpha; oacc[t][i][3] *= alpha;
-                }
-            }
+            const float lm = lane_max16(s);
+            if (k0 == 0) softmax_rescale<true>(s, lm, negm[t], lsum[t], oacc[t]);
+            else if (__any(lm > ATTN_THR)) softmax_rescale<false>(s, lm, negm[t], lsum[t], oacc[t]);
             ATTN_STAMP(101 + 4 * (k0 / KT));
-            // ---- P fragments (bf16): element e of fragment kk <-> key (kk*2 + e/4)*16 + fq*4 + e%4 ----
             bf16x8 pf[2];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                uint32_t tmp[4];
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) tmp[e >> 1] = pack2(s[kk * 2 + (e >> 2)][e & 3], s[kk * 2 + (e >> 2)][(e & 3) + 1]);
-                pf[kk] = *(bf16x8 *)tmp;
-            }
+            softmax_exp<TAIL>(s, nkt, lsum[t], pf);
             ATTN_STAMP(102 + 4 * (k0 / KT));
             // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -324,8 +355,8 @@ __global__ void __launch_bounds__(256) k_attention(AttnArgs a) {
     // ---- store: lane holds O[q_row][dt*16 + fq*4 + r] ----
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
+        const float inv = 1.0f / row_total(lsum[t]);               // (cross-lane: before the divergent exit)
         if (q_row[t] >= a.Tq) continue;
-        const float inv = 1.0f / l_run[t];
         uint16_t *op = a.o + b * a.o_sb + h * a.o_sh + (long long)q_row[t] * a.o_st;
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) {
@@ -380,6 +411,7 @@ __global__ void __launch_bounds__(256) k_attention_tiny(AttnArgs a, int krows) {
             const int d0 = ks * 32 + fq * 8;
             if (q_row < a.Tq && d0 < a.hd) raw = *(const uint4 *)(qp + (long long)q_row * a.q_st + d0);
             qf[ks] = *(bf16x8 *)&raw;
+            if (a.scale_log2e != 1.0f) qf[ks] = prescale_q(qf[ks], a.scale_log2e);
         }
         f32x4 s[4];
 #pragma unroll
@@ -398,32 +430,12 @@ __global__ void __launch_bounds__(256) k_attention_tiny(AttnArgs a, int krows) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (kt * 16 + fq * 4 + r >= a.Tk || (a.causal && kt * 16 + fq * 4 + r > q_row)) s[kt][r] = -3.0e38f;
-        float mx = -3.0e38f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
-        mx = max_xor16_32(mx);
-        const float m = fmaxf(-1.0e30f, mx * a.scale_log2e);         // (k_attention's first tile: running max starts at -1e30)
-        float ps = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            if (kt < nkt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], a.scale_log2e, -m));
-                    s[kt][r] = p;
-                    ps += p;
-                }
-            } else s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        ps = sum_xor16_32(ps);
+        // one key tile: k_attention's first-tile step (same arithmetic, same order)
+        f32x4 negm = f32x4{0.f, 0.f, 0.f, 0.f}, lsum = f32x4{0.f, 0.f, 0.f, 0.f}, none[1];
+        softmax_rescale<true>(s, lane_max16(s), negm, lsum, none);
         bf16x8 pf[2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint32_t tmp[4];
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) tmp[e >> 1] = pack2(s[kk * 2 + (e >> 2)][e & 3], s[kk * 2 + (e >> 2)][(e & 3) + 1]);
-            pf[kk] = *(bf16x8 *)tmp;
-        }
+        softmax_exp<true>(s, nkt, lsum, pf);
+        const float ps = row_total(lsum);
         const float inv = 1.0f / ps;
         uint16_t *op = a.o + b * a.o_sb + h * a.o_sh + (long long)q_row * a.o_st;
 #pragma unroll
@@ -469,12 +481,12 @@ typedef __attribute__((address_space(3))) char lds_char;
 // S^T of QT q-tiles against one 64-key tile (TAIL: the last, ragged one -- sub-tiles past the last key are not multiplied, keys past it masked)
 template <int QT, bool TAIL>
 __device__ __forceinline__ void resident_qk(const AttnArgs &a, const lds_char *sKt, int k0, const int (&kb)[2], const bf16x8 (&qf)[QT][2],
-                                            f32x4 (&s)[QT][4], int fq) {
+                                            const f32x4 (&negm)[QT], f32x4 (&s)[QT][4], int fq) {
     const int nkt = TAIL ? (a.Tk - k0 + 15) >> 4 : 4;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-        for (int t = 0; t < QT; ++t) s[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < QT; ++t) s[t][kt] = negm[t];              // S - m: the reference maximum is the C operand of the first k-step
         if (!TAIL || kt < nkt) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -496,26 +508,29 @@ __device__ __forceinline__ void resident_qk(const AttnArgs &a, const lds_char *s
 }
 
 // online softmax of those scores and O^T += V^T P^T
-template <int QT, bool TAIL>
+template <int QT, bool TAIL, bool FIRST>
 __device__ __forceinline__ void resident_pv(const AttnArgs &a, const lds_char *sVt, int k0, const int (&vb)[4], f32x4 (&s)[QT][4],
-                                            f32x4 (&oacc)[QT][4], float (&m_run)[QT], float (&l_run)[QT]) {
+                                            f32x4 (&oacc)[QT][4], f32x4 (&negm)[QT], f32x4 (&lsum)[QT]) {
     const int nkt = TAIL ? (a.Tk - k0 + 15) >> 4 : 4;
     bf16x8 pf[QT][2];
+    float lm[QT];
 #pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const float alpha = softmax_tile<TAIL>(s[t], nkt, a.scale_log2e, m_run[t], l_run[t]);
-        if (__any(alpha != 1.0f)) {                                 // the running max settles after a few tiles
+    for (int t = 0; t < QT; ++t) lm[t] = lane_max16(s[t]);
+    if (FIRST) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) oacc[t][i] = oacc[t][i] * alpha;
-        }
+        for (int t = 0; t < QT; ++t) softmax_rescale<true>(s[t], lm[t], negm[t], lsum[t], oacc[t]);
+    } else {
+        float mx = lm[0];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint32_t tmp[4];
+        for (int t = 1; t < QT; ++t) mx = fmaxf(mx, lm[t]);
+        if (__any(mx > ATTN_THR)) {                                 // rare: some score of the wave outgrew its reference maximum
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) tmp[e >> 1] = pack2(s[t][kk * 2 + (e >> 2)][e & 3], s[t][kk * 2 + (e >> 2)][(e & 3) + 1]);
-            pf[t][kk] = *(bf16x8 *)tmp;
+            for (int t = 0; t < QT; ++t)                            // (per q-tile, as k_attention decides: the two kernels stay bit-identical)
+                if (__any(lm[t] > ATTN_THR)) softmax_rescale<false>(s[t], lm[t], negm[t], lsum[t], oacc[t]);
         }
     }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) softmax_exp<TAIL>(s[t], nkt, lsum[t], pf[t]);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
@@ -548,13 +563,14 @@ __device__ __forceinline__ void resident_wave(const AttnArgs &a, const lds_char 
             const int d0 = ks * 32 + fq * 8;
             if (q_row[t] < a.Tq && d0 < a.hd) raw = *(const uint4 *)(qp + (long long)q_row[t] * a.q_st + d0);
             qf[t][ks] = *(bf16x8 *)&raw;
+            if (a.scale_log2e != 1.0f) qf[t][ks] = prescale_q(qf[t][ks], a.scale_log2e);
         }
     }
     f32x4 oacc[QT][4];
-    float m_run[QT], l_run[QT];
+    f32x4 negm[QT], lsum[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        m_run[t] = -1.0e30f; l_run[t] = 0.f;
+        negm[t] = f32x4{0.f, 0.f, 0.f, 0.f}; lsum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) oacc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -564,21 +580,26 @@ __device__ __forceinline__ void resident_wave(const AttnArgs &a, const lds_char 
     for (int ks = 0; ks < 2; ++ks) kb[ks] = fr * 128 + (((ks * 4 + fq) ^ (fr >> 1)) << 4);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) vb[dt] = (fq * 4 + (dt ^ fq)) * 128 + fr * 8;
-    const int full = a.Tk >> 6;
-    for (int tile = 0; tile < full; ++tile) {
+    const int full = a.Tk >> 6;                                     // (the resident form is only taken for Tk > 64: the first tile is a full one)
+    {
         f32x4 s[QT][4];
-        resident_qk<QT, false>(a, sK + tile * (64 * 128), tile * 64, kb, qf, s, fq);
-        resident_pv<QT, false>(a, sV + tile * (16 * 512), tile * 64, vb, s, oacc, m_run, l_run);
+        resident_qk<QT, false>(a, sK, 0, kb, qf, negm, s, fq);
+        resident_pv<QT, false, true>(a, sV, 0, vb, s, oacc, negm, lsum);
+    }
+    for (int tile = 1; tile < full; ++tile) {
+        f32x4 s[QT][4];
+        resident_qk<QT, false>(a, sK + tile * (64 * 128), tile * 64, kb, qf, negm, s, fq);
+        resident_pv<QT, false, false>(a, sV + tile * (16 * 512), tile * 64, vb, s, oacc, negm, lsum);
     }
     if (a.Tk & 63) {
         f32x4 s[QT][4];
-        resident_qk<QT, true>(a, sK + full * (64 * 128), full * 64, kb, qf, s, fq);
-        resident_pv<QT, true>(a, sV + full * (16 * 512), full * 64, vb, s, oacc, m_run, l_run);
+        resident_qk<QT, true>(a, sK + full * (64 * 128), full * 64, kb, qf, negm, s, fq);
+        resident_pv<QT, true, false>(a, sV + full * (16 * 512), full * 64, vb, s, oacc, negm, lsum);
     }
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
+        const float inv = 1.0f / row_total(lsum[t]);               // (cross-lane: before the divergent exit)
         if (q_row[t] >= a.Tq) continue;
-        const float inv = 1.0f / l_run[t];
         uint16_t *op = obase + (long long)q_row[t] * a.o_st;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -643,6 +664,212 @@ __global__ void __launch_bounds__(512) k_attention_resident(AttnArgs a, int spli
     }
 }
 
+
+// ---- k_attention32: head_dim <= 64, any sequence length.  One wave = 32 queries on v_mfma_f32_32x32x16_bf16 (a 32-cycle instruction hides
+// ~5 VALU issues; tools/ubench.hip), one workgroup = 4 waves = 128 queries, 2-3 workgroups per CU drifting against each other (MFMA phases of
+// one beside the softmax of another).  K / V walk through LDS in 64-key tiles, double-buffered, ONE barrier per tile: tile t+1 is written after
+// the barrier that opens tile t (its global loads were issued one tile earlier and re-issued for t+2 straight after the write: one register set).
+//   S^T[32 keys x 32 q]  = mfma(a = K fragment [32 keys x 16 d], b = Q^T fragment [16 d x 32 q], c = -m)   lane: q = lane & 31, 16 keys per key block
+//   O^T[32 d x 32 q]    += mfma(a = V^T fragment [32 d x 16 keys], b = P^T fragment [16 keys x 32 q])
+// The k index of the second product is free as long as both operands agree on it: element e of k-step j of key block kb stands for key
+// 32 kb + 16 j + 8 (e >> 2) + 4 hi + (e & 3) (hi = lane >> 5) -- exactly the keys of S accumulators 8 j .. 8 j + 7, so P goes from the
+// exponentials into the B operand with a v_cvt_pk_bf16_f32 per pair and no cross-lane move; the V^T fragment is two transposing reads
+// (ds_read_b64_tr_b16) of [4 keys][16 d] blocks.  Softmax: the fast / slow path scheme above (reference maximum as the C operand).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <bool FIRST>
+__device__ __forceinline__ void rescale32(f32x16 (&s)[2], float lm, f32x16 &negm, f32x16 &lsum, f32x16 (&o)[2]) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lm), __float_as_uint(lm), false, false);
+    const float rm = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const float d = FIRST ? rm : fmaxf(rm, 0.f);
+    s[0] = s[0] - d; s[1] = s[1] - d;
+    negm = negm - d;
+    if (!FIRST) {
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        lsum = lsum * alpha; o[0] = o[0] * alpha; o[1] = o[1] * alpha;
+    }
+}
+
+__device__ __forceinline__ float lane_max32(const f32x16 &x, const f32x16 &y) {
+    float m = fmaxf(fmaxf(x[0], x[1]), x[2]);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) m = fmaxf(fmaxf(m, x[i]), x[i + 1]);
+    m = fmaxf(fmaxf(m, x[15]), y[0]);
+#pragma unroll
+    for (int i = 1; i < 15; i += 2) m = fmaxf(fmaxf(m, y[i]), y[i + 1]);
+    return fmaxf(m, y[15]);
+}
+
+template <int NW>       // waves per workgroup
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) k_attention32(AttnArgs a) {
+    constexpr int NT = NW * 64;
+    constexpr int KT = 64, TILE = 2 * KT * 128;                  // K tile 8 KB + V tile 8 KB
+    constexpr int NLD = KT * 8 / NT;                             // 16-byte pieces of K (and of V) per thread and tile
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+    const int tid = threadIdx.x, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int work = (blockIdx.x & 7) * a.chunk + (blockIdx.x >> 3);       // XCD-chunked: the q-blocks of one head next to each other on one L2
+    if (work >= a.q_tiles * a.B * a.H) return;
+    const int bh = work / a.q_tiles, qblk = work - bh * a.q_tiles;
+    const int b = bh / a.H, h = bh % a.H;
+    const uint16_t *qp = a.q + b * a.q_sb + h * a.q_sh;
+    const uint16_t *kp = a.k + b * a.k_sb + h * a.k_sh;
+    const uint16_t *vp = a.v + b * a.v_sb + h * a.v_sh;
+
+    const int q_row = (qblk * NW + wave) * 32 + ql;
+    bf16x8 qf[4];                                                // B operand of k-step ks: d = 16 ks + 8 hi .. + 8
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        const int d0 = ks * 16 + hi * 8;
+        if (q_row < a.Tq && d0 < a.hd) raw = *(const uint4 *)(qp + (long long)q_row * a.q_st + d0);
+        qf[ks] = *(bf16x8 *)&raw;
+        if (a.scale_log2e != 1.0f) qf[ks] = prescale_q(qf[ks], a.scale_log2e);
+    }
+    f32x16 o[2], negm, lsum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; negm[i] = 0.f; lsum[i] = 0.f; }
+
+    // staging through buffer loads: piece id = it * NT + tid -> key row id >> 3, 16-byte chunk id & 7; the lane's byte offset inside a tile in
+    // voffset, the tile's in soffset; a piece that must read zeros (chunk past head_dim, row past the last key) gets an offset past the
+    // resource's extent -- the load returns 0 without a branch
+    constexpr uint32_t OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void *)kp, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void *)vp, 0, 0x7ffffff0, 0x00020000);
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 kr[NLD], vr[NLD];
+    int lds_k[NLD], lds_v[NLD], f_row[NLD];
+    uint32_t k_off[NLD], v_off[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int id = it * NT + tid, row = id >> 3, c = id & 7;
+        f_row[it] = row;
+        k_off[it] = c * 8 < a.hd ? (uint32_t)((row * a.k_st + c * 8) * 2) : OOB;
+        v_off[it] = c * 8 < a.hd ? (uint32_t)((row * a.v_st + c * 8) * 2) : OOB;
+        lds_k[it] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+        lds_v[it] = KT * 128 + ((row >> 2) * 4 + (c >> 1)) * 128 + (row & 3) * 32 + (c & 1) * 16;
+    }
+    const int k_tile_bytes = (int)(KT * a.k_st * 2), v_tile_bytes = (int)(KT * a.v_st * 2);
+    auto fetch = [&](int t, bool ragged) {                         // tile t -> registers (ragged: the tile holds rows past the last key)
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            uint32_t ko = k_off[it], vo = v_off[it];
+            if (ragged && t * KT + f_row[it] >= a.Tk) { ko = OOB; vo = OOB; }
+            kr[it] = __builtin_amdgcn_raw_buffer_load_b128(krs, ko, t * k_tile_bytes, 0);
+            vr[it] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vo, t * v_tile_bytes, 0);
+        }
+    };
+    auto commit = [&](char *buf) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) { *(u32x4 *)(buf + lds_k[it]) = kr[it]; *(u32x4 *)(buf + lds_v[it]) = vr[it]; }
+    };
+    // fragment addresses inside a tile buffer: K row (32 kb + ql), chunk (2 ks + hi) ^ swizzle(row);  V block (key group 8 kb + 4 j + hi (+2), d-group 2 db + (ql >> 4))
+    int ka[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ka[ks] = ql * 128 + (((2 * ks + hi) ^ ((ql >> 1) & 7)) << 4);
+    const int va = KT * 128 + (hi * 4 + (ql >> 4)) * 128 + (ql & 15) * 8;
+    const bool wave_active = (qblk * NW + wave) * 32 < a.Tq;     // (scalar: wave is)
+
+    // one 64-key tile; FIRST: the tile opens the row (reference maximum := its maximum); mask (scalar): the tile may hold keys past Tk or
+    // (causal) past the query.  ONE instantiation inside the loop: the accumulators keep their registers across iterations.
+    auto compute = [&](const char *buf, int k0, bool mask, auto FIRST_) {
+        constexpr bool FIRST = decltype(FIRST_)::value;
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8 *)(buf + kb * (32 * 128) + ka[ks]);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? negm : s[kb], 0, 0, 0);
+            }
+        }
+        if (mask) {
+            const int lim = (a.causal ? min(a.Tk - 1, q_row) : a.Tk - 1) - k0 - 4 * hi;      // last visible key of this lane's query, tile-relative
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    s[kb][r] = (kb * 32 + (r & 3) + 8 * (r >> 2) > lim) ? -3.0e38f : s[kb][r];
+        }
+        const float lm = lane_max32(s[0], s[1]);
+        if (FIRST) rescale32<true>(s, lm, negm, lsum, o);
+        else if (__any(lm > ATTN_THR)) rescale32<false>(s, lm, negm, lsum, o);
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]);
+            lsum = lsum + s[kb];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t tmp[4];
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) tmp[e >> 1] = pack2(s[kb][8 * j + e], s[kb][8 * j + e + 1]);
+                pf[kb][j] = *(bf16x8 *)tmp;
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char *blk = buf + va + ((8 * kb + 4 * j) * 4 + 2 * db) * 128;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(blk));
+                    const s16x4 hh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(blk + 2 * 4 * 128));
+                    const uint2 l2 = *(const uint2 *)&lo, h2 = *(const uint2 *)&hh;
+                    uint4 raw = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&raw, pf[kb][j], o[db], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    const int n_tiles = (a.Tk + KT - 1) / KT, n_full = a.Tk / KT;
+    fetch(0, n_full == 0);
+    commit(smem);
+    if (n_tiles > 1) fetch(1, 1 >= n_full);
+    __syncthreads();
+    if (n_tiles > 1) {
+        commit(smem + TILE);
+        if (n_tiles > 2) fetch(2, 2 >= n_full);
+    }
+    if (wave_active) compute(smem, 0, n_full == 0 || a.causal, std::true_type{});
+    for (int t = 1; t < n_tiles; ++t) {
+        __syncthreads();                                           // tile t is in buffer t & 1; every wave is done with tile t - 1 (buffer (t + 1) & 1)
+        if (t + 1 < n_tiles) {
+            commit(smem + ((t + 1) & 1) * TILE);
+            if (t + 2 < n_tiles) fetch(t + 2, t + 2 >= n_full);
+        }
+        if (wave_active) compute(smem + (t & 1) * TILE, t * KT, t >= n_full || a.causal, std::false_type{});
+    }
+    // ---- store: lane (q, hi) holds O^T rows d = 32 db + 8 g + 4 hi + (0..3) in o[db][4 g ..]; the two halves of a 16-byte row segment are
+    // traded between lanes q and q + 32 (v_permlane32_swap) so that every lane stores 16 contiguous bytes: lanes < 32 at d = 32 db + 16 p,
+    // lanes >= 32 at d = 32 db + 16 p + 8
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) l += lsum[i];
+    {
+        const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+        l = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const float inv = 1.0f / l;
+    uint16_t *op = a.o + b * a.o_sb + h * a.o_sh + (long long)q_row * a.o_st;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {                           // g = 2 pr (kept by lanes < 32), 2 pr + 1 (kept by lanes >= 32)
+            uint32_t a0 = pack2(o[db][8 * pr + 0] * inv, o[db][8 * pr + 1] * inv), a1 = pack2(o[db][8 * pr + 2] * inv, o[db][8 * pr + 3] * inv);
+            uint32_t b0 = pack2(o[db][8 * pr + 4] * inv, o[db][8 * pr + 5] * inv), b1 = pack2(o[db][8 * pr + 6] * inv, o[db][8 * pr + 7] * inv);
+            // vdst = group 2 pr, src = group 2 pr + 1: lanes >= 32 of vdst trade with lanes < 32 of src
+            const u32x2 x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false), x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            // lanes < 32: (a: own g = 2 pr, d + 0..3 | x[0] upper lanes' g = 2 pr, d + 4..7);  lanes >= 32: (lower lanes' g = 2 pr + 1 | own)
+            const int d0 = db * 32 + pr * 16 + hi * 8;
+            if (q_row < a.Tq && d0 < a.hd) *(uint4 *)(op + d0) = make_uint4(x0[0], x1[0], x0[1], x1[1]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
@@ -690,6 +917,18 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     const bool prof = ovo_prof_enabled();
     if (prof) { ovo_prof_begin(1, 4.0 * p->B * p->H * (double)p->Tq * p->Tk * p->hd, s); ovo_prof_shape(p->B * p->H, p->Tq, p->Tk); }
     struct Done { bool on; hipStream_t s; ~Done() { if (on) ovo_prof_end(s); } } done{prof, s};
+    // head_dim <= 64: 32 x 32 MFMA tiles, K / V streamed (k_attention32); OVO_ATTN32 = 0 / 1 overrides the shape rule (tools/attn_bench.py)
+    {
+        const int force32 = getenv("OVO_ATTN32") ? atoi(getenv("OVO_ATTN32")) : -1;
+        const bool use32 = force32 >= 0 ? force32 != 0 : false;
+        if (use32 && p->hd <= 64) {
+            const long long qb = (p->Tq + 127) / 128, total = qb * p->B * p->H;
+            a.q_tiles = (int)qb; a.chunk = (int)((total + 7) / 8);
+            k_attention32<4><<<(unsigned)(a.chunk * 8), 256, 0, s>>>(a);
+            OVO_CHECK_LAUNCH();
+            return OVO_OK;
+        }
+    }
     // 65-592 keys of head_dim <= 64, not causal: K / V of a head resident in LDS (k_attention_resident)
     if (p->hd <= 64 && p->Tk > 64 && p->Tk <= 592 && !p->causal && !getenv("OVO_ATTN_NO_RESIDENT")) {
         const int krows = (p->Tk + 15) & ~15, nq = (p->Tq + 15) / 16;

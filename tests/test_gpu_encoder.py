@@ -295,6 +295,26 @@ def test_attention_vs_torch(B, H, Tq, Tk, hd):
     assert (out.float() - ref).abs().mean() < 2e-3
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,hd", [(2, 4, 577, 577, 64), (1, 2, 1100, 1100, 56), (2, 2, 196, 196, 56), (1, 2, 300, 700, 128), (1, 1, 130, 4096, 64)])
+def test_attention_rescale_path(B, H, Tq, Tk, hd):
+    """The online softmax keeps a reference maximum per query and only rescales when a score outgrows it by 2^6 (attention.hip, fast / slow path):
+    keys whose scores jump far above everything before them -- at a late tile, for some queries only, and a slow drift upwards -- must go through
+    the rare branch and still match the fp32 softmax (cdna guide rule 26: a rare data-dependent branch needs an input that forces it)."""
+    g = torch.Generator().manual_seed(B + H + Tq + Tk + hd)
+    D, T = H * hd, max(Tq, Tk)
+    qkv = torch.randn(B, T, 3, H, hd, generator=g)
+    qkv[:, :, 1] *= torch.linspace(0.2, 3.0, T).reshape(1, T, 1, 1)                  # scores drift upwards tile after tile
+    for key, qrow in ((Tk - 3, 5), (Tk // 2 + 7, Tq // 2), (70, Tq - 1), (Tk - 1, 0)):
+        qkv[:, key, 1] = 6.0 * qkv[:, qrow, 0] / qkv[:, qrow, 0].norm(dim=-1, keepdim=True) * hd ** 0.5   # one key far above the rest for one query
+    qkv = qkv.to(DEV, torch.bfloat16)
+    out = _attention_call(qkv, B, H, Tq, Tk, hd)
+    q, k, v = (qkv[:, :n, i].float().permute(0, 2, 1, 3) for i, n in ((0, Tq), (1, Tk), (2, Tk)))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, Tq, D)
+    assert torch.isfinite(out.float()).all()
+    torch.testing.assert_close(out.float(), ref, atol=3e-2, rtol=3e-2)
+    assert (out.float() - ref).abs().mean() < 3e-3
+
+
 def _attention_call(qkv, B, H, Tq, Tk, hd):
     from ovo_amd import _lib as L
     D, T = H * hd, qkv.shape[1]

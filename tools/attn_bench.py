@@ -26,8 +26,10 @@ shapes = [(24, 16, 577, 577, 64), (2, 16, 577, 577, 64), (12, 8, 4096, 4096, 56)
           (12288, 8, 4, 16, 56), (300, 16, 49, 196, 56), (300, 16, 49, 49, 56), (8, 16, 2048, 2048, 128)]
 for shape in shapes:
     row = "%-28s" % str(shape)
-    for mode in ("auto", "notiny", "narrow", "wide"):
-        for k in ("OVO_ATTN_NARROW", "OVO_ATTN_WIDE", "OVO_ATTN_NO_TINY", "OVO_ATTN_NO_RESIDENT"): os.environ.pop(k, None)
+    for mode in os.environ.get("MODES", "auto,a32,narrow,wide").split(","):
+        for k in ("OVO_ATTN_NARROW", "OVO_ATTN_WIDE", "OVO_ATTN_NO_TINY", "OVO_ATTN_NO_RESIDENT", "OVO_ATTN32"): os.environ.pop(k, None)
+        if mode == "a32": os.environ["OVO_ATTN32"] = "1"
+        if mode in ("narrow", "wide", "notiny"): os.environ["OVO_ATTN32"] = "0"
         if mode == "narrow": os.environ["OVO_ATTN_NARROW"] = "1"; os.environ["OVO_ATTN_NO_RESIDENT"] = "1"
         if mode == "wide": os.environ["OVO_ATTN_WIDE"] = "1"; os.environ["OVO_ATTN_NO_RESIDENT"] = "1"
         if mode == "notiny": os.environ["OVO_ATTN_NO_TINY"] = "1"
