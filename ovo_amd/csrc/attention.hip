@@ -466,205 +466,6 @@ __global__ void __launch_bounds__(256) k_attention_tiny(AttnArgs a, int krows) {
 }
 
 
-// ---- whole-head-resident form: Tk <= 592 keys of head_dim <= 64 (the ViT-L/14-336 blocks: 577 tokens; Hiera's 14 x 14 windows: 196).
-// k_attention gives every 64 queries a workgroup that walks K / V in tiles -- fetch into registers, commit to LDS, one barrier per tile,
-// one q-tile per wave (every K / V^T fragment read from LDS feeds ONE MFMA: the LDS pipe is as busy as the matrix pipe) -- and measured
-// ~1600 cycles per (16 queries x 64 keys) on a SIMD whose MFMAs need 256.  Here K and V of one (batch, head) pair are copied into LDS
-// ONCE (K: 128-byte rows, 16-byte chunk index XORed with (row >> 1) & 7; V: the [4 keys][16 d] blocks of k_attention with the block's
-// d-group XORed with the key group & 3 -- no padding, 2 x 74 KB at 577 keys), one barrier, and then every wave walks all key tiles for
-// its OWN 2-3 q-tiles out of read-only LDS with no further synchronisation: a fragment feeds 2-3 MFMAs, nothing is handed over between
-// tiles, and the two waves of a SIMD cover each other's softmax with MFMAs.  A workgroup takes a contiguous range of a head's q-tiles
-// (`splits` ranges per head: 577 queries = 37 q-tiles = 19 + 18, eight waves x (3, 3, 3, 2, 2, 2, 2, 2) / (3, 3, 2, ...)); the same
-// arithmetic in the same order as k_attention -- bit-identical results (test_attention_resident_kernel_equals_tiled_kernel).
-typedef __attribute__((address_space(3))) char lds_char;
-
-// S^T of QT q-tiles against one 64-key tile (TAIL: the last, ragged one -- sub-tiles past the last key are not multiplied, keys past it masked)
-template <int QT, bool TAIL>
-__device__ __forceinline__ void resident_qk(const AttnArgs &a, const lds_char *sKt, int k0, const int (&kb)[2], const bf16x8 (&qf)[QT][2],
-                                            const f32x4 (&negm)[QT], f32x4 (&s)[QT][4], int fq) {
-    const int nkt = TAIL ? (a.Tk - k0 + 15) >> 4 : 4;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-        for (int t = 0; t < QT; ++t) s[t][kt] = negm[t];              // S - m: the reference maximum is the C operand of the first k-step
-        if (!TAIL || kt < nkt) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 kf = *(const __attribute__((address_space(3))) bf16x8 *)(sKt + kt * (16 * 128) + kb[ks]);
-#pragma unroll
-                for (int t = 0; t < QT; ++t) s[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[t][kt], 0, 0, 0);
-            }
-        }
-    }
-    if (TAIL) {
-#pragma unroll
-        for (int t = 0; t < QT; ++t)
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (k0 + kt * 16 + fq * 4 + r >= a.Tk) s[t][kt][r] = -3.0e38f;
-    }
-}
-
-// online softmax of those scores and O^T += V^T P^T
-template <int QT, bool TAIL, bool FIRST>
-__device__ __forceinline__ void resident_pv(const AttnArgs &a, const lds_char *sVt, int k0, const int (&vb)[4], f32x4 (&s)[QT][4],
-                                            f32x4 (&oacc)[QT][4], f32x4 (&negm)[QT], f32x4 (&lsum)[QT]) {
-    const int nkt = TAIL ? (a.Tk - k0 + 15) >> 4 : 4;
-    bf16x8 pf[QT][2];
-    float lm[QT];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) lm[t] = lane_max16(s[t]);
-    if (FIRST) {
-#pragma unroll
-        for (int t = 0; t < QT; ++t) softmax_rescale<true>(s[t], lm[t], negm[t], lsum[t], oacc[t]);
-    } else {
-        float mx = lm[0];
-#pragma unroll
-        for (int t = 1; t < QT; ++t) mx = fmaxf(mx, lm[t]);
-        if (__any(mx > ATTN_THR)) {                                 // rare: some score of the wave outgrew its reference maximum
-#pragma unroll
-            for (int t = 0; t < QT; ++t)                            // (per q-tile, as k_attention decides: the two kernels stay bit-identical)
-                if (__any(lm[t] > ATTN_THR)) softmax_rescale<false>(s[t], lm[t], negm[t], lsum[t], oacc[t]);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < QT; ++t) softmax_exp<TAIL>(s[t], nkt, lsum[t], pf[t]);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (TAIL && kk * 2 >= nkt) continue;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(sVt + (kk * 2) * (4 * 512) + vb[dt]));
-            s16x4 hi = s16x4{0, 0, 0, 0};
-            if (!TAIL || kk * 2 + 1 < nkt)
-                hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(sVt + (kk * 2 + 1) * (4 * 512) + vb[dt]));
-            const uint2 l2 = *(const uint2 *)&lo, h2 = *(const uint2 *)&hi;
-            uint4 raw = make_uint4(l2.x, l2.y, h2.x, h2.y);
-#pragma unroll
-            for (int t = 0; t < QT; ++t) oacc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8 *)&raw, pf[t][kk], oacc[t][dt], 0, 0, 0);
-        }
-    }
-}
-
-// One wave, QT q-tiles from q-tile qt0, all key tiles out of the resident K / V.
-template <int QT>
-__device__ __forceinline__ void resident_wave(const AttnArgs &a, const lds_char *sK, const lds_char *sV, const uint16_t *qp, uint16_t *obase, int qt0, int lane) {
-    const int fr = lane & 15, fq = lane >> 4;
-    int q_row[QT];
-    bf16x8 qf[QT][2];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        q_row[t] = (qt0 + t) * 16 + fr;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 raw = make_uint4(0, 0, 0, 0);
-            const int d0 = ks * 32 + fq * 8;
-            if (q_row[t] < a.Tq && d0 < a.hd) raw = *(const uint4 *)(qp + (long long)q_row[t] * a.q_st + d0);
-            qf[t][ks] = *(bf16x8 *)&raw;
-            if (a.scale_log2e != 1.0f) qf[t][ks] = prescale_q(qf[t][ks], a.scale_log2e);
-        }
-    }
-    f32x4 oacc[QT][4];
-    f32x4 negm[QT], lsum[QT];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        negm[t] = f32x4{0.f, 0.f, 0.f, 0.f}; lsum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) oacc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // lane parts of the fragment addresses (bytes): K row (16 kt + fr) chunk (4 ks + fq) ^ (fr >> 1); V block (key group 4 x + fq, d-group dt ^ fq) + 8 fr
-    int kb[2], vb[4];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) kb[ks] = fr * 128 + (((ks * 4 + fq) ^ (fr >> 1)) << 4);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) vb[dt] = (fq * 4 + (dt ^ fq)) * 128 + fr * 8;
-    const int full = a.Tk >> 6;                                     // (the resident form is only taken for Tk > 64: the first tile is a full one)
-    {
-        f32x4 s[QT][4];
-        resident_qk<QT, false>(a, sK, 0, kb, qf, negm, s, fq);
-        resident_pv<QT, false, true>(a, sV, 0, vb, s, oacc, negm, lsum);
-    }
-    for (int tile = 1; tile < full; ++tile) {
-        f32x4 s[QT][4];
-        resident_qk<QT, false>(a, sK + tile * (64 * 128), tile * 64, kb, qf, negm, s, fq);
-        resident_pv<QT, false, false>(a, sV + tile * (16 * 512), tile * 64, vb, s, oacc, negm, lsum);
-    }
-    if (a.Tk & 63) {
-        f32x4 s[QT][4];
-        resident_qk<QT, true>(a, sK + full * (64 * 128), full * 64, kb, qf, negm, s, fq);
-        resident_pv<QT, true, false>(a, sV + full * (16 * 512), full * 64, vb, s, oacc, negm, lsum);
-    }
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const float inv = 1.0f / row_total(lsum[t]);               // (cross-lane: before the divergent exit)
-        if (q_row[t] >= a.Tq) continue;
-        uint16_t *op = obase + (long long)q_row[t] * a.o_st;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int d0 = dt * 16 + fq * 4;
-            if (d0 < a.hd) {
-                uint2 p;
-                p.x = pack2(oacc[t][dt][0] * inv, oacc[t][dt][1] * inv);
-                p.y = pack2(oacc[t][dt][2] * inv, oacc[t][dt][3] * inv);
-                *(uint2 *)(op + d0) = p;
-            }
-        }
-    }
-}
-
-// a.q_tiles = q-tiles (of 16) per head, a.chunk = work items per XCD (work item = (head, split)); `splits` ranges of q-tiles per head
-__global__ void __launch_bounds__(512) k_attention_resident(AttnArgs a, int splits, int krows) {
-    extern __shared__ __attribute__((aligned(16))) char rsm[];
-    lds_char *sK = (lds_char *)rsm, *sV = sK + krows * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-    const int work = (blockIdx.x & 7) * a.chunk + (blockIdx.x >> 3);          // items of one head next to each other on ONE XCD (its L2 serves K / V twice)
-    if (work >= a.B * a.H * splits) return;
-    const int bh = work / splits, split = work - bh * splits;
-    const int b = bh / a.H, h = bh % a.H;
-    const uint16_t *qp = a.q + b * a.q_sb + h * a.q_sh;
-    const uint16_t *kp = a.k + b * a.k_sb + h * a.k_sh;
-    const uint16_t *vp = a.v + b * a.v_sb + h * a.v_sh;
-    // (measured alternatives, tools/attn_bench.py, 24 x 16 heads x 577^2: this copy through registers 81 us; the same image brought in by
-    // LDS-DMA in tile order and consumed behind counted waits + one barrier per key tile 100 us -- waves in lock-step multiply and
-    // exponentiate at the same time, the drift between them IS the overlap; DMA with one wait 85 us)
-    const int pieces = krows * 8;
-    for (int id0 = tid; id0 < pieces; id0 += 4 * blockDim.x) {                 // four 16-byte pieces of K and of V in flight per thread
-        uint4 kr[4], vr[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int id = id0 + u * blockDim.x, row = id >> 3, c = id & 7;
-            kr[u] = make_uint4(0, 0, 0, 0); vr[u] = make_uint4(0, 0, 0, 0);
-            if (id < pieces && row < a.Tk && c * 8 < a.hd) {
-                kr[u] = *(const uint4 *)(kp + (long long)row * a.k_st + c * 8);
-                vr[u] = *(const uint4 *)(vp + (long long)row * a.v_st + c * 8);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int id = id0 + u * blockDim.x, row = id >> 3, c = id & 7, kg = row >> 2;
-            if (id < pieces) {
-                *(uint4 *)(rsm + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kr[u];
-                *(uint4 *)(rsm + krows * 128 + (kg * 4 + ((c >> 1) ^ (kg & 3))) * 128 + (row & 3) * 32 + (c & 1) * 16) = vr[u];
-            }
-        }
-    }
-    __syncthreads();
-    // this workgroup's q-tiles [t0, t0 + nt), dealt to the waves as contiguous runs of 2-3 (the first `rem` waves take one more)
-    const int per = a.q_tiles / splits, extra = a.q_tiles % splits;
-    const int t0 = split * per + (split < extra ? split : extra), nt = per + (split < extra ? 1 : 0);
-    const int base = nt / n_waves, rem = nt % n_waves;
-    int mine = base + (wave < rem ? 1 : 0), first = t0 + wave * base + (wave < rem ? wave : rem);
-    uint16_t *obase = a.o + b * a.o_sb + h * a.o_sh;
-    while (mine > 0) {                                                          // (more than 3 only when a split holds more than 3 q-tiles per wave)
-        if (mine >= 3) { resident_wave<3>(a, sK, sV, qp, obase, first, lane); first += 3; mine -= 3; }
-        else if (mine == 2) { resident_wave<2>(a, sK, sV, qp, obase, first, lane); first += 2; mine -= 2; }
-        else { resident_wave<1>(a, sK, sV, qp, obase, first, lane); first += 1; mine -= 1; }
-    }
-}
-
-
 // ---- k_attention32: head_dim <= 64, any sequence length.  One wave = 32 queries on v_mfma_f32_32x32x16_bf16 (a 32-cycle instruction hides
 // ~5 VALU issues; tools/ubench.hip), one workgroup = 4 waves = 128 queries, 2-3 workgroups per CU drifting against each other (MFMA phases of
 // one beside the softmax of another).  K / V walk through LDS in 64-key tiles, double-buffered, ONE barrier per tile: tile t+1 is written after
@@ -677,7 +478,7 @@ __global__ void __launch_bounds__(512) k_attention_resident(AttnArgs a, int spli
 // (ds_read_b64_tr_b16) of [4 keys][16 d] blocks.  Softmax: the fast / slow path scheme above (reference maximum as the C operand).
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <bool FIRST>
+template <bool FIRST, bool ONES>
 __device__ __forceinline__ void rescale32(f32x16 (&s)[2], float lm, f32x16 &negm, f32x16 &lsum, f32x16 (&o)[2]) {
     const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lm), __float_as_uint(lm), false, false);
     const float rm = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -686,22 +487,22 @@ __device__ __forceinline__ void rescale32(f32x16 (&s)[2], float lm, f32x16 &negm
     negm = negm - d;
     if (!FIRST) {
         const float alpha = __builtin_amdgcn_exp2f(-d);
-        lsum = lsum * alpha; o[0] = o[0] * alpha; o[1] = o[1] * alpha;
+        if (!ONES) lsum = lsum * alpha;
+        o[0] = o[0] * alpha; o[1] = o[1] * alpha;
     }
 }
 
-__device__ __forceinline__ float lane_max32(const f32x16 &x, const f32x16 &y) {
-    float m = fmaxf(fmaxf(x[0], x[1]), x[2]);
+__device__ __forceinline__ float lane_max32(const f32x16 &x, const f32x16 &y) {       // two independent v_max3 chains
+    float m = fmaxf(fmaxf(x[0], x[1]), x[2]), n = fmaxf(fmaxf(y[0], y[1]), y[2]);
 #pragma unroll
-    for (int i = 3; i < 15; i += 2) m = fmaxf(fmaxf(m, x[i]), x[i + 1]);
-    m = fmaxf(fmaxf(m, x[15]), y[0]);
-#pragma unroll
-    for (int i = 1; i < 15; i += 2) m = fmaxf(fmaxf(m, y[i]), y[i + 1]);
-    return fmaxf(m, y[15]);
+    for (int i = 3; i < 15; i += 2) { m = fmaxf(fmaxf(m, x[i]), x[i + 1]); n = fmaxf(fmaxf(n, y[i]), y[i + 1]); }
+    return fmaxf(fmaxf(m, x[15]), fmaxf(n, y[15]));
 }
 
-template <int NW>       // waves per workgroup
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) k_attention32(AttnArgs a) {
+// ONES (head_dim <= 56, e.g. Hiera's 56): the zero padding of V up to 64 columns carries a column of ones at d = 56, so the row sum of the
+// (bf16-rounded) probabilities comes out of the P V product as O^T row 56 -- no add per score, no separate accumulator to rescale.
+template <int NW, bool ONES>       // NW: waves per workgroup
+__global__ void __launch_bounds__(NW * 64, 2) k_attention32(AttnArgs a) {
     constexpr int NT = NW * 64;
     constexpr int KT = 64, TILE = 2 * KT * 128;                  // K tile 8 KB + V tile 8 KB
     constexpr int NLD = KT * 8 / NT;                             // 16-byte pieces of K (and of V) per thread and tile
@@ -740,28 +541,40 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) k_attention32(AttnAr
     u32x4 kr[NLD], vr[NLD];
     int lds_k[NLD], lds_v[NLD], f_row[NLD];
     uint32_t k_off[NLD], v_off[NLD];
+    int f_vrow[NLD];
+    bool f_vone[NLD];
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
         const int id = it * NT + tid, row = id >> 3, c = id & 7;
         f_row[it] = row;
         k_off[it] = c * 8 < a.hd ? (uint32_t)((row * a.k_st + c * 8) * 2) : OOB;
-        v_off[it] = c * 8 < a.hd ? (uint32_t)((row * a.v_st + c * 8) * 2) : OOB;
         lds_k[it] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
-        lds_v[it] = KT * 128 + ((row >> 2) * 4 + (c >> 1)) * 128 + (row & 3) * 32 + (c & 1) * 16;
+        // V: the 8 lanes of a ds_write_b128 group fill ONE 128-byte [4 keys][16 d] block (piece j of the block = key j >> 1, chunk 2 dg + (j & 1));
+        // with lane -> (row, chunk) as for K the group's addresses alias mod 128 bytes: a 4-way bank conflict on every V write (PMC: 48 of 144 LDS cycles per tile)
+        const int blk = id >> 3, j = id & 7, vrow = (blk >> 2) * 4 + (j >> 1), vc = (blk & 3) * 2 + (j & 1);
+        f_vrow[it] = vrow;
+        v_off[it] = vc * 8 < a.hd ? (uint32_t)((vrow * a.v_st + vc * 8) * 2) : OOB;
+        lds_v[it] = KT * 128 + blk * 128 + j * 16;
+        f_vone[it] = ONES && vc == 7;                             // the piece holding d = 56..63
     }
     const int k_tile_bytes = (int)(KT * a.k_st * 2), v_tile_bytes = (int)(KT * a.v_st * 2);
     auto fetch = [&](int t, bool ragged) {                         // tile t -> registers (ragged: the tile holds rows past the last key)
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             uint32_t ko = k_off[it], vo = v_off[it];
-            if (ragged && t * KT + f_row[it] >= a.Tk) { ko = OOB; vo = OOB; }
+            if (ragged && t * KT + f_row[it] >= a.Tk) ko = OOB;
+            if (ragged && t * KT + f_vrow[it] >= a.Tk) vo = OOB;
             kr[it] = __builtin_amdgcn_raw_buffer_load_b128(krs, ko, t * k_tile_bytes, 0);
             vr[it] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vo, t * v_tile_bytes, 0);
         }
     };
     auto commit = [&](char *buf) {
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) { *(u32x4 *)(buf + lds_k[it]) = kr[it]; *(u32x4 *)(buf + lds_v[it]) = vr[it]; }
+        for (int it = 0; it < NLD; ++it) {
+            *(u32x4 *)(buf + lds_k[it]) = kr[it];
+            if (ONES && f_vone[it]) vr[it] = u32x4{0x3f80u, 0u, 0u, 0u};            // V[key][56] = 1.0 (bf16), 57..63 = 0
+            *(u32x4 *)(buf + lds_v[it]) = vr[it];
+        }
     };
     // fragment addresses inside a tile buffer: K row (32 kb + ql), chunk (2 ks + hi) ^ swizzle(row);  V block (key group 8 kb + 4 j + hi (+2), d-group 2 db + (ql >> 4))
     int ka[4];
@@ -776,13 +589,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) k_attention32(AttnAr
         constexpr bool FIRST = decltype(FIRST_)::value;
         f32x16 s[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int kb = 0; kb < 2; ++kb) {                         // two independent accumulation chains, alternating
                 const bf16x8 kf = *(const bf16x8 *)(buf + kb * (32 * 128) + ka[ks]);
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? negm : s[kb], 0, 0, 0);
             }
-        }
+        // (measured and dropped: all eight K fragments and all sixteen V^T fragments fetched ahead of their products -- 32 + 32 more live
+        //  registers, 2 waves per SIMD instead of 3: 4096^2 x 56 global blocks 526 -> 558 us; the third wave hides more than the prefetch)
         if (mask) {
             const int lim = (a.causal ? min(a.Tk - 1, q_row) : a.Tk - 1) - k0 - 4 * hi;      // last visible key of this lane's query, tile-relative
 #pragma unroll
@@ -792,14 +606,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) k_attention32(AttnAr
                     s[kb][r] = (kb * 32 + (r & 3) + 8 * (r >> 2) > lim) ? -3.0e38f : s[kb][r];
         }
         const float lm = lane_max32(s[0], s[1]);
-        if (FIRST) rescale32<true>(s, lm, negm, lsum, o);
-        else if (__any(lm > ATTN_THR)) rescale32<false>(s, lm, negm, lsum, o);
+        if (FIRST) rescale32<true, ONES>(s, lm, negm, lsum, o);
+        else if (__any(lm > ATTN_THR)) rescale32<false, ONES>(s, lm, negm, lsum, o);
         bf16x8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]);
-            lsum = lsum + s[kb];
+            if (!ONES) lsum = lsum + s[kb];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 uint32_t tmp[4];
@@ -847,8 +661,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) k_attention32(AttnAr
     // traded between lanes q and q + 32 (v_permlane32_swap) so that every lane stores 16 contiguous bytes: lanes < 32 at d = 32 db + 16 p,
     // lanes >= 32 at d = 32 db + 16 p + 8
     float l = 0.f;
+    if (ONES) l = hi == 0 ? o[1][12] : 0.f;                       // O^T row 56 = 32 + (12 & 3) + 8 (12 >> 2) + 4 hi at hi = 0
+    else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) l += lsum[i];
+        for (int i = 0; i < 16; ++i) l += lsum[i];
+    }
     {
         const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
         l = __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -890,21 +707,11 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     a.scale_log2e = p->scale * 1.4426950408889634f;
     a.causal = p->causal;
     hipStream_t s = (hipStream_t)stream;
-    // two q-tiles per wave once there are enough 128-query workgroups to fill the chip
-    // (tools/attn_bench.py: 128-query workgroups win once there are >= 2 of them per CU; below that the 64-query form's
-    // 3 waves/SIMD hide more latency: 4096 x 4096, 8 heads, hd 56: 100 us narrow vs 114 us wide)
-    // -- and only for head_dim > 64: the 128-query form needs 198 VGPRs at head_dim 64 (2 waves per SIMD) against 128 (3-4) for the
-    // 64-query form, and with several frames per launch there are always enough workgroups; tools/attn_bench.py, round 2:
-    // 8 x 16 heads x 577^2 (four keyframes' ViT crops) 59.8 us wide vs 37.4 narrow, 4 x 8 x 4096^2 x 56 394 vs 292, while
-    // 8 x 16 x 2048^2 x 128 stays 703 wide vs 849 narrow
-    // -- and for Hiera's 14 x 14 windows (196 queries and keys): two 128-query workgroups per (window, head) stage K / V twice instead of
-    // four times (64 + 64 + 64 + 4 queries): 12 frames' stage-3 windows 118 -> 104 us (tools/attn_bench.py, round 3)
-    const bool wide = (getenv("OVO_ATTN_WIDE") != nullptr) ||
-                      (!getenv("OVO_ATTN_NARROW") && ((p->hd > 64 && p->Tq >= 512 && (long long)((p->Tq + 127) / 128) * p->B * p->H >= 512) ||
-                                                      (p->Tq > 128 && p->Tq <= 256 && p->Tk <= 256 && (long long)p->B * p->H >= 512) ||
-                                                      // head_dim <= 64, long sequences: 12 frames' Hiera global blocks (96 x 4096^2 x 56) 730 us wide vs 772 narrow,
-                                                      // four frames' (32 pairs: 1024 wide workgroups) 394 vs 292 -- wide from ten 128-query workgroups per CU
-                                                      (p->hd <= 64 && p->Tq >= 2048 && (long long)((p->Tq + 127) / 128) * p->B * p->H >= 2560)));
+    // k_attention<HD, QT> (16 x 16 MFMA tiles, 64 or 128 queries per workgroup): head_dim > 64, and whatever k_attention32 cannot address.  History of the
+    // 64- vs 128-query rule (rounds 2-3): DESIGN.md section 3.
+    // (round 4: with the cheaper softmax the 64-query form also wins at head_dim 128 -- 8 x 16 x 2048^2 x 128: 512 us narrow vs 662 wide; the 128-query
+    // form is left for OVO_ATTN_WIDE experiments; head_dim <= 64 goes to k_attention32 above unless OVO_ATTN32=0)
+    const bool wide = getenv("OVO_ATTN_WIDE") != nullptr && !getenv("OVO_ATTN_NARROW");
     const int qpb = wide ? 128 : 64;
     dim3 grid((p->Tq + qpb - 1) / qpb, p->B * p->H);
     a.q_tiles = (int)grid.x; a.chunk = 0;
@@ -917,46 +724,32 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     const bool prof = ovo_prof_enabled();
     if (prof) { ovo_prof_begin(1, 4.0 * p->B * p->H * (double)p->Tq * p->Tk * p->hd, s); ovo_prof_shape(p->B * p->H, p->Tq, p->Tk); }
     struct Done { bool on; hipStream_t s; ~Done() { if (on) ovo_prof_end(s); } } done{prof, s};
-    // head_dim <= 64: 32 x 32 MFMA tiles, K / V streamed (k_attention32); OVO_ATTN32 = 0 / 1 overrides the shape rule (tools/attn_bench.py)
+    // head_dim <= 64 and more than 16 queries: 32 x 32 MFMA tiles, K / V streamed (k_attention32); 128 queries per workgroup, 64 when a (batch, head)
+    // pair has no more.  OVO_ATTN32 = 0 / 1 overrides the shape rule (tools/attn_bench.py: 12 frames' shapes, a32 vs the 16 x 16 kernels with the
+    // same softmax: 577^2 x 64 60.6 vs 66.8 us, 4096^2 x 56 466 vs 622, 196^2 x 56 windows 63 vs 76, 49 x 196 64 vs 79, 49^2 29 vs 34, 64^2 tie;
+    // <= 16 queries x <= 64 keys stay with the one-wave-per-pair kernel: 222 / 79 / 96 us against 287 / 261 / 486)
     {
         const int force32 = getenv("OVO_ATTN32") ? atoi(getenv("OVO_ATTN32")) : -1;
-        const bool use32 = force32 >= 0 ? force32 != 0 : false;
-        if (use32 && p->hd <= 64) {
-            const long long qb = (p->Tq + 127) / 128, total = qb * p->B * p->H;
+        const bool use32 = force32 >= 0 ? force32 != 0 : !(p->Tq <= 16 && p->Tk <= 64);
+        // 16-byte output stores and 32-bit K / V byte offsets inside a (batch, head) slab
+        const bool fits32 = ((uintptr_t)p->o & 15) == 0 && p->o_st % 8 == 0 && p->o_sh % 8 == 0 && p->o_sb % 8 == 0 &&
+                            ((long long)p->Tk + 64) * p->k_st * 2 < (1ll << 31) && ((long long)p->Tk + 64) * p->v_st * 2 < (1ll << 31);
+        if (use32 && fits32 && p->hd <= 64) {
+            const int qpw = p->Tq <= 64 ? 64 : 128;
+            const long long qb = (p->Tq + qpw - 1) / qpw, total = qb * p->B * p->H;
             a.q_tiles = (int)qb; a.chunk = (int)((total + 7) / 8);
-            k_attention32<4><<<(unsigned)(a.chunk * 8), 256, 0, s>>>(a);
+            const unsigned g = (unsigned)(a.chunk * 8);
+            if (qpw == 64) {
+                if (p->hd <= 56) k_attention32<2, true><<<g, 128, 0, s>>>(a);
+                else k_attention32<2, false><<<g, 128, 0, s>>>(a);
+            } else {
+                if (p->hd <= 56) k_attention32<4, true><<<g, 256, 0, s>>>(a);
+                else k_attention32<4, false><<<g, 256, 0, s>>>(a);
+            }
             OVO_CHECK_LAUNCH();
             return OVO_OK;
         }
     }
-    // 65-592 keys of head_dim <= 64, not causal: K / V of a head resident in LDS (k_attention_resident)
-    if (p->hd <= 64 && p->Tk > 64 && p->Tk <= 592 && !p->causal && !getenv("OVO_ATTN_NO_RESIDENT")) {
-        const int krows = (p->Tk + 15) & ~15, nq = (p->Tq + 15) / 16;
-        const size_t lds = (size_t)krows * 256;
-        // one 8-wave workgroup per CU above half the LDS; below it 4-wave workgroups, so that one loads while another multiplies
-        static const int force_threads = getenv("OVO_ATTN_RES_THREADS") ? atoi(getenv("OVO_ATTN_RES_THREADS")) : 0;    // tools/attn_bench.py
-        static const int force_splits = getenv("OVO_ATTN_RES_SPLITS") ? atoi(getenv("OVO_ATTN_RES_SPLITS")) : 0;
-        const int threads = force_threads ? force_threads : (lds > 80 * 1024 ? 512 : 256), waves = threads / 64;
-        // at most 4 q-tiles per wave (a pass of 3 and one of 1: the 13 q-tiles of a 14 x 14 window on four waves, K / V staged once -- 84 us
-        // against 94 as two workgroups of 7 + 6; tools/attn_variants.py) ...
-        int splits = (nq + 4 * waves - 1) / (4 * waves);
-        const long long heads = (long long)p->B * p->H;
-        while (heads * splits < 768 && (splits + 1) * 2 * waves <= nq) ++splits;   // ... and 3+ workgroups per CU while every wave keeps 2 q-tiles
-        if (force_splits) splits = force_splits;
-        static bool attr_done = false;
-        if (heads * splits < 192) goto tiled;                             // too few workgroups for the chip (one frame's two crops: 32 heads): the 64-query tiled form has 10x more
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_attention_resident, hipFuncAttributeMaxDynamicSharedMemorySize, 592 * 256);
-            if (e != hipSuccess) { ovo_set_error("ovo_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
-            attr_done = true;
-        }
-        const long long items = heads * splits;
-        a.q_tiles = nq; a.chunk = (int)((items + 7) / 8);
-        k_attention_resident<<<(unsigned)(a.chunk * 8), threads, lds, s>>>(a, splits, krows);
-        OVO_CHECK_LAUNCH();
-        return OVO_OK;
-    }
-tiled:
     // tiny problems (one key tile, at most four query tiles): one wave per (batch, head) pair
     // (tools/attn_bench.py, 12 frames of hiera_b+: 16 x 16 windows 165 -> 79 us = 4.5 TB/s of q/k/v/o, pooled 4 x 16 blocks 321 -> 89 us;
     //  with 2-4 query tiles per pair -- 64 x 64, 49 x 49 -- the tiled kernel's four waves per pair are ahead: 180 vs 201 us, 33 vs 37)

@@ -1,6 +1,6 @@
 """Attention micro-benchmark over the ViT-L/14-336 and hiera_b+ shapes (12 frames per launch, as the bench's look-ahead groups):
-auto = what ovo_attention picks; notiny = OVO_ATTN_NO_TINY (the tiled kernel for the <= 64-token problems); narrow / wide = the tiled
-kernel with forced 64 / 128-query workgroups (and OVO_ATTN_NO_RESIDENT: not the K / V-resident kernel of the 65..592-key problems).  GB/s = the q / k / v / o bytes of the launch."""
+auto = what ovo_attention picks; a32 = k_attention32 forced (OVO_ATTN32=1); narrow / wide = the 16 x 16-tile kernel with 64 / 128-query
+workgroups (OVO_ATTN32=0); notiny = OVO_ATTN_NO_TINY on top (the tiled kernel for the <= 64-token problems).  GB/s = the q / k / v / o bytes of the launch."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,11 +27,11 @@ shapes = [(24, 16, 577, 577, 64), (2, 16, 577, 577, 64), (12, 8, 4096, 4096, 56)
 for shape in shapes:
     row = "%-28s" % str(shape)
     for mode in os.environ.get("MODES", "auto,a32,narrow,wide").split(","):
-        for k in ("OVO_ATTN_NARROW", "OVO_ATTN_WIDE", "OVO_ATTN_NO_TINY", "OVO_ATTN_NO_RESIDENT", "OVO_ATTN32"): os.environ.pop(k, None)
+        for k in ("OVO_ATTN_NARROW", "OVO_ATTN_WIDE", "OVO_ATTN_NO_TINY", "OVO_ATTN32"): os.environ.pop(k, None)
         if mode == "a32": os.environ["OVO_ATTN32"] = "1"
         if mode in ("narrow", "wide", "notiny"): os.environ["OVO_ATTN32"] = "0"
-        if mode == "narrow": os.environ["OVO_ATTN_NARROW"] = "1"; os.environ["OVO_ATTN_NO_RESIDENT"] = "1"
-        if mode == "wide": os.environ["OVO_ATTN_WIDE"] = "1"; os.environ["OVO_ATTN_NO_RESIDENT"] = "1"
+        if mode == "narrow": os.environ["OVO_ATTN_NARROW"] = "1"
+        if mode == "wide": os.environ["OVO_ATTN_WIDE"] = "1"
         if mode == "notiny": os.environ["OVO_ATTN_NO_TINY"] = "1"
         us, tf, gbs = run(*shape)
         row += "  %s %8.1fus %5.0fTF %5.0fGB/s" % (mode, us, tf, gbs)

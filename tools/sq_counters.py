@@ -7,7 +7,7 @@ for p in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
         rows[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("average per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles summed over waves (MI355X_MICROARCH.md)")
 for k, d in sorted(rows.items()):
-    name = k.replace("(anonymous namespace)::", "").split("(")[0]
+    name = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     if not name.startswith("k_"):
         continue
     print("%-18s launches %3d  " % (name, len(next(iter(d.values())))) + "  ".join("%s %d" % (c.replace("SQ_", ""), round(sum(v) / len(v))) for c, v in sorted(d.items())))
