@@ -46,6 +46,9 @@ int ovo_hip_abi_version(void); /* bumped when a signature changes */
 int ovo_marker(int id, ovo_stream_t stream);
 int ovo_profile_start(void);
 int ovo_profile_stop(double *ms, double *work, int64_t *launches, int n_kinds);
+/* per kind, the ALGORITHMIC bytes of the launches of the last profiled region (GEMM: A + W + C once, + residual / bias operands; attention:
+ * q, k, v, o once) -- the denominator PMC traffic (profiles/pmc_traffic.json) is compared with. */
+int ovo_profile_bytes(double *bytes, int n_kinds);
 
 /* ---------------------------------------------------------------------------------------------
  * Camera / frustum parameters for one frame.  Filled on the host (8-corner and 6-plane math is tiny

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libovo_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 E_UNSUPPORTED = -3          # OVO_E_UNSUPPORTED: the entry point does not cover this shape; the caller takes its general path
 
 
@@ -132,6 +132,7 @@ _SIGNATURES = {
     "ovo_marker": (_I32, [_I32, _P]),
     "ovo_profile_start": (_I32, []),
     "ovo_profile_stop": (_I32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _I32]),
+    "ovo_profile_bytes": (_I32, [C.POINTER(C.c_double), _I32]),
     "ovo_compact_workspace_bytes": (_SZ, [_I64]),
     "ovo_frustum_ids": (_I32, [_P, _I64, _CAM, _P, _P, _P, _SZ, _P]),
     "ovo_project_points": (_I32, [_P, _I64, _I32, _CAM, _P, _P]),

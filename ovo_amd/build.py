@@ -55,12 +55,17 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = True, gemm_debug: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, gemm_debug: bool = False, experimental: bool = False) -> str:
     """`gemm_debug` (tools/ only: python -m ovo_amd.build --force --gemm-debug): the GEMM kernels' early exits / time stamps / ablation knobs
-    (OVO_8P_DEBUG, OVO_8P_STAMPS, OVO_8P_DELAY, OVO_8Q_DEBUG) are compiled in; a production build has none of them."""
+    (OVO_8P_DEBUG, OVO_8P_STAMPS, OVO_8P_DELAY, OVO_8Q_DEBUG) are compiled in; a production build has none of them.
+    `experimental` (--experimental): also compiles the two forms that lost their measurements -- the persistent 256 x 128 GEMM (gemm8q.hip,
+    OVO_GEMM_TILE=256x128p) and the one-launch round chain (k_round_chain, OVO_ROUND_CHAIN=1); their parity tests skip without it."""
     if gemm_debug:
         for f in ("gemm8p.hip", "gemm8q.hip"):
             EXTRA[f] = EXTRA.get(f, []) + ["-DOVO_GEMM_DEBUG"]
+    if experimental:                                   # kernels that were measured and lost (persistent 256 x 128 GEMM, one-launch round chain)
+        for f in ("gemm8q.hip", "geometry.hip"):
+            EXTRA[f] = EXTRA.get(f, []) + ["-DOVO_EXPERIMENTAL"]
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = sources()
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
@@ -76,4 +81,4 @@ def build(force: bool = False, verbose: bool = True, gemm_debug: bool = False) -
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, gemm_debug="--gemm-debug" in sys.argv)
+    build(force="--force" in sys.argv, gemm_debug="--gemm-debug" in sys.argv, experimental="--experimental" in sys.argv)

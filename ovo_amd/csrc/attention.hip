@@ -689,7 +689,24 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attention32(AttnArgs a) {
 
 }  // namespace
 
+namespace {
+struct AttnKnobs {                                   // environment knobs of the dispatcher (see ovo_knobs_dynamic)
+    bool wide, narrow, no_chunk, no_tiny;
+    int force32;
+    void read() {
+        wide = getenv("OVO_ATTN_WIDE"); narrow = getenv("OVO_ATTN_NARROW"); no_chunk = getenv("OVO_ATTN_NO_CHUNK"); no_tiny = getenv("OVO_ATTN_NO_TINY");
+        force32 = getenv("OVO_ATTN32") ? atoi(getenv("OVO_ATTN32")) : -1;
+    }
+};
+const AttnKnobs &attn_knobs() {
+    static AttnKnobs k = [] { AttnKnobs x; x.read(); return x; }();
+    if (ovo_knobs_dynamic()) k.read();
+    return k;
+}
+}  // namespace
+
 extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
+    const AttnKnobs &kn = attn_knobs();
     OVO_REQUIRE(p && p->q && p->k && p->v && p->o, "null pointer");
     OVO_REQUIRE(p->B > 0 && p->H > 0 && p->Tq > 0 && p->Tk > 0, "bad shape");
     OVO_REQUIRE(p->hd > 0 && p->hd <= 128 && p->hd % 8 == 0, "head_dim must be a multiple of 8, <= 128");
@@ -711,25 +728,26 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     // 64- vs 128-query rule (rounds 2-3): DESIGN.md section 3.
     // (round 4: with the cheaper softmax the 64-query form also wins at head_dim 128 -- 8 x 16 x 2048^2 x 128: 512 us narrow vs 662 wide; the 128-query
     // form is left for OVO_ATTN_WIDE experiments; head_dim <= 64 goes to k_attention32 above unless OVO_ATTN32=0)
-    const bool wide = getenv("OVO_ATTN_WIDE") != nullptr && !getenv("OVO_ATTN_NARROW");
+    const bool wide = kn.wide && !kn.narrow;
     const int qpb = wide ? 128 : 64;
     dim3 grid((p->Tq + qpb - 1) / qpb, p->B * p->H);
     a.q_tiles = (int)grid.x; a.chunk = 0;
     // (also the form for more than 65535 batch x head rows -- windowed attention of several frames at once: the y dimension of a grid ends there)
-    if ((grid.x > 1 && !getenv("OVO_ATTN_NO_CHUNK")) || grid.y > 65535) {   // several q-tiles share a head's K / V: keep them on one XCD's L2
+    if ((grid.x > 1 && !kn.no_chunk) || grid.y > 65535) {   // several q-tiles share a head's K / V: keep them on one XCD's L2
         const long long total = (long long)grid.x * grid.y;
         a.chunk = (int)((total + 7) / 8);
         grid = dim3((unsigned)(a.chunk * 8), 1);
     }
     const bool prof = ovo_prof_enabled();
-    if (prof) { ovo_prof_begin(1, 4.0 * p->B * p->H * (double)p->Tq * p->Tk * p->hd, s); ovo_prof_shape(p->B * p->H, p->Tq, p->Tk); }
+    if (prof) { ovo_prof_begin(1, 4.0 * p->B * p->H * (double)p->Tq * p->Tk * p->hd, s); ovo_prof_shape(p->B * p->H, p->Tq, p->Tk);
+                ovo_prof_bytes(2.0 * p->B * p->H * p->hd * (2.0 * p->Tq + 2.0 * p->Tk)); }
     struct Done { bool on; hipStream_t s; ~Done() { if (on) ovo_prof_end(s); } } done{prof, s};
     // head_dim <= 64 and more than 16 queries: 32 x 32 MFMA tiles, K / V streamed (k_attention32); 128 queries per workgroup, 64 when a (batch, head)
     // pair has no more.  OVO_ATTN32 = 0 / 1 overrides the shape rule (tools/attn_bench.py: 12 frames' shapes, a32 vs the 16 x 16 kernels with the
     // same softmax: 577^2 x 64 60.6 vs 66.8 us, 4096^2 x 56 466 vs 622, 196^2 x 56 windows 63 vs 76, 49 x 196 64 vs 79, 49^2 29 vs 34, 64^2 tie;
     // <= 16 queries x <= 64 keys stay with the one-wave-per-pair kernel: 222 / 79 / 96 us against 287 / 261 / 486)
     {
-        const int force32 = getenv("OVO_ATTN32") ? atoi(getenv("OVO_ATTN32")) : -1;
+        const int force32 = kn.force32;
         const bool use32 = force32 >= 0 ? force32 != 0 : !(p->Tq <= 16 && p->Tk <= 64);
         // 16-byte output stores and 32-bit K / V byte offsets inside a (batch, head) slab
         const bool fits32 = ((uintptr_t)p->o & 15) == 0 && p->o_st % 8 == 0 && p->o_sh % 8 == 0 && p->o_sb % 8 == 0 &&
@@ -753,7 +771,7 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     // tiny problems (one key tile, at most four query tiles): one wave per (batch, head) pair
     // (tools/attn_bench.py, 12 frames of hiera_b+: 16 x 16 windows 165 -> 79 us = 4.5 TB/s of q/k/v/o, pooled 4 x 16 blocks 321 -> 89 us;
     //  with 2-4 query tiles per pair -- 64 x 64, 49 x 49 -- the tiled kernel's four waves per pair are ahead: 180 vs 201 us, 33 vs 37)
-    if (p->hd <= 64 && p->Tk <= 64 && p->Tq <= 16 && !getenv("OVO_ATTN_NO_TINY")) {
+    if (p->hd <= 64 && p->Tk <= 64 && p->Tq <= 16 && !kn.no_tiny) {
         const int krows = (p->Tk + 15) & ~15;
         const size_t lds = 4 * (size_t)(krows * (64 + 8) + (krows / 4) * (64 / 16 + 1) * 64) * 2;
         const long long nb = ((long long)p->B * p->H + 3) / 4;

@@ -1,5 +1,6 @@
 // Internal helpers shared by the HIP translation units of libovo_hip.so (gfx950 only).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -16,6 +17,7 @@ void ovo_set_error(const char *fmt, ...);
 bool ovo_prof_enabled();
 void ovo_prof_begin(int kind, double work, hipStream_t s);
 void ovo_prof_shape(int a, int b, int c);       // optional: shape of the launch just begun (OVO_PROF_DUMP lines)
+void ovo_prof_bytes(double bytes);            // optional: algorithmic HBM bytes of the launch just begun (operands read once, result written once)
 void ovo_prof_end(hipStream_t s);
 
 #define OVO_REQUIRE(cond, msg)                                   \
@@ -43,6 +45,14 @@ void ovo_prof_end(hipStream_t s);
             return OVO_E_LAUNCH;                                                  \
         }                                                                         \
     } while (0)
+
+// Tuning knobs (OVO_GEMM_*, OVO_ATTN_*: tools/ and tests only) are read from the environment ONCE per process -- a launch does not call
+// getenv.  Tools and tests that flip them between launches of one process (tools/gemm_bench.py, tools/attn_bench.py, tests/conftest.py) set
+// OVO_KNOBS_DYNAMIC=1 before the first launch: every launch then reads them afresh.
+static inline bool ovo_knobs_dynamic() {
+    static const bool d = getenv("OVO_KNOBS_DYNAMIC") != nullptr;
+    return d;
+}
 
 static inline int ovo_grid(int64_t work_items, int block, int cap = 256 * 8) {
     int64_t g = (work_items + block - 1) / block;

@@ -22,7 +22,7 @@ void ovo_set_error(const char *fmt, ...) {
 
 // ---- profiler: hipEvent pairs around the launches of a kernel family, on the launch stream --------------
 namespace {
-struct Rec { hipEvent_t a, b; int kind; double work; int shape[3]; };
+struct Rec { hipEvent_t a, b; int kind; double work, bytes; int shape[3]; };
 struct Prof {
     bool on = false;
     std::vector<Rec> recs;
@@ -38,7 +38,7 @@ struct Prof {
 bool ovo_prof_enabled() { return g_prof.on; }
 void ovo_prof_begin(int kind, double work, hipStream_t s) {
     if (!g_prof.on || g_prof.recs.size() >= (1u << 20)) return;
-    Rec r; r.kind = kind; r.work = work; r.shape[0] = r.shape[1] = r.shape[2] = 0; r.a = g_prof.get(); r.b = g_prof.get();
+    Rec r; r.kind = kind; r.work = work; r.bytes = 0; r.shape[0] = r.shape[1] = r.shape[2] = 0; r.a = g_prof.get(); r.b = g_prof.get();
     if (!r.a || !r.b) return;
     (void)hipEventRecord(r.a, s);
     g_prof.recs.push_back(r);
@@ -48,6 +48,11 @@ void ovo_prof_shape(int a, int b, int c) {
     Rec &r = g_prof.recs.back();
     r.shape[0] = a; r.shape[1] = b; r.shape[2] = c;
 }
+void ovo_prof_bytes(double bytes) {
+    if (!g_prof.on || g_prof.recs.empty()) return;
+    g_prof.recs.back().bytes = bytes;
+}
+static double g_last_bytes[OVO_PROF_KINDS];
 void ovo_prof_end(hipStream_t s) {
     if (!g_prof.on || g_prof.recs.empty()) return;
     (void)hipEventRecord(g_prof.recs.back().b, s);
@@ -78,7 +83,7 @@ int ovo_marker(int id, ovo_stream_t stream) {
     return OVO_OK;
 }
 const char *ovo_hip_last_error(void) { return g_err; }
-int ovo_hip_abi_version(void) { return 7; }
+int ovo_hip_abi_version(void) { return 8; }
 
 int ovo_profile_start(void) {
     g_prof.recs.clear();
@@ -91,17 +96,24 @@ int ovo_profile_stop(double *ms, double *work, int64_t *launches, int n_kinds) {
     g_prof.on = false;
     OVO_REQUIRE(ms && work && launches && n_kinds > 0 && n_kinds <= OVO_PROF_KINDS, "bad argument");
     for (int i = 0; i < n_kinds; ++i) { ms[i] = 0; work[i] = 0; launches[i] = 0; }
+    for (int i = 0; i < OVO_PROF_KINDS; ++i) g_last_bytes[i] = 0;
     OVO_HIP(hipDeviceSynchronize());
     FILE *dump = getenv("OVO_PROF_DUMP") ? fopen(getenv("OVO_PROF_DUMP"), "a") : nullptr;   // diagnosis: one line per launch
     for (const Rec &r : g_prof.recs) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess || r.kind >= n_kinds) continue;
-        ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1;
+        ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1; g_last_bytes[r.kind] += r.bytes;
         if (dump) fprintf(dump, "%d %d %d %d %.0f %.4f\n", r.kind, r.shape[0], r.shape[1], r.shape[2], r.work, t);
     }
     if (dump) fclose(dump);
     g_prof.recs.clear();
     g_prof.used = 0;
+    return OVO_OK;
+}
+
+int ovo_profile_bytes(double *bytes, int n_kinds) {
+    OVO_REQUIRE(bytes && n_kinds > 0 && n_kinds <= OVO_PROF_KINDS, "bad argument");
+    for (int i = 0; i < n_kinds; ++i) bytes[i] = g_last_bytes[i];
     return OVO_OK;
 }
 

@@ -213,6 +213,24 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
 
 template <int BM, int BN> struct Stages { static constexpr int value = (BM == 128 && BN == 128) || (BM == 64 && BN == 64) ? 4 : 3; };
 
+// environment knobs of the dispatcher (see ovo_knobs_dynamic)
+struct GemmKnobs {
+    bool no_chunk, w4, no_ns2, no_stream, no_8p, has_tile;
+    char tile[16];
+    void read() {
+        no_chunk = getenv("OVO_GEMM_NO_CHUNK"); w4 = getenv("OVO_GEMM_W4"); no_ns2 = getenv("OVO_GEMM_NO_NS2");
+        no_stream = getenv("OVO_GEMM_NO_STREAM"); no_8p = getenv("OVO_GEMM_NO_8P");
+        const char *t = getenv("OVO_GEMM_TILE");
+        has_tile = t != nullptr;
+        snprintf(tile, sizeof(tile), "%s", t ? t : "");
+    }
+};
+static const GemmKnobs &gemm_knobs() {
+    static GemmKnobs k = [] { GemmKnobs x; x.read(); return x; }();
+    if (ovo_knobs_dynamic()) k.read();
+    return k;
+}
+
 template <int BM, int BN, int BK, typename VT, int NW = 4, int NS = Stages<BM, BN>::value>
 int launch(const GemmArgs &g0, hipStream_t s) {
     GemmArgs g = g0;
@@ -230,11 +248,11 @@ int launch(const GemmArgs &g0, hipStream_t s) {
         attr_done = true;
     }
     const bool prof = ovo_prof_enabled();
-    if (prof) { ovo_prof_begin(4 + (BM == 128 ? 0 : 2) + (BN == 128 ? 0 : 1), 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); }   // kinds 4..7: 128x128, 128x64, 64x128, 64x64
+    if (prof) { ovo_prof_begin(4 + (BM == 128 ? 0 : 2) + (BN == 128 ? 0 : 1), 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }   // kinds 4..7: 128x128, 128x64, 64x128, 64x64
     // Chunked order pays when the A panels outweigh the weights (M > N: per-XCD fills A/8 + W instead of A + W/8) or when
     // the n-tile count is not a multiple of 8 (round-robin then spreads every panel over every L2).
     g.tiles = nbm * g.nbn;
-    g.chunk = (g.M > g.N || g.nbn % 8 != 0) && !getenv("OVO_GEMM_NO_CHUNK") ? (g.tiles + 7) / 8 : 0;
+    g.chunk = (g.M > g.N || g.nbn % 8 != 0) && !gemm_knobs().no_chunk ? (g.tiles + 7) / 8 : 0;
     const int grid = g.chunk > 0 ? g.chunk * 8 : g.tiles;
     k_gemm<BM, BN, BK, NS, VT, NW><<<grid, 64 * NW, lds, s>>>(g);
     if (prof) ovo_prof_end(s);
@@ -243,6 +261,7 @@ int launch(const GemmArgs &g0, hipStream_t s) {
 
 template <typename VT>
 int dispatch(const GemmArgs &g, hipStream_t s) {
+    const GemmKnobs &kn = gemm_knobs();
     const bool k64 = g.K % 64 == 0;
     auto blocks = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
     // Tile choice (tools/gemm_bench.py, MI355X): these GEMMs are a handful of workgroup "rounds" long, so round
@@ -257,7 +276,7 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
     // and the Hiera stage-3 GEMMs (800-900) are better off with the deeper ring (tools/gemm_bench.py).
     const long long b12864 = blocks(128, 64);
     const double r512 = (double)((b12864 + 511) / 512), r768 = 1.5 * (double)((b12864 + 767) / 768);
-    const bool ns2_ok = k64 && !getenv("OVO_GEMM_W4") && !getenv("OVO_GEMM_NO_NS2");
+    const bool ns2_ok = k64 && !kn.w4 && !kn.no_ns2;
     bool ns2 = false;
     int bm = 128, bn = 64;
     {
@@ -280,12 +299,12 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
     // the ring kernels above run ~650 TFLOP/s + 4 us at these sizes (tools/gemm_bench.py on MI355X, profiles/r02*_gemm_sweep.txt).
     // Tall short-K products are HBM streams: the weights-resident streaming kernel (gemm_stream.hip) runs them at 3+ TB/s, the tiled
     // kernels below at ~2 (tools/gemm_bench.py, profiles/r02c_gemm_stream.txt).
-    const char *force_tile = getenv("OVO_GEMM_TILE");
-    if (g.M >= 16384 && g.K <= 256 && ((!force_tile && !getenv("OVO_GEMM_NO_STREAM")) || (force_tile && !strcmp(force_tile, "stream")))) {
+    const char *force_tile = kn.has_tile ? kn.tile : nullptr;
+    if (g.M >= 16384 && g.K <= 256 && ((!force_tile && !kn.no_stream) || (force_tile && !strcmp(force_tile, "stream")))) {
         const int rc = gemm_stream_launch(g, std::is_same<VT, bf16x8>::value ? 2 : 1, s);
         if (rc != OVO_E_UNSUPPORTED) return rc;
     }
-    if (k64 && g.M >= 2048 && g.N >= 256 && !getenv("OVO_GEMM_TILE") && !getenv("OVO_GEMM_NO_8P")) {
+    if (k64 && g.M >= 2048 && g.N >= 256 && !force_tile && !kn.no_8p) {
         const double flop = 2.0 * g.M * (double)g.N * g.K, kt = g.K / 64;
         const double bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (double)g.M * g.N * (g.out_dtype == 0 ? 4.0 : 2.0) * (g.add ? 2.0 : 1.0);
         const double t_mem = bytes / 4.0e6;                                            // us at 4 TB/s
@@ -307,7 +326,7 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
             if (rc != OVO_E_UNSUPPORTED) return rc;
         }
     }
-    if (const char *force = getenv("OVO_GEMM_TILE")) {           // tuning knob (tools/gemm_bench.py): "128x128", "64x128", "256x256", ...
+    if (const char *force = force_tile) {                        // tuning knob (tools/gemm_bench.py): "128x128", "64x128", "256x256", ...
         int fm = 0, fn = 0;
         if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm == 64 || fm == 128) && (fn == 64 || fn == 128)) { bm = fm; bn = fn; }
         if (!strcmp(force, "256x128p")) {                          // the persistent form (gemm8q.hip)
@@ -320,7 +339,7 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
     // BK = 64: 8 waves per workgroup on every tile (two workgroups = 16 waves per CU): same LDS and L2 traffic as the 4-wave
     // form, twice the loads in flight and MFMA/LDS phases of different waves overlapping -- QKV 16.7 -> 14.9 us, FC1 25.1 ->
     // 21.7, (4096,1792,448) 18.6 -> 15.8 (tools/gemm_bench.py).  BK = 32 tiles are too small for 512 threads' 16-byte pieces.
-    if (k64 && !getenv("OVO_GEMM_W4")) {
+    if (k64 && !kn.w4) {
         if (bm == 128 && bn == 64 && ns2) return launch<128, 64, 64, VT, 8, 2>(g, s);
         if (bm == 128 && bn == 64) return launch<128, 64, 64, VT, 8, 3>(g, s);
         if (bm == 64 && bn == 128) return launch<64, 128, 64, VT, 8, 3>(g, s);

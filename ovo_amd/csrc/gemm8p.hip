@@ -352,8 +352,9 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     g.dbg = (getenv("OVO_8P_DEBUG") ? atoi(getenv("OVO_8P_DEBUG")) : 0) | ((getenv("OVO_8P_DELAY") ? atoi(getenv("OVO_8P_DELAY")) : 0) << 8);
     g.stamps = getenv("OVO_8P_STAMPS") ? (unsigned long long *)strtoull(getenv("OVO_8P_STAMPS"), nullptr, 0) : nullptr;
 #endif
-    static const bool no_chunk = getenv("OVO_GEMM_NO_CHUNK") != nullptr;        // tuning knobs: read once
-    static const int strip_env = getenv("OVO_GEMM_STRIP") ? atoi(getenv("OVO_GEMM_STRIP")) : -1;
+    static bool no_chunk = getenv("OVO_GEMM_NO_CHUNK") != nullptr;              // tuning knobs: read once (see ovo_knobs_dynamic)
+    static int strip_env = getenv("OVO_GEMM_STRIP") ? atoi(getenv("OVO_GEMM_STRIP")) : -1;
+    if (ovo_knobs_dynamic()) { no_chunk = getenv("OVO_GEMM_NO_CHUNK") != nullptr; strip_env = getenv("OVO_GEMM_STRIP") ? atoi(getenv("OVO_GEMM_STRIP")) : -1; }
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;
     constexpr size_t ring = 2 * (size_t)(BM + BN) * 128;                                  // two K-tile buffers
@@ -366,7 +367,7 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
         attr_done = true;
     }
     const bool prof = ovo_prof_enabled();
-    if (prof) { ovo_prof_begin(BN == 256 ? 3 : 0, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); }     // kinds 3 / 0: 256x256 / 256x128
+    if (prof) { ovo_prof_begin(BN == 256 ? 3 : 0, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }     // kinds 3 / 0: 256x256 / 256x128
     g.tiles = nbm * g.nbn;
     g.chunk = (g.M > g.N || g.nbn % 8 != 0) && !no_chunk ? (g.tiles + 7) / 8 : 0;
     // tile order: measured to matter little (the K-loop is bound by the L2->LDS arrival rate, not by L2 misses); column strips of 8 n-tiles

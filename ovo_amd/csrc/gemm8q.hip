@@ -24,6 +24,7 @@
 //   (bias, polynomial GELU, pack) sit in the draining wave's load segment, the partner wave's 8 MFMAs (128 cycles) cover a fraction of
 //   it, and every other wave waits at the next barrier.  Spread over all four phases of more K-tiles it might reach the "no arithmetic"
 //   times -- which only TIE the 256 x 256 tile (its K-loop does 21 % more flops per LDS byte), so the experiment stops here.
+#ifdef OVO_EXPERIMENTAL   // python -m ovo_amd.build --experimental: bit-identical to the one-tile kernel and measured slower
 #include <stdlib.h>
 
 #include <type_traits>
@@ -396,7 +397,7 @@ int launch8q(const GemmArgs &g0, hipStream_t s) {
         attr_done = true;
     }
     const bool prof = ovo_prof_enabled();
-    if (prof) { ovo_prof_begin(0, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); }     // kind 0: the 256 x 128 tile
+    if (prof) { ovo_prof_begin(0, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }     // kind 0: the 256 x 128 tile
     g.tiles = nbm * g.nbn;
     g.chunk = (g.tiles + 7) / 8;                          // XCD x walks tiles [x chunk, (x + 1) chunk)
     g.strip = 0;
@@ -425,3 +426,10 @@ int gemm8q_launch(const GemmArgs &g, int in_dtype, hipStream_t s) {
 }
 
 }  // namespace ovo_gemm_detail
+
+#else
+#include "gemm_common.h"
+namespace ovo_gemm_detail {
+int gemm8q_launch(const GemmArgs &, int, hipStream_t) { return OVO_E_UNSUPPORTED; }      // not in a production build
+}
+#endif  // OVO_EXPERIMENTAL

@@ -196,6 +196,13 @@ __device__ __forceinline__ void finish_best(const GemmArgs &g, int m, int fq, fl
     }
 }
 
+// algorithmic HBM bytes of a product: every operand read once, the result written once (what PMC traffic is compared with, bench.py roofline)
+inline double gemm_algorithmic_bytes(const GemmArgs &g) {
+    const double mn = (double)g.M * g.N, a_bytes = g.ln_mode ? (double)g.M * g.ln_d * 4.0 : (double)g.M * g.K * 2.0;
+    return a_bytes + (double)g.N * g.K * 2.0 + mn * (g.out_dtype == 0 ? 4.0 : 2.0) + (g.add ? (g.add_rows > 0 ? (double)g.add_rows * g.N * 4.0 : mn * 4.0) : 0.0) +
+           (g.bias ? g.N * 4.0 : 0.0);
+}
+
 // launch of the 256-row ping-pong kernels (gemm8p.hip); bn in {128, 256}; returns OVO_E_UNSUPPORTED when the shape does not fit
 int gemm8p_launch(const GemmArgs &g, int bn, int in_dtype, hipStream_t s);
 // the persistent 256 x 128 form (gemm8q.hip: one DMA ring across a workgroup's tiles, epilogue of tile j behind the K-loop of tile j + 1)

@@ -213,7 +213,7 @@ int launch_stream(const GemmArgs &g, hipStream_t s) {
     if (slots > need) slots = need;
     if (slots < 1) slots = 1;
     const bool prof = ovo_prof_enabled();
-    if (prof) { ovo_prof_begin(8, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); }
+    if (prof) { ovo_prof_begin(8, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }
     k_gemm_stream<KS, NT, VT, NTHREADS, F32A><<<slots * n_groups, NTHREADS, lds, s>>>(g, n_groups);
     if (prof) ovo_prof_end(s);
     return OVO_OK;
@@ -256,10 +256,17 @@ int gemm_stream_launch(const GemmArgs &g, int in_dtype, hipStream_t s) {
 // hiera.hip's entry: `p` as for ovo_gemm with A unused; A = LayerNorm (mode 1) / cast (mode 2) of x[source row, :d] (f32), source row of product
 // row m = its spatial token when `win` describes a window partition (padding rows = zeros), m itself without.  OVO_E_UNSUPPORTED: no
 // instantiation for the shape (the caller normalises / casts into a buffer and calls ovo_gemm).
+static bool stream_off() {                              // OVO_GEMM_NO_STREAM / OVO_GEMM_TILE / OVO_NO_LN_FOLD (see ovo_knobs_dynamic)
+    auto read = [] { return getenv("OVO_GEMM_NO_STREAM") || getenv("OVO_GEMM_TILE") || getenv("OVO_NO_LN_FOLD"); };
+    static bool off = read();
+    if (ovo_knobs_dynamic()) off = read();
+    return off;
+}
+
 int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *x, int d, const float *gamma, const float *beta, float eps, int mode,
                      int pool2x2, ovo_stream_t stream, uint16_t *qpool_out, int qpool_cols) {
     if (!p || !x || p->in_dtype != 2 || p->M < 16384 || p->K > 256 || d <= 0 || d % 8 != 0 || d > p->K || (mode != 1 && mode != 2) ||
-        (mode == 1 && (!gamma || !beta)) || ((uintptr_t)x & 15) != 0 || getenv("OVO_GEMM_NO_STREAM") || getenv("OVO_GEMM_TILE") || getenv("OVO_NO_LN_FOLD"))
+        (mode == 1 && (!gamma || !beta)) || ((uintptr_t)x & 15) != 0 || stream_off())
         return OVO_E_UNSUPPORTED;
     if (p->ldw % 8 != 0 || ((uintptr_t)p->W & 15) != 0 || (p->bias && ((uintptr_t)p->bias & 15) != 0) || p->add || p->N % 4 != 0 || p->K % 32 != 0)
         return OVO_E_UNSUPPORTED;

@@ -1004,6 +1004,7 @@ __global__ void __launch_bounds__(256) k_kf_finish(KfFinish a, Publish pb) {
     dev_publish(a.res, pb, pb.n_host >= 0 ? pb.n_host : *pb.n_dev);
 }
 
+#ifdef OVO_EXPERIMENTAL   // python -m ovo_amd.build --experimental: measured slower than the per-pass launches, kept for the record
 // =================================================================================================
 // k_round_chain: the map + tracking chains of a whole ROUND of keyframes in ONE launch.  A few dozen persistent workgroups walk
 // through every pass of every keyframe, separated by grid-wide barriers (an atomic arrival counter, spin on an agent-scope load).
@@ -1141,6 +1142,7 @@ __global__ void __launch_bounds__(256) k_round_chain(const ChainKf *__restrict__
         grid_sync(gb, gen);                                                                                       // 10: the next keyframe reads the state
     }
 }
+#endif  // OVO_EXPERIMENTAL
 
 }  // namespace
 
@@ -1374,6 +1376,14 @@ int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream) {
 
 
 // ---- a whole round of keyframes in one launch (k_round_chain) -------------------------------------------------------------------
+#ifndef OVO_EXPERIMENTAL
+// production builds carry no one-launch form: 0 bytes = "not built" (RoundLauncher then goes keyframe by keyframe: ovo_keyframe_step)
+size_t ovo_round_chain_params_bytes(void) { return 0; }
+int ovo_round_chain(ovo_round_chain_t *, const ovo_map_step_t *, const ovo_track_step_t *, int, ovo_stream_t) {
+    ovo_set_error("ovo_round_chain: not in this build (python -m ovo_amd.build --force --experimental)");
+    return OVO_E_UNSUPPORTED;
+}
+#else
 size_t ovo_round_chain_params_bytes(void) { return (size_t)8 * CHAIN_MAX_KF * sizeof(ChainKf); }       // a ring of 8 rounds
 
 int ovo_round_chain(ovo_round_chain_t *ctx, const ovo_map_step_t *maps, const ovo_track_step_t *tracks, int n, ovo_stream_t stream) {
@@ -1446,6 +1456,7 @@ int ovo_round_chain(ovo_round_chain_t *ctx, const ovo_map_step_t *maps, const ov
     ctx->next_slot += 1;
     return OVO_OK;
 }
+#endif  // OVO_EXPERIMENTAL
 
 
 int ovo_keyframe_step(const ovo_map_step_t *a, const ovo_track_step_t *t, ovo_stream_t stream) {

@@ -99,6 +99,8 @@ class OVO:
         # native keyframe chain (`ovo_track_step`): the next instance id also lives on the device; results arrive in pinned blocks
         self._track_pending: deque = deque()
         self._track_ring = None
+        self._track_ring_slots = 32                               # FramePipeline sizes it for its rounds (2 x world + margin) before the first keyframe
+        self.last_n_points = 0                                    # map size the last tracked keyframe saw
         self._next_ins_dev = None
         self._own_state = None
         # loop-closure thresholds (ovo.py:62-65); update_map itself is a "next" row
@@ -202,7 +204,7 @@ class OVO:
         lib = L.load()
         h, w = depth_in.shape
         if self._track_ring is None:
-            self._track_ring = L.PinnedRing(8 + 6 * self.MAX_RESULT_MASKS, np.int32, 32)
+            self._track_ring = L.PinnedRing(8 + 6 * self.MAX_RESULT_MASKS, np.int32, getattr(self, "_track_ring_slots", 32))
         a = L.TrackStep()
         if slam is not None:
             dev = slam._xyz.device
@@ -247,7 +249,12 @@ class OVO:
         a.ws_bytes = lib.ovo_track_workspace_bytes(n_masks, a.hist_cols)
         ws = getattr(self, "_track_ws", None)
         if ws is None or ws.numel() < a.ws_bytes or ws.device != point_seg.device:
-            ws = self._track_ws = torch.empty(max(int(a.ws_bytes), 1 << 20), dtype=torch.uint8, device=dev)
+            # grown geometrically (hist_cols rises with every queued keyframe); steps queued or built earlier keep THEIR tensor alive through
+            # pend["keep"] -- they hold its raw address, and a freed block could be handed to the next keyframe's masks or depth copy
+            grow = max(int(a.ws_bytes), 1 << 20, 2 * (ws.numel() if ws is not None else 0))
+            ws = self._track_ws = torch.empty(grow, dtype=torch.uint8, device=dev)
+            if stream is not None:
+                ws.record_stream(stream)                          # allocated on the current stream, used on the chain stream
         a.ws = ws.data_ptr()
         a.next_ins, a.next_ins_host = self._next_ins_dev.data_ptr(), (self.next_ins_id if not self._track_pending else -1)
         seq, slot = self._track_ring.next()
@@ -265,7 +272,7 @@ class OVO:
             done = torch.cuda.Event()
             done.record(stream)
         pend = {"seq": seq, "n_masks": n_masks, "point_seg": point_seg, "binary_maps": binary_maps, "ins": ins_view, "slam": slam,
-                "keep": (depth, seg_map), "done": done, "step": a if defer else None}
+                "keep": (depth, seg_map, ws), "done": done, "step": a if defer else None}
         self._track_pending.append(pend)
         return pend
 

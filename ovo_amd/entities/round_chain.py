@@ -35,6 +35,8 @@ class RoundLauncher:
             return
         handle = L.stream() if stream is None else L.C.c_void_p(stream.cuda_stream)
         rc = L.E_UNSUPPORTED
+        if self.enabled and lib.ovo_round_chain_params_bytes() == 0:    # a production build carries no one-launch form (--experimental does)
+            self.enabled = False
         if self.enabled:
             if self._ctx is None:
                 self._bar = torch.zeros(2, dtype=torch.int64, device=self.device)

@@ -180,6 +180,11 @@ class FramePipeline:
         self.mask_source = None
         self.mask_exchanges = 0
         self._chains: Dict[int, list] = {}                         # first frame index of a round -> its queued chains (software pipelining)
+        self._round_seq: Dict[int, int] = {}                       # first frame index of a round -> sequence number of its last map step
+        # result rings for two rounds in flight (this one being read, the next one pre-queued) plus margin: a full ring would make the
+        # launchers wait for result blocks of steps that are built but not launched yet
+        self.slam.ring_slots(max(64, 4 * self.world + 8))
+        self.ovo._track_ring_slots = max(32, 4 * self.world + 8)
         self.pipeline_rounds = not os.environ.get("OVO_NO_ROUND_PIPELINE")
         self.round_launcher = RoundLauncher(self.device)           # one persistent launch per round instead of ~12 launches per keyframe
         # The chains of consecutive keyframes depend on each other (device-resident map size / instance ids) and so do the keyframes' tails
@@ -192,6 +197,16 @@ class FramePipeline:
             # (rows beyond a keyframe's descriptors keep stale values: every rank knows the counts from the replicated plans and never reads them)
             self._gather(self.xchg)                                # first use of the collective (and of its kernels) outside any timed step
             torch.cuda.synchronize()
+
+    def drain(self) -> None:
+        """End of stream: a round that was pre-queued (software pipelining, `step_round(..., upcoming=...)`) but never stepped has already
+        advanced the map and the per-point instance ids on the device.  Read its result blocks and do the host bookkeeping -- the instances
+        and keyframe queue then match the map again; its keyframes get no descriptors (call `OVO.complete_semantic_info()` for those)."""
+        for first in sorted(self._chains):
+            for p in self._chains.pop(first):
+                self.ovo.detect_and_track_finish(p)
+            self._round_seq.pop(first, None)
+        self.slam.settle()
 
     def _gather(self, t: torch.Tensor) -> torch.Tensor:
         if self.emulate:                                           # stand-in with the collective's output shape and one device copy
@@ -327,7 +342,10 @@ class FramePipeline:
                 self.ovo.detect_and_track_finish(p)                # (assignment happened in place in the mapper's buffer)
                 plans.append(self.ovo._plan_semantic_info() if len(self.ovo.keyframes_queue) > 0 else None)
                 segs.append((self.ovo.last_point_seg, self.ovo.last_mask_rows))
-            n = self.ovo.last_n_points
+            # the map's size after this round: from the round's last map step (a keyframe without masks reports none through the tracker,
+            # and a pre-queued NEXT round may already have moved the mapper's own count past it)
+            seq = self._round_seq.pop(group[0].index, 0)
+            n = self.slam.size_after(seq) if seq else self.ovo.last_n_points
         else:
             for f in group:
                 fd = [f.index, f.rgb_lr, f.depth, f.c2w]
@@ -405,6 +423,9 @@ class FramePipeline:
         keyframe (`ovo_map_step` / `ovo_track_step`)."""
         G.prepare_frame_cameras([(f.depth, f.c2w) for f in group], self.slam._K_host)
         side = self.chain_stream
+        # capacity for the WHOLE round before its first deferred step exists: growing re-allocates the map's buffers, and the steps built
+        # below (and the previous round's, still on the chain stream) hold their addresses
+        self.slam.reserve_round([tuple(f.depth.shape) for f in group], sync=(side,))
         maps, tracks, pend = [], [], []
         # Everything the chains touch is produced ON their stream (the masks' working copy, the per-keyframe buffers): nothing of the chain
         # waits for the main stream, whose queue holds the previous rounds' tails (with a main -> chain dependency the two streams took turns:
@@ -422,8 +443,11 @@ class FramePipeline:
                 if m is not None or p is not None:
                     maps.append(m if m is not None else L.MapStep())
                     tracks.append(p["step"] if p is not None else L.TrackStep())
+            self._round_seq[group[0].index] = self.slam.last_seq   # the map's size after the round = result block of its last map step
             if maps:
                 self.round_launcher.launch(maps, tracks, None)     # (the current stream IS the chain stream here)
+            self.slam.launched()
+            if maps:
                 if side is not None:
                     done = torch.cuda.Event()
                     done.record(side)

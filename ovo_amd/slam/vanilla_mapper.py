@@ -47,6 +47,8 @@ class VanillaMapper:
         self._pending: deque = deque()                     # (sequence number, sub-sampled pixels) of map_launch calls not read back yet
         self._state = torch.zeros(4, dtype=torch.int64, device=self.device)       # {n, next point id, flags, ticket}
         self._ring = L.PinnedRing(4, np.int64, 64)
+        self._deferred = 0                                 # map steps built with defer=True and not handed to a launcher yet
+        self.last_seq = 0                                  # sequence number of the newest map step (its result block holds the map's size after it)
         self._explained = None
         self._ws = None
         self._keep: deque = deque(maxlen=64)
@@ -120,6 +122,42 @@ class VanillaMapper:
     def reserve(self, cap: int) -> None:
         self._reserve(cap)
 
+    def sub_pixels(self, h: int, w: int) -> int:
+        """Upper bound of the points one frame of h x w depth pixels appends (vanilla_mapper.py:67-68: every `downscale`-th pixel)."""
+        ds = self.downscale
+        return ((h + ds - 1) // ds) * ((w + ds - 1) // ds)
+
+    def reserve_round(self, shapes, sync=None) -> None:
+        """Capacity for a whole round of frames (`shapes` = their depth maps' (h, w)) BEFORE its first deferred step is built: growing the
+        map re-allocates the buffers, and steps built earlier in the round (map and tracking) hold the old addresses.  `sync`: streams whose
+        queued work still reads / writes the old buffers (the chain stream); they are drained first -- growth is rare (capacity doubles)."""
+        extra = sum(self.sub_pixels(h, w) for h, w in shapes)
+        if self._n_upper + extra <= self._cap:
+            return
+        if self._deferred:
+            raise L.OvoHipError("reserve_round: deferred steps outstanding")
+        for st in (sync or ()):
+            if st is not None:
+                st.synchronize()
+        self.settle()
+        torch.cuda.current_stream().synchronize()
+        self._reserve(self._n_known + extra)
+        torch.cuda.current_stream().synchronize()          # the copies into the new buffers, before any other stream touches them
+
+    def launched(self, n: int = None) -> None:
+        """The caller handed its deferred steps to a launcher."""
+        self._deferred = 0 if n is None else max(0, self._deferred - n)
+
+    def ring_slots(self, slots: int) -> None:
+        """At least `slots` result blocks (rounds of N keyframes, two rounds in flight: 2 N + margin); only while nothing is in flight."""
+        if slots > self._ring.slots:
+            self.settle()
+            self._ring = L.PinnedRing(4, np.int64, slots)
+
+    def size_after(self, seq: int) -> int:
+        """The map's size after the map step `seq` (its result block; the step must have run)."""
+        return int(self._ring.wait(seq)[2])
+
     @property
     def pcd(self) -> torch.Tensor:
         return self._xyz[:self._n]
@@ -184,12 +222,17 @@ class VanillaMapper:
         ds = self.downscale
         n_sub = ((h + ds - 1) // ds) * ((w + ds - 1) // ds)
         if self._n_upper + n_sub > self._cap:              # growing copies `_n` rows: needs the exact size
+            if self._deferred:                             # un-launched steps hold the old buffers' addresses and `settle` would wait for them forever
+                raise L.OvoHipError("map_launch(defer=True): the map must grow with deferred steps outstanding -- call reserve_round() "
+                                    "for the whole round before building its first step")
             self.settle()
             self._reserve(self._n_known + n_sub)
             if stream is not None:                         # the copies into the new buffers were queued on the current stream
                 stream.wait_stream(torch.cuda.current_stream())
         self.reap()
         if len(self._pending) >= self._ring.slots - 1:
+            if self._deferred:
+                raise L.OvoHipError("map_launch(defer=True): result ring full with deferred steps outstanding (size it with ring_slots())")
             self.settle()
         nb = lib.ovo_compact_workspace_bytes(n_sub) + 8
         if self._ws is None or self._ws.numel() < nb:
@@ -209,7 +252,9 @@ class VanillaMapper:
         a.result_host, a.seq = slot, seq
         self._keep.append((depth, rgb))                    # raw pointers cross the ABI (later, when deferred): keep converted copies alive
         self._pending.append((seq, n_sub))
+        self.last_seq = seq
         if defer:
+            self._deferred += 1
             return a
         L.check(lib.ovo_map_step(L.C.byref(a), L.stream() if stream is None else L.C.c_void_p(stream.cuda_stream)))
         return None

@@ -203,8 +203,10 @@ def frame_camera(near: float, far: float, h: int, w: int, pose: torch.Tensor, in
     global _last_cam
     last = _last_cam
     if last is not None and last[2] == (near, far, h, w) and isinstance(pose, torch.Tensor) and isinstance(intrinsics, torch.Tensor) \
-            and (last[0] is pose or (pose.shape == last[0].shape and pose.dtype == last[0].dtype and pose.device == last[0].device and torch.equal(last[0], pose))) \
-            and (last[1] is intrinsics or (intrinsics.device == last[1].device and intrinsics.dtype == last[1].dtype and torch.equal(last[1], intrinsics))):
+            and ((last[0] is pose and pose._version == last[4]) or
+                 (pose.shape == last[0].shape and pose.dtype == last[0].dtype and pose.device == last[0].device and torch.equal(last[0], pose))) \
+            and ((last[1] is intrinsics and intrinsics._version == last[5]) or
+                 (intrinsics.device == last[1].device and intrinsics.dtype == last[1].dtype and torch.equal(last[1], intrinsics))):
         image = last[3]                                            # the same frame asked again (mapper, then tracker): no key to build
     else:
         p, K = _cpu32(pose).contiguous(), _cpu32(intrinsics)
@@ -213,7 +215,8 @@ def frame_camera(near: float, far: float, h: int, w: int, pose: torch.Tensor, in
         if image is None:
             image = _build_cameras([(float(near), float(far), int(h), int(w), p, key)], K)[0]
             _remember_camera(key, image)
-        _last_cam = (pose, intrinsics, (near, far, h, w), image)
+        # (the same OBJECT counts as the same pose only at the same version: an in-place update bumps `_version`)
+        _last_cam = (pose, intrinsics, (near, far, h, w), image, getattr(pose, "_version", None), getattr(intrinsics, "_version", None))
     cam = L.Camera.from_buffer_copy(image)
     cam.th = float(th)
     return cam

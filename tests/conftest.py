@@ -9,6 +9,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# several tests flip the library's OVO_* tuning knobs (monkeypatch.setenv) between launches of this one process: the library reads them once
+# per process unless this is set before its first launch (ovo_amd/csrc/common.h: ovo_knobs_dynamic)
+os.environ.setdefault("OVO_KNOBS_DYNAMIC", "1")
 
 
 def pytest_configure(config):

@@ -112,6 +112,9 @@ def test_gemm_persistent_kernel_vs_pingpong_kernel(monkeypatch, m, n, k, act):
     next tile's K-loop through counted buffer stores) against the one-tile-per-workgroup ping-pong kernel and torch: same k-order per output
     element, same epilogue arithmetic -> BIT-identical bf16 outputs.  Shapes: 1 to 11 tiles per workgroup, ragged M / N edges, 5 to 28 K-tiles
     (one and two drain steps per K-tile), every activation."""
+    from ovo_amd import _lib as L
+    if L.load().ovo_round_chain_params_bytes() == 0:
+        pytest.skip("gemm8q.hip is not in a production build (python -m ovo_amd.build --force --experimental)")
     dtype = torch.bfloat16
     g = torch.Generator(device="cpu").manual_seed(m + 3 * n + 7 * k)
     a = torch.randn(m, k + 64, generator=g).to(DEV, dtype)[:, :k]             # lda > K

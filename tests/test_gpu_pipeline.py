@@ -139,3 +139,41 @@ def test_keyframe_without_descriptors_releases_its_lookahead_slot():
     assert not pipe.ovo._prefetched_batch                            # every prefetched image was consumed or discarded
     assert all(s["left"] == 0 for s in pipe.ovo._batch_slots)
     assert outs[-1]["n_instances"] > 0
+
+
+def _rounds(extra_capacity, n_rounds=4, world=2, drain_at=None):
+    from ovo_amd.pipeline import FramePipeline, synthetic_frames
+    pipe = FramePipeline(DEV, vit_card="tiny-pe", sam_card="hiera_test", n_map=60_000, n_text=7, scale=0.35, extra_capacity=extra_capacity,
+                         track_th=40, dense=False, emulate=(0, world))
+    frames = synthetic_frames(n_rounds * world, DEV, scale=0.35, n_masks_grid=(3, 4), n_blobs=4)
+    sizes = []
+    for r in range(n_rounds if drain_at is None else drain_at):
+        out = pipe.step_round(frames[r * world:(r + 1) * world], frames[(r + 1) * world:])
+        sizes.append(out["n_points"])
+    if drain_at is not None:
+        pipe.drain()
+    torch.cuda.synchronize()
+    return pipe, sizes
+
+
+def test_round_that_outgrows_the_map_reservation():
+    """A round whose keyframes do not fit the reserved capacity: the map grows ONCE, before the round's first deferred step is
+    built (`VanillaMapper.reserve_round`) -- not in the middle of a round whose earlier steps hold the old buffers' addresses -- and the
+    run equals the pre-reserved one.  `n_points` of a round comes from the round's last map step."""
+    big, sizes_big = _rounds(400_000)
+    small, sizes_small = _rounds(0)                                # 60 000 points reserved: the first round already outgrows it
+    assert small.slam._cap > 65_536 and sizes_small == sizes_big and sizes_big == sorted(sizes_big) and sizes_big[-1] > 60_000
+    assert sizes_big[-1] == big.slam._n == small.slam._n
+    for a, b in ((big.slam.pcd, small.slam.pcd), (big.slam.pcd_ids, small.slam.pcd_ids), (big.slam.pcd_obj_ids, small.slam.pcd_obj_ids)):
+        assert torch.equal(a, b)
+    assert list(big.ovo.objects) == list(small.ovo.objects) and big.ovo.next_ins_id == small.ovo.next_ins_id
+
+
+def test_drain_reads_back_a_prequeued_round():
+    """The next round is queued before this one is read (software pipelining); a stream that ends there calls `drain()`: the host's
+    instances then match what the device already did to the map."""
+    pipe, _ = _rounds(400_000, n_rounds=3, drain_at=2)             # two rounds stepped, the third pre-queued
+    full, _ = _rounds(400_000, n_rounds=3)
+    assert not pipe._chains and not pipe.ovo._track_pending
+    assert torch.equal(pipe.slam.pcd_obj_ids, full.slam.pcd_obj_ids) and pipe.slam._n == full.slam._n
+    assert list(pipe.ovo.objects) == list(full.ovo.objects) and pipe.ovo.next_ins_id == full.ovo.next_ins_id

@@ -1,6 +1,7 @@
 """Attention micro-benchmark over the ViT-L/14-336 and hiera_b+ shapes (12 frames per launch, as the bench's look-ahead groups):
 auto = what ovo_attention picks; a32 = k_attention32 forced (OVO_ATTN32=1); narrow / wide = the 16 x 16-tile kernel with 64 / 128-query
 workgroups (OVO_ATTN32=0); notiny = OVO_ATTN_NO_TINY on top (the tiled kernel for the <= 64-token problems).  GB/s = the q / k / v / o bytes of the launch."""
+import os; os.environ.setdefault("OVO_KNOBS_DYNAMIC", "1")    # this tool flips OVO_* knobs between launches
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,5 @@
 """One attention shape, a few launches -- for rocprofv3 --pmc runs: python tools/attn_one.py B H Tq Tk hd [iters]"""
+import os; os.environ.setdefault("OVO_KNOBS_DYNAMIC", "1")    # this tool flips OVO_* knobs between launches
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

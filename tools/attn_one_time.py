@@ -1,4 +1,5 @@
 """One attention shape, timed: python tools/attn_one_time.py B H Tq Tk hd [iters]  (env knobs of ovo_attention apply)"""
+import os; os.environ.setdefault("OVO_KNOBS_DYNAMIC", "1")    # this tool flips OVO_* knobs between launches
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

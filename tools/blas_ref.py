@@ -1,4 +1,5 @@
 """What does the vendor library (hipBLASLt through torch) reach on our GEMM shapes?  Headroom estimate only -- not a product path."""
+import os; os.environ.setdefault("OVO_KNOBS_DYNAMIC", "1")    # this tool flips OVO_* knobs between launches
 import torch
 dev = "cuda"
 shapes = [(1154, 3072, 1024), (1154, 1024, 1024), (1154, 4096, 1024), (1154, 1024, 4096), (4096, 1792, 448), (4096, 448, 1792), (4096, 1344, 448),

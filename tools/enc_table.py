@@ -1,5 +1,6 @@
 """Per-shape table of the GEMM / attention launches of ONE batched encoder forward (the library's hipEvent profiler, streams folded):
 python tools/enc_table.py {vit|sam} B"""
+import os; os.environ.setdefault("OVO_KNOBS_DYNAMIC", "1")    # this tool flips OVO_* knobs between launches
 import ctypes as C, os, sys, tempfile
 from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

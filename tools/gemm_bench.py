@@ -1,4 +1,5 @@
 """GEMM micro-benchmark over the shapes of the ViT-L/14-336 and hiera_b+ forwards (tile override via OVO_GEMM_TILE)."""
+import os; os.environ.setdefault("OVO_KNOBS_DYNAMIC", "1")    # this tool flips OVO_* knobs between launches
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,8 +1,10 @@
 """Golden vectors for the on-disk formats made by RUNNING the reference's own writers
 (ovo/utils/io_utils.py: rle_encode / rle_decode / write_instances / write_labels / read_labels):
 
-    python tools/gen_io_golden.py        ->  tests/golden/io_formats.npz   (inputs + the bytes the reference wrote)
+    python tools/gen_io_golden.py [--reference /root/reference] [--out DIR]   ->  DIR/io_formats.npz (default tests/golden/; inputs + the bytes
+                                                                                  the reference wrote)
 """
+import argparse
 import json
 import os
 import sys
@@ -15,7 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def main(reference="/root/reference"):
+def main(reference="/root/reference", out_dir=None):
     import gen_golden
     gen_golden.install_stubs()
     for name in ("plyfile", "yaml"):
@@ -87,10 +89,15 @@ def main(reference="/root/reference"):
         logs = {n: open(os.path.join(d, "run", "logger", n)).read() for n in sorted(os.listdir(os.path.join(d, "run", "logger"))) if n.endswith(".log")}
         arrays["log_names"], arrays["log_texts"] = np.asarray(list(logs)), np.asarray(list(logs.values()))
         arrays["log_dirs"] = np.asarray(sorted(n for n in os.listdir(os.path.join(d, "run", "logger")) if not n.endswith(".log")))
-    out = os.path.join(ROOT, "tests", "golden", "io_formats.npz")
+    out = os.path.join(out_dir or os.path.join(ROOT, "tests", "golden"), "io_formats.npz")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     np.savez_compressed(out, **arrays)
     print("wrote", out, os.path.getsize(out) // 1024, "KiB;", len(files), "files from write_instances")
 
 
 if __name__ == "__main__":
-    main()
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--out", default=None, help="directory for io_formats.npz (default: tests/golden/ of this checkout)")
+    a = ap.parse_args()
+    main(a.reference, a.out)
