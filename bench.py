@@ -61,6 +61,9 @@ def parse():
                     "random-init SAM2 weights keep no mask")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dense-merge", choices=("auto", "none", "reduce"), default="auto",
+                    help="N > 1: also time north_star's literal collective -- ONE bucketed RCCL sum-reduce of whole per-GPU dense accumulators "
+                         "f32[map_points, D] (parallel.allreduce_dense_) -- beside the sharded design the keyframe path uses (auto = reduce when N > 1)")
     ap.add_argument("--profile-steps", type=int, default=8)
     ap.add_argument("--projection-world", type=int, default=8, help="N = 1 only: after the timed legs, ONE GPU emulates rank 0 of a job of this many GPUs "
                     "(its own keyframe's encoders + every keyframe's replicated passes + 1/N of the dense rows, all-gather replaced by a local copy) "
@@ -302,6 +305,37 @@ def online_leg(args, dev, frames, sam):
             "note": "same workload, no encoder look-ahead: the encoders of keyframe t are launched when it arrives (overlap with the previous keyframe's tail only)"}
 
 
+def dense_merge_leg(args, dev, D):
+    """north_star's literal collective, timed beside the design the keyframe path uses: every GPU holds a whole dense accumulator
+    f32[map_points, D] + counts and ONE bucketed RCCL sum-reduce merges them (parallel.allreduce_dense_).  The keyframe path instead shards the
+    accumulators by point and exchanges the round's descriptors (`exchange`): no reduce, bit-identical to one process.
+    All ranks call this (collective); rank 0 reports."""
+    from ovo_amd import parallel
+    n = int(args.map_points)
+    acc = torch.zeros((n, D), dtype=torch.float32, device=dev)
+    cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    acc[::4097] = 1.0
+    world = parallel.world_size()
+    calls = parallel.allreduce_dense_(acc, cnt)                    # warm-up (communicator channels, first-use kernels)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    reps = 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        parallel.allreduce_dense_(acc, cnt)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = parallel.max_over_ranks(e0.elapsed_time(e1) / reps, dev)
+    nbytes = acc.numel() * 4 + cnt.numel() * 4
+    del acc, cnt
+    torch.cuda.empty_cache()
+    return {"mode": "reduce", "bytes_per_gpu": nbytes, "collectives": calls, "ms": round(ms, 3), "algbw_gbs": round(nbytes / ms / 1e6, 1),
+            "busbw_gbs": round(nbytes / ms / 1e6 * 2 * (world - 1) / world, 1),
+            "note": f"ONE bucketed sum-reduce of whole per-GPU accumulators f32[{n}, {D}] + i32 counts ({parallel.DENSE_BUCKET_BYTES >> 20} MB buckets), "
+                    "device-timed, max over ranks; NOT on the keyframe path (which shards by point: `exchange`), measured for comparison"}
+
+
 def projection_leg(args, dev, frames, sam):
     """What ONE rank of an N-GPU job does per round, measured on this GPU (FramePipeline(emulate=(0, N))): the encoders and pooling of the one
     keyframe it owns, the replicated map / tracking chain of all N keyframes, store + re-fuse of all N keyframes' descriptors, the dense
@@ -462,6 +496,10 @@ def main():
     online = online_leg(args, dev, frames, sam) if (world == 1 and args.encoder_batch > 1 and not args.no_online) else None
     shared = shared_crops_leg(args, dev, frames, sam) if (world == 1 and not args.no_shared_crops) else None
 
+    dense_merge = None
+    if world > 1 and args.dense_merge in ("auto", "reduce"):
+        dense_merge = dense_merge_leg(args, dev, pipe.D)
+
     cpu, parity = None, None
     if want_cpu:
         idx = [args.warmup + i for i in range(4)]
@@ -509,9 +547,13 @@ def main():
             "online": online, "shared_crops": shared, "roofline": roof, "cpu_baseline": cpu, "parity": parity, "projection": projection,
         }
         if world > 1:
+            dev_ms = pipe.exchange_device_ms(last=args.steps)
             line["exchange"] = {"collectives_per_round": 1, "bytes_per_rank": int(pipe.xchg.numel() * 4), "host_ms_per_round": round(xchg_ms, 3),
+                                "device_ms_per_round": None if dev_ms is None else round(dev_ms, 4),
                                 "backend": torch.distributed.get_backend(),
-                                "note": "all-gather of the round's descriptors, issued inside the timed step"}
+                                "note": "all-gather of the round's descriptors, issued inside the timed step; device_ms = hipEvents around the collective "
+                                        "on its stream (includes what it waits for on that stream after the first event: nothing is queued between)"}
+            line["dense_merge"] = dense_merge
         print(json.dumps(line))
     parallel.barrier()
 

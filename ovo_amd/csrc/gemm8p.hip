@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
             }
         });
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (g.tail_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(3);
 #endif
 }
@@ -354,7 +354,10 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
 #endif
     static bool no_chunk = getenv("OVO_GEMM_NO_CHUNK") != nullptr;              // tuning knobs: read once (see ovo_knobs_dynamic)
     static int strip_env = getenv("OVO_GEMM_STRIP") ? atoi(getenv("OVO_GEMM_STRIP")) : -1;
-    if (ovo_knobs_dynamic()) { no_chunk = getenv("OVO_GEMM_NO_CHUNK") != nullptr; strip_env = getenv("OVO_GEMM_STRIP") ? atoi(getenv("OVO_GEMM_STRIP")) : -1; }
+    static int tail_wait = getenv("OVO_8P_TAILWAIT") ? atoi(getenv("OVO_8P_TAILWAIT")) : 0;
+    if (ovo_knobs_dynamic()) { no_chunk = getenv("OVO_GEMM_NO_CHUNK") != nullptr; strip_env = getenv("OVO_GEMM_STRIP") ? atoi(getenv("OVO_GEMM_STRIP")) : -1;
+                               tail_wait = getenv("OVO_8P_TAILWAIT") ? atoi(getenv("OVO_8P_TAILWAIT")) : 0; }
+    g.tail_wait = tail_wait;
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;
     constexpr size_t ring = 2 * (size_t)(BM + BN) * 128;                                  // two K-tile buffers

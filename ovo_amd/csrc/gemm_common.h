@@ -39,6 +39,7 @@ struct GemmArgs {
     uint16_t *qpool_out;       // with ln_mode, a window map and bf16 output: columns [0, qpool_cols) are NOT stored to C but 2 x 2 max-pooled over the
     int qpool_cols;            // window's tokens into qpool_out[pooled window-major row, qpool_cols] (Hiera's pooled queries, k_qpool)
     int pool_ww;               // with ln_mode and f32 output: > 0 = 2 x 2 max-pool of the window's tokens in the epilogue (window width), C rows = pooled spatial tokens
+    int tail_wait;             // gemm8p: 1 = a wave waits for its epilogue stores before it ends (OVO_8P_TAILWAIT, measurement)
     int dbg;                   // tools/ only (OVO_8P_DEBUG): 1 = leave before anything, 2 = leave after the prologue, 4 = no epilogue
     unsigned long long *stamps;   // tools/ only (OVO_8P_STAMPS = address of u64[tiles][4]): s_memrealtime at start / K-loop / epilogue / end
 };

@@ -85,6 +85,14 @@ class HipSam2AutomaticMaskGenerator:
         self.last_embeddings = emb
         f0, f1 = emb["high_res_feats"]
         logits, iou = self.decoder.forward(emb["image_embed"][0], f1[0], f0[0], multimask=True)       # [P, 3, h, w], [P, 3]
+        return self.stats_launch(logits, iou, H, W)
+
+    @torch.no_grad()
+    def stats_launch(self, logits: torch.Tensor, iou: torch.Tensor, H: int, W: int) -> Dict[str, Any]:
+        """The generator's post-processing from given mask logits f32 [P, m, h, w] and predicted IoUs f32 [P, m] (device tensors): the
+        candidate statistics + their copy to pinned memory; `generate_finish` filters.  (`generate_launch` ends here; tools/check_upstream.py
+        and the tests feed it logits that upstream's own post-processing has seen.)"""
+        lib = L.load()
         self.last_logits, self.last_iou = logits, iou                # kept for inspection / parity tests
         P, nm, h, w = logits.shape
         n = P * nm
@@ -122,7 +130,7 @@ class HipSam2AutomaticMaskGenerator:
                 L.check(lib.ovo_amg_binarize(L.ptr(logits), L.ptr(d_sel), len(sel), lh, lw, H, W, float(self.mask_threshold), L.ptr(masks),
                                              L.stream()))
         return {"masks": masks, "predicted_iou": iou_h[sel], "stability_score": stab[sel], "boxes_xyxy": boxes[keep],
-                "area": st[sel, 2].copy(), "point_index": sel // nm}
+                "area": st[sel, 2].copy(), "point_index": sel // nm, "index": sel}
 
     def generate_device(self, image) -> Dict[str, Any]:
         """image u8 [H, W, 3] (numpy or device tensor) -> dict(masks u8 [n, H, W] on the GPU, predicted_iou f32 [n],

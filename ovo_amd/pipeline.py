@@ -158,6 +158,7 @@ class FramePipeline:
         self.dense = dense
         self.exchange_ms = 0.0                                     # host wall time spent in the rounds' collectives (bench.py reports it)
         self.exchanges = 0
+        self.exchange_events: list = []                            # (start, end) hipEvents around every round's all-gather
         if dense:
             cap = self.slam._cap
             blocks = -(-cap // self.SHARD_BLOCK)
@@ -197,6 +198,12 @@ class FramePipeline:
             # (rows beyond a keyframe's descriptors keep stale values: every rank knows the counts from the replicated plans and never reads them)
             self._gather(self.xchg)                                # first use of the collective (and of its kernels) outside any timed step
             torch.cuda.synchronize()
+
+    def exchange_device_ms(self, last: Optional[int] = None) -> Optional[float]:
+        """Mean device time of the rounds' all-gathers (the newest `last` of them), from the hipEvents around each; None before the first.
+        Call after a synchronize."""
+        ev = self.exchange_events[-last:] if last else self.exchange_events
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
 
     def drain(self) -> None:
         """End of stream: a round that was pre-queued (software pipelining, `step_round(..., upcoming=...)`) but never stepped has already
@@ -368,7 +375,13 @@ class FramePipeline:
             t0 = time.perf_counter()
             if desc_mine is not None:
                 self.xchg[:desc_mine.shape[0]].copy_(desc_mine)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if len(self.exchange_events) < 4096 else None
+            if ev:
+                ev[0].record()
             gathered = self._gather(self.xchg)                     # [world, MAX_DESC, D]: every owner's descriptors, rank-major = keyframe order
+            if ev:                                                 # device time of the collective itself (hipEvents on the stream it runs on)
+                ev[1].record()
+                self.exchange_events.append(ev)
             descs = [gathered[k, :len(p["matched_ins_ids"])] if p is not None else None for k, p in enumerate(plans)]
             self.exchange_ms += 1e3 * (time.perf_counter() - t0)
             self.exchanges += 1

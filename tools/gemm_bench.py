@@ -43,12 +43,14 @@ for s in shapes:
     res = {t: [] for t in tiles}
     for _ in range(ROUNDS):
         for t in tiles:
-            os.environ.pop("OVO_GEMM_NO_8P", None); os.environ.pop("OVO_GEMM_NO_STREAM", None)
+            os.environ.pop("OVO_GEMM_NO_8P", None); os.environ.pop("OVO_GEMM_NO_STREAM", None); os.environ.pop("OVO_8P_TAILWAIT", None)
+            if t.endswith("+w"): os.environ["OVO_8P_TAILWAIT"] = "1"; t0 = t; t = t[:-2]
+            else: t0 = t
             if t == "auto": os.environ.pop("OVO_GEMM_TILE", None)
             elif t == "tiled": os.environ.pop("OVO_GEMM_TILE", None); os.environ["OVO_GEMM_NO_STREAM"] = "1"   # the tiled kernels' own choice (8p or ring)
             elif t == "ring": os.environ.pop("OVO_GEMM_TILE", None); os.environ["OVO_GEMM_NO_8P"] = "1"; os.environ["OVO_GEMM_NO_STREAM"] = "1"     # the 128-row ring kernels' own choice
             else: os.environ["OVO_GEMM_TILE"] = t
-            res[t].append(run(*s)[0])
+            res[t0].append(run(*s)[0])
     row = "%-22s" % str(s)
     for t in tiles:
         us = sorted(res[t])[len(res[t]) // 2]
