@@ -59,6 +59,15 @@ def parse():
     ap.add_argument("--sam-full", action="store_true", help="not the headline workload: also run SAM2's mask decoder on a 16x16 click grid and the "
                     "automatic-mask-generator filters every frame (SURVEY.md f1); tracking still consumes the synthetic masks, because "
                     "random-init SAM2 weights keep no mask")
+    ap.add_argument("--sam-own-masks", action="store_true",
+                    help="with --sam-full (implied): the masks SAM2's generator keeps drive the tracking of their keyframe (the reference's default path, "
+                         "mask_generator.py:102-120) instead of the frame's precomputed masks.  The weights are random-init (no checkpoint offline), whose "
+                         "predicted IoU / stability scores are noise: the generator's two score thresholds and the mask-NMS score threshold are set to 0 "
+                         "(--sam-thresholds) so that a realistic number of masks (~30 per frame) survives the box / mask NMS")
+    ap.add_argument("--sam-thresholds", default="0.0,0.0,0.0", help="pred_iou, stability, mask-NMS score thresholds used by --sam-own-masks")
+    ap.add_argument("--sam-min-own", type=int, default=8,
+                    help="--sam-own-masks: a keyframe whose generator keeps fewer masks than this is tracked with the frame's precomputed masks -- after "
+                         "the whole generator chain ran and was waited for (random-init weights keep ~3 degenerate masks: see the help above)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dense-merge", choices=("auto", "none", "reduce"), default="auto",
@@ -409,8 +418,13 @@ def main():
     # the sustained continuation re-uses the resident frames (new keyframe ids, same pixels): budget its map growth up front
     sustain_rounds = int(args.sustain_seconds * 450 / world) if args.sustain_seconds > 0 else 0
     sam = None if args.sam == "none" else args.sam
+    own = {}
+    if args.sam_own_masks:
+        args.sam_full = True
+        th = [float(x) for x in args.sam_thresholds.split(",")]
+        own = {"own_masks": True, "amg_thresholds": (th[0], th[1]), "nms_score_thr": th[2], "min_own_masks": args.sam_min_own}
     pipe = FramePipeline(dev, vit_card=args.vit, sam_card=sam, n_map=args.map_points, n_text=args.texts, dense=not args.no_dense, sam_full=args.sam_full,
-                         extra_capacity=(base_rounds * world + 2) * 72_000 + sustain_rounds * world * 16_000, seed=0, encoder_batch=args.encoder_batch)
+                         extra_capacity=(base_rounds * world + 2) * 72_000 + sustain_rounds * world * 16_000, seed=0, encoder_batch=args.encoder_batch, **own)
     # every rank holds the whole stream: the order-dependent passes run replicated (pipeline.py); rank k owns frame k of a round
     frames = synthetic_frames(base_rounds * world, dev, seed=int(os.environ.get("OVO_BENCH_SEED", "0")))
     H, W = frames[0].rgb.shape[:2]
@@ -533,6 +547,11 @@ def main():
                                    f"instance and dense-map query; every frame a keyframe; masks from the precomputed-mask seam (32/frame)",
                        "frames_per_step_per_gpu": 1, "map_points": args.map_points, "texts": args.texts, "masks_per_frame": int(frames[0].masks.shape[0]),
                        "sam2": "image encoder + mask decoder (256 clicks) + automatic-mask-generator filters" if args.sam_full else "image encoder",
+                       "masks": (f"SAM2's own: generator (thresholds {args.sam_thresholds}) -> mask NMS -> seg map -> tracking; "
+                                 f"{sum(pipe.own_mask_counts) / max(len(pipe.own_mask_counts), 1):.1f} masks per keyframe over {len(pipe.own_mask_counts)} keyframes; "
+                                 f"{pipe.own_fallbacks} keyframes kept fewer than {pipe.min_own_masks} and were tracked -- after waiting for that chain -- with the frame's "
+                                 f"precomputed masks (random-init weights produce empty / whole-image masks)")
+                                if pipe.own_masks else "precomputed-mask seam (mask_generator.py:94-95)",
                        "encoder_batch": pipe.encoder_batch,
                        "dense_query": "resident class map, rows touched by the keyframe re-evaluated" if (pipe.dense and pipe.incremental_query) else "all rows",
                        "parallelism": (f"rounds of {world} keyframes: rank k owns keyframe k (SAM2 + ViT + pooling), tracking / back-projection replicated in "

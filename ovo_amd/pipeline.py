@@ -104,7 +104,8 @@ class FramePipeline:
     def __init__(self, device="cuda", vit_card: str = "PE-Core-L14-336", sam_card: Optional[str] = "hiera_b+",
                  n_map: int = 1_000_000, n_text: int = 10, dense: bool = True, scale: float = 1.0, extra_capacity: int = 4_000_000,
                  seed: int = 0, depth_filter: bool = True, track_th: int = 100, sam_full: bool = False, points_per_side: int = 16,
-                 encoder_batch: int = 1, k_top_views: int = 10000, emulate: Optional[tuple] = None, share_crops: bool = False):
+                 encoder_batch: int = 1, k_top_views: int = 10000, emulate: Optional[tuple] = None, share_crops: bool = False,
+                 own_masks: bool = False, amg_thresholds: Optional[tuple] = None, nms_score_thr: float = 0.7, min_own_masks: int = 0):
         """`emulate = (rank, world)`: ONE process does exactly what rank `rank` of a `world`-GPU job does per round -- its own keyframe's
         encoders and pooling, every keyframe's replicated passes, 1 / world of the dense rows -- with the round's all-gather replaced by a
         local stand-in (the other owners' descriptors are copies of its own rows).  A timing tool (bench.py `projection`): it measures a
@@ -139,7 +140,19 @@ class FramePipeline:
         if sam_card and sam_full:                                  # SAM2 end to end (f1): decoder + automatic mask generator after the encoder
             from .encoders.sam_decoder import SPECS as DEC_SPECS, HipSamDecoder
             from .entities.sam_amg import HipSam2AutomaticMaskGenerator
-            self.amg = HipSam2AutomaticMaskGenerator(self.sam, HipSamDecoder(DEC_SPECS["sam2"], None, self.device, seed), points_per_side=points_per_side)
+            kw = {} if amg_thresholds is None else {"pred_iou_thresh": float(amg_thresholds[0]), "stability_score_thresh": float(amg_thresholds[1])}
+            self.amg = HipSam2AutomaticMaskGenerator(self.sam, HipSamDecoder(DEC_SPECS["sam2"], None, self.device, seed), points_per_side=points_per_side, **kw)
+        # `own_masks` (with sam_full): the masks SAM2's generator produced for a keyframe drive ITS tracking -- the reference's default path
+        # (mask_generator.py:102-120: generate -> masks_update -> mask2segmap -> ovo.py:182-324), also on one GPU; off: they are produced and
+        # measured but tracking consumes the masks the frame carries (the precomputed-mask seam, mask_generator.py:94-95)
+        self.own_masks = bool(own_masks) and self.amg is not None
+        self.nms_score_thr = float(nms_score_thr)
+        # fewer surviving masks than this: the keyframe is tracked with the masks the frame carries (AFTER the generator, its mask NMS and its seg
+        # map ran: the dependency and the cost are the real chain's).  Random-init SAM2 weights produce empty or whole-image masks of which the mask
+        # NMS keeps ~3 (tools/bin/amg_probe.py), so a throughput run sets this to keep a realistic mask count in the tracker (bench.py --sam-own-masks)
+        self.min_own_masks = int(min_own_masks)
+        self.own_fallbacks = 0
+        self.own_mask_counts: List[int] = []
         # encoder look-ahead: the two encoders of `encoder_batch` consecutive keyframes (of this rank) run as ONE batched forward each
         # (step() is handed the upcoming frames).  Nothing of the encoders depends on the map, and the reference itself computes a
         # keyframe's descriptors kf_queue_delay = 10 keyframes late (ovo.yaml:53), so this changes no result -- only the GEMM height.
@@ -325,7 +338,7 @@ class FramePipeline:
         hit = self._sam_by_frame.pop(mine.index, None)
         if hit is not None:
             self.sam_frame = tuple(t[hit[1]:hit[1] + 1] for t in hit[0])
-        if self.mask_source is not None or (self.amg is not None and self.world > 1):
+        if self.mask_source is not None or (self.amg is not None and (self.world > 1 or self.own_masks)):
             self._exchange_masks(group, amg_pending)
             amg_pending = None
         # ---- the order-dependent passes, for every keyframe of the round, on every rank (replicated map and tracker).  The whole
@@ -479,9 +492,15 @@ class FramePipeline:
         self.sam_out = r
         masks = r["masks"]
         if masks.shape[0] == 0:
+            self.own_mask_counts.append(0)
             return None, None
-        keep = segment_utils.masks_update_device(masks, r["predicted_iou"], r["stability_score"], iou_thr=0.8, score_thr=0.7, inner_thr=0.5)
-        return segment_utils.mask2segmap_device(masks.index_select(0, keep.to(masks.device)), r["stability_score"][keep.numpy()])
+        keep = segment_utils.masks_update_device(masks, r["predicted_iou"], r["stability_score"], iou_thr=0.8, score_thr=self.nms_score_thr, inner_thr=0.5)
+        self.own_mask_counts.append(int(keep.numel()))
+        seg, ordered = segment_utils.mask2segmap_device(masks.index_select(0, keep.to(masks.device)), r["stability_score"][keep.numpy()])
+        if keep.numel() < self.min_own_masks:
+            self.own_fallbacks += 1
+            return None, None
+        return seg, ordered
 
     def _exchange_masks(self, group: List[Frame], amg_pending) -> None:
         """Every keyframe of the round is tracked on every rank with the masks its OWNER's generator produced (mask_generator.py:102-120 runs
