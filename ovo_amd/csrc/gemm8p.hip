@@ -317,6 +317,40 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
             const int n = n0 + wc * WTN + j * 16 + fq * 4;
             bias_r[j] = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        // scores that only feed the argmax (the large-vocabulary query, BASELINE configs[4]: nothing stored, no residual, plain row order): a
+        // row's maximum first (v_max3: half an instruction per score), then the first column that holds it (compare + select, last to first) --
+        // 2.5 VALU instructions per score instead of the ~5 of the running (score, column) pair below; 10 M x 768 x 1000 texts 25.7 -> see DESIGN.md
+        const bool argmax_only = g.best && !g.store && !g.add && g.win_per <= 0 && !g.rope_cos;
+        if (argmax_only) {
+            const bool plain = g.alpha == 1.0f && !g.bias && !g.act;
+            const bool edge = n0 + wc * WTN + WTN > g.n_valid;         // this wave's columns reach past the vocabulary (wave-uniform)
+            static_for<0, 2 * TMH>([&](auto I_) {
+                constexpr int i = decltype(I_)::value;
+                const int m = m0 + wr * WTM + i * 16 + fr;
+                float v[2 * TNH][4];
+#pragma unroll
+                for (int j = 0; j < 2 * TNH; ++j) {
+                    const int n = n0 + wc * WTN + j * 16 + fq * 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r];
+                    if (!plain) math4(g, 0, 0, n, v[j], bias_r[j], make_float4(0.f, 0.f, 0.f, 0.f));
+                    if (edge) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[j][r] = n + r < g.n_valid ? v[j][r] : -3.0e38f;
+                    }
+                }
+                float mx = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[0][2], v[0][3]));
+#pragma unroll
+                for (int j = 1; j < 2 * TNH; ++j) mx = fmaxf(fmaxf(fmaxf(mx, v[j][0]), v[j][1]), fmaxf(v[j][2], v[j][3]));
+                int arg = 0x7fffffff;
+#pragma unroll
+                for (int j = 2 * TNH - 1; j >= 0; --j)
+#pragma unroll
+                    for (int r = 3; r >= 0; --r) arg = v[j][r] == mx ? n0 + wc * WTN + j * 16 + fq * 4 + r : arg;
+                if (!(mx > -3.0e38f)) arg = 0x7fffffff;                 // nothing valid here (as the running form: a score must exceed -3e38 to win)
+                if (m < g.M) finish_best(g, m, fq, mx, arg);
+            });
+        } else
         static_for<0, 2 * TMH>([&](auto I_) {
             constexpr int i = decltype(I_)::value;
             const int m = m0 + wr * WTM + i * 16 + fr;
@@ -393,9 +427,34 @@ int launch8p(const GemmArgs &g, hipStream_t s) {
 
 namespace ovo_gemm_detail {
 
+static int gemm8p_one(const GemmArgs &g, int bn, int in_dtype, hipStream_t s);
+
 int gemm8p_launch(const GemmArgs &g, int bn, int in_dtype, hipStream_t s) {
     if (g.K % 64 != 0 || g.K < 64) return OVO_E_UNSUPPORTED;
-    if ((long long)g.M * g.lda * 2 >= (1ll << 32) || (long long)g.N * g.ldw * 2 >= (1ll << 32)) return OVO_E_UNSUPPORTED;   // 32-bit DMA offsets
+    if ((long long)g.N * g.ldw * 2 >= (1ll << 32)) return OVO_E_UNSUPPORTED;                                              // 32-bit DMA offsets
+    if ((long long)g.M * g.lda * 2 >= (1ll << 32)) {
+        // an activation matrix past 4 GB (the 10 M-point query of BASELINE configs[4]: 15 GB of f16 features): row chunks of < 4 GB, one launch each.
+        // Rows are independent; only the plain row mapping is chunked (no window map, no periodic residual, no operand-load LayerNorm)
+        if (g.win_per > 0 || g.add_rows > 0 || g.ln_mode || g.rope_cos) return OVO_E_UNSUPPORTED;
+        const long long rows = (((1ll << 32) - 1) / (g.lda * 2)) & ~255ll;
+        if (rows < 256) return OVO_E_UNSUPPORTED;
+        const size_t csz = g.out_dtype == 0 ? 4 : 2;
+        for (long long m0 = 0; m0 < g.M; m0 += rows) {
+            GemmArgs c = g;
+            c.M = (int)((g.M - m0) < rows ? (g.M - m0) : rows);
+            c.A = g.A + m0 * g.lda * 2;
+            if (g.C) c.C = (char *)g.C + m0 * g.ldc * csz;
+            if (g.add) c.add = g.add + m0 * g.ld_add;
+            if (g.best) c.best = g.best + m0;
+            const int rc = gemm8p_one(c, bn, in_dtype, s);
+            if (rc != OVO_OK) return rc;
+        }
+        return OVO_OK;
+    }
+    return gemm8p_one(g, bn, in_dtype, s);
+}
+
+static int gemm8p_one(const GemmArgs &g, int bn, int in_dtype, hipStream_t s) {
     if (bn == 256) return in_dtype == 2 ? launch8p<256, 256, 2, bf16x8>(g, s) : launch8p<256, 256, 2, f16x8>(g, s);
     if (bn == 128) return in_dtype == 2 ? launch8p<256, 128, 4, bf16x8>(g, s) : launch8p<256, 128, 4, f16x8>(g, s);
     return OVO_E_UNSUPPORTED;
