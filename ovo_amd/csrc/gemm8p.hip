@@ -79,6 +79,11 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int fr = lane & 15, fq = lane >> 4;
+    // GELU table (gemm_common.h) behind the K-tile ring AND the epilogue slabs: filled now, first read after the K-loop's last barrier
+    constexpr int LUT_OFF = (STAGED && 8 * (BM / WARPS_M / 2) * ((BN / (8 / WARPS_M)) * 4 + 16) > 2 * (BM + BN) * 128) ? 8 * (BM / WARPS_M / 2) * ((BN / (8 / WARPS_M)) * 4 + 16)
+                                                                                                                        : 2 * (BM + BN) * 128;
+    const float2 *lut = (STAGED && g.act == 1 && g.gelu_lut) ? (const float2 *)(smem + LUT_OFF) : nullptr;
+    if (lut) gelu_lut_fill((float2 *)(smem + LUT_OFF), tid, 512);
 #ifdef OVO_GEMM_DEBUG        // tools/ builds only (python -m ovo_amd.build --gemm-debug): early exits, per-phase time stamps, de-phased starts
     if (g.dbg & 1) return;
     auto stamp = [&](int k) { if (g.stamps && tid == 0) g.stamps[(long long)tile * 4 + k] = __builtin_amdgcn_s_memrealtime(); };
@@ -265,7 +270,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     if (md < 0) continue;
                     const float4 addv = g.add ? *(const float4 *)(g.add + add_row(g, m, md) * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                     float v[4] = {a[0], a[1], a[2], a[3]};
-                    math4(g, tk, nh, n, v, bias, addv);
+                    math4(g, tk, nh, n, v, bias, addv, lut);
                     { const f32x4 vv = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(vv, (f32x4 *)((float *)g.C + md * g.ldc + n)); }
                 }
             } else {                                      // 2-byte rows: 8 lanes x 16 bytes per row, 8 rows per instruction
@@ -291,8 +296,8 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                         if (in1) add1 = *(const float4 *)(ap + 4);
                     }
                     float v0[4] = {a0[0], a0[1], a0[2], a0[3]}, v1[4] = {a1[0], a1[1], a1[2], a1[3]};
-                    math4(g, tk, nh0, n, v0, bias0, add0);
-                    math4(g, tk, nh1, n + 4, v1, bias1, add1);
+                    math4(g, tk, nh0, n, v0, bias0, add0, lut);
+                    math4(g, tk, nh1, n + 4, v1, bias1, add1, lut);
                     uint4 p;
                     if (g.out_dtype == 2) { p.x = pack_bf16(v0[0], v0[1]); p.y = pack_bf16(v0[2], v0[3]); p.z = pack_bf16(v1[0], v1[1]); p.w = pack_bf16(v1[2], v1[3]); }
                     else { p.x = pack_f16(v0[0], v0[1]); p.y = pack_f16(v0[2], v0[3]); p.z = pack_f16(v1[0], v1[1]); p.w = pack_f16(v1[2], v1[3]); }
@@ -392,11 +397,14 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     if (ovo_knobs_dynamic()) { no_chunk = getenv("OVO_GEMM_NO_CHUNK") != nullptr; strip_env = getenv("OVO_GEMM_STRIP") ? atoi(getenv("OVO_GEMM_STRIP")) : -1;
                                tail_wait = getenv("OVO_8P_TAILWAIT") ? atoi(getenv("OVO_8P_TAILWAIT")) : 0; }
     g.tail_wait = tail_wait;
+    static int gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
+    if (ovo_knobs_dynamic()) gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
+    g.gelu_lut = !gelu_poly;
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;
     constexpr size_t ring = 2 * (size_t)(BM + BN) * 128;                                  // two K-tile buffers
     constexpr size_t slabs = 8 * (size_t)(BM / WARPS_M / 2) * ((BN / (8 / WARPS_M)) * 4 + 16);     // epilogue: 8 x HM rows x (4 WTN + 16) bytes
-    constexpr size_t lds = STAGED && slabs > ring ? slabs : ring;
+    constexpr size_t lds = (STAGED && slabs > ring ? slabs : ring) + (STAGED ? GELU_LUT_BYTES : 0);
     static bool attr_done = false;              // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)k_gemm8p<BM, BN, WARPS_M, VT, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

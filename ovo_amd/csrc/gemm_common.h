@@ -39,6 +39,7 @@ struct GemmArgs {
     uint16_t *qpool_out;       // with ln_mode, a window map and bf16 output: columns [0, qpool_cols) are NOT stored to C but 2 x 2 max-pooled over the
     int qpool_cols;            // window's tokens into qpool_out[pooled window-major row, qpool_cols] (Hiera's pooled queries, k_qpool)
     int pool_ww;               // with ln_mode and f32 output: > 0 = 2 x 2 max-pool of the window's tokens in the epilogue (window width), C rows = pooled spatial tokens
+    int gelu_lut;              // gemm8p / gemm_stream: 1 = GELU (act 1) through the LDS table (default), 0 = the packed polynomial (OVO_GELU_POLY)
     int tail_wait;             // gemm8p: 1 = a wave waits for its epilogue stores before it ends (OVO_8P_TAILWAIT, measurement)
     int dbg;                   // tools/ only (OVO_8P_DEBUG): 1 = leave before anything, 2 = leave after the prologue, 4 = no epilogue
     unsigned long long *stamps;   // tools/ only (OVO_8P_STAMPS = address of u64[tiles][4]): s_memrealtime at start / K-loop / epilogue / end
@@ -100,8 +101,33 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
     return __builtin_elementwise_fma(hx, p * zc, hx);
 }
 
-__device__ __forceinline__ void act4(float *v, int act) {
-    if (act == 1) {
+// GELU through a table in LDS (round 4).  The polynomial above is 19 packed instructions per PAIR of values -- and a packed f32 instruction
+// issues at ~6.3 cycles with two waves per SIMD (tools/ubench.hip), i.e. ~60 cycles per value: the GELU of an FC1 epilogue cost 30-44 us of a
+// 130-165 us launch (ViT / Hiera stage 3) and ~40 % of the streaming FC1s of Hiera stages 1-2.  Here Phi(x) = (1 + erf(x / sqrt 2)) / 2 is
+// tabulated on [-6, 6) in steps of 1/64 as (value, difference to the next entry): 768 x 8 bytes, filled by the workgroup itself in its prologue
+// (two erff per thread); a value costs clamp, fma, cvt, fract, shift-add, ds_read_b64, fma, mul = 7 plain VALU instructions + one LDS read.
+// Linear interpolation error <= h^2 / 8 max|Phi''| = 7e-6; |GELU error| <= 9.1e-6 absolute over all x (the polynomial: 8.6e-6).
+constexpr int GELU_LUT_N = 768;
+constexpr int GELU_LUT_BYTES = GELU_LUT_N * 8;
+__device__ __forceinline__ void gelu_lut_fill(float2 *t, int tid, int nthreads) {
+    for (int i = tid; i < GELU_LUT_N; i += nthreads) {
+        const float x0 = (float)(i - GELU_LUT_N / 2) * (1.0f / 64.0f), x1 = (float)(i + 1 - GELU_LUT_N / 2) * (1.0f / 64.0f);
+        const float p0 = 0.5f * (1.0f + erff(x0 * 0.70710678118654752f)), p1 = 0.5f * (1.0f + erff(x1 * 0.70710678118654752f));
+        t[i] = make_float2(p0, p1 - p0);
+    }
+}
+__device__ __forceinline__ float gelu_lut(float x, const float2 *t) {
+    const float u = fmaf(__builtin_amdgcn_fmed3f(x, -6.0f, 5.984375f), 64.0f, 384.0f);      // [0, 767]
+    const int i = (int)u;
+    const float2 e = t[i];
+    return x * fmaf(__builtin_amdgcn_fractf(u), e.y, e.x);
+}
+
+__device__ __forceinline__ void act4(float *v, int act, const float2 *lut = nullptr) {
+    if (act == 1 && lut) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_lut(v[r], lut);
+    } else if (act == 1) {
         const f32x2 a = gelu2(f32x2{v[0], v[1]}), b = gelu2(f32x2{v[2], v[3]});
         v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
     } else if (act == 2) {                                       // QuickGELU x * sigmoid(1.702 x)   (open_clip "-qg" cards)
@@ -141,11 +167,11 @@ __device__ __forceinline__ long long add_row(const GemmArgs &g, int m, long long
 
 // `tok` = m % rope_T and `nh` = n % rope_hd (only read with rope_cos set): callers that walk rows keep them incrementally -- an integer
 // division by a run-time value is ~35 VALU instructions, once per 4 outputs it was a third of the QKV epilogue.
-__device__ __forceinline__ void math4(const GemmArgs &g, int tok, int nh, int n, float (&v)[4], float4 bias, float4 addv) {
+__device__ __forceinline__ void math4(const GemmArgs &g, int tok, int nh, int n, float (&v)[4], float4 bias, float4 addv, const float2 *lut = nullptr) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
     v[0] += bias.x; v[1] += bias.y; v[2] += bias.z; v[3] += bias.w;
-    if (g.act) act4(v, g.act);
+    if (g.act) act4(v, g.act, lut);
     if (g.rope_cos && n < g.rope_cols && tok >= g.rope_t0) {
         // rotary embedding of the (2i, 2i+1) pairs this lane holds: row = token m % T, column within the head n % hd
         const long long at = (long long)tok * g.rope_hd + nh;

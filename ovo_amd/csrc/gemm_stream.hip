@@ -26,6 +26,8 @@ __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_grou
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *cs = (float *)(smem + S::W_BYTES);
     float *lg = cs + NG, *lb = lg + K;                               // F32A: LayerNorm weight / bias of the K (padded) input channels
+    const float2 *lut = (g.act == 1 && g.gelu_lut) ? (const float2 *)(cs + NG + (F32A ? 2 * K : 0)) : nullptr;      // GELU table (gemm_common.h)
+    if (lut) gelu_lut_fill((float2 *)lut, threadIdx.x, NTHREADS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int group = blockIdx.x % n_groups, slot = blockIdx.x / n_groups, slots = gridDim.x / n_groups;
     const int n0 = group * NG;
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_grou
             const f32x4 bv = *(const f32x4 *)(cl + j * 16);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[j][r] * g.alpha + bv[r];
-            if (g.act) act4(v, g.act);
+            if (g.act) act4(v, g.act, lut);
             if (ap) {
                 const f32x4 r = *(const f32x4 *)(ap + j * 16);
                 v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_grou
 template <int KS, int NT, typename VT, bool F32A = false>
 int launch_stream(const GemmArgs &g, hipStream_t s) {
     constexpr int K = KS * 32, NG = NT * 16;
-    constexpr size_t lds = (size_t)NG * K * 2 + NG * sizeof(float) + (F32A ? 2 * K * sizeof(float) : 0);
+    constexpr size_t lds = (size_t)NG * K * 2 + NG * sizeof(float) + (F32A ? 2 * K * sizeof(float) : 0) + GELU_LUT_BYTES;
     // > half the LDS: one workgroup per CU -- 16 waves (128 VGPRs each), or 12 when the accumulators of a wide group need more; else two or more of 8 waves
     // (the f32 A path holds a row's 8 KS floats next to the fragments: one step fewer waves, or the accumulators spill)
     constexpr int NTHREADS = lds > 80 * 1024 ? (F32A ? ((NT > 16 || KS >= 8) ? 512 : 768) : (NT > 16 ? 768 : 1024)) : 512;
@@ -214,7 +216,11 @@ int launch_stream(const GemmArgs &g, hipStream_t s) {
     if (slots < 1) slots = 1;
     const bool prof = ovo_prof_enabled();
     if (prof) { ovo_prof_begin(8, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }
-    k_gemm_stream<KS, NT, VT, NTHREADS, F32A><<<slots * n_groups, NTHREADS, lds, s>>>(g, n_groups);
+    GemmArgs gg = g;
+    static int gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
+    if (ovo_knobs_dynamic()) gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
+    gg.gelu_lut = !gelu_poly;
+    k_gemm_stream<KS, NT, VT, NTHREADS, F32A><<<slots * n_groups, NTHREADS, lds, s>>>(gg, n_groups);
     if (prof) ovo_prof_end(s);
     return OVO_OK;
 }

@@ -87,6 +87,7 @@ def test_gemm_pingpong_kernel_vs_ring_kernel_and_torch(monkeypatch, tile, m, n, 
     w = (torch.randn(n, k, generator=g) * k ** -0.5).to(DEV, dtype)
     bias, add = torch.randn(n, generator=g).to(DEV), torch.randn(m, n, generator=g).to(DEV)
     monkeypatch.delenv("OVO_GEMM_TILE", raising=False)
+    monkeypatch.setenv("OVO_GELU_POLY", "1")                                 # bit-identity holds for the same GELU form: the ring kernel has the polynomial only
     ring = _gemm(a, w, bias, add=add, act=1)
     ring_b = _gemm(a, w, bias, out_dtype=torch.bfloat16)
     monkeypatch.setenv("OVO_GEMM_TILE", tile)
@@ -95,6 +96,10 @@ def test_gemm_pingpong_kernel_vs_ring_kernel_and_torch(monkeypatch, tile, m, n, 
     ref = torch.nn.functional.gelu(a.float() @ w.float().T + bias) + add
     torch.testing.assert_close(out, ref, atol=3e-4, rtol=3e-4)
     assert torch.equal(out, ring) and torch.equal(out_b, ring_b)
+    monkeypatch.delenv("OVO_GELU_POLY")                                      # the default: GELU through the LDS table (gemm_common.h: gelu_lut)
+    lut = _gemm(a, w, bias, add=add, act=1)
+    torch.testing.assert_close(lut, ref, atol=3e-4, rtol=3e-4)
+    assert (lut - out).abs().max() < 4e-5                                    # two approximations of erf-GELU, each within 1e-5 of it
     x = add.clone()                                                          # in-place residual: C aliases add
     from ovo_amd import _lib as L
     gg = L.Gemm()
@@ -151,6 +156,7 @@ def test_gemm_stream_kernel_vs_tiled_kernel_and_torch(monkeypatch, m, n, k):
     a = torch.randn(m, k + 64, generator=g).to(DEV, dtype)[:, :k]
     w = (torch.randn(n, k, generator=g) * k ** -0.5).to(DEV, dtype)
     bias, add = torch.randn(n, generator=g).to(DEV), torch.randn(m, n, generator=g).to(DEV)
+    monkeypatch.setenv("OVO_GELU_POLY", "1")                       # (bit-identity across kernels needs the same GELU form; the table form is checked below)
     monkeypatch.setenv("OVO_GEMM_NO_STREAM", "1")
     tiled = _gemm(a, w, bias, add=add, act=1)
     tiled_b = _gemm(a, w, bias, out_dtype=torch.bfloat16)
@@ -163,6 +169,10 @@ def test_gemm_stream_kernel_vs_tiled_kernel_and_torch(monkeypatch, m, n, k):
     torch.testing.assert_close(out, ref, atol=3e-4, rtol=3e-4)
     torch.testing.assert_close(out_nb.float(), 0.5 * (a.float() @ w.float().T), atol=0.03, rtol=0.01)
     assert torch.equal(out, tiled) and torch.equal(out_b, tiled_b)
+    monkeypatch.delenv("OVO_GELU_POLY")
+    lut = _gemm(a, w, bias, add=add, act=1)                        # default: GELU through the LDS table
+    torch.testing.assert_close(lut, ref, atol=3e-4, rtol=3e-4)
+    assert (lut - out).abs().max() < 4e-5
     x = add.clone()                                                # in-place residual: C aliases add
     from ovo_amd import _lib as L
     gg = L.Gemm()
