@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(256) k_attention_tiny(AttnArgs a, int krows) {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <bool FIRST, bool ONES>
-__device__ __forceinline__ void rescale32(f32x16 (&s)[2], float lm, f32x16 &negm, f32x16 &lsum, f32x16 (&o)[2]) {
+__device__ __forceinline__ void rescale32(f32x16 (&s)[2], float lm, f32x16 &negm, f32x4 &lsum, f32x16 (&o)[2]) {
     const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lm), __float_as_uint(lm), false, false);
     const float rm = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
     const float d = FIRST ? rm : fmaxf(rm, 0.f);
@@ -503,7 +503,7 @@ __device__ __forceinline__ float lane_max32(const f32x16 &x, const f32x16 &y) { 
 // (bf16-rounded) probabilities comes out of the P V product as O^T row 56 -- no add per score, no separate accumulator to rescale.
 // (measured and dropped: a 128-register build of the head_dim <= 56 form for 4 waves per SIMD -- 17 spilled registers inside the loop: 489 -> 577 us)
 template <int NW, bool ONES>       // NW: waves per workgroup
-__global__ void __launch_bounds__(NW * 64, 2) k_attention32(AttnArgs a) {
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) k_attention32(AttnArgs a) {
     constexpr int NT = NW * 64;
     constexpr int KT = 64, TILE = 2 * KT * 128;                  // K tile 8 KB + V tile 8 KB
     constexpr int NLD = KT * 8 / NT;                             // 16-byte pieces of K (and of V) per thread and tile
@@ -528,9 +528,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attention32(AttnArgs a) {
         qf[ks] = *(bf16x8 *)&raw;
         if (a.scale_log2e != 1.0f) qf[ks] = prescale_q(qf[ks], a.scale_log2e);
     }
-    f32x16 o[2], negm, lsum;
+    f32x16 o[2], negm;
+    f32x4 lsum = f32x4{0.f, 0.f, 0.f, 0.f};                      // the lane's part of the row sum, folded to four partial sums per tile (unused with ONES)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; negm[i] = 0.f; lsum[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; negm[i] = 0.f; }
 
     // staging through buffer loads: piece id = it * NT + tid -> key row id >> 3, 16-byte chunk id & 7; the lane's byte offset inside a tile in
     // voffset, the tile's in soffset; a piece that must read zeros (chunk past head_dim, row past the last key) gets an offset past the
@@ -586,13 +587,16 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attention32(AttnArgs a) {
 
     // one 64-key tile; FIRST: the tile opens the row (reference maximum := its maximum); mask (scalar): the tile may hold keys past Tk or
     // (causal) past the query.  ONE instantiation inside the loop: the accumulators keep their registers across iterations.
-    auto compute = [&](const char *buf, int k0, bool mask, auto FIRST_) {
+    // NKB = 1: only the tile's first 32-key block holds keys (the LAST tile of 577 = 9 x 64 + 1 or 196 = 3 x 64 + 4 keys: half the tile's
+    // products and exponentials; instantiated outside the loop only)
+    auto compute = [&](const char *buf, int k0, bool mask, auto FIRST_, auto NKB_) {
         constexpr bool FIRST = decltype(FIRST_)::value;
+        constexpr int NKB = decltype(NKB_)::value;
         f32x16 s[2];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {                         // two independent accumulation chains, alternating
+            for (int kb = 0; kb < NKB; ++kb) {                       // two independent accumulation chains, alternating
                 const bf16x8 kf = *(const bf16x8 *)(buf + kb * (32 * 128) + ka[ks]);
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? negm : s[kb], 0, 0, 0);
             }
@@ -601,20 +605,25 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attention32(AttnArgs a) {
         if (mask) {
             const int lim = (a.causal ? min(a.Tk - 1, q_row) : a.Tk - 1) - k0 - 4 * hi;      // last visible key of this lane's query, tile-relative
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     s[kb][r] = (kb * 32 + (r & 3) + 8 * (r >> 2) > lim) ? -3.0e38f : s[kb][r];
         }
+        if (NKB == 1) s[1] = s[0];                                   // (maximum and rescale below walk both blocks)
         const float lm = lane_max32(s[0], s[1]);
         if (FIRST) rescale32<true, ONES>(s, lm, negm, lsum, o);
         else if (__any(lm > ATTN_THR)) rescale32<false, ONES>(s, lm, negm, lsum, o);
         bf16x8 pf[2][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]);
-            if (!ONES) lsum = lsum + s[kb];
+            if (!ONES) {                                             // 16 -> 8 -> 4 partial sums: as many adds as a 16-register accumulator, 12 registers fewer
+                typedef __attribute__((ext_vector_type(8))) float f32x8;
+                const f32x8 u = __builtin_shufflevector(s[kb], s[kb], 0, 1, 2, 3, 4, 5, 6, 7) + __builtin_shufflevector(s[kb], s[kb], 8, 9, 10, 11, 12, 13, 14, 15);
+                lsum = lsum + (__builtin_shufflevector(u, u, 0, 1, 2, 3) + __builtin_shufflevector(u, u, 4, 5, 6, 7));
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 uint32_t tmp[4];
@@ -624,7 +633,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attention32(AttnArgs a) {
             }
         }
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -649,14 +658,26 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attention32(AttnArgs a) {
         commit(smem + TILE);
         if (n_tiles > 2) fetch(2, 2 >= n_full);
     }
-    if (wave_active) compute(smem, 0, n_full == 0 || a.causal, std::true_type{});
-    for (int t = 1; t < n_tiles; ++t) {
+    using One = std::integral_constant<int, 1>;
+    using Two = std::integral_constant<int, 2>;
+    const int last = n_tiles - 1;
+    const bool half_last = a.Tk - last * KT <= 32;               // the last tile's second key block is empty
+    if (wave_active) {
+        if (last == 0 && half_last) compute(smem, 0, true, std::true_type{}, One{});
+        else compute(smem, 0, n_full == 0 || a.causal, std::true_type{}, Two{});
+    }
+    for (int t = 1; t < last; ++t) {                               // full tiles: ONE instantiation inside the loop
         __syncthreads();                                           // tile t is in buffer t & 1; every wave is done with tile t - 1 (buffer (t + 1) & 1)
-        if (t + 1 < n_tiles) {
-            commit(smem + ((t + 1) & 1) * TILE);
-            if (t + 2 < n_tiles) fetch(t + 2, t + 2 >= n_full);
+        commit(smem + ((t + 1) & 1) * TILE);
+        if (t + 2 < n_tiles) fetch(t + 2, t + 2 >= n_full);
+        if (wave_active) compute(smem + (t & 1) * TILE, t * KT, a.causal != 0, std::false_type{}, Two{});
+    }
+    if (last >= 1) {
+        __syncthreads();
+        if (wave_active) {
+            if (half_last) compute(smem + (last & 1) * TILE, last * KT, true, std::false_type{}, One{});
+            else compute(smem + (last & 1) * TILE, last * KT, last >= n_full || a.causal, std::false_type{}, Two{});
         }
-        if (wave_active) compute(smem + (t & 1) * TILE, t * KT, t >= n_full || a.causal, std::false_type{});
     }
     // ---- store: lane (q, hi) holds O^T rows d = 32 db + 8 g + 4 hi + (0..3) in o[db][4 g ..]; the two halves of a 16-byte row segment are
     // traded between lanes q and q + 32 (v_permlane32_swap) so that every lane stores 16 contiguous bytes: lanes < 32 at d = 32 db + 16 p,
@@ -664,8 +685,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attention32(AttnArgs a) {
     float l = 0.f;
     if (ONES) l = hi == 0 ? o[1][12] : 0.f;                       // O^T row 56 = 32 + (12 & 3) + 8 (12 >> 2) + 4 hi at hi = 0
     else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) l += lsum[i];
+        l = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
     }
     {
         const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
