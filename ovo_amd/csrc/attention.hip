@@ -478,8 +478,8 @@ __global__ void __launch_bounds__(256) k_attention_tiny(AttnArgs a, int krows) {
 // (ds_read_b64_tr_b16) of [4 keys][16 d] blocks.  Softmax: the fast / slow path scheme above (reference maximum as the C operand).
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <bool FIRST, bool ONES>
-__device__ __forceinline__ void rescale32(f32x16 (&s)[2], float lm, f32x16 &negm, f32x4 &lsum, f32x16 (&o)[2]) {
+template <bool FIRST, bool ONES, int DB>
+__device__ __forceinline__ void rescale32(f32x16 (&s)[2], float lm, f32x16 &negm, f32x4 &lsum, f32x16 (&o)[DB]) {
     const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lm), __float_as_uint(lm), false, false);
     const float rm = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
     const float d = FIRST ? rm : fmaxf(rm, 0.f);
@@ -488,7 +488,8 @@ __device__ __forceinline__ void rescale32(f32x16 (&s)[2], float lm, f32x16 &negm
     if (!FIRST) {
         const float alpha = __builtin_amdgcn_exp2f(-d);
         if (!ONES) lsum = lsum * alpha;
-        o[0] = o[0] * alpha; o[1] = o[1] * alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[db] = o[db] * alpha;
     }
 }
 
@@ -502,11 +503,15 @@ __device__ __forceinline__ float lane_max32(const f32x16 &x, const f32x16 &y) { 
 // ONES (head_dim <= 56, e.g. Hiera's 56): the zero padding of V up to 64 columns carries a column of ones at d = 56, so the row sum of the
 // (bf16-rounded) probabilities comes out of the P V product as O^T row 56 -- no add per score, no separate accumulator to rescale.
 // (measured and dropped: a 128-register build of the head_dim <= 56 form for 4 waves per SIMD -- 17 spilled registers inside the loop: 489 -> 577 us)
-template <int NW, bool ONES>       // NW: waves per workgroup
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) k_attention32(AttnArgs a) {
+template <int NW, int KS, int DB, bool ONES>       // NW: waves per workgroup; KS: 16-wide k-steps of Q K^T (head_dim <= 16 KS); DB: 32-row blocks of O^T (head_dim <= 32 DB)
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && KS == 4) ? 3 : 2) k_attention32(AttnArgs a) {
     constexpr int NT = NW * 64;
-    constexpr int KT = 64, TILE = 2 * KT * 128;                  // K tile 8 KB + V tile 8 KB
-    constexpr int NLD = KT * 8 / NT;                             // 16-byte pieces of K (and of V) per thread and tile
+    constexpr int KCH = 2 * KS, VCH = 4 * DB;                    // 16-byte chunks of a K row / a V row in LDS
+    // K rows: 128 bytes with the chunk index XOR-swizzled (head_dim <= 64), else 32 KS + 16 bytes (the 16-byte pad spreads the 16 rows of a
+    // ds_read_b128 lane group over all 64 banks: rows are -12 resp. +4 dwords apart mod 64); V: [key group][d-group][4 keys][16 d] blocks of 128 bytes
+    constexpr int KRB = KS == 4 ? 128 : 32 * KS + 16, DGN = 2 * DB;
+    constexpr int KT = 64, KBYTES = KT * KRB, TILE = KBYTES + KT * VCH * 16;
+    constexpr int NLDK = (KT * KCH + NT - 1) / NT, NLDV = (KT * VCH + NT - 1) / NT;      // 16-byte pieces of K / of V per thread and tile
     __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -519,70 +524,83 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) k_attention32(AttnAr
     const uint16_t *vp = a.v + b * a.v_sb + h * a.v_sh;
 
     const int q_row = (qblk * NW + wave) * 32 + ql;
-    bf16x8 qf[4];                                                // B operand of k-step ks: d = 16 ks + 8 hi .. + 8
+    bf16x8 qf[KS];                                               // B operand of k-step ks: d = 16 ks + 8 hi .. + 8
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         uint4 raw = make_uint4(0, 0, 0, 0);
         const int d0 = ks * 16 + hi * 8;
         if (q_row < a.Tq && d0 < a.hd) raw = *(const uint4 *)(qp + (long long)q_row * a.q_st + d0);
         qf[ks] = *(bf16x8 *)&raw;
         if (a.scale_log2e != 1.0f) qf[ks] = prescale_q(qf[ks], a.scale_log2e);
     }
-    f32x16 o[2], negm;
+    f32x16 o[DB], negm;
     f32x4 lsum = f32x4{0.f, 0.f, 0.f, 0.f};                      // the lane's part of the row sum, folded to four partial sums per tile (unused with ONES)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; negm[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) {
+        negm[i] = 0.f;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[db][i] = 0.f;
+    }
 
-    // staging through buffer loads: piece id = it * NT + tid -> key row id >> 3, 16-byte chunk id & 7; the lane's byte offset inside a tile in
-    // voffset, the tile's in soffset; a piece that must read zeros (chunk past head_dim, row past the last key) gets an offset past the
-    // resource's extent -- the load returns 0 without a branch
+    // staging through buffer loads: the lane's byte offset inside a tile in voffset, the tile's in soffset; a piece that must read zeros (chunk
+    // past head_dim, row past the last key, piece index past the tile) gets an offset past the resource's extent -- the load returns 0 without a branch
     constexpr uint32_t OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void *)kp, 0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void *)vp, 0, 0x7ffffff0, 0x00020000);
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    u32x4 kr[NLD], vr[NLD];
-    int lds_k[NLD], lds_v[NLD], f_row[NLD];
-    uint32_t k_off[NLD], v_off[NLD];
-    int f_vrow[NLD];
-    bool f_vone[NLD];
+    u32x4 kr[NLDK], vr[NLDV];
+    int lds_k[NLDK], lds_v[NLDV], f_row[NLDK], f_vrow[NLDV];
+    uint32_t k_off[NLDK], v_off[NLDV];
+    bool f_vone[NLDV];
 #pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-        const int id = it * NT + tid, row = id >> 3, c = id & 7;
+    for (int it = 0; it < NLDK; ++it) {                            // K piece id -> key row id / KCH, chunk id % KCH
+        const int id = it * NT + tid, row = id / KCH, c = id - row * KCH;
+        const bool live = id < KT * KCH;
         f_row[it] = row;
-        k_off[it] = c * 8 < a.hd ? (uint32_t)((row * a.k_st + c * 8) * 2) : OOB;
-        lds_k[it] = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+        k_off[it] = (live && c * 8 < a.hd) ? (uint32_t)((row * a.k_st + c * 8) * 2) : OOB;
+        lds_k[it] = live ? row * KRB + ((KS == 4 ? (c ^ ((row >> 1) & 7)) : c) << 4) : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < NLDV; ++it) {
         // V: the 8 lanes of a ds_write_b128 group fill ONE 128-byte [4 keys][16 d] block (piece j of the block = key j >> 1, chunk 2 dg + (j & 1));
         // with lane -> (row, chunk) as for K the group's addresses alias mod 128 bytes: a 4-way bank conflict on every V write (PMC: 48 of 144 LDS cycles per tile)
-        const int blk = id >> 3, j = id & 7, vrow = (blk >> 2) * 4 + (j >> 1), vc = (blk & 3) * 2 + (j & 1);
+        const int id = it * NT + tid, blk = id >> 3, j = id & 7, kg = blk / DGN, dg = blk - kg * DGN, vrow = kg * 4 + (j >> 1), vc = dg * 2 + (j & 1);
+        const bool live = id < KT * VCH;
         f_vrow[it] = vrow;
-        v_off[it] = vc * 8 < a.hd ? (uint32_t)((vrow * a.v_st + vc * 8) * 2) : OOB;
-        lds_v[it] = KT * 128 + blk * 128 + j * 16;
-        f_vone[it] = ONES && vc == 7;                             // the piece holding d = 56..63
+        v_off[it] = (live && vc * 8 < a.hd) ? (uint32_t)((vrow * a.v_st + vc * 8) * 2) : OOB;
+        lds_v[it] = live ? KBYTES + blk * 128 + j * 16 : -1;
+        f_vone[it] = ONES && live && vc == VCH - 1;                // the piece holding the last 8 d columns (all padding with ONES)
     }
     const int k_tile_bytes = (int)(KT * a.k_st * 2), v_tile_bytes = (int)(KT * a.v_st * 2);
     auto fetch = [&](int t, bool ragged) {                         // tile t -> registers (ragged: the tile holds rows past the last key)
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            uint32_t ko = k_off[it], vo = v_off[it];
+        for (int it = 0; it < NLDK; ++it) {
+            uint32_t ko = k_off[it];
             if (ragged && t * KT + f_row[it] >= a.Tk) ko = OOB;
-            if (ragged && t * KT + f_vrow[it] >= a.Tk) vo = OOB;
             kr[it] = __builtin_amdgcn_raw_buffer_load_b128(krs, ko, t * k_tile_bytes, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < NLDV; ++it) {
+            uint32_t vo = v_off[it];
+            if (ragged && t * KT + f_vrow[it] >= a.Tk) vo = OOB;
             vr[it] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vo, t * v_tile_bytes, 0);
         }
     };
     auto commit = [&](char *buf) {
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            *(u32x4 *)(buf + lds_k[it]) = kr[it];
-            if (ONES && f_vone[it]) vr[it] = u32x4{0x3f80u, 0u, 0u, 0u};            // V[key][56] = 1.0 (bf16), 57..63 = 0
-            *(u32x4 *)(buf + lds_v[it]) = vr[it];
+        for (int it = 0; it < NLDK; ++it)
+            if ((KT * KCH) % NT == 0 || lds_k[it] >= 0) *(u32x4 *)(buf + lds_k[it]) = kr[it];
+#pragma unroll
+        for (int it = 0; it < NLDV; ++it) {
+            if (ONES && f_vone[it]) vr[it] = u32x4{0x3f80u, 0u, 0u, 0u};            // V[key][32 DB - 8] = 1.0 (bf16), the seven columns after it 0
+            if ((KT * VCH) % NT == 0 || lds_v[it] >= 0) *(u32x4 *)(buf + lds_v[it]) = vr[it];
         }
     };
-    // fragment addresses inside a tile buffer: K row (32 kb + ql), chunk (2 ks + hi) ^ swizzle(row);  V block (key group 8 kb + 4 j + hi (+2), d-group 2 db + (ql >> 4))
-    int ka[4];
+    // fragment addresses inside a tile buffer: K row (32 kb + ql), chunk 2 ks + hi (swizzled at head_dim <= 64);  V block (key group 8 kb + 4 j + hi (+2), d-group 2 db + (ql >> 4))
+    int ka[KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) ka[ks] = ql * 128 + (((2 * ks + hi) ^ ((ql >> 1) & 7)) << 4);
-    const int va = KT * 128 + (hi * 4 + (ql >> 4)) * 128 + (ql & 15) * 8;
+    for (int ks = 0; ks < KS; ++ks) ka[ks] = ql * KRB + ((KS == 4 ? ((2 * ks + hi) ^ ((ql >> 1) & 7)) : (2 * ks + hi)) << 4);
+    const int va = KBYTES + (hi * DGN + (ql >> 4)) * 128 + (ql & 15) * 8;
     const bool wave_active = (qblk * NW + wave) * 32 < a.Tq;     // (scalar: wave is)
 
     // one 64-key tile; FIRST: the tile opens the row (reference maximum := its maximum); mask (scalar): the tile may hold keys past Tk or
@@ -594,10 +612,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) k_attention32(AttnAr
         constexpr int NKB = decltype(NKB_)::value;
         f32x16 s[2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {                       // two independent accumulation chains, alternating
-                const bf16x8 kf = *(const bf16x8 *)(buf + kb * (32 * 128) + ka[ks]);
+                const bf16x8 kf = *(const bf16x8 *)(buf + kb * (32 * KRB) + ka[ks]);
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? negm : s[kb], 0, 0, 0);
             }
         // (measured and dropped: all eight K fragments and all sixteen V^T fragments fetched ahead of their products -- 32 + 32 more live
@@ -612,8 +630,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) k_attention32(AttnAr
         }
         if (NKB == 1) s[1] = s[0];                                   // (maximum and rescale below walk both blocks)
         const float lm = lane_max32(s[0], s[1]);
-        if (FIRST) rescale32<true, ONES>(s, lm, negm, lsum, o);
-        else if (__any(lm > ATTN_THR)) rescale32<false, ONES>(s, lm, negm, lsum, o);
+        if (FIRST) rescale32<true, ONES, DB>(s, lm, negm, lsum, o);
+        else if (__any(lm > ATTN_THR)) rescale32<false, ONES, DB>(s, lm, negm, lsum, o);
         bf16x8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
@@ -637,10 +655,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) k_attention32(AttnAr
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const char *blk = buf + va + ((8 * kb + 4 * j) * 4 + 2 * db) * 128;
+                for (int db = 0; db < DB; ++db) {
+                    const char *blk = buf + va + ((8 * kb + 4 * j) * DGN + 2 * db) * 128;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(blk));
-                    const s16x4 hh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(blk + 2 * 4 * 128));
+                    const s16x4 hh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(blk + 2 * DGN * 128));
                     const uint2 l2 = *(const uint2 *)&lo, h2 = *(const uint2 *)&hh;
                     uint4 raw = make_uint4(l2.x, l2.y, h2.x, h2.y);
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8 *)&raw, pf[kb][j], o[db], 0, 0, 0);
@@ -683,7 +701,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) k_attention32(AttnAr
     // traded between lanes q and q + 32 (v_permlane32_swap) so that every lane stores 16 contiguous bytes: lanes < 32 at d = 32 db + 16 p,
     // lanes >= 32 at d = 32 db + 16 p + 8
     float l = 0.f;
-    if (ONES) l = hi == 0 ? o[1][12] : 0.f;                       // O^T row 56 = 32 + (12 & 3) + 8 (12 >> 2) + 4 hi at hi = 0
+    if (ONES) l = hi == 0 ? o[DB - 1][12] : 0.f;                  // O^T row 32 DB - 8 = 32 (DB - 1) + (12 & 3) + 8 (12 >> 2) + 4 hi at hi = 0
     else {
         l = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
     }
@@ -694,7 +712,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) k_attention32(AttnAr
     const float inv = 1.0f / l;
     uint16_t *op = a.o + b * a.o_sb + h * a.o_sh + (long long)q_row * a.o_st;
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
+    for (int db = 0; db < DB; ++db) {
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {                           // g = 2 pr (kept by lanes < 32), 2 pr + 1 (kept by lanes >= 32)
             uint32_t a0 = pack2(o[db][8 * pr + 0] * inv, o[db][8 * pr + 1] * inv), a1 = pack2(o[db][8 * pr + 2] * inv, o[db][8 * pr + 3] * inv);
@@ -763,7 +781,7 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     if (prof) { ovo_prof_begin(1, 4.0 * p->B * p->H * (double)p->Tq * p->Tk * p->hd, s); ovo_prof_shape(p->B * p->H, p->Tq, p->Tk);
                 ovo_prof_bytes(2.0 * p->B * p->H * p->hd * (2.0 * p->Tq + 2.0 * p->Tk)); }
     struct Done { bool on; hipStream_t s; ~Done() { if (on) ovo_prof_end(s); } } done{prof, s};
-    // head_dim <= 64 and more than 16 queries: 32 x 32 MFMA tiles, K / V streamed (k_attention32); 128 queries per workgroup, 64 when a (batch, head)
+    // More than 16 queries or 64 keys: 32 x 32 MFMA tiles, K / V streamed (k_attention32); 128 queries per workgroup, 64 when a (batch, head)
     // pair has no more.  OVO_ATTN32 = 0 / 1 overrides the shape rule (tools/attn_bench.py: 12 frames' shapes, a32 vs the 16 x 16 kernels with the
     // same softmax: 577^2 x 64 60.6 vs 66.8 us, 4096^2 x 56 466 vs 622, 196^2 x 56 windows 63 vs 76, 49 x 196 64 vs 79, 49^2 29 vs 34, 64^2 tie;
     // <= 16 queries x <= 64 keys stay with the one-wave-per-pair kernel: 222 / 79 / 96 us against 287 / 261 / 486)
@@ -773,18 +791,23 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
         // 16-byte output stores and 32-bit K / V byte offsets inside a (batch, head) slab
         const bool fits32 = ((uintptr_t)p->o & 15) == 0 && p->o_st % 8 == 0 && p->o_sh % 8 == 0 && p->o_sb % 8 == 0 &&
                             ((long long)p->Tk + 64) * p->k_st * 2 < (1ll << 31) && ((long long)p->Tk + 64) * p->v_st * 2 < (1ll << 31);
-        if (use32 && fits32 && p->hd <= 64) {
-            const int qpw = p->Tq <= 64 ? 64 : 128;
+        if (use32 && fits32) {
+            // head_dim <= 64: KS 4 / DB 2; <= 80: 5 / 3 (SigLIP's 72, hiera_l's 72, ViT-H's 80); <= 96: 6 / 3; <= 128: 8 / 4.  The ones column needs 8 free d
+            // columns at the end of the last 32-row block.  64-query workgroups only in the head_dim <= 64 form (its staging fits 128 threads' registers)
+            const int qpw = (p->Tq <= 64 && p->hd <= 64) ? 64 : 128;
             const long long qb = (p->Tq + qpw - 1) / qpw, total = qb * p->B * p->H;
             a.q_tiles = (int)qb; a.chunk = (int)((total + 7) / 8);
             const unsigned g = (unsigned)(a.chunk * 8);
             if (qpw == 64) {
-                if (p->hd <= 56) k_attention32<2, true><<<g, 128, 0, s>>>(a);
-                else k_attention32<2, false><<<g, 128, 0, s>>>(a);
-            } else {
-                if (p->hd <= 56) k_attention32<4, true><<<g, 256, 0, s>>>(a);
-                else k_attention32<4, false><<<g, 256, 0, s>>>(a);
-            }
+                if (p->hd <= 56) k_attention32<2, 4, 2, true><<<g, 128, 0, s>>>(a);
+                else k_attention32<2, 4, 2, false><<<g, 128, 0, s>>>(a);
+            } else if (p->hd <= 56) k_attention32<4, 4, 2, true><<<g, 256, 0, s>>>(a);
+            else if (p->hd <= 64) k_attention32<4, 4, 2, false><<<g, 256, 0, s>>>(a);
+            else if (p->hd <= 80) k_attention32<4, 5, 3, true><<<g, 256, 0, s>>>(a);
+            else if (p->hd <= 88) k_attention32<4, 6, 3, true><<<g, 256, 0, s>>>(a);
+            else if (p->hd <= 96) k_attention32<4, 6, 3, false><<<g, 256, 0, s>>>(a);
+            else if (p->hd <= 120) k_attention32<4, 8, 4, true><<<g, 256, 0, s>>>(a);
+            else k_attention32<4, 8, 4, false><<<g, 256, 0, s>>>(a);
             OVO_CHECK_LAUNCH();
             return OVO_OK;
         }

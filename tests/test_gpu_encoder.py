@@ -346,7 +346,8 @@ def _attention_call(qkv, B, H, Tq, Tk, hd):
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,hd", [(24, 16, 577, 577, 64), (30, 8, 196, 196, 56), (10, 16, 49, 196, 56), (2, 4, 100, 300, 64), (1, 2, 577, 592, 64),
-                                          (3, 1, 33, 65, 40), (2, 2, 1200, 128, 64), (1, 1, 16, 80, 8), (300, 2, 197, 197, 64), (64, 2, 64, 64, 56)])
+                                          (3, 1, 33, 65, 40), (2, 2, 1200, 128, 64), (1, 1, 16, 80, 8), (300, 2, 197, 197, 64), (64, 2, 64, 64, 56),
+                                          (4, 8, 256, 256, 72), (2, 16, 257, 257, 80), (2, 3, 300, 333, 96), (2, 4, 700, 1500, 128), (3, 2, 130, 200, 120), (2, 2, 90, 130, 88)])
 def test_attention32_kernel_vs_16x16_kernel(B, H, Tq, Tk, hd, monkeypatch):
     """k_attention32 (32 x 32 x 16 MFMA tiles, 32 queries per wave, row sum through the ones column when head_dim <= 56) against k_attention (16 x 16 x 32
     tiles): the same softmax scheme, the same rounding points (Q prescaled to bf16, P in bf16, fp32 accumulation) -- only the summation order inside the
