@@ -500,6 +500,12 @@ __device__ __forceinline__ float lane_max32(const f32x16 &x, const f32x16 &y) { 
     return fmaxf(fmaxf(m, x[15]), fmaxf(n, y[15]));
 }
 
+// (measured and dropped: a software-pipelined form -- tile t + 1's score products issued between tile t's exponentials, its lane maximum under tile t's
+//  P V products, K one tile ahead of V through the same two buffers, two score sets alternating roles; bit-identical outputs, 231 VGPRs = 2 waves per
+//  SIMD: 4096^2 x 56 457 -> 450 us, but 577^2 x 64 59.5 -> 71.8 and 196^2 windows 58.7 -> 70.0.  tools/ubench.hip says why: a 32 x 32 x 16 MFMA with its
+//  A operand read from LDS plus this kernel's VALU mix (max3, 2 exp, cvt, fma per product) costs 50 cycles per SIMD at two waves and 45 with one LDS
+//  read per two products, against 35 for the bare product -- the VALU issues extend the product's slot whichever wave they come from, so overlapping
+//  them inside one wave buys what the three drifting waves per SIMD already get)
 // ONES (head_dim <= 56, e.g. Hiera's 56): the zero padding of V up to 64 columns carries a column of ones at d = 56, so the row sum of the
 // (bf16-rounded) probabilities comes out of the P V product as O^T row 56 -- no add per score, no separate accumulator to rescale.
 // (measured and dropped: a 128-register build of the head_dim <= 56 form for 4 waves per SIMD -- 17 spilled registers inside the loop: 489 -> 577 us)
@@ -725,6 +731,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && KS == 4) ? 3 : 2) k_atten
         }
     }
 }
+
 
 }  // namespace
 

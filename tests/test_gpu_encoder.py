@@ -328,7 +328,7 @@ def test_attention_rescale_path(B, H, Tq, Tk, hd):
     assert (out.float() - ref).abs().mean() < 3e-3
 
 
-def _attention_call(qkv, B, H, Tq, Tk, hd):
+def _attention_call(qkv, B, H, Tq, Tk, hd, causal=0):
     from ovo_amd import _lib as L
     D, T = H * hd, qkv.shape[1]
     out = torch.zeros(B, Tq, D, dtype=torch.bfloat16, device=DEV)
@@ -339,7 +339,7 @@ def _attention_call(qkv, B, H, Tq, Tk, hd):
     a.q_sh = a.k_sh = a.v_sh = hd
     a.q_st = a.k_st = a.v_st = 3 * D
     a.o_sb, a.o_sh, a.o_st = Tq * D, hd, D
-    a.B, a.H, a.Tq, a.Tk, a.hd, a.scale = B, H, Tq, Tk, hd, hd ** -0.5
+    a.B, a.H, a.Tq, a.Tk, a.hd, a.scale, a.causal = B, H, Tq, Tk, hd, hd ** -0.5, causal
     L.check(L.load().ovo_attention(C.byref(a), L.stream()))
     torch.cuda.synchronize()
     return out

@@ -24,7 +24,7 @@ def run(B, H, Tq, Tk, hd, iters=30):
     us = 1e3 * e0.elapsed_time(e1) / iters
     return us, 4.0 * B * H * Tq * Tk * hd / us / 1e6, 2.0 * B * H * hd * (2 * Tq + 2 * Tk) / us / 1e3
 shapes = [(24, 16, 577, 577, 64), (2, 16, 577, 577, 64), (12, 8, 4096, 4096, 56), (300, 8, 196, 196, 56), (12288, 2, 64, 64, 56), (12288, 4, 16, 64, 56), (12288, 4, 16, 16, 56),
-          (12288, 8, 4, 16, 56), (300, 16, 49, 196, 56), (300, 16, 49, 49, 56), (8, 16, 2048, 2048, 128)]
+          (12288, 8, 4, 16, 56), (300, 16, 49, 196, 56), (300, 16, 49, 49, 56), (8, 16, 2048, 2048, 128), (24, 16, 729, 729, 72), (65, 16, 257, 257, 80)]
 for shape in shapes:
     row = "%-28s" % str(shape)
     for mode in os.environ.get("MODES", "auto,a32,narrow,wide").split(","):

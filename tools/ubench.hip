@@ -15,12 +15,14 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 #define REP16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
 enum { T_EXP, T_FMA, T_PKFMA, T_MAX3, T_CVT, T_PKMUL, T_ADD, T_PKADD, T_SWAP32, T_MFMA16, T_MFMA32, T_MFMA16_EXP16, T_MFMA16_EXP32, T_MFMA16_FMA32,
-       T_MFMA16_MIX, T_MFMA16_SRCC, T_LDSB128, T_M32_F2, T_M32_F4, T_M32_F6, T_M32_F8, T_M32_MIX4, T_M32_MIX5, T_M32_EXP2, T_M32_EXP4, T_N };
+       T_MFMA16_MIX, T_MFMA16_SRCC, T_LDSB128, T_M32_F2, T_M32_F4, T_M32_F6, T_M32_F8, T_M32_MIX4, T_M32_MIX5, T_M32_EXP2, T_M32_EXP4, T_M32_LDS, T_M32_LDS2, T_M32_LDSTR, T_M32_LDS_MIX5, T_M32_LDS2_MIX5, T_N };
 static const char *names[T_N] = {"v_exp_f32 x32", "v_fma_f32 x32", "v_pk_fma_f32 x16 (32 values)", "v_max3_f32 x32", "v_cvt_pk_bf16_f32 x16", "v_pk_mul_f32 x16",
                                  "v_add_f32 x32", "v_pk_add_f32 x16", "v_permlane32_swap x16", "mfma16x16x32 x16", "mfma32x32x16 x8", "mfma16 x16 + exp x16",
                                  "mfma16 x16 + exp x32", "mfma16 x16 + fma x32", "mfma16 x16 + (8 max3, 16 exp, 8 cvt)", "mfma16 x16, srcC != dst", "ds_read_b128 x16",
                                  "mfma32 x8 + 2 fma each", "mfma32 x8 + 4 fma each", "mfma32 x8 + 6 fma each", "mfma32 x8 + 8 fma each",
-                                 "mfma32 x8 + (max3, 2 exp, cvt) each", "mfma32 x8 + (max3, 2 exp, cvt, fma) each", "mfma32 x8 + 2 exp each", "mfma32 x8 + 4 exp each"};
+                                 "mfma32 x8 + (max3, 2 exp, cvt) each", "mfma32 x8 + (max3, 2 exp, cvt, fma) each", "mfma32 x8 + 2 exp each", "mfma32 x8 + 4 exp each",
+                                 "mfma32 x8, A from ds_read_b128 each", "mfma32 x8, one ds_read_b128 per 2", "mfma32 x8, A from 2 ds_read_b64_tr each",
+                                 "mfma32 x8, ds_read_b128 + mix5 each", "mfma32 x8, ds_read_b128 per 2 + mix5 each"};
 
 template <int T>
 __global__ void __launch_bounds__(1024) k(float *out, long long *cyc, int iters) {
@@ -158,6 +160,19 @@ __global__ void __launch_bounds__(512) k32(float *out, long long *cyc, int iters
     for (int i = 0; i < 8; ++i) acc32[i] = (f32x16)(0.f);
     bf16x8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.01f * (threadIdx.x & 7)); b[i] = (__bf16)(0.02f * (threadIdx.x & 3)); }
+    __shared__ __attribute__((aligned(16))) char lds32[32768];
+    for (int i = threadIdx.x; i < 32768 / 4; i += blockDim.x) ((uint32_t *)lds32)[i] = 0x3c003c00u;
+    __syncthreads();
+    const char *lp = lds32 + (threadIdx.x & 63) * 16 + ((threadIdx.x >> 6) & 3) * 8192;      // conflict-free: 64 lanes x 16 bytes contiguous
+    const char *lt = lds32 + (threadIdx.x & 63) * 8 + ((threadIdx.x >> 6) & 3) * 8192;
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    const uint32_t lpa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)lp;
+    bf16x8 av[2] = {a, a};
+#define LDA(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(av[((i) + 1) & 1]) : "v"(lpa), "n"(((i) & 7) * 1024));
+#define MFL(i, j) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); acc32[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[(j) & 1], b, acc32[i], 0, 0, 0);
+#define LDT(i) { const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(lt + ((i) & 7) * 1024)); \
+                 const s16x4 hh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(lt + ((i) & 7) * 1024 + 512)); \
+                 const uint2 l2 = *(const uint2 *)&lo, h2 = *(const uint2 *)&hh; uint4 raw = make_uint4(l2.x, l2.y, h2.x, h2.y); av[((i) + 1) & 1] = *(bf16x8 *)&raw; }
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #define MF(i) acc32[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc32[i], 0, 0, 0);
@@ -201,6 +216,27 @@ __global__ void __launch_bounds__(512) k32(float *out, long long *cyc, int iters
 #define M(i) MF(i) EXP(4 * i) EXP(4 * i + 1) EXP(4 * i + 2) EXP(4 * i + 3)
             M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 #undef M
+        } else if constexpr (T == T_M32_LDS) {
+#define M(i) LDA(i) MFL(i, i)
+            M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#undef M
+        } else if constexpr (T == T_M32_LDS2) {
+#define M(i) LDA(i) MFL(2 * i, i) MFL(2 * i + 1, i)
+            M(0) M(1) M(2) M(3)
+#undef M
+        } else if constexpr (T == T_M32_LDSTR) {
+#define M(i) LDT(i) MFL(i, i)
+            M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#undef M
+        } else if constexpr (T == T_M32_LDS_MIX5) {
+#define M(i) LDA(i) MFL(i, i) MX3(4 * i) EXP(4 * i + 1) FMA(4 * i + 16) EXP(4 * i + 2) CVT(4 * i + 3)
+            M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#undef M
+        } else if constexpr (T == T_M32_LDS2_MIX5) {
+#define X5(i) MX3(4 * (i)) EXP(4 * (i) + 1) FMA(4 * (i) + 16) EXP(4 * (i) + 2) CVT(4 * (i) + 3)
+#define M(i) LDA(i) MFL(2 * i, i) X5(2 * i) MFL(2 * i + 1, i) X5(2 * i + 1)
+            M(0) M(1) M(2) M(3)
+#undef M
         }
     }
     const long long t1 = __builtin_readcyclecounter();
@@ -216,7 +252,7 @@ __global__ void __launch_bounds__(512) k32(float *out, long long *cyc, int iters
 template <int T>
 void run32(float *out, long long *cyc) {
     const int iters = 2000, n_per_iter = 8;
-    for (int threads = 256; threads <= 512; threads *= 2) {
+    for (int threads = 256; threads <= 512; threads += 256) {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
         k32<T><<<256, threads>>>(out, cyc, 10);
@@ -242,5 +278,6 @@ int main() {
     run<T_MFMA16_FMA32>(out, cyc, 16); run<T_MFMA16_MIX>(out, cyc, 16); run<T_LDSB128>(out, cyc, 16);
     run32<T_MFMA32>(out, cyc); run32<T_M32_F2>(out, cyc); run32<T_M32_F4>(out, cyc); run32<T_M32_F6>(out, cyc); run32<T_M32_F8>(out, cyc);
     run32<T_M32_MIX4>(out, cyc); run32<T_M32_MIX5>(out, cyc); run32<T_M32_EXP2>(out, cyc); run32<T_M32_EXP4>(out, cyc);
+    run32<T_M32_LDS>(out, cyc); run32<T_M32_LDS2>(out, cyc); run32<T_M32_LDSTR>(out, cyc); run32<T_M32_LDS_MIX5>(out, cyc); run32<T_M32_LDS2_MIX5>(out, cyc);
     return 0;
 }
