@@ -242,6 +242,12 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
         // such groups per lane the store ISSUE (one request per row segment) cost more than the K-loop of a K = 1024 tile.  Instead each
         // wave transposes its tile through a private LDS slab (two passes of HM rows, rows padded by 16 bytes against bank conflicts)
         // and then reads rows back so that every store / residual load instruction covers whole 128-256-byte row segments.
+        // (measured and dropped, round 4: 2-byte outputs WITHOUT the LDS round trip -- the lane's 4 columns of two neighbouring accumulator tiles packed
+        //  and traded with v_permlane16_swap (8 consecutive columns per lane), then the two 32-column halves traded between lanes fr and fr ^ 8 (DPP
+        //  row_ror:8) so that a 16-byte store per lane covers 8 rows x 128 bytes exactly as below; bit-identical, no barrier, no LDS.  256 x 128 tiles
+        //  gained 2-3 % (8192 x 2048 x 1024: 39.5 -> 37.8 us), 256 x 256 tiles LOST 15 % (34.8 -> 40.8 us; 13848 x 4096 x 1024 118.5 -> 147.8), the bench
+        //  373.6 -> 362.1 frames/s: sixteen stores per wave issued back to back by all 2048 waves of the chip drain slower than the same stores spread
+        //  out by the slab passes.  Debug bits 4 / 8 split this epilogue's 7.9 us of a K = 1024 round into 5.0 us LDS + arithmetic and 2.9 us stores.)
         OVO_BARRIER();                                    // every wave's LDS-DMA has landed and every fragment read is done: LDS is free
         constexpr int ROWB = WTN * 4 + 16;
         char *slab = smem + wave * (HM * ROWB);
