@@ -141,7 +141,11 @@ class FramePipeline:
             from .encoders.sam_decoder import SPECS as DEC_SPECS, HipSamDecoder
             from .entities.sam_amg import HipSam2AutomaticMaskGenerator
             kw = {} if amg_thresholds is None else {"pred_iou_thresh": float(amg_thresholds[0]), "stability_score_thresh": float(amg_thresholds[1])}
-            self.amg = HipSam2AutomaticMaskGenerator(self.sam, HipSamDecoder(DEC_SPECS["sam2"], None, self.device, seed), points_per_side=points_per_side, **kw)
+            hs = HIERA_SPECS[sam_card]
+            fit = [d for d in DEC_SPECS.values() if d.hidden == hs.fpn_dim and d.image_size == hs.image_size and d.embed_size * 16 == hs.image_size]
+            if not fit:
+                raise ValueError(f"no SAM2 mask decoder spec for encoder {sam_card} (FPN width {hs.fpn_dim}, input {hs.image_size})")
+            self.amg = HipSam2AutomaticMaskGenerator(self.sam, HipSamDecoder(fit[0], None, self.device, seed), points_per_side=points_per_side, **kw)
         # `own_masks` (with sam_full): the masks SAM2's generator produced for a keyframe drive ITS tracking -- the reference's default path
         # (mask_generator.py:102-120: generate -> masks_update -> mask2segmap -> ovo.py:182-324), also on one GPU; off: they are produced and
         # measured but tracking consumes the masks the frame carries (the precomputed-mask seam, mask_generator.py:94-95)

@@ -177,3 +177,46 @@ def test_drain_reads_back_a_prequeued_round():
     assert not pipe._chains and not pipe.ovo._track_pending
     assert torch.equal(pipe.slam.pcd_obj_ids, full.slam.pcd_obj_ids) and pipe.slam._n == full.slam._n
     assert list(pipe.ovo.objects) == list(full.ovo.objects) and pipe.ovo.next_ins_id == full.ovo.next_ins_id
+
+
+def _own_run(frames, **kw):
+    from ovo_amd.pipeline import FramePipeline
+    pipe = FramePipeline(DEV, vit_card="tiny-pe", sam_card="hiera_test256", n_map=60_000, n_text=7, scale=0.35, extra_capacity=200_000, track_th=40, **kw)
+    pipe.join_each_step = True
+    trace, used = [], []
+    for i, f in enumerate(frames):
+        out = pipe.step(f, frames[i + 1:])
+        torch.cuda.synchronize()
+        cur = pipe.masks.frames[f.index]                            # the Frame the round tracked with (its masks replaced in own-mask mode)
+        used.append((cur.seg_map.clone(), cur.masks.clone()))
+        trace.append((out["n_points"], out["n_instances"], out["dense_cls"].cpu().numpy().copy(), pipe.ovo.last_clip_embeds.cpu().numpy().copy()))
+    return trace, used, pipe
+
+
+def test_own_sam2_masks_drive_the_round():
+    """`own_masks` (bench.py --sam-own-masks): a keyframe is tracked with what ITS generator produced -- generate -> mask NMS (masks_update) ->
+    mask2segmap, the reference's default chain (mask_generator.py:102-120) -- not with the masks the frame carries.
+    (1) the masks in use differ from the carried ones and their count is the generator's; (2) replaying the frames with exactly those masks
+    through the precomputed-mask seam reproduces the run bit for bit (the own-mask path adds nothing but the masks); (3) a keyframe whose
+    generator keeps fewer than `min_own_masks` masks falls back to the carried masks, after the generator ran, and is counted."""
+    from ovo_amd.pipeline import Frame, synthetic_frames
+    frames = synthetic_frames(3, DEV, scale=0.35, n_masks_grid=(3, 4), n_blobs=4)
+    own, used, pipe = _own_run(frames, sam_full=True, points_per_side=6, own_masks=True, amg_thresholds=(0.0, 0.0), nms_score_thr=0.0)
+    assert pipe.own_masks and pipe.own_fallbacks == 0 and len(pipe.own_mask_counts) == len(frames)
+    assert all(c > 0 for c in pipe.own_mask_counts)
+    for f, (seg, masks), c in zip(frames, used, pipe.own_mask_counts):
+        assert masks.shape[0] == c and masks.shape[1:] == f.masks.shape[1:]
+        assert masks.shape != f.masks.shape or not torch.equal(masks.view(torch.uint8), f.masks.view(torch.uint8))
+        assert int(seg.max()) < c and int(seg.min()) >= -1
+    replay = [Frame(f.index, f.rgb, f.rgb_lr, f.depth, f.c2w, seg, masks.view(torch.bool)) for f, (seg, masks) in zip(frames, used)]
+    seam, _, _ = _own_run(replay)
+    for a, b in zip(own, seam):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    # fallback: the generator's masks are too few -> the carried masks are tracked, as without own_masks at all
+    fb, used_fb, pipe_fb = _own_run(frames, sam_full=True, points_per_side=6, own_masks=True, amg_thresholds=(0.0, 0.0), nms_score_thr=0.0, min_own_masks=10 ** 6)
+    assert pipe_fb.own_fallbacks == len(frames) and pipe_fb.own_mask_counts == pipe.own_mask_counts
+    plain, _, _ = _own_run(frames)
+    for a, b, (seg, masks), f in zip(fb, plain, used_fb, frames):
+        assert torch.equal(masks, f.masks) and torch.equal(seg, f.seg_map)
+        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
