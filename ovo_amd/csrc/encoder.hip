@@ -138,29 +138,32 @@ __global__ void __launch_bounds__(256) k_vit_embed(const float *__restrict__ pat
 __global__ void __launch_bounds__(256) k_im2col(const float *__restrict__ img, int B, int C, int H, int W, int ksz, int stride, int pad,
                                                 int oh, int ow, uint16_t *__restrict__ out, int kpad) {
     // eight consecutive patch columns per thread, one 16-byte store (kpad % 8 == 0): the one-element-per-thread form wrote 2 bytes per
-    // lane and moved 0.7 TB/s on the 1024^2 SAM2 input (four frames: 223 us)
-    const int k8 = kpad >> 3;
-    const long long total = (long long)B * oh * ow * k8;
+    // lane and moved 0.7 TB/s on the 1024^2 SAM2 input (four frames: 223 us).  Index arithmetic in 32 bits (the launch checks the sizes), the
+    // (channel, ky, kx) of the eight columns advanced incrementally: five 64-bit and twenty-four 32-bit divisions per thread were ~1100 VALU
+    // instructions for 16 bytes of output (137 us per four frames = 1 TB/s)
+    const uint32_t k8 = (uint32_t)kpad >> 3;
+    const uint32_t total = (uint32_t)B * oh * ow * k8;
     const int kk = ksz * ksz, kreal = C * kk;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int kb = (int)(i % k8) * 8;
-        const long long row = i / k8;
-        const int ox = (int)(row % ow), oy = (int)((row / ow) % oh), b = (int)(row / ((long long)ow * oh));
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t row = i / k8, kb = (i - row * k8) * 8;
+        const uint32_t t1 = row / (uint32_t)ow, ox = row - t1 * (uint32_t)ow;
+        const uint32_t b = t1 / (uint32_t)oh, oy = t1 - b * (uint32_t)oh;
+        int c = (int)(kb / (uint32_t)kk), rem = (int)kb - c * kk, ky = rem / ksz, kx = rem - ky * ksz;
+        const int y0 = (int)oy * stride - pad, x0 = (int)ox * stride - pad;
         uint16_t v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int k = kb + e;
             float f = 0.f;
-            if (k < kreal) {
-                const int c = k / kk, ky = (k % kk) / ksz, kx = k % ksz;
-                const int y = oy * stride - pad + ky, x = ox * stride - pad + kx;
+            if ((int)kb + e < kreal) {
+                const int y = y0 + ky, x = x0 + kx;
                 if (y >= 0 && y < H && x >= 0 && x < W) f = img[(((long long)b * C + c) * H + y) * W + x];
             }
             v[e] = f2bf(f);
+            if (++kx == ksz) { kx = 0; if (++ky == ksz) { ky = 0; ++c; } }
         }
         uint4 p;
         p.x = v[0] | ((uint32_t)v[1] << 16); p.y = v[2] | ((uint32_t)v[3] << 16); p.z = v[4] | ((uint32_t)v[5] << 16); p.w = v[6] | ((uint32_t)v[7] << 16);
-        *(uint4 *)(out + row * kpad + kb) = p;
+        *(uint4 *)(out + (long long)row * kpad + kb) = p;
     }
 }
 
@@ -554,6 +557,7 @@ int ovo_im2col(const float *img, int B, int C, int H, int W, int ksz, int stride
     const int oh = (H + 2 * pad - ksz) / stride + 1, ow = (W + 2 * pad - ksz) / stride + 1;
     OVO_REQUIRE(oh > 0 && ow > 0, "empty output");
     OVO_REQUIRE(kpad % 8 == 0 && ((uintptr_t)out & 15) == 0, "kpad must be a multiple of 8 and the output 16-byte aligned");
+    OVO_REQUIRE((long long)B * oh * ow * (kpad / 8) < (1ll << 32), "more than 2^32 16-byte pieces: split the batch");
     k_im2col<<<ovo_grid((long long)B * oh * ow * (kpad / 8), 256), 256, 0, (hipStream_t)stream>>>(img, B, C, H, W, ksz, stride, pad, oh, ow,
                                                                                                  (uint16_t *)out, kpad);
     OVO_CHECK_LAUNCH();

@@ -45,20 +45,25 @@ __global__ void __launch_bounds__(256) k_ln_window(const float *__restrict__ x, 
                                                    const float *__restrict__ beta, float eps, uint16_t *__restrict__ out) {
     constexpr int RPW = 64 / LPR;                       // rows per wave
     const int lane = threadIdx.x & 63, sl = lane % LPR, sub = lane / LPR;
-    const long long waves = (long long)gridDim.x * 4;
-    const int per_win = g.wh * g.ww, d4 = d >> 2, kp4 = kp >> 2;
-    const long long n_iter = (g.rows + RPW - 1) / RPW;
-    for (long long it = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); it < n_iter; it += waves) {
-        const long long r = it * RPW + sub;
-        bool real = r < g.rows;
+    const uint32_t waves = gridDim.x * 4u;
+    const int d4 = d >> 2, kp4 = kp >> 2;
+    const uint32_t per_win = (uint32_t)(g.wh * g.ww), n_rows = (uint32_t)g.rows;       // (the launch checks rows < 2^31)
+    const uint32_t n_iter = (n_rows + RPW - 1) / RPW;
+    for (uint32_t it = blockIdx.x * 4u + (threadIdx.x >> 6); it < n_iter; it += waves) {
+        // row -> (image, window, position): four 32-bit divisions, on the SCALAR unit when the whole wave works on one row.  (The 64-bit
+        // long-long form of these seven quotients / remainders was ~700 VALU instructions per row: the kernel issued more than it loaded)
+        uint32_t r = it * RPW + sub;
+        if (LPR == 64) r = __builtin_amdgcn_readfirstlane(r);
+        bool real = r < n_rows;
         const float *src = x;
         if (real) {
-            const long long win = r / per_win;
-            const int in = (int)(r % per_win), ly = in / g.ww, lx = in % g.ww;
-            const int wx = (int)(win % g.nww), wy = (int)((win / g.nww) % g.nwh), b = (int)(win / ((long long)g.nww * g.nwh));
-            const int y = wy * g.wh + ly, xx = wx * g.ww + lx;
+            const uint32_t win = r / per_win, in = r - win * per_win;
+            const uint32_t ly = in / (uint32_t)g.ww, lx = in - ly * (uint32_t)g.ww;
+            const uint32_t q2 = win / (uint32_t)g.nww, wx = win - q2 * (uint32_t)g.nww;
+            const uint32_t b = q2 / (uint32_t)g.nwh, wy = q2 - b * (uint32_t)g.nwh;
+            const int y = (int)(wy * g.wh + ly), xx = (int)(wx * g.ww + lx);
             if (y >= g.H || xx >= g.W) {                // padding row of a partial window: zeros
-                uint2 *o = (uint2 *)(out + r * kp);
+                uint2 *o = (uint2 *)(out + (long long)r * kp);
                 for (int i = sl; i < kp4; i += LPR) o[i] = make_uint2(0, 0);
                 real = false;
             } else src = x + (((long long)b * g.H + y) * g.W + xx) * d;
@@ -89,7 +94,7 @@ __global__ void __launch_bounds__(256) k_ln_window(const float *__restrict__ x, 
         for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
         const float rstd = rsqrtf(q / (float)d + eps);
         if (!real) continue;
-        uint2 *o = (uint2 *)(out + r * kp);
+        uint2 *o = (uint2 *)(out + (long long)r * kp);
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = sl + LPR * j;
@@ -115,6 +120,38 @@ void launch_ln_window(const float *x, const Grid &g, int d, int kp, const float 
 }
 
 // q of a packed qkv buffer [rows, 3*C] (window order, window wh x ww) -> pooled q [rows/4, C]: 2x2 max.
+// Eight channels per thread (16-byte loads and stores) and 32-bit index arithmetic when C % 8 == 0 and the pooled tensor has < 2^32 elements; the
+// one-element-per-thread form with its three 64-bit divisions per 2-byte output (kept for odd widths) took 46-85 us on stage 1's 786 432 x 112 q.
+__global__ void __launch_bounds__(256) k_qpool8(const uint16_t *__restrict__ qkv, uint32_t total8, int wh, int ww, int C, uint16_t *__restrict__ qp) {
+    const uint32_t oh = wh / 2, ow = ww / 2, c8n = C / 8;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += gridDim.x * blockDim.x) {
+        const uint32_t t1 = i / c8n, c = (i - t1 * c8n) * 8;
+        const uint32_t t2 = t1 / ow, ox = t1 - t2 * ow;
+        const uint32_t win = t2 / oh, oy = t2 - win * oh;
+        const uint16_t *base = qkv + ((long long)win * wh * ww) * 3 * C + c;
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const uint4 v = *(const uint4 *)(base + ((long long)(2 * oy + dy) * ww + (2 * ox + dx)) * 3 * C);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    m[2 * e] = fmaxf(m[2 * e], __uint_as_float(w[e] << 16));
+                    m[2 * e + 1] = fmaxf(m[2 * e + 1], __uint_as_float(w[e] & 0xffff0000u));
+                }
+            }
+        uint4 o;                                                 // (a maximum of bf16 values is one of them: the upper halves are the result)
+        o.x = (__float_as_uint(m[0]) >> 16) | (__float_as_uint(m[1]) & 0xffff0000u);
+        o.y = (__float_as_uint(m[2]) >> 16) | (__float_as_uint(m[3]) & 0xffff0000u);
+        o.z = (__float_as_uint(m[4]) >> 16) | (__float_as_uint(m[5]) & 0xffff0000u);
+        o.w = (__float_as_uint(m[6]) >> 16) | (__float_as_uint(m[7]) & 0xffff0000u);
+        *(uint4 *)(qp + (long long)t1 * C + c) = o;
+    }
+}
 __global__ void __launch_bounds__(256) k_qpool(const uint16_t *__restrict__ qkv, long long n_windows, int wh, int ww, int C,
                                                uint16_t *__restrict__ qp) {
     const int oh = wh / 2, ow = ww / 2;
@@ -290,7 +327,7 @@ int gemm_from_f32(const float *x, const Grid &g, int d, int kp, const float *gam
         const ovo_window_t w = {g.B, g.H, g.W, g.wh, g.ww};
         const int rc = ovo_gemm_detail::gemm_f32a_stream(&q, g.ws > 0 ? &w : nullptr, x, d, gamma, beta, eps, mode, 0, s);
         if (rc != OVO_E_UNSUPPORTED) return rc;
-        OVO_REQUIRE(d <= 2048, "LayerNorm rows of more than 2048 columns");
+        OVO_REQUIRE(d <= 2048 && g.rows < (1ll << 31), "LayerNorm rows of more than 2048 columns / more than 2^31 rows");
         if (mode == 1) launch_ln_window(x, g, d, kp, gamma, beta, eps, h, (hipStream_t)s);
         else k_cast_pad<<<ovo_grid(g.rows * kp, 256), 256, 0, (hipStream_t)s>>>(x, g.rows, d, kp, h);
         h_done = true;
@@ -388,7 +425,12 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         a.k = k.qkv + dout; a.v = k.qkv + 2 * dout; a.o = k.att;
         a.k_sb = a.v_sb = (int64_t)tk * 3 * dout; a.k_sh = a.v_sh = hd; a.k_st = a.v_st = 3 * dout;
         if (p.pool[i]) {
-            if (!q_pooled) k_qpool<<<ovo_grid(n_win * tq * dout, 256), 256, 0, hs>>>(k.qkv, n_win, g.wh, g.ww, dout, k.qp);
+            if (!q_pooled) {
+                const long long total8 = n_win * tq * (dout / 8);
+                if (dout % 8 == 0 && total8 < (1ll << 32) && (((uintptr_t)k.qkv | (uintptr_t)k.qp) & 15) == 0)
+                    k_qpool8<<<ovo_grid(total8, 256, 256 * 16), 256, 0, hs>>>(k.qkv, (uint32_t)total8, g.wh, g.ww, dout, k.qp);
+                else k_qpool<<<ovo_grid(n_win * tq * dout, 256), 256, 0, hs>>>(k.qkv, n_win, g.wh, g.ww, dout, k.qp);
+            }
             a.q = k.qp; a.q_sb = (int64_t)tq * dout; a.q_sh = hd; a.q_st = dout;
         } else {
             a.q = k.qkv; a.q_sb = a.k_sb; a.q_sh = hd; a.q_st = 3 * dout;
