@@ -43,6 +43,10 @@ __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_grou
     const float *cl = cs + fq * 4;
     const int blocks = (g.M + 15) / 16;
     constexpr int WPB = NTHREADS / 64;
+    // (measured and dropped, round 4: the next block's A rows fetched as soon as this block's rows are packed into fragments, to fly under its products
+    //  and stores -- K = 256 products gained 4-7 % ((196608, 896, 256) 307 -> 294 us), K = 128 products lost 10-15 % to the wave of occupancy the extra
+    //  registers cost ((786432, 448, 128) 326 -> 367); a full second register set one block ahead spilled 88 registers.  These launches are write-heavy
+    //  streams -- 705 MB written for 352 MB read at (786432, 448, 128) -- at 3.2-3.5 TB/s of algorithmic bytes)
     for (int b = slot * WPB + wave; b < blocks; b += slots * WPB) {
         const int m = b * 16 + fr, mc = m < g.M ? m : g.M - 1;
         VT af[KS];
