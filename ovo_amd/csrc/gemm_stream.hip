@@ -3,8 +3,8 @@
 // tiled kernels (gemm.hip) ran them at ~2 TB/s: with 2-4 K-tiles a workgroup is all prologue and epilogue.  Here (skinny.h) a column
 // group of the weights (<= 256 columns, <= 128 KB) is LDS-resident for the life of a workgroup, every wave streams its own 16-row blocks
 // of A straight from global memory into MFMA fragments and finishes them in registers (bias, activation, residual, window -> spatial
-// row mapping, cast), with no barrier after the weights are in.  Column groups of one product run side by side (blockIdx.x % groups),
-// so the A rows they share meet in L2.
+// row mapping, cast), with no barrier after the weights are in.  Column groups of one product run side by side ON ONE XCD (see the
+// blockIdx mapping), so the A rows they share meet in that XCD's L2.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -20,7 +20,7 @@ namespace {
 // normalised bf16 copy of the stream is never written or read: k_ln_window / k_cast_pad and their 6 bytes per element of HBM traffic disappear for
 // the layers this kernel runs (Hiera stages 1-2, the FPN laterals of those stages, conv_s0 / conv_s1).
 template <int KS, int NT, typename VT, int NTHREADS, bool F32A = false>
-__global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_groups) {
+__global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_groups, int slots) {
     constexpr int K = KS * 32, NG = NT * 16;
     using S = ovo_skinny::Skinny<K, NG, VT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -29,7 +29,12 @@ __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_grou
     const float2 *lut = (g.act == 1 && g.gelu_lut) ? (const float2 *)(cs + NG + (F32A ? 2 * K : 0)) : nullptr;      // GELU table (gemm_common.h)
     if (lut) gelu_lut_fill((float2 *)lut, threadIdx.x, NTHREADS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    const int group = blockIdx.x % n_groups, slot = blockIdx.x / n_groups, slots = gridDim.x / n_groups;
+    // The column groups of one slot read the SAME rows of A: they must share an L2, i.e. sit on one XCD (workgroup i goes to XCD i % 8) and start
+    // together.  With group = i % n_groups, slot = i / n_groups the groups of a slot landed on DIFFERENT XCDs and every one of them fetched the rows
+    // itself (PMC, tools/pmc_shapes.py: (196608, 896, 256) fetched 404 MB for 100 MB of A -- four groups, four reads; these launches are HBM-bound)
+    const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+    const int group = within % n_groups, slot = (within / n_groups) * 8 + xcd;
+    if (slot >= slots) return;
     const int n0 = group * NG;
     S::load_w(smem, (const uint16_t *)g.W + (long long)n0 * g.ldw, g.ldw, tid, NTHREADS);
     for (int i = tid; i < NG; i += NTHREADS) cs[i] = g.bias ? g.bias[n0 + i] : 0.f;
@@ -224,7 +229,7 @@ int launch_stream(const GemmArgs &g, hipStream_t s) {
     static int gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     if (ovo_knobs_dynamic()) gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     gg.gelu_lut = !gelu_poly;
-    k_gemm_stream<KS, NT, VT, NTHREADS, F32A><<<slots * n_groups, NTHREADS, lds, s>>>(gg, n_groups);
+    k_gemm_stream<KS, NT, VT, NTHREADS, F32A><<<(slots + 7) / 8 * 8 * n_groups, NTHREADS, lds, s>>>(gg, n_groups, slots);
     if (prof) ovo_prof_end(s);
     return OVO_OK;
 }
