@@ -17,6 +17,7 @@ void ovo_set_error(const char *fmt, ...);
 bool ovo_prof_enabled();
 void ovo_prof_begin(int kind, double work, hipStream_t s);
 void ovo_prof_shape(int a, int b, int c);       // optional: shape of the launch just begun (OVO_PROF_DUMP lines)
+void ovo_prof_flags(int flags);            // optional: epilogue / operand variant of the launch just begun (gemm_common.h: gemm_flags), last field of an OVO_PROF_DUMP line
 void ovo_prof_bytes(double bytes);            // optional: algorithmic HBM bytes of the launch just begun (operands read once, result written once)
 void ovo_prof_end(hipStream_t s);
 

@@ -22,7 +22,7 @@ void ovo_set_error(const char *fmt, ...) {
 
 // ---- profiler: hipEvent pairs around the launches of a kernel family, on the launch stream --------------
 namespace {
-struct Rec { hipEvent_t a, b; int kind; double work, bytes; int shape[3]; };
+struct Rec { hipEvent_t a, b; int kind; double work, bytes; int shape[3], flags; };
 struct Prof {
     bool on = false;
     std::vector<Rec> recs;
@@ -38,7 +38,7 @@ struct Prof {
 bool ovo_prof_enabled() { return g_prof.on; }
 void ovo_prof_begin(int kind, double work, hipStream_t s) {
     if (!g_prof.on || g_prof.recs.size() >= (1u << 20)) return;
-    Rec r; r.kind = kind; r.work = work; r.bytes = 0; r.shape[0] = r.shape[1] = r.shape[2] = 0; r.a = g_prof.get(); r.b = g_prof.get();
+    Rec r; r.kind = kind; r.work = work; r.bytes = 0; r.shape[0] = r.shape[1] = r.shape[2] = 0; r.flags = 0; r.a = g_prof.get(); r.b = g_prof.get();
     if (!r.a || !r.b) return;
     (void)hipEventRecord(r.a, s);
     g_prof.recs.push_back(r);
@@ -47,6 +47,10 @@ void ovo_prof_shape(int a, int b, int c) {
     if (!g_prof.on || g_prof.recs.empty()) return;
     Rec &r = g_prof.recs.back();
     r.shape[0] = a; r.shape[1] = b; r.shape[2] = c;
+}
+void ovo_prof_flags(int flags) {
+    if (!g_prof.on || g_prof.recs.empty()) return;
+    g_prof.recs.back().flags = flags;
 }
 void ovo_prof_bytes(double bytes) {
     if (!g_prof.on || g_prof.recs.empty()) return;
@@ -103,7 +107,7 @@ int ovo_profile_stop(double *ms, double *work, int64_t *launches, int n_kinds) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess || r.kind >= n_kinds) continue;
         ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1; g_last_bytes[r.kind] += r.bytes;
-        if (dump) fprintf(dump, "%d %d %d %d %.0f %.4f\n", r.kind, r.shape[0], r.shape[1], r.shape[2], r.work, t);
+        if (dump) fprintf(dump, "%d %d %d %d %.0f %.4f %d\n", r.kind, r.shape[0], r.shape[1], r.shape[2], r.work, t, r.flags);
     }
     if (dump) fclose(dump);
     g_prof.recs.clear();

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "gemm_common.h"
+#include "gemm_tuned.h"
 
 using namespace ovo_gemm_detail;
 
@@ -215,11 +216,11 @@ template <int BM, int BN> struct Stages { static constexpr int value = (BM == 12
 
 // environment knobs of the dispatcher (see ovo_knobs_dynamic)
 struct GemmKnobs {
-    bool no_chunk, w4, no_ns2, no_stream, no_8p, has_tile;
+    bool no_chunk, w4, no_ns2, no_stream, no_8p, no_tuned, has_tile;
     char tile[16];
     void read() {
         no_chunk = getenv("OVO_GEMM_NO_CHUNK"); w4 = getenv("OVO_GEMM_W4"); no_ns2 = getenv("OVO_GEMM_NO_NS2");
-        no_stream = getenv("OVO_GEMM_NO_STREAM"); no_8p = getenv("OVO_GEMM_NO_8P");
+        no_stream = getenv("OVO_GEMM_NO_STREAM"); no_8p = getenv("OVO_GEMM_NO_8P"); no_tuned = getenv("OVO_GEMM_NO_TUNED");
         const char *t = getenv("OVO_GEMM_TILE");
         has_tile = t != nullptr;
         snprintf(tile, sizeof(tile), "%s", t ? t : "");
@@ -248,7 +249,7 @@ int launch(const GemmArgs &g0, hipStream_t s) {
         attr_done = true;
     }
     const bool prof = ovo_prof_enabled();
-    if (prof) { ovo_prof_begin(4 + (BM == 128 ? 0 : 2) + (BN == 128 ? 0 : 1), 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }   // kinds 4..7: 128x128, 128x64, 64x128, 64x64
+    if (prof) { ovo_prof_begin(4 + (BM == 128 ? 0 : 2) + (BN == 128 ? 0 : 1), 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_flags(gemm_flags(g)); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }   // kinds 4..7: 128x128, 128x64, 64x128, 64x64
     // Chunked order pays when the A panels outweigh the weights (M > N: per-XCD fills A/8 + W instead of A + W/8) or when
     // the n-tile count is not a multiple of 8 (round-robin then spreads every panel over every L2).
     g.tiles = nbm * g.nbn;
@@ -300,6 +301,15 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
     // Tall short-K products are HBM streams: the weights-resident streaming kernel (gemm_stream.hip) runs them at 3+ TB/s, the tiled
     // kernels below at ~2 (tools/gemm_bench.py, profiles/r02c_gemm_stream.txt).
     const char *force_tile = kn.has_tile ? kn.tile : nullptr;
+    if (!force_tile && !kn.no_tuned) {                               // measured choices first (gemm_tuned.h, tools/gemm_tune.py); family knobs still win
+        const int f = gemm_flags(g);
+        for (const TunedTile &e : kTunedTiles)
+            if (e.M == g.M && e.N == g.N && e.K == g.K && e.flags == f && e.tile) {
+                const bool is8p = e.tile[0] == '2', is_stream = e.tile[0] == 's';
+                if (!(is8p && kn.no_8p) && !(is_stream && kn.no_stream)) force_tile = e.tile;
+                break;
+            }
+    }
     if (g.M >= 16384 && g.K <= 256 && ((!force_tile && !kn.no_stream) || (force_tile && !strcmp(force_tile, "stream")))) {
         const int rc = gemm_stream_launch(g, std::is_same<VT, bf16x8>::value ? 2 : 1, s);
         if (rc != OVO_E_UNSUPPORTED) return rc;

@@ -421,7 +421,7 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
         attr_done = true;
     }
     const bool prof = ovo_prof_enabled();
-    if (prof) { ovo_prof_begin(BN == 256 ? 3 : 0, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }     // kinds 3 / 0: 256x256 / 256x128
+    if (prof) { ovo_prof_begin(BN == 256 ? 3 : 0, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_flags(gemm_flags(g)); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }     // kinds 3 / 0: 256x256 / 256x128
     g.tiles = nbm * g.nbn;
     g.chunk = (g.M > g.N || g.nbn % 8 != 0) && !no_chunk ? (g.tiles + 7) / 8 : 0;
     // tile order: measured to matter little (the K-loop is bound by the L2->LDS arrival rate, not by L2 misses); column strips of 8 n-tiles

@@ -397,7 +397,7 @@ int launch8q(const GemmArgs &g0, hipStream_t s) {
         attr_done = true;
     }
     const bool prof = ovo_prof_enabled();
-    if (prof) { ovo_prof_begin(0, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }     // kind 0: the 256 x 128 tile
+    if (prof) { ovo_prof_begin(0, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_flags(gemm_flags(g)); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }     // kind 0: the 256 x 128 tile
     g.tiles = nbm * g.nbn;
     g.chunk = (g.tiles + 7) / 8;                          // XCD x walks tiles [x chunk, (x + 1) chunk)
     g.strip = 0;

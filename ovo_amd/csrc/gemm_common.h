@@ -223,6 +223,13 @@ __device__ __forceinline__ void finish_best(const GemmArgs &g, int m, int fq, fl
     }
 }
 
+// variant of a product as the profiler and the tuned-tile table (gemm_tuned.h) see it: bit 0 f32 output, 1 residual add, 2-3 activation, 4 rotary epilogue,
+// 5 window remap of the output / residual rows, 6 f32 A with LayerNorm / cast in the load, 7 fused argmax, 8 periodic residual
+inline int gemm_flags(const GemmArgs &g) {
+    return (g.out_dtype == 0 ? 1 : 0) | (g.add ? 2 : 0) | ((g.act & 3) << 2) | (g.rope_cos ? 16 : 0) | (g.win_per > 0 ? 32 : 0) | (g.ln_mode ? 64 : 0) |
+           (g.best ? 128 : 0) | (g.add_rows > 0 ? 256 : 0);
+}
+
 // algorithmic HBM bytes of a product: every operand read once, the result written once (what PMC traffic is compared with, bench.py roofline)
 inline double gemm_algorithmic_bytes(const GemmArgs &g) {
     const double mn = (double)g.M * g.N, a_bytes = g.ln_mode ? (double)g.M * g.ln_d * 4.0 : (double)g.M * g.K * 2.0;

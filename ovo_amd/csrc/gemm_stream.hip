@@ -224,7 +224,7 @@ int launch_stream(const GemmArgs &g, hipStream_t s) {
     if (slots > need) slots = need;
     if (slots < 1) slots = 1;
     const bool prof = ovo_prof_enabled();
-    if (prof) { ovo_prof_begin(8, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }
+    if (prof) { ovo_prof_begin(8, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_flags(gemm_flags(g)); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }
     GemmArgs gg = g;
     static int gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     if (ovo_knobs_dynamic()) gelu_poly = getenv("OVO_GELU_POLY") != nullptr;

@@ -36,7 +36,7 @@ if os.environ.get("OVO_PROF_DUMP"):
     L.check(lib.ovo_profile_stop(ms, work, n, 9))
     agg = collections.OrderedDict()
     for line in open(os.environ["OVO_PROF_DUMP"]):
-        k, a, b, c, w, t = line.split(); e = agg.setdefault((int(k), int(a), int(b), int(c)), [0, 0.0, 0.0]); e[0] += 1; e[1] += float(t); e[2] += float(w)
+        k, a, b, c, w, t = line.split()[:6]; e = agg.setdefault((int(k), int(a), int(b), int(c)), [0, 0.0, 0.0]); e[0] += 1; e[1] += float(t); e[2] += float(w)
     for (k, a, b, c), (cnt, t, w) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
         print(f"kind {k} shape {(a, b, c)!s:26s} x{cnt:3d} {1e3 * t / cnt:9.1f} us  total {t:7.3f} ms  {w / t / 1e9:7.0f} TF")
     print("gemm+attn ms:", sum(ms))

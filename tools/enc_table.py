@@ -26,7 +26,7 @@ ms, work, n = (C.c_double * 9)(), (C.c_double * 9)(), (C.c_int64 * 9)()
 L.check(lib.ovo_profile_stop(ms, work, n, 9))
 rows = defaultdict(lambda: [0, 0.0, 0.0])
 for line in open(dump):
-    k, a, b, c, w, t = line.split()
+    k, a, b, c, w, t = line.split()[:6]
     e = rows[(int(k), int(a), int(b), int(c))]
     e[0] += 1; e[1] += float(t); e[2] += float(w)
 names = {0: "256x128", 3: "256x256", 4: "128x128", 5: "128x64", 6: "64x128", 7: "64x64", 8: "stream", 1: "attn", 2: "track"}
