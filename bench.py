@@ -73,7 +73,10 @@ def parse():
     ap.add_argument("--dense-merge", choices=("auto", "none", "reduce"), default="auto",
                     help="N > 1: also time north_star's literal collective -- ONE bucketed RCCL sum-reduce of whole per-GPU dense accumulators "
                          "f32[map_points, D] (parallel.allreduce_dense_) -- beside the sharded design the keyframe path uses (auto = reduce when N > 1)")
-    ap.add_argument("--profile-steps", type=int, default=8)
+    ap.add_argument("--profile-steps", type=int, default=24,
+                    help="steps of each of the two profiled passes behind `roofline` (as run / isolated); two whole look-ahead groups at the default "
+                         "--encoder-batch 12, so the profiled launches have the timed region's shapes (8 steps profiled 4-keyframe forwards: all GEMMs "
+                         "555 TFLOP/s isolated against 603 at the timed shapes on one box)")
     ap.add_argument("--projection-world", type=int, default=8, help="N = 1 only: after the timed legs, ONE GPU emulates rank 0 of a job of this many GPUs "
                     "(its own keyframe's encoders + every keyframe's replicated passes + 1/N of the dense rows, all-gather replaced by a local copy) "
                     "and reports the round time under `projection` (0 = off)")
