@@ -80,8 +80,8 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int fr = lane & 15, fq = lane >> 4;
     // GELU table (gemm_common.h) behind the K-tile ring AND the epilogue slabs: filled now, first read after the K-loop's last barrier
-    constexpr int LUT_OFF = (STAGED && 8 * (BM / WARPS_M / 2) * ((BN / (8 / WARPS_M)) * 4 + 16) > 2 * (BM + BN) * 128) ? 8 * (BM / WARPS_M / 2) * ((BN / (8 / WARPS_M)) * 4 + 16)
-                                                                                                                        : 2 * (BM + BN) * 128;
+    constexpr int SLAB32 = 8 * (BM / WARPS_M / 2) * ((BN / (8 / WARPS_M)) * 4 + 16), SLAB16 = 8 * (BM / WARPS_M) * ((BN / (8 / WARPS_M)) * 2 + 16), RING = 2 * (BM + BN) * 128;
+    constexpr int LUT_OFF = STAGED ? (SLAB32 > RING ? (SLAB32 > SLAB16 ? SLAB32 : SLAB16) : (SLAB16 > RING ? SLAB16 : RING)) : RING;
     const float2 *lut = (STAGED && g.act == 1 && g.gelu_lut) ? (const float2 *)(smem + LUT_OFF) : nullptr;
     if (lut) gelu_lut_fill((float2 *)(smem + LUT_OFF), tid, 512);
 #ifdef OVO_GEMM_DEBUG        // tools/ builds only (python -m ovo_amd.build --gemm-debug): early exits, per-phase time stamps, de-phased starts
@@ -249,6 +249,88 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
         //  373.6 -> 362.1 frames/s: sixteen stores per wave issued back to back by all 2048 waves of the chip drain slower than the same stores spread
         //  out by the slab passes.  Debug bits 4 / 8 split this epilogue's 7.9 us of a K = 1024 round into 5.0 us LDS + arithmetic and 2.9 us stores.)
         OVO_BARRIER();                                    // every wave's LDS-DMA has landed and every fragment read is done: LDS is free
+        // epilogue kinds with a branch-free body in the accumulator layout (32 copies of the generic math4 -- every activation, rotary, residual -- were
+        // 15 000 instructions of straight-line code: the 256 x 256 tile's epilogue ran out of the instruction cache and LOST 7 us): 0 plain, 1 table GELU, 2 rotary (OVO_8P_SLAB16=2 only: its 64 table loads per lane
+        // in this layout -- 16 rows x 64 bytes per instruction -- measured 114.9 us against 103.0 for the row-layout loop below on the ViT's QKV)
+        const int kind16 = (g.out_dtype != 0 && !g.add && g.slab16) ? ((g.act == 0 && !g.rope_cos) ? 0 : ((g.act == 1 && lut && !g.rope_cos) ? 1 : ((g.act == 0 && g.rope_cos && g.slab16 > 1) ? 2 : -1))) : -1;
+        if (kind16 >= 0) {
+            // 2-byte outputs without a residual: bias / activation / rotary are applied in the accumulator layout (a lane's 4 consecutive columns) and the
+            // tile crosses LDS already ROUNDED -- half the slab bytes of the f32 form below, and the whole wave tile fits one pass (8 x 128 rows x 144 B).
+            // Row stride 144 B = 36 dwords: the 16 rows x 8-byte pieces of a ds_write_b64 half-wave cover the 64 banks once (36 fr mod 64 = 16 distinct
+            // multiples of 4); reads pair rows r and r + 8 in one 16-lane group (8 x 36 = 32 mod 64: the two rows' 128 bytes take opposite halves).
+            constexpr int RB2 = WTN * 2 + 16, WROWS = 2 * HM;
+            static_assert(WTN == 64, "read mapping below: 8 lanes x 16 bytes per row");
+            char *slab = smem + wave * (WROWS * RB2);
+            const int nw = n0 + wc * WTN;
+            float4 bias_r[2 * TNH];
+            int nh_r[2 * TNH];
+#pragma unroll
+            for (int j = 0; j < 2 * TNH; ++j) {
+                const int n = nw + j * 16 + fq * 4;
+                bias_r[j] = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                nh_r[j] = g.rope_cos ? n % g.rope_hd : 0;
+            }
+            auto write_all = [&](auto KIND_) {
+                constexpr int KIND = decltype(KIND_)::value;
+                int tok = 0, tstep = 0;
+                if (KIND == 2) { tok = (m0 + wr * WTM + fr) % g.rope_T; tstep = 16 % g.rope_T; }
+                static_for<0, 2 * TMH>([&](auto I_) {
+                    constexpr int i = decltype(I_)::value;
+                    const int tk = tok;
+                    if (KIND == 2) { tok += tstep; if (tok >= g.rope_T) tok -= g.rope_T; }
+#pragma unroll
+                    for (int j = 0; j < 2 * TNH; ++j) {
+                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] *= g.alpha;                    // (the operations of math4, in its order)
+                        v[0] += bias_r[j].x; v[1] += bias_r[j].y; v[2] += bias_r[j].z; v[3] += bias_r[j].w;
+                        if (KIND == 1) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_lut(v[r], lut);
+                        }
+                        if (KIND == 2) {
+                            const int n = nw + j * 16 + fq * 4;
+                            if (n < g.rope_cols && tk >= g.rope_t0) {
+                                const long long at = (long long)tk * g.rope_hd + nh_r[j];
+                                const float4 cc = *(const float4 *)(g.rope_cos + at), sn = *(const float4 *)(g.rope_sin + at);
+                                const float y0 = v[0] * cc.x - v[1] * sn.x, y1 = v[1] * cc.y + v[0] * sn.y;
+                                const float y2 = v[2] * cc.z - v[3] * sn.z, y3 = v[3] * cc.w + v[2] * sn.w;
+                                v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
+                            }
+                        }
+                        uint2 p;
+                        if (g.out_dtype == 2) { p.x = pack_bf16(v[0], v[1]); p.y = pack_bf16(v[2], v[3]); }
+                        else { p.x = pack_f16(v[0], v[1]); p.y = pack_f16(v[2], v[3]); }
+                        *(uint2 *)(slab + (i * 16 + fr) * RB2 + (j * 16 + fq * 4) * 2) = p;
+                    }
+                });
+            };
+            if (kind16 == 0) write_all(std::integral_constant<int, 0>{});
+            else if (kind16 == 1) write_all(std::integral_constant<int, 1>{});
+            else write_all(std::integral_constant<int, 2>{});
+            OVO_FENCE();
+            const int q = lane >> 3, c = (lane & 7) * 8, n = nw + c;
+            const bool in0 = n < g.N, in1 = n + 4 < g.N;
+#pragma unroll 4
+            for (int it = 0; it < WROWS / 8; ++it) {
+                const int r = 16 * (it >> 1) + 4 * (it & 1) + (q >> 1) + 8 * (q & 1), m = m0 + wr * WTM + r;
+                const uint4 p = *(const uint4 *)(slab + r * RB2 + c * 2);
+                const long long md = (m < g.M && in0) ? row_dest(g, m) : -1;
+                if (md < 0) continue;
+                uint16_t *dst = (uint16_t *)g.C + md * g.ldc + n;
+#ifdef OVO_GEMM_DEBUG
+                if ((g.dbg & 8) && p.x != 0x12345678u) continue;
+#endif
+                if (in1 && ((uintptr_t)dst & 15) == 0) __builtin_nontemporal_store(*(const __attribute__((ext_vector_type(4))) unsigned *)&p, (__attribute__((ext_vector_type(4))) unsigned *)dst);
+                else {
+                    *(uint2 *)dst = make_uint2(p.x, p.y);
+                    if (in1) *(uint2 *)(dst + 4) = make_uint2(p.z, p.w);
+                }
+            }
+            if (g.tail_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(3);
+            return;
+        }
         constexpr int ROWB = WTN * 4 + 16;
         char *slab = smem + wave * (HM * ROWB);
 #pragma unroll
@@ -406,6 +488,10 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     if (ovo_knobs_dynamic()) { no_chunk = getenv("OVO_GEMM_NO_CHUNK") != nullptr; strip_env = getenv("OVO_GEMM_STRIP") ? atoi(getenv("OVO_GEMM_STRIP")) : -1;
                                tail_wait = getenv("OVO_8P_TAILWAIT") ? atoi(getenv("OVO_8P_TAILWAIT")) : 0; }
     g.tail_wait = tail_wait;
+    auto read_slab16 = [] { return getenv("OVO_8P_NO_SLAB16") ? 0 : (getenv("OVO_8P_SLAB16") ? atoi(getenv("OVO_8P_SLAB16")) : 1); };
+    static int slab16 = read_slab16();
+    if (ovo_knobs_dynamic()) slab16 = read_slab16();
+    g.slab16 = slab16;
     static int gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     if (ovo_knobs_dynamic()) gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     g.gelu_lut = !gelu_poly;
@@ -413,7 +499,9 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     const int nbm = (g.M + BM - 1) / BM;
     constexpr size_t ring = 2 * (size_t)(BM + BN) * 128;                                  // two K-tile buffers
     constexpr size_t slabs = 8 * (size_t)(BM / WARPS_M / 2) * ((BN / (8 / WARPS_M)) * 4 + 16);     // epilogue: 8 x HM rows x (4 WTN + 16) bytes
-    constexpr size_t lds = (STAGED && slabs > ring ? slabs : ring) + (STAGED ? GELU_LUT_BYTES : 0);
+    constexpr size_t slabs16 = 8 * (size_t)(BM / WARPS_M) * ((BN / (8 / WARPS_M)) * 2 + 16);                   // 2-byte epilogue: 8 x WTM rows x (2 WTN + 16) bytes
+    constexpr size_t lds = (STAGED ? (slabs > ring ? (slabs > slabs16 ? slabs : slabs16) : (slabs16 > ring ? slabs16 : ring)) : ring) + (STAGED ? GELU_LUT_BYTES : 0);
+    static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_done = false;              // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)k_gemm8p<BM, BN, WARPS_M, VT, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
