@@ -331,8 +331,31 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
             stamp(3);
             return;
         }
+        // The f32-slab form, instantiated per epilogue KIND so that the two forms the encoders run all day are branch-free and short (see kind16 above:
+        // code size decides here): 3 = f32 output += f32 residual (out projection / FC2), 2 = 2-byte output with rotary (the ViT's QKV), -1 = anything
+        // (math4 with every activation, either output type).
         constexpr int ROWB = WTN * 4 + 16;
         char *slab = smem + wave * (HM * ROWB);
+        auto rows_out = [&](auto KIND_) {
+        constexpr int KIND = decltype(KIND_)::value;
+        auto mathk = [&](int tk, int nh, int n, float (&v)[4], float4 bias, float4 addv) __attribute__((always_inline)) {
+            if constexpr (KIND < 0) math4(g, tk, nh, n, v, bias, addv, lut);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= g.alpha;            // (math4's operations, in its order)
+                v[0] += bias.x; v[1] += bias.y; v[2] += bias.z; v[3] += bias.w;
+                if constexpr (KIND == 2) {
+                    if (n < g.rope_cols && tk >= g.rope_t0) {
+                        const long long at = (long long)tk * g.rope_hd + nh;
+                        const float4 c = *(const float4 *)(g.rope_cos + at), sn = *(const float4 *)(g.rope_sin + at);
+                        const float y0 = v[0] * c.x - v[1] * sn.x, y1 = v[1] * c.y + v[0] * sn.y;
+                        const float y2 = v[2] * c.z - v[3] * sn.z, y3 = v[3] * c.w + v[2] * sn.w;
+                        v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
+                    }
+                }
+                if constexpr (KIND == 3) { v[0] += addv.x; v[1] += addv.y; v[2] += addv.z; v[3] += addv.w; }
+            }
+        };
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -342,12 +365,12 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     *(f32x4 *)(slab + (i * 16 + fr) * ROWB + (j * 16 + fq * 4) * 4) = acc[pass * TMH + i][j];
             OVO_FENCE();
             const int mw = m0 + wr * WTM + pass * HM, nw = n0 + wc * WTN;
-            if (g.out_dtype == 0) {                       // f32 rows: 16 lanes x 16 bytes per row, 4 rows per instruction
+            if (KIND == 3 || (KIND < 0 && g.out_dtype == 0)) {                       // f32 rows: 16 lanes x 16 bytes per row, 4 rows per instruction
                 constexpr int LPR = WTN / 4, RPI = 64 / LPR;
                 const int c = (lane % LPR) * 4, n = nw + c;
                 const float4 bias = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 int tok = 0, nh = 0, tstep = 0;           // rotary position of the lane's row, advanced RPI rows per trip
-                if (g.rope_cos) { tok = (mw + lane / LPR) % g.rope_T; nh = n % g.rope_hd; tstep = RPI % g.rope_T; }
+                if (KIND < 0 && g.rope_cos) { tok = (mw + lane / LPR) % g.rope_T; nh = n % g.rope_hd; tstep = RPI % g.rope_T; }
 #pragma unroll 4
                 for (int it = 0; it < HM / RPI; ++it) {
                     const int r = it * RPI + lane / LPR, m = mw + r, tk = tok;
@@ -356,9 +379,9 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     const f32x4 a = *(const f32x4 *)(slab + r * ROWB + c * 4);
                     const long long md = (m < g.M && n < g.N) ? row_dest(g, m) : -1;
                     if (md < 0) continue;
-                    const float4 addv = g.add ? *(const float4 *)(g.add + add_row(g, m, md) * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 addv = (KIND == 3 || g.add) ? *(const float4 *)(g.add + add_row(g, m, md) * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                     float v[4] = {a[0], a[1], a[2], a[3]};
-                    math4(g, tk, nh, n, v, bias, addv, lut);
+                    mathk(tk, nh, n, v, bias, addv);
                     { const f32x4 vv = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(vv, (f32x4 *)((float *)g.C + md * g.ldc + n)); }
                 }
             } else {                                      // 2-byte rows: 8 lanes x 16 bytes per row, 8 rows per instruction
@@ -368,7 +391,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                 const float4 bias0 = (g.bias && in0) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 bias1 = (g.bias && in1) ? *(const float4 *)(g.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 int tok = 0, nh0 = 0, nh1 = 0, tstep = 0;
-                if (g.rope_cos) { tok = (mw + lane / LPR) % g.rope_T; nh0 = n % g.rope_hd; nh1 = (n + 4) % g.rope_hd; tstep = RPI % g.rope_T; }
+                if (KIND == 2 || (KIND < 0 && g.rope_cos)) { tok = (mw + lane / LPR) % g.rope_T; nh0 = n % g.rope_hd; nh1 = (n + 4) % g.rope_hd; tstep = RPI % g.rope_T; }
 #pragma unroll 4
                 for (int it = 0; it < HM / RPI; ++it) {
                     const int r = it * RPI + lane / LPR, m = mw + r, tk = tok;
@@ -378,14 +401,14 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     const long long md = (m < g.M && in0) ? row_dest(g, m) : -1;
                     if (md < 0) continue;
                     float4 add0 = make_float4(0.f, 0.f, 0.f, 0.f), add1 = add0;
-                    if (g.add) {
+                    if (KIND < 0 && g.add) {
                         const float *ap = g.add + add_row(g, m, md) * g.ld_add + n;
                         add0 = *(const float4 *)ap;
                         if (in1) add1 = *(const float4 *)(ap + 4);
                     }
                     float v0[4] = {a0[0], a0[1], a0[2], a0[3]}, v1[4] = {a1[0], a1[1], a1[2], a1[3]};
-                    math4(g, tk, nh0, n, v0, bias0, add0, lut);
-                    math4(g, tk, nh1, n + 4, v1, bias1, add1, lut);
+                    mathk(tk, nh0, n, v0, bias0, add0);
+                    mathk(tk, nh1, n + 4, v1, bias1, add1);
                     uint4 p;
                     if (g.out_dtype == 2) { p.x = pack_bf16(v0[0], v0[1]); p.y = pack_bf16(v0[2], v0[3]); p.z = pack_bf16(v1[0], v1[1]); p.w = pack_bf16(v1[2], v1[3]); }
                     else { p.x = pack_f16(v0[0], v0[1]); p.y = pack_f16(v0[2], v0[3]); p.z = pack_f16(v1[0], v1[1]); p.w = pack_f16(v1[2], v1[3]); }
@@ -404,6 +427,10 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
             }
             OVO_FENCE();                                  // the slab is rewritten by the next pass: its reads above come first (same wave)
         }
+        };
+        if (g.out_dtype == 0 && g.add && g.act == 0 && !g.rope_cos) rows_out(std::integral_constant<int, 3>{});
+        else if (g.out_dtype != 0 && !g.add && g.act == 0 && g.rope_cos) rows_out(std::integral_constant<int, 2>{});
+        else rows_out(std::integral_constant<int, -1>{});
     } else {
         // ---- epilogue straight from the accumulators (the fused-argmax form needs a row's columns in neighbouring lanes):
         // acc[i][j][r] = C[m = m0 + wr WTM + 16 i + fr][n = n0 + wc WTN + 16 j + 4 fq + r]

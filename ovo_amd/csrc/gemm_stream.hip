@@ -117,7 +117,18 @@ __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_grou
             const f32x4 bv = *(const f32x4 *)(cl + j * 16);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[j][r] * g.alpha + bv[r];
-            if (g.act) act4(v, g.act, lut);
+            // GELU or nothing (the launch refuses other activations: the tiled kernels take them).  The generic act4 -- six activations, inlined into every
+            // one of the NT column tiles of four epilogue forms -- made these kernels 26-40 K instructions long; the block loop ran out of the
+            // instruction cache: (196608, 896, 256) 290 -> 246 us, (196608, 672, 256) 321 -> 271 with this body
+            if (g.act) {
+                if (lut) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_lut(v[r], lut);
+                } else {
+                    const f32x2 a = gelu2(f32x2{v[0], v[1]}), b = gelu2(f32x2{v[2], v[3]});
+                    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+                }
+            }
             if (ap) {
                 const f32x4 r = *(const f32x4 *)(ap + j * 16);
                 v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
@@ -240,7 +251,7 @@ namespace ovo_gemm_detail {
 
 // Returns OVO_E_UNSUPPORTED when the shape has no instantiation (the caller then takes a tiled kernel).
 int gemm_stream_launch(const GemmArgs &g, int in_dtype, hipStream_t s) {
-    if (g.best || g.rope_cos || in_dtype != 2) return OVO_E_UNSUPPORTED;
+    if (g.best || g.rope_cos || in_dtype != 2 || g.act > 1) return OVO_E_UNSUPPORTED;
     if (g.M < 16384 || ((uintptr_t)g.C & 15) != 0 || g.ldc % 4 != 0) return OVO_E_UNSUPPORTED;
     // column groups: the widest of 256 / 224 / 112 / 64 / 32 that divides N (hiera_b+'s 112-multiples, powers of two); 288 / 144 for
     // hiera_l's stage 1 (K = 192: 144 channels padded)
@@ -283,7 +294,7 @@ int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *
     if (!p || !x || p->in_dtype != 2 || p->M < 16384 || p->K > 256 || d <= 0 || d % 8 != 0 || d > p->K || (mode != 1 && mode != 2) ||
         (mode == 1 && (!gamma || !beta)) || ((uintptr_t)x & 15) != 0 || stream_off())
         return OVO_E_UNSUPPORTED;
-    if (p->ldw % 8 != 0 || ((uintptr_t)p->W & 15) != 0 || (p->bias && ((uintptr_t)p->bias & 15) != 0) || p->add || p->N % 4 != 0 || p->K % 32 != 0)
+    if (p->ldw % 8 != 0 || ((uintptr_t)p->W & 15) != 0 || (p->bias && ((uintptr_t)p->bias & 15) != 0) || p->add || p->N % 4 != 0 || p->K % 32 != 0 || p->act > 1)
         return OVO_E_UNSUPPORTED;
     GemmArgs g = {};
     g.A = nullptr; g.lda = 0; g.W = (const char *)p->W; g.ldw = p->ldw; g.bias = p->bias;
