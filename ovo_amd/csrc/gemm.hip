@@ -151,7 +151,11 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
 #endif
     }
 
-    // epilogue: acc[i][j][r] = C[m = m0+wm0+16i+fr][n = n0+wn0+16j+4fq+r]
+    // epilogue: acc[i][j][r] = C[m = m0+wm0+16i+fr][n = n0+wn0+16j+4fq+r].  One body per KIND, so that the forms the encoders launch hundreds of times per
+    // frame are short and branch-free (every activation + rotary + argmax inlined into each of the TM x TN tiles is cold code fetched per workgroup):
+    // 0 = 2-byte output, bias only; 1 = 2-byte output, GELU; 3 = f32 output += f32 residual; -1 = everything else
+    auto epilogue = [&](auto KIND_) {
+    constexpr int KIND = decltype(KIND_)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm0 + i * 16 + fr;
@@ -166,8 +170,13 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
             v[0] += bias_r[j].x; v[1] += bias_r[j].y; v[2] += bias_r[j].z; v[3] += bias_r[j].w;
-            if (g.act) act4(v, g.act);
-            if (g.rope_cos && n < g.rope_cols) {
+            if constexpr (KIND == 1) {
+                const f32x2 ga = gelu2(f32x2{v[0], v[1]}), gb = gelu2(f32x2{v[2], v[3]});
+                v[0] = ga.x; v[1] = ga.y; v[2] = gb.x; v[3] = gb.y;
+            } else if constexpr (KIND < 0) {
+                if (g.act) act4(v, g.act);
+            }
+            if (KIND < 0 && g.rope_cos && n < g.rope_cols) {
                 // rotary embedding of the (2i, 2i+1) pairs this lane holds: row = token m % T, column within the head n % hd
                 const int t = m % g.rope_T;
                 if (t >= g.rope_t0) {
@@ -178,14 +187,14 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
                     v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
                 }
             }
-            if (g.add) { v[0] += add_r[i][j].x; v[1] += add_r[i][j].y; v[2] += add_r[i][j].z; v[3] += add_r[i][j].w; }
-            if (g.best) {
+            if (KIND == 3 || (KIND < 0 && g.add)) { v[0] += add_r[i][j].x; v[1] += add_r[i][j].y; v[2] += add_r[i][j].z; v[3] += add_r[i][j].w; }
+            if (KIND < 0 && g.best) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (n + r < g.n_valid && v[r] > row_best) { row_best = v[r]; row_arg = n + r; }   // ascending columns: ties keep the first
                 if (!g.store) continue;
             }
-            if (g.out_dtype == 0) {
+            if (KIND == 3 || (KIND < 0 && g.out_dtype == 0)) {
                 *(float4 *)((float *)g.C + md[i] * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 uint2 p;
@@ -194,7 +203,7 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
                 *(uint2 *)((uint16_t *)g.C + md[i] * g.ldc + n) = p;
             }
         }
-        if (g.best) {
+        if (KIND < 0 && g.best) {
             // the row's columns of this wave tile sit in the 4 lanes that share fr: two xor-shuffles, then ONE 64-bit atomicMax per
             // row and wave on (order-preserving float bits << 32 | ~column): larger score wins, equal scores keep the smaller column
 #pragma unroll
@@ -210,6 +219,12 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
             }
         }
     }
+    };
+    const bool simple = !g.best && !g.rope_cos;
+    if (simple && g.out_dtype != 0 && !g.add && g.act == 0) epilogue(std::integral_constant<int, 0>{});
+    else if (simple && g.out_dtype != 0 && !g.add && g.act == 1) epilogue(std::integral_constant<int, 1>{});
+    else if (simple && g.out_dtype == 0 && g.add && g.act == 0) epilogue(std::integral_constant<int, 3>{});
+    else epilogue(std::integral_constant<int, -1>{});
 }
 
 template <int BM, int BN> struct Stages { static constexpr int value = (BM == 128 && BN == 128) || (BM == 64 && BN == 64) ? 4 : 3; };

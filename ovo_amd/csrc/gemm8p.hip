@@ -242,17 +242,19 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
         // such groups per lane the store ISSUE (one request per row segment) cost more than the K-loop of a K = 1024 tile.  Instead each
         // wave transposes its tile through a private LDS slab (two passes of HM rows, rows padded by 16 bytes against bank conflicts)
         // and then reads rows back so that every store / residual load instruction covers whole 128-256-byte row segments.
-        // (measured and dropped, round 4: 2-byte outputs WITHOUT the LDS round trip -- the lane's 4 columns of two neighbouring accumulator tiles packed
-        //  and traded with v_permlane16_swap (8 consecutive columns per lane), then the two 32-column halves traded between lanes fr and fr ^ 8 (DPP
-        //  row_ror:8) so that a 16-byte store per lane covers 8 rows x 128 bytes exactly as below; bit-identical, no barrier, no LDS.  256 x 128 tiles
-        //  gained 2-3 % (8192 x 2048 x 1024: 39.5 -> 37.8 us), 256 x 256 tiles LOST 15 % (34.8 -> 40.8 us; 13848 x 4096 x 1024 118.5 -> 147.8), the bench
-        //  373.6 -> 362.1 frames/s: sixteen stores per wave issued back to back by all 2048 waves of the chip drain slower than the same stores spread
-        //  out by the slab passes.  Debug bits 4 / 8 split this epilogue's 7.9 us of a K = 1024 round into 5.0 us LDS + arithmetic and 2.9 us stores.)
-        OVO_BARRIER();                                    // every wave's LDS-DMA has landed and every fragment read is done: LDS is free
+        // (measured and dropped, round 4: 2-byte outputs WITHOUT any LDS round trip -- the lane's 4 columns of two neighbouring accumulator tiles packed and
+        //  traded with v_permlane16_swap (8 consecutive columns per lane), then the two 32-column halves traded between lanes fr and fr ^ 8 (DPP row_ror:8) so
+        //  that a 16-byte store per lane covers 8 rows x 128 bytes; no barrier, bit-identical.  With the generic math4 inlined 32 times it lost 15 % on the
+        //  256 x 256 tile (instruction cache, see kind16 below); with the branch-free bodies it is 1-7 % AHEAD of the rounded-slab form in the micro-benchmark
+        //  (FC1 + GELU 121.9 -> 117.3 us, Hiera stage-3 FC1 + GELU 116.1 -> 108.2) and 1-1.5 % BEHIND it in the bench (397.8 / 400.1 vs 404.0 / 403.9 frames/s):
+        //  every wave's sixteen stores leave back to back with nothing between them, which the other stream's kernels pay for.  Debug bits 4 / 8 split the f32-slab
+        //  epilogue's 7.9 us of a K = 1024 round into 5.0 us LDS + arithmetic and 2.9 us stores.)
         // epilogue kinds with a branch-free body in the accumulator layout (32 copies of the generic math4 -- every activation, rotary, residual -- were
-        // 15 000 instructions of straight-line code: the 256 x 256 tile's epilogue ran out of the instruction cache and LOST 7 us): 0 plain, 1 table GELU, 2 rotary (OVO_8P_SLAB16=2 only: its 64 table loads per lane
-        // in this layout -- 16 rows x 64 bytes per instruction -- measured 114.9 us against 103.0 for the row-layout loop below on the ViT's QKV)
-        const int kind16 = (g.out_dtype != 0 && !g.add && g.slab16) ? ((g.act == 0 && !g.rope_cos) ? 0 : ((g.act == 1 && lut && !g.rope_cos) ? 1 : ((g.act == 0 && g.rope_cos && g.slab16 > 1) ? 2 : -1))) : -1;
+        // 15 000 instructions of straight-line code: the 256 x 256 tile's epilogue ran out of the instruction cache and LOST 7 us): 0 plain, 1 table GELU.
+        // (Rotary stays with the row-layout loop below: in this layout its 64 table loads per lane cover 16 rows x 64 bytes per instruction, and the ViT's
+        // QKV measured 114.9 us -- 117.8 with all of a column tile's table rows fetched ahead of their arithmetic -- against 101-103.)
+        const int kind16 = (g.out_dtype != 0 && !g.add && g.slab16) ? ((g.act == 0 && !g.rope_cos) ? 0 : ((g.act == 1 && lut && !g.rope_cos) ? 1 : -1)) : -1;
+        OVO_BARRIER();                                    // every wave's LDS-DMA has landed and every fragment read is done: LDS is free
         if (kind16 >= 0) {
             // 2-byte outputs without a residual: bias / activation / rotary are applied in the accumulator layout (a lane's 4 consecutive columns) and the
             // tile crosses LDS already ROUNDED -- half the slab bytes of the f32 form below, and the whole wave tile fits one pass (8 x 128 rows x 144 B).
@@ -263,21 +265,15 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
             char *slab = smem + wave * (WROWS * RB2);
             const int nw = n0 + wc * WTN;
             float4 bias_r[2 * TNH];
-            int nh_r[2 * TNH];
 #pragma unroll
             for (int j = 0; j < 2 * TNH; ++j) {
                 const int n = nw + j * 16 + fq * 4;
                 bias_r[j] = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                nh_r[j] = g.rope_cos ? n % g.rope_hd : 0;
             }
             auto write_all = [&](auto KIND_) {
                 constexpr int KIND = decltype(KIND_)::value;
-                int tok = 0, tstep = 0;
-                if (KIND == 2) { tok = (m0 + wr * WTM + fr) % g.rope_T; tstep = 16 % g.rope_T; }
                 static_for<0, 2 * TMH>([&](auto I_) {
                     constexpr int i = decltype(I_)::value;
-                    const int tk = tok;
-                    if (KIND == 2) { tok += tstep; if (tok >= g.rope_T) tok -= g.rope_T; }
 #pragma unroll
                     for (int j = 0; j < 2 * TNH; ++j) {
                         float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
@@ -288,16 +284,6 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = gelu_lut(v[r], lut);
                         }
-                        if (KIND == 2) {
-                            const int n = nw + j * 16 + fq * 4;
-                            if (n < g.rope_cols && tk >= g.rope_t0) {
-                                const long long at = (long long)tk * g.rope_hd + nh_r[j];
-                                const float4 cc = *(const float4 *)(g.rope_cos + at), sn = *(const float4 *)(g.rope_sin + at);
-                                const float y0 = v[0] * cc.x - v[1] * sn.x, y1 = v[1] * cc.y + v[0] * sn.y;
-                                const float y2 = v[2] * cc.z - v[3] * sn.z, y3 = v[3] * cc.w + v[2] * sn.w;
-                                v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
-                            }
-                        }
                         uint2 p;
                         if (g.out_dtype == 2) { p.x = pack_bf16(v[0], v[1]); p.y = pack_bf16(v[2], v[3]); }
                         else { p.x = pack_f16(v[0], v[1]); p.y = pack_f16(v[2], v[3]); }
@@ -306,8 +292,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                 });
             };
             if (kind16 == 0) write_all(std::integral_constant<int, 0>{});
-            else if (kind16 == 1) write_all(std::integral_constant<int, 1>{});
-            else write_all(std::integral_constant<int, 2>{});
+            else write_all(std::integral_constant<int, 1>{});
             OVO_FENCE();
             const int q = lane >> 3, c = (lane & 7) * 8, n = nw + c;
             const bool in0 = n < g.N, in1 = n + 4 < g.N;
@@ -515,10 +500,9 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     if (ovo_knobs_dynamic()) { no_chunk = getenv("OVO_GEMM_NO_CHUNK") != nullptr; strip_env = getenv("OVO_GEMM_STRIP") ? atoi(getenv("OVO_GEMM_STRIP")) : -1;
                                tail_wait = getenv("OVO_8P_TAILWAIT") ? atoi(getenv("OVO_8P_TAILWAIT")) : 0; }
     g.tail_wait = tail_wait;
-    auto read_slab16 = [] { return getenv("OVO_8P_NO_SLAB16") ? 0 : (getenv("OVO_8P_SLAB16") ? atoi(getenv("OVO_8P_SLAB16")) : 1); };
-    static int slab16 = read_slab16();
-    if (ovo_knobs_dynamic()) slab16 = read_slab16();
-    g.slab16 = slab16;
+    static int no_slab16 = getenv("OVO_8P_NO_SLAB16") != nullptr;
+    if (ovo_knobs_dynamic()) no_slab16 = getenv("OVO_8P_NO_SLAB16") != nullptr;
+    g.slab16 = !no_slab16;
     static int gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     if (ovo_knobs_dynamic()) gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     g.gelu_lut = !gelu_poly;
