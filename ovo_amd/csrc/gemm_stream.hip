@@ -117,17 +117,14 @@ __global__ void __launch_bounds__(NTHREADS) k_gemm_stream(GemmArgs g, int n_grou
             const f32x4 bv = *(const f32x4 *)(cl + j * 16);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[j][r] * g.alpha + bv[r];
-            // GELU or nothing (the launch refuses other activations: the tiled kernels take them).  The generic act4 -- six activations, inlined into every
+            // table GELU or nothing (the launch refuses other activations: the tiled kernels take them).  The generic act4 -- six activations, inlined into every
             // one of the NT column tiles of four epilogue forms -- made these kernels 26-40 K instructions long; the block loop ran out of the
             // instruction cache: (196608, 896, 256) 290 -> 246 us, (196608, 672, 256) 321 -> 271 with this body
+            // (the table form only: with OVO_GELU_POLY=1 the launch declines GELU products as well -- the packed polynomial beside the table in every
+            // tile was another 5 K instructions and 246 -> 271 us on the same product)
             if (g.act) {
-                if (lut) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_lut(v[r], lut);
-                } else {
-                    const f32x2 a = gelu2(f32x2{v[0], v[1]}), b = gelu2(f32x2{v[2], v[3]});
-                    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
-                }
+                for (int r = 0; r < 4; ++r) v[r] = gelu_lut(v[r], lut);
             }
             if (ap) {
                 const f32x4 r = *(const f32x4 *)(ap + j * 16);
@@ -237,9 +234,7 @@ int launch_stream(const GemmArgs &g, hipStream_t s) {
     const bool prof = ovo_prof_enabled();
     if (prof) { ovo_prof_begin(8, 2.0 * g.M * (double)g.N * g.K, s); ovo_prof_shape(g.M, g.N, g.K); ovo_prof_flags(gemm_flags(g)); ovo_prof_bytes(gemm_algorithmic_bytes(g)); }
     GemmArgs gg = g;
-    static int gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
-    if (ovo_knobs_dynamic()) gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
-    gg.gelu_lut = !gelu_poly;
+    gg.gelu_lut = 1;
     k_gemm_stream<KS, NT, VT, NTHREADS, F32A><<<(slots + 7) / 8 * 8 * n_groups, NTHREADS, lds, s>>>(gg, n_groups, slots);
     if (prof) ovo_prof_end(s);
     return OVO_OK;
@@ -251,7 +246,9 @@ namespace ovo_gemm_detail {
 
 // Returns OVO_E_UNSUPPORTED when the shape has no instantiation (the caller then takes a tiled kernel).
 int gemm_stream_launch(const GemmArgs &g, int in_dtype, hipStream_t s) {
-    if (g.best || g.rope_cos || in_dtype != 2 || g.act > 1) return OVO_E_UNSUPPORTED;
+    static int gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
+    if (ovo_knobs_dynamic()) gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
+    if (g.best || g.rope_cos || in_dtype != 2 || g.act > 1 || (g.act == 1 && gelu_poly)) return OVO_E_UNSUPPORTED;
     if (g.M < 16384 || ((uintptr_t)g.C & 15) != 0 || g.ldc % 4 != 0) return OVO_E_UNSUPPORTED;
     // column groups: the widest of 256 / 224 / 112 / 64 / 32 that divides N (hiera_b+'s 112-multiples, powers of two); 288 / 144 for
     // hiera_l's stage 1 (K = 192: 144 channels padded)
