@@ -400,7 +400,7 @@ static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, 
     g.best = best; g.store = store; g.n_valid = n_valid; g.add_rows = (int)add_rows; g.strip = 0;
     g.rope_cos = g.rope_sin = nullptr; g.rope_T = 1; g.rope_hd = 4; g.rope_cols = 0; g.rope_t0 = 0;
     g.ln_x = g.ln_g = g.ln_b = nullptr; g.ln_eps = 0.f; g.ln_d = 0; g.ln_mode = 0; g.pool_ww = 0; g.qpool_out = nullptr; g.qpool_cols = 0;
-    g.dbg = 0; g.slab16 = 0; g.stamps = nullptr; g.win_per = 0; g.win_ww = g.win_wh = g.win_nww = g.win_nwin = 1; g.win_H = g.win_W = 0;
+    g.dbg = 0; g.slab16 = 0; g.rope_lds = 0; g.stamps = nullptr; g.win_per = 0; g.win_ww = g.win_wh = g.win_nww = g.win_nwin = 1; g.win_H = g.win_W = 0;
     if (win) {
         OVO_REQUIRE(win->B > 0 && win->H > 0 && win->W > 0 && win->wh > 0 && win->ww > 0, "bad window descriptor");
         const int nwh = (win->H + win->wh - 1) / win->wh, nww = (win->W + win->ww - 1) / win->ww;

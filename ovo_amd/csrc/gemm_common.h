@@ -41,6 +41,7 @@ struct GemmArgs {
     int pool_ww;               // with ln_mode and f32 output: > 0 = 2 x 2 max-pool of the window's tokens in the epilogue (window width), C rows = pooled spatial tokens
     int gelu_lut;              // gemm8p / gemm_stream: 1 = GELU (act 1) through the LDS table (default), 0 = the packed polynomial (OVO_GELU_POLY)
     int tail_wait;             // gemm8p: 1 = a wave waits for its epilogue stores before it ends (OVO_8P_TAILWAIT, measurement)
+    int rope_lds;              // k_gemm8p: the rotary epilogue stages its table slice in LDS (OVO_8P_ROPE_LDS)
     int slab16;                // k_gemm8p: 2-byte outputs cross the epilogue's LDS slab already rounded (OVO_8P_NO_SLAB16: the f32 slab)
     int dbg;                   // tools/ only (OVO_8P_DEBUG): 1 = leave before anything, 2 = leave after the prologue, 4 = no epilogue, 8 = epilogue without the 2-byte stores
     unsigned long long *stamps;   // tools/ only (OVO_8P_STAMPS = address of u64[tiles][4]): s_memrealtime at start / K-loop / epilogue / end
