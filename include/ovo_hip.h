@@ -37,9 +37,10 @@ const char *ovo_hip_last_error(void);
 int ovo_hip_abi_version(void); /* bumped when a signature changes */
 
 /* Optional profiler for bench.py's roofline figures: between start and stop every launch of a profiled kernel
- * family is bracketed by hipEvents on its own stream.  Kinds (n_kinds <= 9): 1 = fused attention (work = flops),
+ * family is bracketed by hipEvents on its own stream.  Kinds (n_kinds <= 10): 1 = fused attention (work = flops),
  * 2 = fused point-map tracking pass (bytes), 4..7 = MFMA GEMM with tile 128x128 / 128x64 / 64x128 / 64x64, 3 / 0 = the 256x256 /
- * 256x128 ping-pong GEMM, 8 = the weights-resident streaming GEMM (flops).
+ * 256x128 ping-pong GEMM, 8 = the weights-resident streaming GEMM (flops), 9 = the dense scatter-accumulate (scan + apply launches of
+ * ovo_scatter_accum_touched; work = bytes = hits x (2 x 4 D + 12) + 2 n, the hit count read back from the device after the launch).
  * stop synchronises the device and returns, per kind, total milliseconds, total work and launch count. */
 /* An empty one-thread kernel (`k_marker`): bench.py brackets its timed region with two of them so that a rocprofv3 kernel trace of the
  * same command can be cut to exactly that region (tools/kstats_region.py). */
@@ -278,6 +279,9 @@ int ovo_gemm_argmax(const ovo_gemm_t *g, uint64_t *best, int store_scores, int n
 int ovo_decode_best(const uint64_t *best, int64_t n, float th, int64_t *out_cls, float *out_conf, ovo_stream_t stream);
 
 /* O = softmax(Q K^T * scale) V per (batch, head); bf16 in/out, fp32 softmax and accumulation.
+ * scale == 0 (ABI v9): Q arrives ALREADY multiplied by scale * log2(e) -- folded into the projection that produced it, in fp32,
+ * before its bf16 rounding -- and the kernel applies no factor (scores leave the MFMA in log2 units).  With scale != 0 the
+ * kernel multiplies the bf16 Q fragments itself, which rounds every query a second time.
  * Element (b, h, t, d) of X lives at X + b*x_sb + h*x_sh + t*x_st + d (strides in ELEMENTS, d contiguous), so
  * the packed QKV GEMM output [B, T, 3, H, hd] is consumed in place.  hd % 8 == 0, hd <= 128.
  * Windowed attention (Hiera) = windows folded into B; pooled queries = Tq < Tk. */
@@ -386,6 +390,9 @@ typedef struct {
                        /* 2: SigLIP attention-pool head over ln_post(tokens) -> f32 [B, width]  */
     int32_t kpad;      /* 3*patch*patch rounded up to a multiple of 32                          */
     float ln_eps;
+    int32_t q_prescaled; /* 1 = the q rows of every qkv_w / qkv_b (and map_q) already carry log2(e) / sqrt(head_dim), folded in  */
+                         /* fp32 at load time BEFORE the bf16 rounding: the attention kernels then apply no factor to Q at all   */
+                         /* (a factor applied to the bf16 Q inside the kernel is a second rounding of every query). ABI v9       */
 } ovo_vit_config_t;
 
 typedef struct {
@@ -434,6 +441,7 @@ typedef struct {
     int32_t fpn_dim;               /* 256 */
     int32_t hi_res;                /* apply conv_s0 (->32) / conv_s1 (->64) to the two fine levels */
     float ln_eps;                  /* 1e-6 */
+    int32_t q_prescaled;           /* 1 = q rows of qkv_w / qkv_b carry log2(e) / sqrt(head_dim) (see ovo_vit_config_t); ABI v9 */
 } ovo_hiera_config_t;
 
 typedef struct {

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libovo_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 E_UNSUPPORTED = -3          # OVO_E_UNSUPPORTED: the entry point does not cover this shape; the caller takes its general path
 
 
@@ -63,7 +63,7 @@ class Attention(C.Structure):
 class VitConfig(C.Structure):
     """ovo_vit_config_t"""
     _fields_ = [(n, C.c_int32) for n in ("image_size", "patch", "width", "layers", "heads", "mlp_dim", "out_dim", "n_prefix",
-                                          "act", "pre_ln", "use_rope", "pool", "kpad")] + [("ln_eps", _F32)]
+                                          "act", "pre_ln", "use_rope", "pool", "kpad")] + [("ln_eps", _F32), ("q_prescaled", C.c_int32)]
 
 
 class VitLayer(C.Structure):
@@ -84,7 +84,7 @@ class HieraConfig(C.Structure):
     """ovo_hiera_config_t"""
     _fields_ = [("image_size", C.c_int32), ("dims", C.c_int32 * 4), ("heads", C.c_int32 * 4), ("blocks", C.c_int32 * 4),
                 ("window", C.c_int32 * 4), ("n_global", C.c_int32), ("global_blocks", C.c_int32 * 8), ("fpn_dim", C.c_int32),
-                ("hi_res", C.c_int32), ("ln_eps", _F32)]
+                ("hi_res", C.c_int32), ("ln_eps", _F32), ("q_prescaled", C.c_int32)]
 
 
 class HieraBlock(C.Structure):
@@ -335,3 +335,26 @@ class PinnedRing:
                 load().ovo_host_free(self.base)
         except Exception:
             pass
+
+
+LOG2E = 1.4426950408889634
+
+
+def q_prescale_enabled() -> bool:
+    """The encoders fold log2(e) / sqrt(head_dim) into the q rows of their QKV projections at load time (OVO_Q_PRESCALE=0: the
+    attention kernel multiplies the bf16 queries itself -- a second rounding of every query; kept for A/B measurements)."""
+    return os.environ.get("OVO_Q_PRESCALE", "1") != "0"
+
+
+def fold_q_scale(weight: torch.Tensor, bias: Optional[torch.Tensor], q_rows: int, head_dim: int):
+    """(weight, bias) f32 copies whose first `q_rows` output rows carry log2(e) / sqrt(head_dim): softmax(q k^T / sqrt(hd)) =
+    softmax2(q' k^T) with q' = q log2(e) / sqrt(hd), so ovo_attention (scale = 0) applies no factor to its bf16 queries.  The
+    product is taken in f32 BEFORE the matrix is rounded to bf16 -- one rounding per weight, as without the fold."""
+    c = LOG2E / float(head_dim) ** 0.5
+    w = weight.detach().float().clone()
+    w[:q_rows] *= c
+    b = None
+    if bias is not None:
+        b = bias.detach().float().clone()
+        b[:q_rows] *= c
+    return w, b

@@ -63,8 +63,9 @@ __device__ __forceinline__ float sum_xor16_32(float v) {
 // ---- online softmax, restated for the instruction mix of gfx950 (tools/ubench.hip: a lone wave issues one VALU instruction per ~8 cycles, two waves of
 // a SIMD one per ~4; v_exp_f32 ~9; beside a stream of MFMAs every VALU instruction still costs 1-4 cycles of the SIMD).  Round 3's form spent ~80 VALU
 // instructions per (16 queries x 64 keys) on a tile whose 16 MFMAs need 264 cycles.  Here:
-//   * the scale (1/sqrt(hd) * log2 e) is folded into Q once (`prescale_q`; the encoders fold it into the q rows of the QKV weights instead and
-//     pass scale_log2e == 1), so a score leaves the MFMA in log2 units;
+//   * a score leaves the MFMA in log2 units: the encoders fold 1/sqrt(hd) * log2 e into the q rows of their QKV weights at load time (in fp32,
+//     before the bf16 rounding; ovo_attention_t.scale == 0 -> scale_log2e == 1 here, no factor applied).  A caller that passes a scale instead gets
+//     `prescale_q`: the bf16 Q fragments multiplied and ROUNDED AGAIN -- 2e-3 max output error at unit-variance q / k against 4e-7;
 //   * the running reference maximum m of a query enters the QK^T product as its C operand (`negm` = four copies of -m, re-used by every first
 //     k-step of the tile -- srcC and vdst of an MFMA are separate registers), so the MFMA delivers S' = S - m: no subtraction pass;
 //   * FAST PATH (every tile after the first, unless some score of the wave outgrew the reference by more than THR): p = exp2(S') straight from the
@@ -767,10 +768,11 @@ extern "C" int ovo_attention(const ovo_attention_t *p, ovo_stream_t stream) {
     a.q_sb = p->q_sb; a.q_sh = p->q_sh; a.q_st = p->q_st; a.k_sb = p->k_sb; a.k_sh = p->k_sh; a.k_st = p->k_st;
     a.v_sb = p->v_sb; a.v_sh = p->v_sh; a.v_st = p->v_st; a.o_sb = p->o_sb; a.o_sh = p->o_sh; a.o_st = p->o_st;
     a.B = p->B; a.H = p->H; a.Tq = p->Tq; a.Tk = p->Tk; a.hd = p->hd;
-    a.scale_log2e = p->scale * 1.4426950408889634f;
+    a.scale_log2e = p->scale == 0.0f ? 1.0f : p->scale * 1.4426950408889634f;       // 0: the projection already carries scale * log2 e
     a.causal = p->causal;
     hipStream_t s = (hipStream_t)stream;
-    // k_attention<HD, QT> (16 x 16 MFMA tiles, 64 or 128 queries per workgroup): head_dim > 64, and whatever k_attention32 cannot address.  History of the
+    // k_attention<HD, QT> (16 x 16 MFMA tiles, 64 or 128 queries per workgroup): only what k_attention32 below cannot address (misaligned output rows,
+    // K / V slabs past 2 GB, OVO_ATTN32=0) -- every head_dim up to 128 goes to k_attention32 first.  History of the
     // 64- vs 128-query rule (rounds 2-3): DESIGN.md section 3.
     // (round 4: with the cheaper softmax the 64-query form also wins at head_dim 128 -- 8 x 16 x 2048^2 x 128: 512 us narrow vs 662 wide; the 128-query
     // form is left for OVO_ATTN_WIDE experiments; head_dim <= 64 goes to k_attention32 above unless OVO_ATTN32=0)

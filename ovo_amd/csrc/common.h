@@ -13,13 +13,15 @@ void ovo_set_error(const char *fmt, ...);
 
 // optional hipEvent profiler (core.hip): kinds 1 = attention (flops), 2 = point-map tracking pass (bytes), 4..7 = MFMA GEMM tiles 128x128 / 128x64 / 64x128 / 64x64,
 // 3 / 0 = the 256x256 / 256x128 ping-pong GEMM (flops), 8 = the weights-resident streaming GEMM (flops)
-#define OVO_PROF_KINDS 9
+#define OVO_PROF_KINDS 10
 bool ovo_prof_enabled();
 void ovo_prof_begin(int kind, double work, hipStream_t s);
 void ovo_prof_shape(int a, int b, int c);       // optional: shape of the launch just begun (OVO_PROF_DUMP lines)
 void ovo_prof_flags(int flags);            // optional: epilogue / operand variant of the launch just begun (gemm_common.h: gemm_flags), last field of an OVO_PROF_DUMP line
 void ovo_prof_bytes(double bytes);            // optional: algorithmic HBM bytes of the launch just begun (operands read once, result written once)
 void ovo_prof_end(hipStream_t s);
+// after ovo_prof_end: work (and algorithmic bytes) of the launch = per_item * (*device_count, read back on the stream now) + fixed
+void ovo_prof_count(const int32_t *device_count, double per_item, double fixed, hipStream_t s);
 
 #define OVO_REQUIRE(cond, msg)                                   \
     do {                                                         \

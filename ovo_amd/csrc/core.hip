@@ -22,12 +22,14 @@ void ovo_set_error(const char *fmt, ...) {
 
 // ---- profiler: hipEvent pairs around the launches of a kernel family, on the launch stream --------------
 namespace {
-struct Rec { hipEvent_t a, b; int kind; double work, bytes; int shape[3], flags; };
+struct Rec { hipEvent_t a, b; int kind; double work, bytes; int shape[3], flags; int cslot; double per_item, fixed; };
 struct Prof {
     bool on = false;
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
+    int32_t *counts = nullptr;                                   // pinned: device-side item counts of launches whose work the host does not know
+    int n_counts = 0;
     hipEvent_t get() {
         if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
         return pool[used++];
@@ -38,7 +40,7 @@ struct Prof {
 bool ovo_prof_enabled() { return g_prof.on; }
 void ovo_prof_begin(int kind, double work, hipStream_t s) {
     if (!g_prof.on || g_prof.recs.size() >= (1u << 20)) return;
-    Rec r; r.kind = kind; r.work = work; r.bytes = 0; r.shape[0] = r.shape[1] = r.shape[2] = 0; r.flags = 0; r.a = g_prof.get(); r.b = g_prof.get();
+    Rec r; r.kind = kind; r.work = work; r.bytes = 0; r.shape[0] = r.shape[1] = r.shape[2] = 0; r.flags = 0; r.cslot = -1; r.per_item = r.fixed = 0; r.a = g_prof.get(); r.b = g_prof.get();
     if (!r.a || !r.b) return;
     (void)hipEventRecord(r.a, s);
     g_prof.recs.push_back(r);
@@ -60,6 +62,15 @@ static double g_last_bytes[OVO_PROF_KINDS];
 void ovo_prof_end(hipStream_t s) {
     if (!g_prof.on || g_prof.recs.empty()) return;
     (void)hipEventRecord(g_prof.recs.back().b, s);
+}
+void ovo_prof_count(const int32_t *device_count, double per_item, double fixed, hipStream_t s) {
+    constexpr int SLOTS = 1 << 16;
+    if (!g_prof.on || g_prof.recs.empty() || !device_count) return;
+    if (!g_prof.counts && hipHostMalloc((void **)&g_prof.counts, SLOTS * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { g_prof.counts = nullptr; return; }
+    if (g_prof.n_counts >= SLOTS) return;
+    Rec &r = g_prof.recs.back();
+    r.cslot = g_prof.n_counts++; r.per_item = per_item; r.fixed = fixed;
+    (void)hipMemcpyAsync(g_prof.counts + r.cslot, device_count, sizeof(int32_t), hipMemcpyDeviceToHost, s);      // behind the end event: not in the timed pair
 }
 
 template <typename T>
@@ -87,11 +98,12 @@ int ovo_marker(int id, ovo_stream_t stream) {
     return OVO_OK;
 }
 const char *ovo_hip_last_error(void) { return g_err; }
-int ovo_hip_abi_version(void) { return 8; }
+int ovo_hip_abi_version(void) { return 9; }
 
 int ovo_profile_start(void) {
     g_prof.recs.clear();
     g_prof.used = 0;
+    g_prof.n_counts = 0;
     g_prof.on = true;
     return OVO_OK;
 }
@@ -106,8 +118,10 @@ int ovo_profile_stop(double *ms, double *work, int64_t *launches, int n_kinds) {
     for (const Rec &r : g_prof.recs) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess || r.kind >= n_kinds) continue;
-        ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1; g_last_bytes[r.kind] += r.bytes;
-        if (dump) fprintf(dump, "%d %d %d %d %.0f %.4f %d\n", r.kind, r.shape[0], r.shape[1], r.shape[2], r.work, t, r.flags);
+        double wk = r.work, by = r.bytes;
+        if (r.cslot >= 0 && g_prof.counts) wk = by = r.per_item * (double)g_prof.counts[r.cslot] + r.fixed;
+        ms[r.kind] += t; work[r.kind] += wk; launches[r.kind] += 1; g_last_bytes[r.kind] += by;
+        if (dump) fprintf(dump, "%d %d %d %d %.0f %.4f %d\n", r.kind, r.shape[0], r.shape[1], r.shape[2], wk, t, r.flags);
     }
     if (dump) fclose(dump);
     g_prof.recs.clear();

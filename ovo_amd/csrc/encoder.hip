@@ -557,7 +557,8 @@ int ovo_im2col(const float *img, int B, int C, int H, int W, int ksz, int stride
     const int oh = (H + 2 * pad - ksz) / stride + 1, ow = (W + 2 * pad - ksz) / stride + 1;
     OVO_REQUIRE(oh > 0 && ow > 0, "empty output");
     OVO_REQUIRE(kpad % 8 == 0 && ((uintptr_t)out & 15) == 0, "kpad must be a multiple of 8 and the output 16-byte aligned");
-    OVO_REQUIRE((long long)B * oh * ow * (kpad / 8) < (1ll << 32), "more than 2^32 16-byte pieces: split the batch");
+    // (the kernel's 32-bit grid-stride index must not wrap: total + one grid stride -- at most 2048 x 256 threads -- stays below 2^32)
+    OVO_REQUIRE((long long)B * oh * ow * (kpad / 8) < (1ll << 32) - (1ll << 22), "more than 2^32 16-byte pieces: split the batch");
     k_im2col<<<ovo_grid((long long)B * oh * ow * (kpad / 8), 256), 256, 0, (hipStream_t)stream>>>(img, B, C, H, W, ksz, stride, pad, oh, ow,
                                                                                                  (uint16_t *)out, kpad);
     OVO_CHECK_LAUNCH();

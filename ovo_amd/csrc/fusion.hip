@@ -82,20 +82,76 @@ __global__ void __launch_bounds__(256) k_fuse_views_add(const float *__restrict_
     }
 }
 
-// Dense fusion: one wave per point slot; lanes stride the descriptor with float4.
-// HBM traffic per matched point: D*4 read-modify-write of acc (desc rows stay in L2).
-__global__ void __launch_bounds__(256) k_scatter_accum(const int16_t *__restrict__ point_seg, int64_t n,
-                                                       const int32_t *__restrict__ mask_row, int n_masks,
-                                                       const float *__restrict__ desc, int D, float *__restrict__ acc,
-                                                       int32_t *__restrict__ cnt, int32_t *__restrict__ touched = nullptr,
-                                                       int32_t *__restrict__ n_touched = nullptr, int32_t *__restrict__ n_next = nullptr,
-                                                       int shard_rank = 0, int shard_count = 1, int block_log2 = 0) {
+// ---- dense fusion: acc[point] += desc[mask_row[seg(point)]], cnt[point] += 1 for every point a mask of this keyframe covers --------------------------
+// HBM traffic per matched point: D*4 read-modify-write of acc (desc rows stay in L2); a point is hit at most once per launch (one segment per point).
+//
+// Round 5: the one-kernel form (each wave scans 64 points and serves its own hits one after the other, every hit a dependent load -> add -> store
+// chain per 1 KB piece) ran at 2.0 TB/s of PMC bytes -- 98.6 us for 198 MB at the headline workload.  Hits are clustered: the
+// frustum's points are consecutive map rows, so a few hundred of the 8192 waves held 64 hits each (64 x 4 dependent round trips to HBM) while most
+// held none -- the launch lasted as long as its fullest wave.  Now:
+//   k_scatter_scan  : the scan only -- segment id -> descriptor row, shard filter, the compacted list of hit rows (`touched`, one atomic per 64 points);
+//   k_scatter_apply : the hits of the list dealt round-robin to 8192 waves (count read from the device), one 4 KB row per wave at a time, TWO rows
+//                     in flight per wave with every 16-byte load of both issued before the first add (NV x 4 loads per lane).
+// Without a `touched` list (ovo_scatter_accum: no workspace in its signature) the scan serves its own hits, with the same unrolled body.
+template <int NV>
+__device__ __forceinline__ void accum_rows(float *__restrict__ acc, const float *__restrict__ desc, int32_t *__restrict__ cnt, int D4, int D, int lane,
+                                           int64_t p0, int r0, int64_t p1, int r1, bool two) {
+    float4 *a0 = (float4 *)(acc + p0 * D), *a1 = (float4 *)(acc + p1 * D);
+    const float4 *d0 = (const float4 *)(desc + (int64_t)r0 * D), *d1 = (const float4 *)(desc + (int64_t)r1 * D);
+    float4 x0[NV], y0[NV], x1[NV], y1[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int k = v * 64 + lane;
+        if (k < D4) { x0[v] = a0[k]; y0[v] = d0[k]; }
+    }
+    if (two) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int k = v * 64 + lane;
+            if (k < D4) { x1[v] = a1[k]; y1[v] = d1[k]; }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int k = v * 64 + lane;
+        if (k < D4) a0[k] = make_float4(x0[v].x + y0[v].x, x0[v].y + y0[v].y, x0[v].z + y0[v].z, x0[v].w + y0[v].w);
+    }
+    if (two) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int k = v * 64 + lane;
+            if (k < D4) a1[k] = make_float4(x1[v].x + y1[v].x, x1[v].y + y1[v].y, x1[v].z + y1[v].z, x1[v].w + y1[v].w);
+        }
+    }
+    if (lane == 0) { cnt[p0] += 1; if (two) cnt[p1] += 1; }
+}
+// rows wider than 5 x 64 float4 (D > 1280): the plain strided loop
+__device__ __forceinline__ void accum_row_wide(float *__restrict__ acc, const float *__restrict__ desc, int32_t *__restrict__ cnt, int D4, int D, int lane,
+                                               int64_t p, int r) {
+    float4 *a4 = (float4 *)(acc + p * D);
+    const float4 *d4 = (const float4 *)(desc + (int64_t)r * D);
+    for (int k = lane; k < D4; k += 64) {
+        float4 a = a4[k];
+        const float4 b = d4[k];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        a4[k] = a;
+    }
+    if (lane == 0) cnt[p] += 1;
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) k_scatter_scan(const int16_t *__restrict__ point_seg, int64_t n,
+                                                      const int32_t *__restrict__ mask_row, int n_masks,
+                                                      const float *__restrict__ desc, int D, float *__restrict__ acc,
+                                                      int32_t *__restrict__ cnt, int32_t *__restrict__ touched,
+                                                      int32_t *__restrict__ n_touched, int32_t *__restrict__ n_next,
+                                                      int shard_rank, int shard_count, int block_log2) {
     const int lane = threadIdx.x & 63;
     if (n_next && blockIdx.x == 0 && threadIdx.x == 0) *n_next = 0;   // the NEXT keyframe's counter (nobody reads it before that launch)
     const int64_t waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int D4 = D >> 2;
     for (int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64; base < n; base += waves * 64) {
-        // each lane inspects one point of the 64-point chunk, then the wave serves the hits one by one
+        // each lane inspects one point of the 64-point chunk
         const int64_t i = base + lane;
         int row = -1;
         int64_t li = i;                                            // row of acc / cnt: the point itself, or its slot in this rank's shard
@@ -110,29 +166,75 @@ __global__ void __launch_bounds__(256) k_scatter_accum(const int16_t *__restrict
             }
         }
         unsigned long long hits = __ballot(row >= 0);
-        if (touched && hits) {                                     // compacted list of the rows this keyframe changed: one atomic per chunk
-            int at = 0;
-            if (lane == 0) at = atomicAdd(n_touched, __popcll(hits));
-            at = __shfl(at, 0, 64);
-            if (row >= 0) touched[at + __popcll(hits & ((1ull << lane) - 1ull))] = (int32_t)li;
-        }
-        while (hits) {
-            const int src = __ffsll((long long)hits) - 1;
-            hits &= hits - 1;
-            const int r = __shfl(row, src, 64);
-            const int64_t p = __shfl(li, src, 64);
-            const float4 *d4 = (const float4 *)(desc + (int64_t)r * D);
-            float4 *a4 = (float4 *)(acc + p * D);
-            for (int k = lane; k < D4; k += 64) {
-                float4 a = a4[k];
-                const float4 b = d4[k];
-                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-                a4[k] = a;
+        if (touched) {                                             // compacted list of the rows this keyframe changes: one atomic per chunk;
+            if (hits) {                                            // k_scatter_apply does the arithmetic
+                int at = 0;
+                if (lane == 0) at = atomicAdd(n_touched, __popcll(hits));
+                at = __shfl(at, 0, 64);
+                if (row >= 0) touched[at + __popcll(hits & ((1ull << lane) - 1ull))] = (int32_t)li;
             }
-            for (int k = (D4 << 2) + lane; k < D; k += 64) acc[p * D + k] += desc[(int64_t)r * D + k];
-            if (lane == 0) cnt[p] += 1;
+            continue;
+        }
+        while (hits) {                                             // no list: the wave serves its hits itself, two at a time
+            const int s0 = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const bool two = hits != 0;
+            const int s1 = two ? __ffsll((long long)hits) - 1 : s0;
+            if (two) hits &= hits - 1;
+            const int r0 = __shfl(row, s0, 64), r1 = __shfl(row, s1, 64);
+            const int64_t p0 = __shfl(li, s0, 64), p1 = __shfl(li, s1, 64);
+            if (NV > 0) accum_rows<(NV > 0 ? NV : 1)>(acc, desc, cnt, D4, D, lane, p0, r0, p1, r1, two);
+            else { accum_row_wide(acc, desc, cnt, D4, D, lane, p0, r0); if (two) accum_row_wide(acc, desc, cnt, D4, D, lane, p1, r1); }
         }
     }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) k_scatter_apply(const int32_t *__restrict__ touched, const int32_t *__restrict__ n_touched,
+                                                       const int16_t *__restrict__ point_seg, const int32_t *__restrict__ mask_row,
+                                                       const float *__restrict__ desc, int D, float *__restrict__ acc, int32_t *__restrict__ cnt,
+                                                       int shard_rank, int shard_count, int block_log2) {
+    const int lane = threadIdx.x & 63;
+    const int W = gridDim.x * (blockDim.x >> 6), w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int count = *n_touched, D4 = D >> 2;
+    // the global point of local row li (the inverse of the scan's shard map): its segment names the descriptor row
+    auto desc_row = [&](int li) {
+        int64_t i = li;
+        if (shard_count > 1) {
+            const int64_t lb = (int64_t)li >> block_log2;
+            i = ((lb * shard_count + shard_rank) << block_log2) | (li & ((1 << block_log2) - 1));
+        }
+        return mask_row[point_seg[i]];
+    };
+    for (int h = w; h < count; h += 2 * W) {
+        const bool two = h + W < count;
+        const int p0 = __builtin_amdgcn_readfirstlane(touched[h]), p1 = __builtin_amdgcn_readfirstlane(touched[two ? h + W : h]);
+        const int r0 = __builtin_amdgcn_readfirstlane(desc_row(p0)), r1 = __builtin_amdgcn_readfirstlane(desc_row(p1));
+        if (NV > 0) accum_rows<(NV > 0 ? NV : 1)>(acc, desc, cnt, D4, D, lane, p0, r0, p1, r1, two);
+        else { accum_row_wide(acc, desc, cnt, D4, D, lane, p0, r0); if (two) accum_row_wide(acc, desc, cnt, D4, D, lane, p1, r1); }
+    }
+}
+
+int launch_scatter(const int16_t *point_seg, int64_t n, const int32_t *mask_row, int n_masks, const float *desc, int D, float *acc, int32_t *cnt,
+                   int32_t *touched, int32_t *n_touched, int32_t *n_next, int shard_rank, int shard_count, int block_log2, hipStream_t s) {
+    const int nv = (D / 4 + 63) / 64;
+    const int g_scan = ovo_grid((n + 63) / 64 * 64, 256);
+    const bool prof = touched && ovo_prof_enabled();
+    if (prof) ovo_prof_begin(9, 0.0, s);                         // bytes follow from the hit count, read back after the end event (ovo_prof_count)
+#define SCAN(NV) k_scatter_scan<NV><<<g_scan, 256, 0, s>>>(point_seg, n, mask_row, n_masks, desc, D, acc, cnt, touched, n_touched, n_next, shard_rank, shard_count, block_log2)
+#define APPLY(NV) k_scatter_apply<NV><<<2048, 256, 0, s>>>(touched, n_touched, point_seg, mask_row, desc, D, acc, cnt, shard_rank, shard_count, block_log2)
+    switch (nv) {
+    case 1: SCAN(1); if (touched) APPLY(1); break;
+    case 2: SCAN(2); if (touched) APPLY(2); break;
+    case 3: SCAN(3); if (touched) APPLY(3); break;
+    case 4: SCAN(4); if (touched) APPLY(4); break;
+    case 5: SCAN(5); if (touched) APPLY(5); break;
+    default: SCAN(0); if (touched) APPLY(0); break;
+    }
+#undef SCAN
+#undef APPLY
+    if (prof) { ovo_prof_end(s); ovo_prof_count(n_touched, 2.0 * D * 4.0 + 12.0, 2.0 * (double)n, s); }   // per hit: the row read + written, its list entry, cnt; + the segment ids
+    return OVO_OK;
 }
 
 }  // namespace
@@ -167,9 +269,7 @@ int ovo_scatter_accum_touched(const int16_t *point_seg, int64_t n, const int32_t
     if (n == 0) return OVO_OK;
     OVO_REQUIRE(point_seg && mask_row && desc && acc && cnt && (touched == nullptr) == (n_touched == nullptr), "null pointer");
     OVO_REQUIRE((((uintptr_t)desc | (uintptr_t)acc) & 15) == 0 && D % 4 == 0, "acc/desc must be 16-byte aligned, D % 4 == 0");
-    k_scatter_accum<<<ovo_grid((n + 63) / 64 * 64, 256), 256, 0, (hipStream_t)stream>>>(point_seg, n, mask_row, n_masks,
-                                                                                       desc, D, acc, cnt, touched, n_touched, n_next,
-                                                                                       shard_rank, shard_count, block_log2);
+    launch_scatter(point_seg, n, mask_row, n_masks, desc, D, acc, cnt, touched, n_touched, n_next, shard_rank, shard_count, block_log2, (hipStream_t)stream);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }
@@ -190,8 +290,7 @@ int ovo_scatter_accum(const int16_t *point_seg, int64_t n, const int32_t *mask_r
     if (n == 0) return OVO_OK;
     OVO_REQUIRE(point_seg && mask_row && desc && acc && cnt, "null pointer");
     OVO_REQUIRE((((uintptr_t)desc | (uintptr_t)acc) & 15) == 0 && D % 4 == 0, "acc/desc must be 16-byte aligned, D % 4 == 0");
-    k_scatter_accum<<<ovo_grid((n + 63) / 64 * 64, 256), 256, 0, (hipStream_t)stream>>>(point_seg, n, mask_row, n_masks,
-                                                                                       desc, D, acc, cnt);
+    launch_scatter(point_seg, n, mask_row, n_masks, desc, D, acc, cnt, nullptr, nullptr, nullptr, 0, 1, 0, (hipStream_t)stream);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

@@ -358,7 +358,10 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
             const int rc = gemm8q_launch(g, std::is_same<VT, bf16x8>::value ? 2 : 1, s);
             if (rc != OVO_E_UNSUPPORTED) return rc;
         }
-        if (fm == 256 && (fn == 256 || fn == 128) && k64) return gemm8p_launch(g, fn, std::is_same<VT, bf16x8>::value ? 2 : 1, s);
+        if (fm == 256 && (fn == 256 || fn == 128) && k64) {      // (the tuned table keys on (M, N, K, flags) only: a launch the ping-pong kernel declines --
+            const int rc = gemm8p_launch(g, fn, std::is_same<VT, bf16x8>::value ? 2 : 1, s);      // 32-bit DMA offsets -- falls through to the ring kernels)
+            if (rc != OVO_E_UNSUPPORTED) return rc;
+        }
     }
     if (bm == 128 && bn == 128) return k64 ? launch<128, 128, 64, VT, 8, 3>(g, s) : launch<128, 128, 32, VT, 8, 3>(g, s);
     // BK = 64: 8 waves per workgroup on every tile (two workgroups = 16 waves per CU): same LDS and L2 traffic as the 4-wave

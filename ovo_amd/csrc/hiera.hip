@@ -427,7 +427,7 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         if (p.pool[i]) {
             if (!q_pooled) {
                 const long long total8 = n_win * tq * (dout / 8);
-                if (dout % 8 == 0 && total8 < (1ll << 32) && (((uintptr_t)k.qkv | (uintptr_t)k.qp) & 15) == 0)
+                if (dout % 8 == 0 && total8 < (1ll << 32) - (1ll << 22) && (((uintptr_t)k.qkv | (uintptr_t)k.qp) & 15) == 0)
                     k_qpool8<<<ovo_grid(total8, 256, 256 * 16), 256, 0, hs>>>(k.qkv, (uint32_t)total8, g.wh, g.ww, dout, k.qp);
                 else k_qpool<<<ovo_grid(n_win * tq * dout, 256), 256, 0, hs>>>(k.qkv, n_win, g.wh, g.ww, dout, k.qp);
             }
@@ -444,7 +444,7 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
             att_rows = -1;                                       // every column written: the next padded layout starts from a fresh fill
         }
         a.o_sb = (int64_t)tq * kout; a.o_sh = hd; a.o_st = kout;
-        a.B = (int)n_win; a.H = p.heads[i]; a.Tq = tq; a.Tk = tk; a.hd = hd; a.scale = 1.0f / sqrtf((float)hd);
+        a.B = (int)n_win; a.H = p.heads[i]; a.Tq = tq; a.Tk = tk; a.hd = hd; a.scale = cfg->q_prescaled ? 0.0f : 1.0f / sqrtf((float)hd);
         TRY(ovo_attention(&a, stream));
         // output projection; its epilogue also takes the rows from window order (pooled window size) back to spatial order and
         // adds the residual (ovo_gemm_unwindow; k_unwindow_add was a pass of its own).  In place: same-dim blocks add onto x; at a

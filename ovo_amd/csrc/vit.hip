@@ -87,7 +87,7 @@ int ovo_vit_forward(const ovo_vit_config_t *cfg, const ovo_vit_weights_t *w, con
     TRY(ovo_vit_embed(k.patch, w->prefix, c.n_prefix, w->pos, B, P, D, c.pre_ln ? w->ln_pre_g : nullptr,
                       c.pre_ln ? w->ln_pre_b : nullptr, c.ln_eps, k.x, stream));
 
-    const float scale = 1.0f / sqrtf((float)hd);
+    const float scale = c.q_prescaled ? 0.0f : 1.0f / sqrtf((float)hd);      // 0: the q rows of qkv_w / qkv_b (and map_q) carry log2 e / sqrt(hd)
     for (int l = 0; l < c.layers; ++l) {
         const ovo_vit_layer_t &L = w->layers[l];
         TRY(ovo_layernorm(k.x, D, M, D, L.ln1_g, L.ln1_b, c.ln_eps, k.h, D, 2, stream));

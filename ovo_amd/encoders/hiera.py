@@ -155,11 +155,16 @@ class HipHiera:
             return x.data_ptr()
 
         plan = block_plan(spec)
+        self.q_prescaled = L.q_prescale_enabled()
+        stage_of = [s for s, nb in enumerate(spec.stages) for _ in range(nb)]
         self._blocks = (L.HieraBlock * len(plan))()
         for i, (din, dout) in enumerate(plan):
             p, b = f"trunk.blocks.{i}.", self._blocks[i]
             b.ln1_g, b.ln1_b = vec(sd[p + "norm1.weight"]), vec(sd[p + "norm1.bias"])
-            b.qkv_w, b.qkv_b = mat(sd[p + "attn.qkv.weight"]), vec(sd[p + "attn.qkv.bias"])
+            qw, qb = sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]
+            if self.q_prescaled:                           # log2 e / sqrt(hd) into the q rows (the 2 x 2 max-pool of q commutes with a positive factor)
+                qw, qb = L.fold_q_scale(qw, qb, dout, dout // spec.heads[stage_of[i]])
+            b.qkv_w, b.qkv_b = mat(qw), vec(qb)
             b.out_w, b.out_b = mat(sd[p + "attn.proj.weight"]), vec(sd[p + "attn.proj.bias"])
             b.ln2_g, b.ln2_b = vec(sd[p + "norm2.weight"]), vec(sd[p + "norm2.bias"])
             b.fc1_w, b.fc1_b = mat(sd[p + "mlp.layers.0.weight"]), vec(sd[p + "mlp.layers.0.bias"])
@@ -188,6 +193,7 @@ class HipHiera:
         for i, gb in enumerate(spec.global_blocks):
             cfg.global_blocks[i] = gb
         cfg.fpn_dim, cfg.hi_res, cfg.ln_eps = spec.fpn_dim, int(self.hi_res), 1e-6
+        cfg.q_prescaled = int(self.q_prescaled)
         self._cfg = cfg
         self._ws: Optional[torch.Tensor] = None
 

@@ -127,6 +127,7 @@ class HipSamDecoder:
         self.sd = sd
         c = spec.hidden
         self.w: Dict[str, torch.Tensor] = {}
+        self.q_prescaled = L.q_prescale_enabled()
 
         def up(name, t, dtype):
             self.w[name] = t.to(self.device, dtype).contiguous()
@@ -139,8 +140,11 @@ class HipSamDecoder:
         blocks = [t + f"layers.{i}." for i in range(spec.depth)]
         for b in blocks:
             sa = b + "self_attn."
-            up(sa + "qk.w", torch.cat([sd[sa + "q_proj.weight"], sd[sa + "k_proj.weight"]]), torch.bfloat16)
-            up(sa + "qk.b", torch.cat([sd[sa + "q_proj.bias"], sd[sa + "k_proj.bias"]]).float(), torch.float32)
+            qkw, qkb = torch.cat([sd[sa + "q_proj.weight"], sd[sa + "k_proj.weight"]]), torch.cat([sd[sa + "q_proj.bias"], sd[sa + "k_proj.bias"]])
+            if self.q_prescaled:                                  # token self-attention (ovo_attention): log2 e / sqrt(hd) into the q rows, in f32
+                qkw, qkb = L.fold_q_scale(qkw, qkb, c, c // spec.heads)
+            up(sa + "qk.w", qkw, torch.bfloat16)
+            up(sa + "qk.b", qkb.float(), torch.float32)
             lin(sa + "v_proj"); lin(sa + "out_proj")
             for a in ("cross_attn_token_to_image.", "cross_attn_image_to_token."):
                 for p in ("q_proj", "k_proj", "v_proj", "out_proj"):
@@ -261,15 +265,16 @@ class HipSamDecoder:
         return out
 
     @staticmethod
-    def _attn(q, k, v, o, B, H, Tq, Tk, hd, qs, ks, vs, os_):
-        """q/k/v/o: (tensor, element offset); *s: (batch, head, token) strides in elements."""
+    def _attn(q, k, v, o, B, H, Tq, Tk, hd, qs, ks, vs, os_, prescaled=False):
+        """q/k/v/o: (tensor, element offset); *s: (batch, head, token) strides in elements.  prescaled: q already carries
+        log2(e) / sqrt(hd) (folded into its projection at load time) -> scale 0 = no factor inside the kernel."""
         a = L.Attention()
         a.q, a.k, a.v, a.o = (t.data_ptr() + off * t.element_size() for t, off in (q, k, v, o))
         a.q_sb, a.q_sh, a.q_st = qs
         a.k_sb, a.k_sh, a.k_st = ks
         a.v_sb, a.v_sh, a.v_st = vs
         a.o_sb, a.o_sh, a.o_st = os_
-        a.B, a.H, a.Tq, a.Tk, a.hd, a.scale = B, H, Tq, Tk, hd, hd ** -0.5
+        a.B, a.H, a.Tq, a.Tk, a.hd, a.scale = B, H, Tq, Tk, hd, (0.0 if prescaled else hd ** -0.5)
         L.check(L.load().ovo_attention(C.byref(a), L.stream()))
 
     def _rows(self, x, R, Cc, *, base=None, base_rows=0, norm=None, eps=1e-5, pe=None, pe_rows=0, y=None, y16=None, ype16=None):
@@ -347,7 +352,7 @@ class HipSamDecoder:
             qk = self._gemm(self.tok16 if i == 0 else qpe16, b + "self_attn.qk", bf)      # [R, 2c]
             v = self._gemm(self.tok16 if i == 0 else q16, b + "self_attn.v_proj", bf)     # [R, c]
             self._attn((qk, 0), (qk, c), (v, 0), (o_tok, 0), P, H, T, T, hd_s, (T * 2 * c, hd_s, 2 * c), (T * 2 * c, hd_s, 2 * c),
-                       (T * c, hd_s, c), (T * c, hd_s, c))
+                       (T * c, hd_s, c), (T * c, hd_s, c), prescaled=self.q_prescaled)
             self._gemm(o_tok, b + "self_attn.out_proj", f32, add=None if i == 0 else q, out=q)
             self._rows(q, R, c, norm=b + "norm1", pe=tok0, pe_rows=R, y=q, y16=q16, ype16=qpe16)
             # ---- tokens attend to the image

@@ -97,6 +97,7 @@ class HipTextEncoder:
                 self.w["proj.b"] = sd["text_projection.bias"].to(dev, f32).contiguous()
         else:
             self.w["proj.w"] = sd["text_projection"].t().to(dev, bf).contiguous()
+        self.q_prescaled = L.q_prescale_enabled()
         pad = (-spec.hidden) % 32                                        # zero hidden units up to a multiple of 32 (so400m: 4304 -> 4320)
         self.layers = 0
         while f"transformer.resblocks.{self.layers}.ln_1.weight" in sd:
@@ -105,6 +106,8 @@ class HipTextEncoder:
                 self.w[p + n + ".g"], self.w[p + n + ".b"] = sd[p + n + ".weight"].to(dev, f32), sd[p + n + ".bias"].to(dev, f32)
             for n, src in (("qkv", "attn.in_proj_"), ("out", "attn.out_proj."), ("fc1", "mlp.c_fc."), ("fc2", "mlp.c_proj.")):
                 wt, bs = sd[p + src + "weight"].float(), sd[p + src + "bias"].float()
+                if n == "qkv" and self.q_prescaled:                      # log2 e / sqrt(hd) into the q rows, in f32, before the bf16 rounding
+                    wt, bs = L.fold_q_scale(wt, bs, spec.width, spec.width // spec.heads)
                 if pad and n == "fc1":
                     wt, bs = torch.cat([wt, wt.new_zeros(pad, wt.shape[1])]), torch.cat([bs, bs.new_zeros(pad)])
                 if pad and n == "fc2":
@@ -159,7 +162,7 @@ class HipTextEncoder:
             a.q_sh = a.k_sh = a.v_sh = hd
             a.q_st = a.k_st = a.v_st = 3 * w
             a.o_sb, a.o_sh, a.o_st = t * w, hd, w
-            a.B, a.H, a.Tq, a.Tk, a.hd, a.scale, a.causal = b, H, t, t, hd, hd ** -0.5, int(spec.causal)
+            a.B, a.H, a.Tq, a.Tk, a.hd, a.scale, a.causal = b, H, t, t, hd, (0.0 if self.q_prescaled else hd ** -0.5), int(spec.causal)
             L.check(lib.ovo_attention(C.byref(a), L.stream()))
             self._gemm(att, p + "out", f32, add=x, out=x)
             rows(p + "ln_2", y16=h16)

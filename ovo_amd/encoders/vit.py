@@ -196,6 +196,7 @@ class HipViT:
             self._keep.append(x)
             return L.ptr(x)
 
+        self.q_prescaled = L.q_prescale_enabled()
         extra = spec.mlp_pad - spec.mlp_dim               # zero hidden units: act(0) = 0 and their fc2 columns are 0
 
         def pad_rows(t):
@@ -220,7 +221,10 @@ class HipViT:
                 fw, fb = fw * ls2.float()[:, None], fb * ls2.float()
             ly = self._layers[i]
             ly.ln1_g, ly.ln1_b = vec(sd[p + "ln_1.weight"]), vec(sd[p + "ln_1.bias"])
-            ly.qkv_w, ly.qkv_b = mat(sd[p + "attn.in_proj_weight"]), vec(sd[p + "attn.in_proj_bias"])
+            qw, qb = sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"]
+            if self.q_prescaled:                           # log2 e / sqrt(hd) into the q rows, in f32, before the bf16 rounding
+                qw, qb = L.fold_q_scale(qw, qb, d, d // spec.heads)
+            ly.qkv_w, ly.qkv_b = mat(qw), vec(qb)
             ly.out_w, ly.out_b = mat(ow), vec(ob)
             ly.ln2_g, ly.ln2_b = vec(sd[p + "ln_2.weight"]), vec(sd[p + "ln_2.bias"])
             ly.fc1_w, ly.fc1_b = mat(pad_rows(sd[p + "mlp.c_fc.weight"])), vec(pad_rows(sd[p + "mlp.c_fc.bias"]))
@@ -238,6 +242,8 @@ class HipViT:
         if spec.map_pool:
             a = "attn_pool."
             q = torch.nn.functional.linear(sd[a + "latent"].float().reshape(1, d), sd[a + "q.weight"].float(), sd[a + "q.bias"].float())
+            if self.q_prescaled:
+                q = q * (L.LOG2E / float(d // spec.heads) ** 0.5)
             w.map_q = mat(q.reshape(d))
             w.map_kv_w, w.map_kv_b = mat(sd[a + "kv.weight"]), vec(sd[a + "kv.bias"])
             w.map_proj_w, w.map_proj_b = mat(sd[a + "proj.weight"]), vec(sd[a + "proj.bias"])
@@ -264,7 +270,7 @@ class HipViT:
         if c is None:
             s = self.spec
             c = L.VitConfig(s.image_size, s.patch, s.width, s.layers, s.heads, s.mlp_pad, s.out_dim, int(s.cls_token),
-                            {"gelu": 1, "quick_gelu": 2, "gelu_tanh": 5}[s.act], int(s.pre_ln), int(s.use_rope), pool, s.kpad, s.ln_eps)
+                            {"gelu": 1, "quick_gelu": 2, "gelu_tanh": 5}[s.act], int(s.pre_ln), int(s.use_rope), pool, s.kpad, s.ln_eps, int(self.q_prescaled))
             self._cfg[pool] = c
         return c
 

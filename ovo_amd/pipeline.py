@@ -461,6 +461,7 @@ class FramePipeline:
         # waits for the main stream, whose queue holds the previous rounds' tails (with a main -> chain dependency the two streams took turns:
         # tail(r - 1) -> chains(r + 1) -> tail(r + 1) ..., 4.5 ms per round).  The other direction is an event: chain k -> tail k.
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            round_seq = 0                                          # sequence number of the round's LAST map step (0: none was built)
             for f in group:
                 fd = [f.index, f.rgb_lr, f.depth, f.c2w]
                 self.slam.track_camera(fd)
@@ -468,12 +469,16 @@ class FramePipeline:
                 if f.ready is not None and side is not None:
                     side.wait_event(f.ready)                       # the frame's upload, if it is still in flight
                 m = self.slam.map_launch(fd, c2w, defer=True)
+                if m is not None:
+                    round_seq = self.slam.last_seq
                 p = self.ovo.detect_and_track_launch([f.index, f.rgb, f.depth, ratio], self.slam, c2w, defer=True)
                 pend.append(p)
                 if m is not None or p is not None:
                     maps.append(m if m is not None else L.MapStep())
                     tracks.append(p["step"] if p is not None else L.TrackStep())
-            self._round_seq[group[0].index] = self.slam.last_seq   # the map's size after the round = result block of its last map step
+            # the map's size after the round = result block of its last map step; a round in which no keyframe had valid depth built none
+            # (the mapper's last_seq then names an OLDER round's slot, possibly reused): the consumer falls back to the tracker's count
+            self._round_seq[group[0].index] = round_seq
             if maps:
                 self.round_launcher.launch(maps, tracks, None)     # (the current stream IS the chain stream here)
             self.slam.launched()

@@ -235,8 +235,10 @@ class VanillaMapper:
                 raise L.OvoHipError("map_launch(defer=True): result ring full with deferred steps outstanding (size it with ring_slots())")
             self.settle()
         nb = lib.ovo_compact_workspace_bytes(n_sub) + 8
+        # built-but-unlaunched steps and the previous round on the chain stream hold these buffers' raw addresses: grow geometrically, and every
+        # step keeps the tensors it points at alive through `_keep` below (a dropped block could be handed to another tensor while still in use)
         if self._ws is None or self._ws.numel() < nb:
-            self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            self._ws = torch.empty(max(nb, 2 * (self._ws.numel() if self._ws is not None else 0)), dtype=torch.uint8, device=dev)
         ws = self._ws
         if self._explained is None or self._explained.numel() < h * w:
             self._explained = torch.empty(h * w, dtype=torch.uint8, device=dev)
@@ -250,7 +252,7 @@ class VanillaMapper:
         a.ds, a.erode, a.n_upper = ds, int(self.k_pooling > 1), self._n_upper
         a.explained, a.ws, a.ws_bytes = self._explained.data_ptr(), ws.data_ptr(), nb
         a.result_host, a.seq = slot, seq
-        self._keep.append((depth, rgb))                    # raw pointers cross the ABI (later, when deferred): keep converted copies alive
+        self._keep.append((depth, rgb, ws, self._explained))   # raw pointers cross the ABI (later, when deferred): keep what the step points at alive
         self._pending.append((seq, n_sub))
         self.last_seq = seq
         if defer:
