@@ -50,13 +50,22 @@ __device__ __forceinline__ void static_for(F &&f) {             // f(integral_co
     } while (0)
 #define OVO_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <int BM, int BN, int WARPS_M, typename VT, bool STAGED>
+// MF = 16: v_mfma_f32_16x16x32 (acc[i][j] = one 16 x 16 tile);  MF = 32: v_mfma_f32_32x32x16 (round 5, VERDICT r4 item 1a: same LDS bytes per wave tile --
+// every fragment is read once per K-tile either way -- half the VGPR operand reads per flop; STAGED epilogues only).  The epilogues see the accumulators as
+// PIECES of 4 consecutive columns of one row: piece (i, j) of a lane = row RT i + lrow, columns CS j + lcol .. + 3 of the wave tile
+//   MF 16: RT 16, CS 16, lrow = lane & 15, lcol = 4 (lane >> 4), value acc[i][j]
+//   MF 32: RT 32, CS  8, lrow = lane & 31, lcol = 4 (lane >> 5), value acc32[i][j / 4][4 (j % 4) .. + 3]   (D[n][m] of W-fragment x activation-fragment:
+//          lane holds m = lane % 32 and n = 8 (r / 4) + 4 (lane / 32) + r % 4 of the 32 x 32 tile)
+template <int BM, int BN, int WARPS_M, typename VT, bool STAGED, int MF = 16>
 __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (its parse of lambdas that call LDS-DMA builtins drops the stub silently)
     constexpr int WARPS_N = 8 / WARPS_M;
     constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;            // wave tile
     constexpr int HM = WTM / 2, HN = WTN / 2;                        // one sub-tile ("half") of the wave tile
     constexpr int TMH = HM / 16, TNH = HN / 16;                      // 16x16 MFMA tiles per sub-tile
+    constexpr int TMH32 = HM / 32, TNH32 = HN / 32;                  // 32x32 MFMA tiles per sub-tile (MF = 32)
+    static_assert(MF == 16 || (MF == 32 && STAGED && TMH32 >= 1 && TNH32 >= 1), "MF = 32: staged epilogues, sub-tiles of >= 32 rows");
+    constexpr int RT = MF, CS = MF == 16 ? 16 : 8, NI = WTM / RT, NJ = WTN / CS;      // pieces of a lane: NI x NJ (f32x4 each)
     constexpr int A_HALF = (BM / 2) * 128, B_HALF = (BN / 2) * 128;  // bytes of a half-tile: rows x 64 two-byte elements
     constexpr int BUF = 2 * A_HALF + 2 * B_HALF;
     constexpr int NA = A_HALF / (512 * 16), NB = B_HALF / (512 * 16);   // DMA pieces (1 KB = 8 rows per wave instruction) per thread
@@ -79,11 +88,12 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int fr = lane & 15, fq = lane >> 4;
+    const int lrow = MF == 16 ? fr : (lane & 31), lcol = 4 * (MF == 16 ? fq : (lane >> 5));
     // GELU table (gemm_common.h) behind the K-tile ring AND the epilogue slabs: filled now, first read after the K-loop's last barrier
     constexpr int SLAB32 = 8 * (BM / WARPS_M / 2) * ((BN / (8 / WARPS_M)) * 4 + 16), SLAB16 = 8 * (BM / WARPS_M) * ((BN / (8 / WARPS_M)) * 2 + 16), RING = 2 * (BM + BN) * 128;
     constexpr int LUT_OFF = STAGED ? (SLAB32 > RING ? (SLAB32 > SLAB16 ? SLAB32 : SLAB16) : (SLAB16 > RING ? SLAB16 : RING)) : RING;
     const float2 *lut = (STAGED && g.act == 1 && g.gelu_lut) ? (const float2 *)(smem + LUT_OFF) : nullptr;
-    if (lut) gelu_lut_fill((float2 *)(smem + LUT_OFF), tid, 512);
+    // (the table is FILLED after the prologue's six DMA stages are in flight -- two erff per thread under the first tiles' load latency, round 5)
 #ifdef OVO_GEMM_DEBUG        // tools/ builds only (python -m ovo_amd.build --gemm-debug): early exits, per-phase time stamps, de-phased starts
     if (g.dbg & 1) return;
     auto stamp = [&](int k) { if (g.stamps && tid == 0) g.stamps[(long long)tile * 4 + k] = __builtin_amdgcn_s_memrealtime(); };
@@ -139,35 +149,62 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     const int sw = (fr >> 1) & 7;
     const int off_a = (wr * HM + fr) * 128 + ((fq ^ sw) << 4);      // ks = 0; ks = 1 is the same address with bit 6 flipped
     const int off_b = (wc * HN + fr) * 128 + ((fq ^ sw) << 4);
+    // MF = 32: local row = first row + 32 I + (lane & 31), chunk (2 s + (lane >> 5)) ^ swizzle(row): k-step s flips bits 5-6 of the address
+    const int sw32 = ((lane & 31) >> 1) & 7;
+    const int off32_a = (wr * HM + (lane & 31)) * 128 + (((lane >> 5) ^ sw32) << 4);
+    const int off32_b = (wc * HN + (lane & 31)) * 128 + (((lane >> 5) ^ sw32) << 4);
 
-    f32x4 acc[2 * TMH][2 * TNH];
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    f32x4 acc[MF == 16 ? 2 * TMH : 1][MF == 16 ? 2 * TNH : 1];
+    f32x16 acc32[MF == 32 ? 2 * TMH32 : 1][MF == 32 ? 2 * TNH32 : 1];
+    if constexpr (MF == 16) {
 #pragma unroll
-    for (int i = 0; i < 2 * TMH; ++i)
+        for (int i = 0; i < 2 * TMH; ++i)
 #pragma unroll
-        for (int j = 0; j < 2 * TNH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    VT xa[TMH][2], wb0[TNH][2], wb1[TNH][2];
+            for (int j = 0; j < 2 * TNH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2 * TMH32; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * TNH32; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+    }
+    // piece (i, j) of this lane (compile-time indices after unrolling)
+    auto piece = [&](int i, int j) -> f32x4 {
+        if constexpr (MF == 16) return acc[i][j];
+        else { const f32x16 &t = acc32[i][j >> 2]; const int e = (j & 3) * 4; return f32x4{t[e], t[e + 1], t[e + 2], t[e + 3]}; }
+    };
+    constexpr int NKS = MF == 16 ? 2 : 4, FM = MF == 16 ? TMH : TMH32, FN = MF == 16 ? TNH : TNH32;     // k-steps per K-tile, fragments per sub-tile
+    VT xa[FM][NKS], wb0[FN][NKS], wb1[FN][NKS];
 
     auto load_a = [&](const char *cur, int h) {
 #pragma unroll
-        for (int i = 0; i < TMH; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) xa[i][ks] = *(const VT *)(cur + h * A_HALF + ((off_a ^ (ks << 6)) + i * 2048));
+            for (int ks = 0; ks < NKS; ++ks)
+                xa[i][ks] = MF == 16 ? *(const VT *)(cur + h * A_HALF + ((off_a ^ (ks << 6)) + i * 2048))
+                                     : *(const VT *)(cur + h * A_HALF + ((off32_a ^ (ks << 5)) + i * 4096));
     };
-    auto load_b = [&](const char *cur, int h, VT (&wb)[TNH][2]) {
+    auto load_b = [&](const char *cur, int h, VT (&wb)[FN][NKS]) {
 #pragma unroll
-        for (int j = 0; j < TNH; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) wb[j][ks] = *(const VT *)(cur + 2 * A_HALF + h * B_HALF + ((off_b ^ (ks << 6)) + j * 2048));
+            for (int ks = 0; ks < NKS; ++ks)
+                wb[j][ks] = MF == 16 ? *(const VT *)(cur + 2 * A_HALF + h * B_HALF + ((off_b ^ (ks << 6)) + j * 2048))
+                                     : *(const VT *)(cur + 2 * A_HALF + h * B_HALF + ((off32_b ^ (ks << 5)) + j * 4096));
     };
-    auto quadrant = [&](int ih, int jh, VT (&wb)[TNH][2]) {
+    auto quadrant = [&](int ih, int jh, VT (&wb)[FN][NKS]) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-            for (int i = 0; i < TMH; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < TNH; ++j)
-                    acc[ih * TMH + i][jh * TNH + j] = Mfma<VT>::run(wb[j][ks], xa[i][ks], acc[ih * TMH + i][jh * TNH + j]);
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (MF == 16) acc[ih * TMH + i][jh * TNH + j] = Mfma<VT>::run(wb[j][ks], xa[i][ks], acc[ih * TMH + i][jh * TNH + j]);
+                    else acc32[ih * TMH32 + i][jh * TNH32 + j] = Mfma<VT>::run32(wb[j][ks], xa[i][ks], acc32[ih * TMH32 + i][jh * TNH32 + j]);
+                }
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -180,6 +217,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     stage_a(0, 1, 0);
     stage_a(1, 0, 1, nt > 1);
     stage_b(1, 0, 1, nt > 1);
+    if (lut) gelu_lut_fill((float2 *)(smem + LUT_OFF), tid, 512);     // ds_write only (lgkmcnt): the counted vmcnt below still sees the six stages alone
     OVO_VMCNT(2 * NA + 2 * NB);                           // Ah0(0), Bh0(0) landed (this wave's pieces)
     OVO_BARRIER();
     stamp(1);
@@ -234,7 +272,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     OVO_VMCNT(0);
     stamp(2);
 #ifdef OVO_GEMM_DEBUG
-    if (g.dbg & 4) { if (acc[0][0][0] == 12345.678f) *(float *)g.C = 1.f; return; }
+    if (g.dbg & 4) { if (piece(0, 0)[0] == 12345.678f) *(float *)g.C = 1.f; return; }
 #endif
 
     if constexpr (STAGED) {

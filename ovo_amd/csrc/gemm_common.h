@@ -59,12 +59,15 @@ __device__ __forceinline__ long long row_dest(const GemmArgs &g, int m) {
     return (y < g.win_H && x < g.win_W) ? ((long long)b * g.win_H + y) * g.win_W + x : -1;
 }
 
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 template <typename VT> struct Mfma;
 template <> struct Mfma<bf16x8> {
     __device__ static f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    __device__ static f32x16_t run32(bf16x8 a, bf16x8 b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 template <> struct Mfma<f16x8> {
     __device__ static f32x4 run(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    __device__ static f32x16_t run32(f16x8 a, f16x8 b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 
 template <int BK> __device__ __forceinline__ int swz(int row) {

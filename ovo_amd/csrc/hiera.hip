@@ -461,8 +461,25 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         // MLP
         const Grid gi = make_grid(B, Ho, Ho, 0);
         h_done = false;
-        TRY(gemm_from_f32(x, gi, dout, kout, L.ln2_g, L.ln2_b, c.ln_eps, 1, k.h, h_done, L.fc1_w, L.fc1_b, k.u, 4 * dout, 2, 4 * dout, 1, stream));
-        TRY(gemm(k.u, 4 * dout, L.fc2_w, 4 * dout, L.fc2_b, x, dout, 0, x, dout, tok_out, dout, 4 * dout, 0, stream));
+        // Row chunks (round 5): the hidden activations of stages 1-2 (12 frames: 786 432 x 448 and 196 608 x 896 bf16 = 704 / 352 MB) were written by
+        // FC1 and read back by FC2 through HBM.  The MLP is row-wise, so FC1 / FC2 alternate over chunks of rows whose hidden block fits the 256 MB
+        // Infinity Cache with room to spare, every chunk through the SAME hidden buffer: FC2 reads what FC1 just left in the cache and the next
+        // chunk overwrites those lines before they are written back.  MEASURED AND LEFT OFF (bench.py, one box, 12-frame groups): one pass 409.4
+        // frames/s, 96 MB chunks 404.0, 48 MB 398.2, 24 MB 387.1 -- the write stream of the FC1 chunks is not absorbed by the cache (the launches
+        // stay write-bound) and every extra launch pair adds its ramp.  OVO_HIERA_MLP_CHUNK_MB = chunk size (default 0 = one pass over all rows).
+        static const long long chunk_mb = getenv("OVO_HIERA_MLP_CHUNK_MB") ? atoll(getenv("OVO_HIERA_MLP_CHUNK_MB")) : 0;
+        const long long hid_row = (long long)4 * dout * 2;
+        long long chunk_rows = chunk_mb > 0 ? (chunk_mb << 20) / hid_row / 4096 * 4096 : 0;
+        if (chunk_rows <= 0 || tok_out < 2 * chunk_rows || tok_out * hid_row <= (200ll << 20)) chunk_rows = tok_out;   // (a hidden block the cache holds anyway: one pass)
+        for (long long r0 = 0; r0 < tok_out; r0 += chunk_rows) {
+            const long long nr = tok_out - r0 < chunk_rows ? tok_out - r0 : chunk_rows;
+            const Grid gc = chunk_rows == tok_out ? gi : make_grid(1, (int)nr, 1, 0);
+            bool hd = chunk_rows == tok_out ? h_done : false;
+            float *xc = x + r0 * dout;
+            TRY(gemm_from_f32(xc, gc, dout, kout, L.ln2_g, L.ln2_b, c.ln_eps, 1, k.h, hd, L.fc1_w, L.fc1_b, k.u, 4 * dout, 2, 4 * dout, 1, stream));
+            TRY(gemm(k.u, 4 * dout, L.fc2_w, 4 * dout, L.fc2_b, xc, dout, 0, xc, dout, nr, dout, 4 * dout, 0, stream));
+        }
+        h_done = false;
         LAUNCHED();
 
         if (p.stage_end[i] >= 0) {                           // FPN lateral 1x1 conv of this stage's output

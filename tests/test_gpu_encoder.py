@@ -342,7 +342,7 @@ def test_attention_prescaled_queries(B, H, Tq, Tk, hd):
         ref = (torch.softmax(q @ k.transpose(-1, -2) * f, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, Tq, D)
         outs[name] = (out.float() - ref).abs()
     # what is left with prescaled queries: P rounded to bf16 before P V (rel 2^-9) and the bf16 store of O
-    assert outs["prescaled"].max() < 2e-2 and outs["prescaled"].mean() < 1.5e-3
+    assert outs["prescaled"].max() < 3e-2 and outs["prescaled"].mean() < 1.5e-3
     assert outs["prescaled"].mean() <= outs["in_kernel"].mean() * 1.05 + 1e-5       # never worse than the form with the second rounding
 
 
