@@ -40,6 +40,7 @@ __device__ __forceinline__ void static_for(F &&f) {             // f(integral_co
     }
 }
 
+#define OVO_8P_MFMA32_DEFAULT 0
 #define OVO_FENCE() asm volatile("" ::: "memory")
 #define OVO_BARRIER()                      \
     do {                                   \
@@ -302,19 +303,20 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
             static_assert(WTN == 64, "read mapping below: 8 lanes x 16 bytes per row");
             char *slab = smem + wave * (WROWS * RB2);
             const int nw = n0 + wc * WTN;
-            float4 bias_r[2 * TNH];
+            float4 bias_r[NJ];
 #pragma unroll
-            for (int j = 0; j < 2 * TNH; ++j) {
-                const int n = nw + j * 16 + fq * 4;
+            for (int j = 0; j < NJ; ++j) {
+                const int n = nw + j * CS + lcol;
                 bias_r[j] = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             auto write_all = [&](auto KIND_) {
                 constexpr int KIND = decltype(KIND_)::value;
-                static_for<0, 2 * TMH>([&](auto I_) {
+                static_for<0, NI>([&](auto I_) {
                     constexpr int i = decltype(I_)::value;
 #pragma unroll
-                    for (int j = 0; j < 2 * TNH; ++j) {
-                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    for (int j = 0; j < NJ; ++j) {
+                        const f32x4 pc = piece(i, j);
+                        float v[4] = {pc[0], pc[1], pc[2], pc[3]};
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] *= g.alpha;                    // (the operations of math4, in its order)
                         v[0] += bias_r[j].x; v[1] += bias_r[j].y; v[2] += bias_r[j].z; v[3] += bias_r[j].w;
@@ -325,7 +327,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                         uint2 p;
                         if (g.out_dtype == 2) { p.x = pack_bf16(v[0], v[1]); p.y = pack_bf16(v[2], v[3]); }
                         else { p.x = pack_f16(v[0], v[1]); p.y = pack_f16(v[2], v[3]); }
-                        *(uint2 *)(slab + (i * 16 + fr) * RB2 + (j * 16 + fq * 4) * 2) = p;
+                        *(uint2 *)(slab + (i * RT + lrow) * RB2 + (j * CS + lcol) * 2) = p;
                     }
                 });
             };
@@ -382,10 +384,10 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-            for (int i = 0; i < TMH; ++i)
+            for (int i = 0; i < NI / 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2 * TNH; ++j)
-                    *(f32x4 *)(slab + (i * 16 + fr) * ROWB + (j * 16 + fq * 4) * 4) = acc[pass * TMH + i][j];
+                for (int j = 0; j < NJ; ++j)
+                    *(f32x4 *)(slab + (i * RT + lrow) * ROWB + (j * CS + lcol) * 4) = piece(pass * (NI / 2) + i, j);
             OVO_FENCE();
             const int mw = m0 + wr * WTM + pass * HM, nw = n0 + wc * WTN;
             if (KIND == 3 || (KIND < 0 && g.out_dtype == 0)) {                       // f32 rows: 16 lanes x 16 bytes per row, 4 rows per instruction
@@ -470,10 +472,10 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
             for (int pass = 0; pass < NPASS; ++pass) {
                 if (pass) OVO_BARRIER();                            // every wave is done with the previous slice
 #pragma unroll
-                for (int il = 0; il < PR / 16; ++il)
+                for (int il = 0; il < PR / RT; ++il)
 #pragma unroll
-                    for (int j = 0; j < 2 * TNH; ++j)
-                        *(f32x4 *)(sl + (il * 16 + fr) * ROWB + (j * 16 + fq * 4) * 4) = acc[pass * (PR / 16) + il][j];
+                    for (int j = 0; j < NJ; ++j)
+                        *(f32x4 *)(sl + (il * RT + lrow) * ROWB + (j * CS + lcol) * 4) = piece(pass * (PR / RT) + il, j);
 #pragma unroll
                 for (int k = 0; k < NPIECE; ++k) {
                     const int id = k * 512 + tid, c4 = id & 15, r = (id >> 4) % PR, wrg = ((id >> 4) / PR) % WARPS_M, tbl = (id >> 4) / (PR * WARPS_M);
@@ -520,7 +522,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
         else if (g.out_dtype != 0 && !g.add && g.act == 0 && g.rope_cos && g.rope_hd == 64 && n0 % 64 == 0 && g.rope_lds) rope_out();
         else if (g.out_dtype != 0 && !g.add && g.act == 0 && g.rope_cos) rows_out(std::integral_constant<int, 2>{});
         else rows_out(std::integral_constant<int, -1>{});
-    } else {
+    } else if constexpr (MF == 16) {
         // ---- epilogue straight from the accumulators (the fused-argmax form needs a row's columns in neighbouring lanes):
         // acc[i][j][r] = C[m = m0 + wr WTM + 16 i + fr][n = n0 + wc WTN + 16 j + 4 fq + r]
         float4 bias_r[2 * TNH];
@@ -590,7 +592,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
 #endif
 }
 
-template <int BM, int BN, int WARPS_M, typename VT, bool STAGED>
+template <int BM, int BN, int WARPS_M, typename VT, bool STAGED, int MF = 16>
 int launch8p_(const GemmArgs &g0, hipStream_t s) {
     GemmArgs g = g0;
     g.dbg = 0; g.stamps = nullptr;
@@ -624,7 +626,7 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     static_assert(lds_all <= 160 * 1024, "LDS");
     static bool attr_done = false;              // per instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_gemm8p<BM, BN, WARPS_M, VT, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
+        hipError_t e = hipFuncSetAttribute((const void *)k_gemm8p<BM, BN, WARPS_M, VT, STAGED, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
         if (e != hipSuccess) { ovo_set_error("ovo_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
         attr_done = true;
     }
@@ -637,14 +639,21 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     g.strip = strip_env >= 0 ? strip_env : (g.nbn >= 16 ? 8 : 0);
     if (g.strip > 0) g.chunk = (g.tiles + 7) / 8;
     const int grid = g.chunk > 0 ? g.chunk * 8 : g.tiles;
-    k_gemm8p<BM, BN, WARPS_M, VT, STAGED><<<grid, 512, (STAGED && g.rope_cos) ? lds_all : lds, s>>>(g);
+    k_gemm8p<BM, BN, WARPS_M, VT, STAGED, MF><<<grid, 512, (STAGED && g.rope_cos) ? lds_all : lds, s>>>(g);
     if (prof) ovo_prof_end(s);
     return OVO_OK;
 }
 
 template <int BM, int BN, int WARPS_M, typename VT>
 int launch8p(const GemmArgs &g, hipStream_t s) {
-    return g.best ? launch8p_<BM, BN, WARPS_M, VT, false>(g, s) : launch8p_<BM, BN, WARPS_M, VT, true>(g, s);
+    // OVO_8P_MFMA32 = 1: the 32 x 32 x 16 MFMA K-loop for the staged epilogues (bf16; measured against the 16 x 16 x 32 loop in profiles/r05*_gemm_mfma32.txt)
+    static int mf32 = getenv("OVO_8P_MFMA32") ? atoi(getenv("OVO_8P_MFMA32")) : OVO_8P_MFMA32_DEFAULT;
+    if (ovo_knobs_dynamic()) mf32 = getenv("OVO_8P_MFMA32") ? atoi(getenv("OVO_8P_MFMA32")) : OVO_8P_MFMA32_DEFAULT;
+    if (g.best) return launch8p_<BM, BN, WARPS_M, VT, false>(g, s);
+    if constexpr (std::is_same<VT, bf16x8>::value) {
+        if (mf32) return launch8p_<BM, BN, WARPS_M, VT, true, 32>(g, s);
+    }
+    return launch8p_<BM, BN, WARPS_M, VT, true>(g, s);
 }
 
 

@@ -111,6 +111,71 @@ def test_gemm_pingpong_kernel_vs_ring_kernel_and_torch(monkeypatch, tile, m, n, 
     torch.testing.assert_close(x, add + a.float() @ w.float().T + bias, atol=3e-4, rtol=3e-4)
 
 
+@pytest.mark.parametrize("tile", ["256x256", "256x128"])
+@pytest.mark.parametrize("m,n,k", [(4616, 3072, 1024), (1154, 1024, 448), (300, 260, 64), (700, 132, 1792), (257, 516, 128), (513, 260, 320)])
+def test_gemm_pingpong_mfma32_loop_vs_mfma16_loop_and_torch(monkeypatch, tile, m, n, k):
+    """The ping-pong kernel's K-loop on v_mfma_f32_32x32x16_bf16 (OVO_8P_MFMA32=1, gemm8p.hip MF = 32: another accumulator layout, so every staged
+    epilogue form walks the accumulators as 4-column pieces) against the 16 x 16 x 32 loop and the fp32 product of the same rounded operands:
+    f32 + residual + GELU (generic body), bf16 plain / table GELU (rounded slab), in-place f32 residual (kind 3), rotary (LDS table slice and the
+    per-wave form)."""
+    from ovo_amd import _lib as L
+    dtype = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(m + 3 * n + 7 * k + 1)
+    a = torch.randn(m, k + 64, generator=g).to(DEV, dtype)[:, :k]
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(DEV, dtype)
+    bias, add = torch.randn(n, generator=g).to(DEV), torch.randn(m, n, generator=g).to(DEV)
+    monkeypatch.setenv("OVO_GEMM_TILE", tile)
+
+    def forms():
+        out = {"f32_gelu_add": _gemm(a, w, bias, add=add, act=1), "bf16": _gemm(a, w, bias, out_dtype=dtype),
+               "bf16_gelu": _gemm(a, w, bias, act=1, out_dtype=dtype), "bf16_qgelu_alpha": _gemm(a, w, bias, act=2, alpha=0.75, out_dtype=dtype)}
+        x = add.clone()
+        gg = L.Gemm()
+        gg.A, gg.lda, gg.W, gg.ldw, gg.bias = a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr()
+        gg.C, gg.ldc, gg.add, gg.ld_add = x.data_ptr(), n, x.data_ptr(), n
+        gg.M, gg.N, gg.K, gg.in_dtype, gg.out_dtype, gg.act, gg.alpha = m, n, k, 2, 0, 0, 1.0
+        L.check(L.load().ovo_gemm(C.byref(gg), L.stream()))
+        out["f32_inplace"] = x
+        return out
+    monkeypatch.setenv("OVO_8P_MFMA32", "0")
+    ref16 = forms()
+    monkeypatch.setenv("OVO_8P_MFMA32", "1")
+    got = forms()
+    z = a.float() @ w.float().T + bias
+    torch.testing.assert_close(got["f32_gelu_add"], torch.nn.functional.gelu(z) + add, atol=3e-4, rtol=3e-4)
+    torch.testing.assert_close(got["f32_inplace"], add + z, atol=3e-4, rtol=3e-4)
+    for name in got:
+        a16, a32 = ref16[name].float(), got[name].float()
+        tol = 2e-2 if ref16[name].dtype == dtype else 2e-4                   # bf16 outputs: one ulp where the f32 sums straddle a rounding boundary
+        assert (a16 - a32).abs().max() <= tol, (name, float((a16 - a32).abs().max()))
+        assert (a16 != a32).float().mean() < 0.02, name                      # ... and only rarely
+
+
+@pytest.mark.parametrize("b,t,heads,hd", [(8, 577, 16, 64), (5, 50, 4, 72)])
+def test_gemm_rope_epilogue_mfma32_loop(monkeypatch, b, t, heads, hd):
+    """ovo_gemm_rope through the 32 x 32 x 16 loop (head_dim 64: the LDS table-slice form; 72: the per-wave form) against the 16 x 16 x 32 loop."""
+    from ovo_amd import _lib as L
+    g0 = torch.Generator().manual_seed(9)
+    d, m = heads * hd, b * t
+    a = torch.randn(m, d, generator=g0).to(DEV, torch.bfloat16)
+    w = (torch.randn(3 * d, d, generator=g0) * d ** -0.5).to(DEV, torch.bfloat16)
+    bias = torch.randn(3 * d, generator=g0).to(DEV)
+    ang = (torch.rand(t, hd // 2, generator=g0) * 6.28).repeat_interleave(2, dim=1)
+    cos, sin = ang.cos().contiguous().to(DEV), ang.sin().contiguous().to(DEV)
+    monkeypatch.setenv("OVO_GEMM_TILE", "256x256")
+    outs = []
+    for mf in ("0", "1"):
+        monkeypatch.setenv("OVO_8P_MFMA32", mf)
+        out = torch.empty(m, 3 * d, dtype=torch.bfloat16, device=DEV)
+        gg = L.Gemm()
+        gg.A, gg.lda, gg.W, gg.ldw, gg.bias, gg.C, gg.ldc = a.data_ptr(), d, w.data_ptr(), d, bias.data_ptr(), out.data_ptr(), 3 * d
+        gg.M, gg.N, gg.K, gg.in_dtype, gg.out_dtype, gg.act, gg.alpha = m, 3 * d, d, 2, 2, 0, 1.0
+        rp = L.Rope(cos.data_ptr(), sin.data_ptr(), t, hd, 2 * d, 1)
+        L.check(L.load().ovo_gemm_rope(C.byref(gg), C.byref(rp), L.stream()))
+        outs.append(out.float())
+    assert (outs[0] - outs[1]).abs().max() <= 4e-2 and (outs[0] != outs[1]).float().mean() < 0.02
+
+
 @pytest.mark.parametrize("m,n,k,act", [(13848, 3072, 1024, 0), (4616, 4096, 1024, 1), (49152, 1344, 448, 0), (4100, 1792, 448, 1), (300, 272, 320, 2),
                                        (70000, 128, 512, 0), (2308, 400, 1792, 5), (65800, 256, 384, 1), (257, 4112, 576, 0)])
 def test_gemm_persistent_kernel_vs_pingpong_kernel(monkeypatch, m, n, k, act):

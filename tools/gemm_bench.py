@@ -44,7 +44,9 @@ for s in shapes:
     for _ in range(ROUNDS):
         for t in tiles:
             os.environ.pop("OVO_GEMM_NO_8P", None); os.environ.pop("OVO_GEMM_NO_STREAM", None); os.environ.pop("OVO_8P_TAILWAIT", None)
+            os.environ["OVO_8P_MFMA32"] = "0"
             if t.endswith("+w"): os.environ["OVO_8P_TAILWAIT"] = "1"; t0 = t; t = t[:-2]
+            elif t.endswith("+32"): os.environ["OVO_8P_MFMA32"] = "1"; t0 = t; t = t[:-3]     # the ping-pong kernel's 32 x 32 x 16 MFMA K-loop
             else: t0 = t
             if t == "auto": os.environ.pop("OVO_GEMM_TILE", None)
             elif t == "tiled": os.environ.pop("OVO_GEMM_TILE", None); os.environ["OVO_GEMM_NO_STREAM"] = "1"   # the tiled kernels' own choice (8p or ring)
