@@ -271,6 +271,15 @@ int ovo_gemm_unwindow(const ovo_gemm_t *g, const ovo_window_t *win, ovo_stream_t
  * B x H/2 x W/2 pooled tokens in SPATIAL order -- the projection of every single token is never written. */
 int ovo_gemm_f32a(const ovo_gemm_t *g, const ovo_window_t *win, const float *x, int d, const float *gamma, const float *beta,
                   float eps, int mode, int pool2x2, ovo_stream_t stream);
+/* The MLP half of a transformer block on the f32 residual stream, in place and in ONE launch (Hiera stages 1-2 inside
+ * SAM2AutomaticMaskGenerator.generate, mask_generator.py:113; sam2 MultiScaleBlock `x = x + mlp(norm2(x))`):
+ *     x[r, :] += W2 . GELU(W1 . LayerNorm(x[r, :]; ln_g, ln_b, eps) + b1) + b2
+ * x f32 [rows, d] (16-byte aligned), W1 bf16 [hidden, ldw1 >= d] (columns >= d zero), W2 bf16 [d, ldw2 >= hidden], hidden = 4 d.
+ * The hidden activations never reach memory (as two products they are 2 x rows x hidden x 2 bytes of HBM traffic).
+ * Returns OVO_E_UNSUPPORTED -- nothing launched -- for widths without an instantiation ((d, ldw1) in (112, 128), (224, 256), (96, 128),
+ * (192, 192), (144, 192)) or rows < 16384: run ovo_gemm_f32a + ovo_gemm then (ovo_hiera_forward does exactly that). */
+int ovo_mlp_f32(float *x, int64_t rows, int d, const float *ln_g, const float *ln_b, float eps, const void *w1, int64_t ldw1,
+                const float *b1, int hidden, const void *w2, int64_t ldw2, const float *b2, ovo_stream_t stream);
 /* The large-vocabulary query (BASELINE.json config 5) with the argmax FUSED into the GEMM epilogue: per row and wave one
  * 64-bit atomicMax on (order-preserving bits of the score << 32 | ~column) into best u64[M] (ZERO on entry; columns >=
  * n_valid -- vocabulary padding -- never win).  store_scores = 0 never writes the score matrix at all (g->C may be NULL).

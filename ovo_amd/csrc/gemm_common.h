@@ -253,4 +253,9 @@ int gemm_stream_launch(const GemmArgs &g, int in_dtype, hipStream_t s);
 int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *x, int d, const float *gamma, const float *beta, float eps, int mode,
                      int pool2x2, ovo_stream_t stream, uint16_t *qpool_out = nullptr, int qpool_cols = 0);
 
+// x f32 [rows, d] += fc2(GELU(fc1(LayerNorm(x)))) in ONE launch, the hidden row never leaving registers (mlp_stream.hip); OVO_E_UNSUPPORTED when the
+// widths have no instantiation or rows < 16384 (nothing launched: the caller runs the two products)
+int mlp_stream_launch(float *x, long long rows, int d, const float *ln_g, const float *ln_b, float eps, const void *w1, long long ldw1, const float *b1,
+                      int hid, const void *w2, long long ldw2, const float *b2, hipStream_t s);
+
 }  // namespace ovo_gemm_detail

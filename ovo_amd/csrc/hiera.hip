@@ -471,7 +471,10 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         const long long hid_row = (long long)4 * dout * 2;
         long long chunk_rows = chunk_mb > 0 ? (chunk_mb << 20) / hid_row / 4096 * 4096 : 0;
         if (chunk_rows <= 0 || tok_out < 2 * chunk_rows || tok_out * hid_row <= (200ll << 20)) chunk_rows = tok_out;   // (a hidden block the cache holds anyway: one pass)
-        for (long long r0 = 0; r0 < tok_out; r0 += chunk_rows) {
+        // stages 1-2 (hidden width 4 dout, tall streams): LayerNorm -> FC1 -> GELU -> FC2 -> + residual in one pass, the hidden row in registers (mlp_stream.hip)
+        const int fused = ovo_gemm_detail::mlp_stream_launch(x, tok_out, dout, L.ln2_g, L.ln2_b, c.ln_eps, L.fc1_w, kout, L.fc1_b, 4 * dout, L.fc2_w, 4 * dout, L.fc2_b, hs);
+        if (fused != OVO_OK && fused != OVO_E_UNSUPPORTED) return fused;
+        for (long long r0 = fused == OVO_OK ? tok_out : 0; r0 < tok_out; r0 += chunk_rows) {
             const long long nr = tok_out - r0 < chunk_rows ? tok_out - r0 : chunk_rows;
             const Grid gc = chunk_rows == tok_out ? gi : make_grid(1, (int)nr, 1, 0);
             bool hd = chunk_rows == tok_out ? h_done : false;

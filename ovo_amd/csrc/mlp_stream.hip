@@ -1,0 +1,309 @@
+// mlp_stream.hip -- the MLP half of a Hiera stage-1 / stage-2 block in ONE pass over the residual stream (round 5):
+//
+//     x[row, :] += W2 . GELU(W1 . LayerNorm(x[row, :]) + b1) + b2            x f32 [rows, D], W1 bf16 [HID, K1 >= D], W2 bf16 [D, HID]
+//
+// (sam2 hieradet.py MultiScaleBlock: `x = x + self.drop_path(self.mlp(self.norm2(x)))`, reached through SAM2AutomaticMaskGenerator.generate at
+// /root/reference/ovo/entities/mask_generator.py:113.)  As two launches (gemm_stream.hip FC1 + the tiled FC2) the hidden activations -- 12 frames:
+// 786 432 x 448 and 196 608 x 896 bf16 = 704 / 352 MB -- were written by FC1 and read back by FC2: 2.46 GB of HBM traffic per stage-1 block for
+// 0.70 GB of residual stream in and out, 622 us per block at ~4 TB/s.  Here the hidden row never leaves the registers of the wave that made it:
+//
+//   * a wave owns RB blocks of 16 rows; their LayerNorm-ed bf16 A fragments (in-lane statistics, as gemm_stream.hip's f32-A loader) stay in registers;
+//   * the hidden dimension is walked in chunks of HC = 64 units.  Per chunk the workgroup holds W1[chunk rows, :] and W2[:, chunk columns] in LDS
+//     (double-buffered: the next chunk's 30 / 60 KB go into the other buffer by LDS-DMA under this chunk's products; ONE barrier per chunk), every wave multiplies its rows by the W1 chunk (v_mfma_f32_16x16x32_bf16, operands swapped: a lane's accumulator
+//     holds 4 consecutive hidden units of one row), applies bias + table GELU, rounds to bf16 and feeds the result straight back as the B operand
+//     of the FC2 partial product -- no LDS round trip, no cross-lane move: the W1 rows of a chunk are laid out in LDS in the ORDER the FC2
+//     fragment wants them (LDS row 16 j + 4 fq + r holds hidden unit 32 (j / 2) + 8 fq + 4 (j % 2) + r, so that the two accumulator tiles 2 ks,
+//     2 ks + 1 of lane (fr, fq) are exactly hidden units 32 ks + 8 fq + 0..7 of row fr = its B fragment of k-step ks);
+//   * a wave carries RB row blocks through every chunk (their FC2 accumulators live across the chunks): what a chunk costs beside its products -- one
+//     barrier, the wait for its DMA -- is paid once per RB x 16 x 8 rows;
+//   * FC2's accumulators (D / 16 tiles per row block) live across the chunks; the epilogue adds b2 and the residual (x re-read: L2 / Infinity Cache)
+//     and stores f32 rows in place.
+// Same roundings as the two-launch path (A, hidden in bf16; f32 accumulation in ascending k), same GELU table.
+#include <stdlib.h>
+
+#include "skinny.h"
+
+using namespace ovo_gemm_detail;
+
+namespace {
+
+struct MlpArgs {
+    float *x; long long rows;
+    const float *ln_g, *ln_b; float eps;
+    const uint16_t *w1; long long ldw1; const float *b1;
+    const uint16_t *w2; long long ldw2; const float *b2;
+};
+
+// K1 = padded input width (multiple of 32 >= D), D = model width, HID = hidden width, RB = 16-row blocks per wave, RI = row blocks that share one
+// read of the weight fragments (RB / RI passes over a chunk's fragments: more rows per chunk amortise its barrier and DMA wait, registers bound RI)
+template <int K1, int D, int HID, int RB, int RI, int NTHREADS, bool POLY, int HC>
+__global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slots) {
+    constexpr int NCH = HID / HC, KS1 = K1 / 32, NT1 = HC / 16, KS2 = HC / 32, NT2 = D / 16;
+    constexpr int CPR1 = K1 / 8, CPR2 = HC / 8;                                 // 16-byte chunks per LDS row of the two weight blocks
+    constexpr int W1_BYTES = HC * K1 * 2, W2_BYTES = D * HC * 2, BUF = W1_BYTES + W2_BYTES;
+    constexpr int P1 = HC * CPR1, P2 = D * CPR2, PIECES = P1 + P2, PPT = (PIECES + NTHREADS - 1) / NTHREADS;      // 16-byte pieces per chunk / per thread
+    static_assert(HID % HC == 0 && D % 16 == 0 && K1 % 32 == 0 && K1 >= D && D % 8 == 0, "shape");
+    using S1 = ovo_skinny::Skinny<K1, HC>;
+    using S2 = ovo_skinny::Skinny<HC, D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *b1s = (float *)(smem + 2 * BUF);            // b1 in LDS-row order of each chunk (the permutation below)
+    float *b2s = b1s + HID, *lg = b2s + D, *lb = lg + K1;
+    const float2 *lut = (const float2 *)(lb + K1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    constexpr int WPB = NTHREADS / 64;
+
+    // hidden unit (within its chunk) held by LDS row q of the W1 block
+    auto unit_of = [](int q) { const int j = q >> 4, n = q & 15; return 32 * (j >> 1) + 8 * (n >> 2) + 4 * (j & 1) + (n & 3); };
+    if (!POLY) gelu_lut_fill((float2 *)lut, tid, NTHREADS);
+    for (int i = tid; i < HID; i += NTHREADS) b1s[i] = g.b1[(i / HC) * HC + unit_of(i % HC)];
+    for (int i = tid; i < D; i += NTHREADS) b2s[i] = g.b2[i];
+    for (int i = tid; i < K1; i += NTHREADS) { lg[i] = i < D ? g.ln_g[i] : 0.f; lb[i] = i < D ? g.ln_b[i] : 0.f; }
+
+    // one chunk's weights, global -> LDS by DMA (global_load_lds_dwordx4: no staging registers; a wave instruction fills 64 consecutive 16-byte
+    // slots).  Slot id < P1: W1 block, LDS row q = id / CPR1 (hidden unit chunk * HC + unit_of(q)), slot id % CPR1 holds source chunk slot ^ swz(q);
+    // else W2 block, row n = (id - P1) / CPR2, columns [chunk * HC, + HC).  P1 and P2 are multiples of 64: a wave's 64 slots are all W1 or all W2.
+    static_assert(P1 % 64 == 0 && P2 % 64 == 0, "a wave instruction must not straddle the two blocks");
+    int src_off[PPT];                                   // element offset of this lane's piece at chunk 0 (its step per chunk is wave-uniform)
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        const int id = p * NTHREADS + tid;
+        if (id < P1) {
+            const int q = id / CPR1, c = (id % CPR1) ^ S1::swz(q);
+            src_off[p] = (int)(unit_of(q) * g.ldw1 + c * 8);
+        } else {
+            const int n = (id - P1) / CPR2, c = ((id - P1) % CPR2) ^ S2::swz(n);
+            src_off[p] = (int)(n * g.ldw2 + c * 8);
+        }
+    }
+    auto dma = [&](int chunk, int buf) {
+        char *base = smem + buf * BUF;
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            const int id0 = p * NTHREADS + wave * 64;                // wave-uniform
+            if (id0 >= PIECES) continue;
+            const uint16_t *src = (id0 < P1 ? g.w1 + (long long)chunk * HC * g.ldw1 : g.w2 + (long long)chunk * HC) + src_off[p];
+            glds16(src, base + id0 * 16);
+        }
+    };
+
+    const long long blocks = (g.rows + 15) / 16, groups = (blocks + WPB * RB - 1) / (WPB * RB);
+    for (long long grp = blockIdx.x; grp < groups; grp += n_slots) {
+        // (all waves of the workgroup run the same number of chunk iterations: the barriers below are workgroup-wide even for a wave without rows)
+        __syncthreads();                                             // every wave is done with the previous group's buffers (first group: the tables above are written)
+        dma(0, 0);
+        // ---- this wave's rows: LayerNorm in the load (two-pass statistics over the 4 lanes (fr, 0..3) that hold a row), bf16 A fragments
+        bf16x8 af[RB][KS1];
+        long long row[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const long long b = (grp * WPB + wave) * RB + rb;
+            const long long m = b * 16 + fr;
+            row[rb] = (b < blocks && m < g.rows) ? m : -1;
+            const float *xp = g.x + (row[rb] < 0 ? 0 : row[rb]) * D;
+            float xv[KS1][8];
+            float sum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const int d0 = (ks * 4 + fq) * 8;
+                float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+                if (row[rb] >= 0 && d0 < D) { lo = *(const float4 *)(xp + d0); hi = *(const float4 *)(xp + d0 + 4); }
+                xv[ks][0] = lo.x; xv[ks][1] = lo.y; xv[ks][2] = lo.z; xv[ks][3] = lo.w;
+                xv[ks][4] = hi.x; xv[ks][5] = hi.y; xv[ks][6] = hi.z; xv[ks][7] = hi.w;
+                sum += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+            }
+            sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum / (float)D;
+            float q = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                if ((ks * 4 + fq) * 8 < D) {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const float a0 = xv[ks][e] - mean, a1 = xv[ks][e + 1] - mean;
+                        q += a0 * a0 + a1 * a1;
+                    }
+                }
+            }
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            const float rstd = rsqrtf(q / (float)D + g.eps);
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const int d0 = (ks * 4 + fq) * 8;
+                uint32_t pk[4];
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const float y0 = (xv[ks][e] - mean) * rstd * lg[d0 + e] + lb[d0 + e];
+                    const float y1 = (xv[ks][e + 1] - mean) * rstd * lg[d0 + e + 1] + lb[d0 + e + 1];
+                    pk[e >> 1] = (row[rb] >= 0 && d0 < D) ? pack_bf16(y0, y1) : 0u;
+                }
+                af[rb][ks] = *(const bf16x8 *)pk;
+            }
+        }
+        f32x4 acc2[RB][NT2];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) acc2[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int c = 0; c < NCH; ++c) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of chunk c have landed ...
+            __syncthreads();                                         // ... and everybody's: chunk c is in buffer c & 1; every wave is done with buffer (c + 1) & 1
+            if (c + 1 < NCH) dma(c + 1, (c + 1) & 1);
+            const char *w1 = smem + (c & 1) * BUF, *w2 = w1 + W1_BYTES;
+            static_assert(RB % RI == 0, "row blocks per fragment pass");
+#pragma unroll
+            for (int r0 = 0; r0 < RB; r0 += RI) {
+                // one FC2 k-step (32 hidden units = two FC1 column tiles) at a time: FC1 tiles 2 kp, 2 kp + 1 over all of K1, bias + table GELU + bf16 --
+                // the lane's two tiles ARE its FC2 fragment of k-step kp --, then that k-step of the FC2 partial.  (All four FC1 tiles of a chunk at
+                // once held 16 more accumulators, 8 more weight fragments and 8 more bias registers live: 72 spilled registers at K1 = 256, RB = 2.)
+                const float *bc = b1s + c * HC + fq * 4;
+#pragma unroll
+                for (int kp = 0; kp < KS2; ++kp) {
+                    f32x4 acc1[RI][2];
+#pragma unroll
+                    for (int ri = 0; ri < RI; ++ri) acc1[ri][0] = acc1[ri][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        const char *wp = w1 + (fr * CPR1 + ((ks * 4 + fq) ^ S1::swz(fr))) * 16 + (2 * kp) * (16 * CPR1 * 16);
+                        const bf16x8 wa = *(const bf16x8 *)wp, wb = *(const bf16x8 *)(wp + 16 * CPR1 * 16);
+#pragma unroll
+                        for (int ri = 0; ri < RI; ++ri) {
+                            acc1[ri][0] = Mfma<bf16x8>::run(wa, af[r0 + ri][ks], acc1[ri][0]);
+                            acc1[ri][1] = Mfma<bf16x8>::run(wb, af[r0 + ri][ks], acc1[ri][1]);
+                        }
+                    }
+                    bf16x8 hf[RI];
+#pragma unroll
+                    for (int ri = 0; ri < RI; ++ri) {
+                        uint32_t pk[4];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x4 bv = *(const f32x4 *)(bc + (2 * kp + h) * 16);
+                            if (POLY) {                              // packed polynomial erf (gemm_common.h: gelu2), no LDS access
+                                const f32x2 a = gelu2(f32x2{acc1[ri][h][0] + bv[0], acc1[ri][h][1] + bv[1]});
+                                const f32x2 b = gelu2(f32x2{acc1[ri][h][2] + bv[2], acc1[ri][h][3] + bv[3]});
+                                pk[2 * h] = pack_bf16(a.x, a.y);
+                                pk[2 * h + 1] = pack_bf16(b.x, b.y);
+                            } else {
+                                float v[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = gelu_lut(acc1[ri][h][r] + bv[r], lut);
+                                pk[2 * h] = pack_bf16(v[0], v[1]);
+                                pk[2 * h + 1] = pack_bf16(v[2], v[3]);
+                            }
+                        }
+                        hf[ri] = *(const bf16x8 *)pk;
+                    }
+                    // FC2 partial, k-step kp: acc2[r0 + ri][j] += H . W2[:, chunk]^T
+                    constexpr int JG = 4;                            // fragments per read group (the last group takes what is left)
+#pragma unroll
+                    for (int j0 = 0; j0 < NT2; j0 += JG) {
+                        bf16x8 w[JG];
+                        const char *wp = w2 + (fr * CPR2 + ((kp * 4 + fq) ^ S2::swz(fr))) * 16;
+#pragma unroll
+                        for (int jj = 0; jj < JG; ++jj)
+                            if (j0 + jj < NT2) w[jj] = *(const bf16x8 *)(wp + (j0 + jj) * (16 * CPR2 * 16));
+#pragma unroll
+                        for (int jj = 0; jj < JG; ++jj)
+                            if (j0 + jj < NT2) {
+#pragma unroll
+                                for (int ri = 0; ri < RI; ++ri) acc2[r0 + ri][j0 + jj] = Mfma<bf16x8>::run(w[jj], hf[ri], acc2[r0 + ri][j0 + jj]);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        // ---- epilogue: + b2 + residual, f32 rows in place (4 lanes x 16 B = 64 contiguous bytes per row and instruction)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            if (row[rb] < 0) continue;
+            float *xp = g.x + row[rb] * D + fq * 4;
+            const float *bc = b2s + fq * 4;
+#pragma unroll
+            for (int j = 0; j < NT2; ++j) {
+                const f32x4 r = *(const f32x4 *)(xp + j * 16), bv = *(const f32x4 *)(bc + j * 16);
+                *(float4 *)(xp + j * 16) = make_float4(acc2[rb][j][0] + bv[0] + r[0], acc2[rb][j][1] + bv[1] + r[1], acc2[rb][j][2] + bv[2] + r[2],
+                                                       acc2[rb][j][3] + bv[3] + r[3]);
+                if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+template <int K1, int D, int HID, int RB, int RI, int NTHREADS, bool POLY, int HC>
+int launch_mlp(const MlpArgs &g, hipStream_t s) {
+    constexpr size_t lds = 2 * (size_t)(HC * K1 * 2 + D * HC * 2) + (size_t)(HID + D + 2 * K1) * sizeof(float) + GELU_LUT_BYTES;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_mlp_stream<K1, D, HID, RB, RI, NTHREADS, POLY, HC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { ovo_set_error("ovo_mlp_stream: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
+        attr_done = true;
+    }
+    // 8 waves per CU (2 per SIMD, up to 256 VGPRs each): ONE workgroup of 512 threads, or TWO of 256 when their LDS fits twice -- two barrier
+    // domains, so one workgroup's LayerNorm loads / epilogue stores (its HBM phases) run under the other's chunk products.  Each workgroup walks
+    // row groups blockIdx.x, + slots, ...
+    constexpr int PER_CU = (NTHREADS <= 256 && 2 * lds + 2048 <= 160 * 1024) ? 2 : 1;
+    const long long blocks = (g.rows + 15) / 16, groups = (blocks + (NTHREADS / 64) * RB - 1) / ((NTHREADS / 64) * RB);
+    const int slots = (int)(groups < 256 * PER_CU ? groups : 256 * PER_CU);
+    const bool prof = ovo_prof_enabled();
+    // profiler kind 8 (the streaming GEMMs): flops of both products; algorithmic bytes = the stream in and out + the weights
+    if (prof) { ovo_prof_begin(8, 2.0 * (double)g.rows * HID * (double)(K1 + D), s); ovo_prof_shape((int)g.rows, HID, K1); ovo_prof_flags(1 | 2 | 4 | 64);
+                ovo_prof_bytes(8.0 * (double)g.rows * D + 2.0 * HID * (K1 + D)); }
+    k_mlp_stream<K1, D, HID, RB, RI, NTHREADS, POLY, HC><<<slots, NTHREADS, lds, s>>>(g, slots);
+    if (prof) ovo_prof_end(s);
+    return OVO_OK;
+}
+
+}  // namespace
+
+namespace ovo_gemm_detail {
+
+// x f32 [rows, d] += fc2(GELU(fc1(LayerNorm(x)))) in one launch.  OVO_E_UNSUPPORTED (nothing launched) for shapes without an instantiation:
+// the caller runs the two products.  Instantiations: Hiera hiera_b+ / hiera_s / hiera_t stage 1-2 widths (112, 224 | 96, 192) and hiera_l's 144.
+int mlp_stream_launch(float *x, long long rows, int d, const float *ln_g, const float *ln_b, float eps, const void *w1, long long ldw1, const float *b1,
+                      int hid, const void *w2, long long ldw2, const float *b2, hipStream_t s) {
+    auto read_off = [] { return getenv("OVO_NO_MLP_FUSE") != nullptr || getenv("OVO_GEMM_NO_STREAM") != nullptr || getenv("OVO_GEMM_TILE") != nullptr; };
+    static int off = read_off(), gelu_poly = getenv("OVO_GELU_POLY") != nullptr;                   // (see ovo_knobs_dynamic)
+    if (ovo_knobs_dynamic()) { off = read_off(); gelu_poly = getenv("OVO_GELU_POLY") != nullptr; }
+    if (off || gelu_poly || rows < 16384 || hid != 4 * d || !x || !ln_g || !ln_b || !w1 || !b1 || !w2 || !b2) return OVO_E_UNSUPPORTED;
+    if (ldw1 % 8 != 0 || ldw2 % 8 != 0 || (((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)x) & 15) != 0) return OVO_E_UNSUPPORTED;
+    MlpArgs g;
+    g.x = x; g.rows = rows; g.ln_g = ln_g; g.ln_b = ln_b; g.eps = eps;
+    g.w1 = (const uint16_t *)w1; g.ldw1 = ldw1; g.b1 = b1; g.w2 = (const uint16_t *)w2; g.ldw2 = ldw2; g.b2 = b2;
+    const int k1 = (int)ldw1;
+    // GELU: the table in LDS (gemm_common.h: gelu_lut), as the two-launch path.  The packed polynomial (OVO_MLP_GELU_POLY=1) measured SLOWER here --
+    // (786432, 112 -> 448): 408-444 us against 353-376 (profiles/r05a_mlp_stream_variants.txt): the kernel is bound by VALU issue beside the MFMAs,
+    // and 9.5 packed instructions per value cost more of it than 7 plain ones + an LDS gather.  OVO_MLP_RB: variant number (measurement runs).
+    static int rb_env = getenv("OVO_MLP_RB") ? atoi(getenv("OVO_MLP_RB")) : 0, lut_env = getenv("OVO_MLP_GELU_POLY") == nullptr;
+    if (ovo_knobs_dynamic()) { rb_env = getenv("OVO_MLP_RB") ? atoi(getenv("OVO_MLP_RB")) : 0; lut_env = getenv("OVO_MLP_GELU_POLY") == nullptr; }
+#define GO(KK, DD, RB, RI, NTH, HCC, CODE)                                                                                             \
+    if (d == DD && k1 == KK && (rb_env == 0 || rb_env == CODE))                                                                        \
+        return lut_env ? launch_mlp<KK, DD, 4 * DD, RB, RI, NTH, false, HCC>(g, s) : launch_mlp<KK, DD, 4 * DD, RB, RI, NTH, true, HCC>(g, s);
+    // CODE (OVO_MLP_RB) = variant number of the measurement runs
+    // measured (tools/mlp_bench.py, profiles/r05a_mlp_stream_variants.txt; 12 frames of hiera_b+; the two launches: 604 / 410 us):
+    //   variant 2 = two 256-thread workgroups per CU (stage 2 with 32-unit chunks so that its LDS fits twice): 337-341 / 279-285 us  <- default
+    //   variant 1 = one 512-thread workgroup per CU, 64-unit chunks:                                            353-404 / 284-303
+    //   variant 3 = 4 / 2 row blocks per wave in 256-thread workgroups (20 / 72 spilled registers):             355-360 / 341
+    // bench.py on one box: 405.4 (variant 1) / 423.4 (2) / 418.4 (3) frames/s
+    GO(128, 112, 2, 2, 256, 64, 2) GO(128, 112, 2, 2, 512, 64, 1) GO(128, 112, 4, 2, 256, 64, 3)
+    GO(256, 224, 1, 1, 256, 32, 2) GO(256, 224, 1, 1, 512, 64, 1) GO(256, 224, 2, 1, 256, 32, 3)
+    if (rb_env) return OVO_E_UNSUPPORTED;
+    GO(128, 96, 2, 2, 256, 64, 2) GO(192, 192, 1, 1, 256, 32, 2)          // hiera_t / hiera_s
+    GO(192, 144, 1, 1, 256, 32, 2)                                         // hiera_l stage 1 (its stage 2, 288 -> K 320, takes the two launches)
+#undef GO
+    return OVO_E_UNSUPPORTED;
+}
+
+}  // namespace ovo_gemm_detail
+
+extern "C" int ovo_mlp_f32(float *x, int64_t rows, int d, const float *ln_g, const float *ln_b, float eps, const void *w1, int64_t ldw1, const float *b1,
+                           int hidden, const void *w2, int64_t ldw2, const float *b2, ovo_stream_t stream) {
+    OVO_REQUIRE(x && ln_g && ln_b && w1 && b1 && w2 && b2 && rows >= 0 && d > 0 && hidden > 0, "bad argument");
+    if (rows == 0) return OVO_OK;
+    const int rc = ovo_gemm_detail::mlp_stream_launch(x, rows, d, ln_g, ln_b, eps, w1, ldw1, b1, hidden, w2, ldw2, b2, (hipStream_t)stream);
+    if (rc != OVO_OK) return rc;
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}

@@ -553,6 +553,60 @@ def test_gemm_with_layernorm_in_the_operand_load(M, N, K, d, win, mode, act, out
     assert lib.ovo_gemm_f32a(C.byref(small), None, x.data_ptr(), d, gamma.data_ptr(), beta.data_ptr(), 1e-6, mode, 0, L.stream()) == L.E_UNSUPPORTED
 
 
+@pytest.mark.parametrize("rows,d,k1", [(65536, 112, 128), (32768 + 40, 224, 256), (16384 + 5, 96, 128), (20000, 192, 192), (16400, 144, 192)])
+def test_fused_mlp_stream_vs_two_products_and_torch(rows, d, k1):
+    """ovo_mlp_f32 (mlp_stream.hip): x += fc2(GELU(fc1(LayerNorm(x)))) in one launch, the hidden row never leaving the registers, against
+    (a) the two launches it replaces -- ovo_gemm_f32a (LayerNorm in the operand load, table GELU) into a bf16 hidden matrix, then ovo_gemm with the
+    in-place f32 residual: the same roundings and the same k order, so the results agree to f32 summation noise -- and (b) the fp32 formula in
+    torch on the same bf16-rounded weights.  Ragged row counts (a last 16-row block that is partly / wholly past the end), every instantiated
+    width (hiera_b+ 112 / 224, hiera_t / s 96 / 192, hiera_l 144)."""
+    from ovo_amd import _lib as L
+    lib = L.load()
+    hid = 4 * d
+    g = torch.Generator().manual_seed(rows + d)
+    x0 = (torch.randn(rows, d, generator=g) * 2 + 0.5).to(DEV)
+    gamma, beta = (torch.randn(d, generator=g) * 0.5 + 1).to(DEV), (torch.randn(d, generator=g) * 0.1).to(DEV)
+    w1 = torch.zeros(hid, k1, dtype=torch.bfloat16, device=DEV)
+    w1[:, :d] = (torch.randn(hid, d, generator=g) * d ** -0.5).to(DEV, torch.bfloat16)
+    w2 = (torch.randn(d, hid, generator=g) * hid ** -0.5).to(DEV, torch.bfloat16)
+    b1, b2 = torch.randn(hid, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    # (a) two launches
+    xa = x0.clone()
+    h = torch.empty(rows, hid, dtype=torch.bfloat16, device=DEV)
+    q = L.Gemm()
+    q.A, q.lda, q.W, q.ldw, q.bias, q.C, q.ldc, q.add, q.ld_add = None, k1, w1.data_ptr(), k1, b1.data_ptr(), h.data_ptr(), hid, None, 0
+    q.M, q.N, q.K, q.in_dtype, q.out_dtype, q.act, q.alpha = rows, hid, k1, 2, 2, 1, 1.0
+    rc = lib.ovo_gemm_f32a(C.byref(q), None, xa.data_ptr(), d, gamma.data_ptr(), beta.data_ptr(), 1e-6, 1, 0, L.stream())
+    two = rc == 0
+    if two:
+        q2 = L.Gemm()
+        q2.A, q2.lda, q2.W, q2.ldw, q2.bias, q2.C, q2.ldc, q2.add, q2.ld_add = h.data_ptr(), hid, w2.data_ptr(), hid, b2.data_ptr(), xa.data_ptr(), d, xa.data_ptr(), d
+        q2.M, q2.N, q2.K, q2.in_dtype, q2.out_dtype, q2.act, q2.alpha = rows, d, hid, 2, 0, 0, 1.0
+        L.check(lib.ovo_gemm(C.byref(q2), L.stream()))
+    # fused
+    xf = torch.cat([x0, torch.full((64, d), 7.0, device=DEV)])            # guard rows behind the end: must stay untouched
+    L.check(lib.ovo_mlp_f32(xf.data_ptr(), rows, d, gamma.data_ptr(), beta.data_ptr(), 1e-6, w1.data_ptr(), k1, b1.data_ptr(), hid,
+                            w2.data_ptr(), hid, b2.data_ptr(), L.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(xf[rows:], torch.full((64, d), 7.0, device=DEV))
+    got = xf[:rows]
+    # (b) torch
+    mean = x0.mean(1, keepdim=True)
+    ln = (x0 - mean) * torch.rsqrt(((x0 - mean) ** 2).mean(1, keepdim=True) + 1e-6) * gamma + beta
+    hh = torch.nn.functional.gelu(ln.to(torch.bfloat16).float() @ w1[:, :d].float().T + b1).to(torch.bfloat16).float()
+    ref = x0 + hh @ w2.float().T + b2
+    rms = (ref - x0).pow(2).mean().sqrt()
+    err = (got - ref).abs()
+    print(f"fused MLP ({rows}, {d}): vs torch max {err.max().item():.2e} rms {err.pow(2).mean().sqrt().item():.2e} (update rms {rms.item():.2e})")
+    assert err.max() < 3e-2 * rms and err.pow(2).mean().sqrt() < 2e-3 * rms     # a hidden value rounding the other way moves an output by 2^-9 |h w2|
+    if two:
+        dd = (got - xa).abs()
+        print(f"   vs the two launches: max {dd.max().item():.2e}, {(got != xa).float().mean().item():.3%} of the elements differ")
+        assert dd.max() < 2e-2 * rms and dd.pow(2).mean().sqrt() < 5e-4 * rms
+    assert lib.ovo_mlp_f32(xf.data_ptr(), 1024, d, gamma.data_ptr(), beta.data_ptr(), 1e-6, w1.data_ptr(), k1, b1.data_ptr(), hid,
+                           w2.data_ptr(), hid, b2.data_ptr(), L.stream()) == L.E_UNSUPPORTED       # short streams: the two products
+
+
 def test_layernorm_embed_im2col_rope():
     from ovo_amd import _lib as L
     lib = L.load()
