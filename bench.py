@@ -200,6 +200,26 @@ def pmc_traffic(tile: str):
     return round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n) if n else None
 
 
+def pmc_traffic_stamp():
+    """Where `roofline.traffic` comes from: the committed PMC reduction carries the hash of the kernel sources it was measured on (tools/pmc_traffic.py);
+    this says whether the sources of THIS run are the same."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        measured = json.load(fh).get("csrc_sha16")
+    root = os.path.join(ROOT, "ovo_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(root, f), "rb") as fh:
+                h.update(fh.read())
+    here = h.hexdigest()[:16]
+    return {"source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not collected in this run)",
+            "measured_on_csrc_sha16": measured, "this_run_csrc_sha16": here, "same_kernel_sources": bool(measured) and measured == here}
+
+
 def profile_pass(pipe, feed, rounds, lib):
     """hipEvent pairs around every GEMM / attention / track_project launch of `rounds` steps (on the launching streams)."""
     from ovo_amd import _lib as L
@@ -218,7 +238,7 @@ def profile_pass(pipe, feed, rounds, lib):
         ("k_gemm_stream<bf16> (ovo_amd/csrc/gemm_stream.hip)" if dom == 8 else f"k_gemm<{tiles[dom]},64,bf16> (ovo_amd/csrc/gemm.hip)")
     return {"bound": "mfma", "kernel": name, "achieved": round(tf, 1),
             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-            "traffic": pmc_traffic(tiles[dom]),
+            "traffic": pmc_traffic(tiles[dom]), "traffic_stamp": pmc_traffic_stamp(),
             "algorithmic_bytes_per_launch": round(nbytes[dom] / max(n[dom], 1)),
             "launches_per_frame": n[dom] / steps, "avg_launch_us": round(1e3 * ms[dom] / max(n[dom], 1), 2),
             "gemm_tiles_ms_per_frame": {tiles[k]: round(ms[k] / steps, 3) for k in tiles},

@@ -24,6 +24,10 @@ timeout 300 python tools/replicated_cost.py 64 8 > $OUT/replicated_cost.txt 2>&1
 (for w in 1 2 4 8; do echo "world $w"; timeout 300 python tools/round_emulation.py $w; done) > $OUT/round_emulation.txt 2>&1
 timeout 600 python tools/vit_bench.py > $OUT/vit_bench.txt 2>&1
 timeout 300 python tools/attn_bench.py > $OUT/attn_bench.txt 2>&1
+timeout 300 python tools/scatter_bench.py > $OUT/scatter_bench.txt 2>&1; timeout 300 python tools/scatter_bench.py 5000000 768 60000 >> $OUT/scatter_bench.txt 2>&1
+RBS=0 timeout 300 python tools/mlp_bench.py > $OUT/mlp_bench.txt 2>&1
+# BASELINE configs[3]'s process layout on ONE GPU over gloo (8 ranks, 5 M-point map): executes rings, staging and shards at world 8; not a scaling number
+(export OVO_FORCE_DEVICE=0 OVO_DIST_BACKEND=gloo; timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 8 --steps 8 --warmup 2 --map-points 5000000 --no-cpu-baseline --no-roofline --dense-merge none 2>&1 | tail -1) > $OUT/bench_world8_one_gpu_5m.json
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $R/bench.py --no-cpu-baseline --steps 24 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/prof_bench.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/pmc_fetch.log 2>&1

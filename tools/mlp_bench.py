@@ -39,7 +39,9 @@ def run(rows, d, k1, iters=20):
         L.check(lib.ovo_gemm_f32a(C.byref(q), None, x.data_ptr(), d, gamma.data_ptr(), beta.data_ptr(), 1e-6, 1, 0, L.stream()))
         L.check(lib.ovo_gemm(C.byref(q2), L.stream()))
     out = {}
-    for name, fn in (("fused", fused), ("two launches", two)):
+    legs = (("fused", fused),) if os.environ.get("ONLY_FUSED") else (("fused", fused), ("two launches", two))
+    iters = int(os.environ.get("ITERS", iters))
+    for name, fn in legs:
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -51,6 +53,7 @@ def run(rows, d, k1, iters=20):
         torch.cuda.synchronize()
         out[name] = 1e3 * e0.elapsed_time(e1) / iters
     by = 8.0 * rows * d
+    out.setdefault("two launches", float("nan"))
     print(f"({rows}, d {d}, hidden {hid}): fused {out['fused']:7.1f} us = {by / out['fused'] / 1e3:6.0f} GB/s of the stream in + out, "
           f"{4.0 * rows * hid * d / out['fused'] / 1e6:5.0f} TFLOP/s;  two launches {out['two launches']:7.1f} us")
 

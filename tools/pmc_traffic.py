@@ -43,6 +43,19 @@ def calib_factor(dirname, counter, pattern, true_bytes):
     return None, None
 
 
+def csrc_sha16():
+    """sha256[:16] over the kernel sources (ovo_amd/csrc, sorted): bench.py prints it beside `traffic` and says whether the sources it runs are the
+    ones the counters were taken on (the GPU box has no .git)."""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ovo_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(root, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fetch-dir", required=True)
@@ -70,7 +83,7 @@ def main():
         kernels[short(k)] = {"launches": max(fn, wn), "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                              "hbm_bytes_per_launch": (fb or 0.0) + (wb or 0.0)}
     with open(a.out, "w") as fh:
-        json.dump({"unit": "bytes per launch (KiB counters x 1024; FETCH_SIZE x 2 on gfx950)", "notes": notes, "kernels": kernels}, fh, indent=1)
+        json.dump({"unit": "bytes per launch (KiB counters x 1024; FETCH_SIZE x 2 on gfx950)", "notes": notes, "csrc_sha16": csrc_sha16(), "kernels": kernels}, fh, indent=1)
     top = sorted(kernels.items(), key=lambda kv: -(kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]))[:12]
     for k, v in top:
         print(f"{v['launches']:6d} x {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB  {k}")
