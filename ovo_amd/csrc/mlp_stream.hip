@@ -21,6 +21,8 @@
 // Same roundings as the two-launch path (A, hidden in bf16; f32 accumulation in ascending k), same GELU table.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "skinny.h"
 
 using namespace ovo_gemm_detail;
@@ -32,12 +34,14 @@ struct MlpArgs {
     const float *ln_g, *ln_b; float eps;
     const uint16_t *w1; long long ldw1; const float *b1;
     const uint16_t *w2; long long ldw2; const float *b2;
+    int dbg;                       // OVO_MLP_DBG (diagnosis): 1 = a barrier after every chunk's products, 2 = wait for every DMA right after its issue
 };
 
 // K1 = padded input width (multiple of 32 >= D), D = model width, HID = hidden width, RB = 16-row blocks per wave, RI = row blocks that share one
 // read of the weight fragments (RB / RI passes over a chunk's fragments: more rows per chunk amortise its barrier and DMA wait, registers bound RI)
 template <int K1, int D, int HID, int RB, int RI, int NTHREADS, bool POLY, int HC>
 __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slots) {
+#if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (its parse of lambdas that call LDS-DMA builtins drops the stub silently)
     constexpr int NCH = HID / HC, KS1 = K1 / 32, NT1 = HC / 16, KS2 = HC / 32, NT2 = D / 16;
     constexpr int CPR1 = K1 / 8, CPR2 = HC / 8;                                 // 16-byte chunks per LDS row of the two weight blocks
     constexpr int W1_BYTES = HC * K1 * 2, W2_BYTES = D * HC * 2, BUF = W1_BYTES + W2_BYTES;
@@ -45,16 +49,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
     static_assert(HID % HC == 0 && D % 16 == 0 && K1 % 32 == 0 && K1 >= D && D % 8 == 0, "shape");
     using S1 = ovo_skinny::Skinny<K1, HC>;
     using S2 = ovo_skinny::Skinny<HC, D>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *b1s = (float *)(smem + 2 * BUF);            // b1 in LDS-row order of each chunk (the permutation below)
-    float *b2s = b1s + HID, *lg = b2s + D, *lb = lg + K1;
-    const float2 *lut = (const float2 *)(lb + K1);
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // the two weight buffers (DMA destinations) ONLY
+    // The tables live in STATIC LDS objects of their own: the compiler's wait-count pass orders every LDS read that may alias an in-flight LDS-DMA
+    // behind an s_waitcnt vmcnt(0).  Fragment reads at constant offsets of the other buffer are provably disjoint; a table gather at a run-time index
+    // into the same dynamic array was not -- the next chunk's DMA then had to land before the first GELU of this chunk (seen in the ISA).  Distinct
+    // LDS variables carry distinct alias scopes.
+    __shared__ __attribute__((aligned(16))) float b1s[HID];      // b1 in LDS-row order of each chunk (the permutation below)
+    __shared__ __attribute__((aligned(16))) float b2s[D], lg[K1], lb[K1];
+    __shared__ __attribute__((aligned(16))) float2 lut_s[POLY ? 1 : GELU_LUT_N];
+    const float2 *lut = lut_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     constexpr int WPB = NTHREADS / 64;
 
     // hidden unit (within its chunk) held by LDS row q of the W1 block
     auto unit_of = [](int q) { const int j = q >> 4, n = q & 15; return 32 * (j >> 1) + 8 * (n >> 2) + 4 * (j & 1) + (n & 3); };
-    if (!POLY) gelu_lut_fill((float2 *)lut, tid, NTHREADS);
+    if (!POLY) gelu_lut_fill(lut_s, tid, NTHREADS);
     for (int i = tid; i < HID; i += NTHREADS) b1s[i] = g.b1[(i / HC) * HC + unit_of(i % HC)];
     for (int i = tid; i < D; i += NTHREADS) b2s[i] = g.b2[i];
     for (int i = tid; i < K1; i += NTHREADS) { lg[i] = i < D ? g.ln_g[i] : 0.f; lb[i] = i < D ? g.ln_b[i] : 0.f; }
@@ -75,22 +84,29 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
             src_off[p] = (int)(n * g.ldw2 + c * 8);
         }
     }
-    auto dma = [&](int chunk, int buf) {
-        char *base = smem + buf * BUF;
+    // (the buffer index is a compile-time constant everywhere: with a run-time `(c & 1) * BUF` the compiler cannot tell the DMA's LDS destination
+    //  from the other buffer's fragment reads and puts an s_waitcnt vmcnt(0) in front of the first ds_read after every DMA issue -- the next
+    //  chunk's weights then land BEFORE this chunk's products start instead of under them)
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)g.w1, 0, (int)((long long)HID * g.ldw1 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)g.w2, 0, (int)((long long)D * g.ldw2 * 2), 0x00020000);
+    auto dma = [&](int chunk, auto BUF_) {
+        char *base = smem + decltype(BUF_)::value * BUF;
 #pragma unroll
         for (int p = 0; p < PPT; ++p) {
             const int id0 = p * NTHREADS + wave * 64;                // wave-uniform
             if (id0 >= PIECES) continue;
-            const uint16_t *src = (id0 < P1 ? g.w1 + (long long)chunk * HC * g.ldw1 : g.w2 + (long long)chunk * HC) + src_off[p];
-            glds16(src, base + id0 * 16);
+            // buffer_load_dwordx4 ... lds: resource = the weight matrix (SGPRs), voffset = the lane's byte offset, soffset = the chunk's
+            if (id0 < P1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void *)(base + id0 * 16), 16, src_off[p] * 2, chunk * HC * (int)g.ldw1 * 2, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (__attribute__((address_space(3))) void *)(base + id0 * 16), 16, src_off[p] * 2, chunk * HC * 2, 0, 0);
         }
+        if (g.dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     const long long blocks = (g.rows + 15) / 16, groups = (blocks + WPB * RB - 1) / (WPB * RB);
     for (long long grp = blockIdx.x; grp < groups; grp += n_slots) {
         // (all waves of the workgroup run the same number of chunk iterations: the barriers below are workgroup-wide even for a wave without rows)
         __syncthreads();                                             // every wave is done with the previous group's buffers (first group: the tables above are written)
-        dma(0, 0);
+        dma(0, std::integral_constant<int, 0>{});
         // ---- this wave's rows: LayerNorm in the load (two-pass statistics over the 4 lanes (fr, 0..3) that hold a row), bf16 A fragments
         bf16x8 af[RB][KS1];
         long long row[RB];
@@ -145,11 +161,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
 #pragma unroll
             for (int j = 0; j < NT2; ++j) acc2[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int c = 0; c < NCH; ++c) {
+        auto chunk_body = [&](auto PAR_, int c) {
+            constexpr int PAR = decltype(PAR_)::value;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of chunk c have landed ...
-            __syncthreads();                                         // ... and everybody's: chunk c is in buffer c & 1; every wave is done with buffer (c + 1) & 1
-            if (c + 1 < NCH) dma(c + 1, (c + 1) & 1);
-            const char *w1 = smem + (c & 1) * BUF, *w2 = w1 + W1_BYTES;
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                         // ... and everybody's: chunk c is in buffer PAR; every wave is done with buffer PAR ^ 1
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < NCH) dma(c + 1, std::integral_constant<int, PAR ^ 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            const char *w1 = smem + PAR * BUF, *w2 = w1 + W1_BYTES;
             static_assert(RB % RI == 0, "row blocks per fragment pass");
 #pragma unroll
             for (int r0 = 0; r0 < RB; r0 += RI) {
@@ -213,6 +233,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
                     }
                 }
             }
+            if (g.dbg & 1) __syncthreads();
+        };
+        {
+            int c = 0;
+            for (; c + 1 < NCH; c += 2) {                            // two chunks per trip: static buffer parity
+                chunk_body(std::integral_constant<int, 0>{}, c);
+                chunk_body(std::integral_constant<int, 1>{}, c + 1);
+            }
+            if (c < NCH) chunk_body(std::integral_constant<int, 0>{}, c);
         }
         // ---- epilogue: + b2 + residual, f32 rows in place (4 lanes x 16 B = 64 contiguous bytes per row and instruction)
 #pragma unroll
@@ -229,22 +258,23 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
             }
         }
     }
+#endif
 }
 
 template <int K1, int D, int HID, int RB, int RI, int NTHREADS, bool POLY, int HC>
 int launch_mlp(const MlpArgs &g, hipStream_t s) {
-    constexpr size_t lds = 2 * (size_t)(HC * K1 * 2 + D * HC * 2) + (size_t)(HID + D + 2 * K1) * sizeof(float) + GELU_LUT_BYTES;
-    static_assert(lds <= 160 * 1024, "LDS");
+    constexpr size_t lds = 2 * (size_t)(HC * K1 * 2 + D * HC * 2);                                   // dynamic: the weight buffers
+    constexpr size_t lds_all = lds + (size_t)(HID + D + 2 * K1) * sizeof(float) + GELU_LUT_BYTES + 64;   // + the static tables
+    static_assert(lds_all <= 160 * 1024, "LDS");
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)k_mlp_stream<K1, D, HID, RB, RI, NTHREADS, POLY, HC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { ovo_set_error("ovo_mlp_stream: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
         attr_done = true;
     }
-    // 8 waves per CU (2 per SIMD, up to 256 VGPRs each): ONE workgroup of 512 threads, or TWO of 256 when their LDS fits twice -- two barrier
-    // domains, so one workgroup's LayerNorm loads / epilogue stores (its HBM phases) run under the other's chunk products.  Each workgroup walks
-    // row groups blockIdx.x, + slots, ...
-    constexpr int PER_CU = (NTHREADS <= 256 && 2 * lds + 2048 <= 160 * 1024) ? 2 : 1;
+    // 8 waves per CU (2 per SIMD, up to 256 VGPRs each): ONE workgroup of 512 threads (the diagnosis variants: two of 256 when their LDS fits
+    // twice).  Each workgroup walks row groups blockIdx.x, + slots, ...
+    constexpr int PER_CU = (NTHREADS <= 256 && 2 * lds_all + 2048 <= 160 * 1024) ? 2 : 1;
     const long long blocks = (g.rows + 15) / 16, groups = (blocks + (NTHREADS / 64) * RB - 1) / ((NTHREADS / 64) * RB);
     const int slots = (int)(groups < 256 * PER_CU ? groups : 256 * PER_CU);
     const bool prof = ovo_prof_enabled();
@@ -271,6 +301,7 @@ int mlp_stream_launch(float *x, long long rows, int d, const float *ln_g, const 
     if (ldw1 % 8 != 0 || ldw2 % 8 != 0 || (((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)x) & 15) != 0) return OVO_E_UNSUPPORTED;
     MlpArgs g;
     g.x = x; g.rows = rows; g.ln_g = ln_g; g.ln_b = ln_b; g.eps = eps;
+    g.dbg = getenv("OVO_MLP_DBG") ? atoi(getenv("OVO_MLP_DBG")) : 0;
     g.w1 = (const uint16_t *)w1; g.ldw1 = ldw1; g.b1 = b1; g.w2 = (const uint16_t *)w2; g.ldw2 = ldw2; g.b2 = b2;
     const int k1 = (int)ldw1;
     // GELU: the table in LDS (gemm_common.h: gelu_lut), as the two-launch path.  The packed polynomial (OVO_MLP_GELU_POLY=1) measured SLOWER here --
@@ -282,16 +313,20 @@ int mlp_stream_launch(float *x, long long rows, int d, const float *ln_g, const 
     if (d == DD && k1 == KK && (rb_env == 0 || rb_env == CODE))                                                                        \
         return lut_env ? launch_mlp<KK, DD, 4 * DD, RB, RI, NTH, false, HCC>(g, s) : launch_mlp<KK, DD, 4 * DD, RB, RI, NTH, true, HCC>(g, s);
     // CODE (OVO_MLP_RB) = variant number of the measurement runs
-    // measured (tools/mlp_bench.py, profiles/r05a_mlp_stream_variants.txt; 12 frames of hiera_b+; the two launches: 604 / 410 us):
-    //   variant 2 = two 256-thread workgroups per CU (stage 2 with 32-unit chunks so that its LDS fits twice): 337-341 / 279-285 us  <- default
-    //   variant 1 = one 512-thread workgroup per CU, 64-unit chunks:                                            353-404 / 284-303
-    //   variant 3 = 4 / 2 row blocks per wave in 256-thread workgroups (20 / 72 spilled registers):             355-360 / 341
-    // bench.py on one box: 405.4 (variant 1) / 423.4 (2) / 418.4 (3) frames/s
-    GO(128, 112, 2, 2, 256, 64, 2) GO(128, 112, 2, 2, 512, 64, 1) GO(128, 112, 4, 2, 256, 64, 3)
-    GO(256, 224, 1, 1, 256, 32, 2) GO(256, 224, 1, 1, 512, 64, 1) GO(256, 224, 2, 1, 256, 32, 3)
+    // ONE 512-thread workgroup per CU is the production form (variant 1).  Measured (tools/mlp_bench.py, profiles/r05a_mlp_stream_variants.txt; 12
+    // frames of hiera_b+; the two launches: 600 / 397 us): 343-346 / 260 us per block once the next chunk's DMA really flies under this chunk's
+    // products (static buffer parity + tables in their own LDS objects, see the kernel), 353-404 / 284-303 before.
+    // Variants 2 / 3 -- TWO 256-thread workgroups per CU (32-unit chunks at width 224 so that the LDS fits twice; 2 or 4 / 2 row blocks per wave) --
+    // were 5-10 % faster in some sessions (320-391 / 267-288 us) but variant 2 is NOT DETERMINISTIC: under tools' stress run (random allocations and
+    // GEMMs between launches) 1 of 400 launches at 65 536 rows and every launch at 786 432 rows differed from the first in whole 16-row blocks
+    // (errors up to 0.23), variant 1 in none of 460; a wait for every DMA right after its issue (OVO_MLP_DBG=2) removes it, an extra barrier per
+    // chunk does not.  The cause was not found (two workgroups' LDS-DMA on one CU is the only difference): they stay reachable through
+    // OVO_MLP_RB=2 / 3 for diagnosis only and `test_fused_mlp_stream_is_deterministic` holds the production form to bit-identical repeats.
+    GO(128, 112, 2, 2, 512, 64, 1) GO(128, 112, 2, 2, 256, 64, 2) GO(128, 112, 4, 2, 256, 64, 3)
+    GO(256, 224, 1, 1, 512, 64, 1) GO(256, 224, 1, 1, 256, 32, 2) GO(256, 224, 2, 1, 256, 32, 3)
     if (rb_env) return OVO_E_UNSUPPORTED;
-    GO(128, 96, 2, 2, 256, 64, 2) GO(192, 192, 1, 1, 256, 32, 2)          // hiera_t / hiera_s
-    GO(192, 144, 1, 1, 256, 32, 2)                                         // hiera_l stage 1 (its stage 2, 288 -> K 320, takes the two launches)
+    GO(128, 96, 2, 2, 512, 64, 1) GO(192, 192, 1, 1, 512, 64, 1)          // hiera_t / hiera_s
+    GO(192, 144, 1, 1, 512, 64, 1)                                         // hiera_l stage 1 (its stage 2, 288 -> K 320, takes the two launches)
 #undef GO
     return OVO_E_UNSUPPORTED;
 }
