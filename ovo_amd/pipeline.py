@@ -531,6 +531,12 @@ class FramePipeline:
             seg_map = torch.empty((H, W), dtype=torch.int32, device=self.device)      # mask2segmap's painting of the received bits
             L.check(L.load().ovo_paint_segmap(L.ptr(u), u.shape[0], H * W, L.ptr(seg_map), L.stream()))
             self.masks.frames[f.index] = Frame(f.index, f.rgb, f.rgb_lr, f.depth, f.c2w, seg_map, u.view(torch.bool).reshape(-1, H, W), f.ready)
+        # The received masks and their seg maps were produced on THIS stream (collective copy-back, unpack, paint); the round's chains run on the
+        # chain stream, which by design waits for nothing of the main stream (`_launch_chains`: its other inputs are resident frame tensors).  These
+        # are not: without this edge the chain's working copy could read a block the unpack had not written yet -- found by the world-8 one-GPU
+        # run, where eight processes' kernels interleave (wrong descriptors for the last round's instances in 2 of 3 runs; never seen at world 2).
+        if self.chain_stream is not None:
+            self.chain_stream.wait_stream(torch.cuda.current_stream())
 
     # ------------------------------------------------------------------ dense shards
     def local_rows(self, n: int) -> int:

@@ -128,7 +128,9 @@ def _ranks_equal_single_process(world, n_frames, encoder_batch, own_masks):
     for k in ("pcd", "ids", "obj_ids", "colors", "table", "acc", "cnt", "cls", "conf", "sim", "inst_cls"):
         if not torch.equal(got[k], ref[k]):
             bad = (got[k] != ref[k]).reshape(got[k].shape[0], -1).any(1).nonzero().reshape(-1)
-            raise AssertionError((k, bad.numel(), bad[:10].tolist(), got[k][bad[:5]].tolist(), ref[k][bad[:5]].tolist()))
+            diff = (got[k].double() - ref[k].double()).abs().reshape(got[k].shape[0], -1).max(1).values[bad]
+            raise AssertionError((k, bad.numel(), bad[:16].tolist(), [float(f"{v:.3g}") for v in diff[:16].tolist()],
+                                  got[k][bad[:2]].reshape(2, -1)[:, :5].tolist(), ref[k][bad[:2]].reshape(2, -1)[:, :5].tolist()))
     assert got["objects"] == ref["objects"] and got["next_ins_id"] == ref["next_ins_id"]
     assert got["kfs"] == ref["kfs"] and got["top"] == ref["top"]
     assert got["desc"].keys() == ref["desc"].keys()
