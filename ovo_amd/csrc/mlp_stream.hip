@@ -317,7 +317,7 @@ int mlp_stream_launch(float *x, long long rows, int d, const float *ln_g, const 
     // frames of hiera_b+; the two launches: 600 / 397 us): 343-346 / 260 us per block once the next chunk's DMA really flies under this chunk's
     // products (static buffer parity + tables in their own LDS objects, see the kernel), 353-404 / 284-303 before.
     // Variants 2 / 3 -- TWO 256-thread workgroups per CU (32-unit chunks at width 224 so that the LDS fits twice; 2 or 4 / 2 row blocks per wave) --
-    // were 5-10 % faster in some sessions (320-391 / 267-288 us) but variant 2 is NOT DETERMINISTIC: under tools' stress run (random allocations and
+    // were 5-10 % faster in some sessions (320-391 / 267-288 us) but variant 2 is NOT DETERMINISTIC: under tools/mlp_stress.py (random allocations and
     // GEMMs between launches) 1 of 400 launches at 65 536 rows and every launch at 786 432 rows differed from the first in whole 16-row blocks
     // (errors up to 0.23), variant 1 in none of 460; a wait for every DMA right after its issue (OVO_MLP_DBG=2) removes it, an extra barrier per
     // chunk does not.  The cause was not found (two workgroups' LDS-DMA on one CU is the only difference): they stay reachable through

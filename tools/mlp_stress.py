@@ -1,3 +1,7 @@
+"""Determinism stress of the fused MLP kernel (mlp_stream.hip): repeated launches on one input, with random allocations (shifting addresses) and a
+GEMM between them, compared bit for bit with the first launch.  Variant 1 (one 512-thread workgroup per CU) is the production form; variants 2 / 3
+(two 256-thread workgroups per CU) are reachable for diagnosis and FAIL this (mlp_stream_launch).  OVO_MLP_DBG: 1 = extra barrier per chunk,
+2 = wait for every DMA right after its issue.   python tools/mlp_stress.py"""
 import ctypes as C, os, sys, random
 os.environ["OVO_KNOBS_DYNAMIC"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
