@@ -42,7 +42,7 @@ struct MlpArgs {
 template <int K1, int D, int HID, int RB, int RI, int NTHREADS, bool POLY, int HC>
 __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slots) {
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (its parse of lambdas that call LDS-DMA builtins drops the stub silently)
-    constexpr int NCH = HID / HC, KS1 = K1 / 32, NT1 = HC / 16, KS2 = HC / 32, NT2 = D / 16;
+    constexpr int NCH = HID / HC, KS1 = K1 / 32, KS2 = HC / 32, NT2 = D / 16;
     constexpr int CPR1 = K1 / 8, CPR2 = HC / 8;                                 // 16-byte chunks per LDS row of the two weight blocks
     constexpr int W1_BYTES = HC * K1 * 2, W2_BYTES = D * HC * 2, BUF = W1_BYTES + W2_BYTES;
     constexpr int P1 = HC * CPR1, P2 = D * CPR2, PIECES = P1 + P2, PPT = (PIECES + NTHREADS - 1) / NTHREADS;      // 16-byte pieces per chunk / per thread
@@ -301,7 +301,9 @@ int mlp_stream_launch(float *x, long long rows, int d, const float *ln_g, const 
     if (ldw1 % 8 != 0 || ldw2 % 8 != 0 || (((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)x) & 15) != 0) return OVO_E_UNSUPPORTED;
     MlpArgs g;
     g.x = x; g.rows = rows; g.ln_g = ln_g; g.ln_b = ln_b; g.eps = eps;
-    g.dbg = getenv("OVO_MLP_DBG") ? atoi(getenv("OVO_MLP_DBG")) : 0;
+    static int dbg_env = getenv("OVO_MLP_DBG") ? atoi(getenv("OVO_MLP_DBG")) : 0;                  // diagnosis (tools/mlp_stress.py)
+    if (ovo_knobs_dynamic()) dbg_env = getenv("OVO_MLP_DBG") ? atoi(getenv("OVO_MLP_DBG")) : 0;
+    g.dbg = dbg_env;
     g.w1 = (const uint16_t *)w1; g.ldw1 = ldw1; g.b1 = b1; g.w2 = (const uint16_t *)w2; g.ldw2 = ldw2; g.b2 = b2;
     const int k1 = (int)ldw1;
     // GELU: the table in LDS (gemm_common.h: gelu_lut), as the two-launch path.  The packed polynomial (OVO_MLP_GELU_POLY=1) measured SLOWER here --
