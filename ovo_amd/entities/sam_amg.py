@@ -45,13 +45,61 @@ def box_nms(boxes: np.ndarray, scores: np.ndarray, iou_threshold: float) -> np.n
     return np.asarray(keep, dtype=np.int64)
 
 
+def remove_small_regions(mask: np.ndarray, area_thresh: float, mode: str):
+    """sam2 / segment_anything `utils.amg.remove_small_regions` restated [upstream-knowledge, UNPINNED: neither package is available offline]:
+    mode "holes" fills background components smaller than `area_thresh` that the mask encloses or touches, mode "islands" removes foreground
+    components smaller than it (if ALL are smaller, the largest stays).  8-connectivity, like cv2.connectedComponentsWithStats(m, 8) there;
+    scipy.ndimage.label gives the same components (component numbering differs, the result does not depend on it).  Returns (mask, changed)."""
+    from scipy import ndimage
+    assert mode in ("holes", "islands")
+    correct_holes = mode == "holes"
+    working = np.logical_xor(correct_holes, mask.astype(bool))
+    regions, n = ndimage.label(working, structure=np.ones((3, 3), dtype=bool))
+    sizes = np.bincount(regions.reshape(-1), minlength=n + 1)[1:]                  # label 0 = background of `working`
+    small = [i + 1 for i, sz in enumerate(sizes) if sz < area_thresh]
+    if len(small) == 0:
+        return mask.astype(bool), False
+    fill = [0] + small
+    if not correct_holes:
+        fill = [i for i in range(n + 1) if i not in fill]
+        if len(fill) == 0:                                                         # every region is below the threshold: keep the largest
+            fill = [int(np.argmax(sizes)) + 1]
+    return np.isin(regions, fill), True
+
+
+def postprocess_small_regions(masks: np.ndarray, boxes_xyxy: np.ndarray, min_area: int, nms_thresh: float):
+    """`SAM2AutomaticMaskGenerator.postprocess_small_regions` restated [UNPINNED]: holes, then islands, smaller than `min_area` are removed from
+    every kept mask; boxes are recomputed; a box NMS that prefers UNCHANGED masks (score 1) over changed ones (score 0) drops duplicates the
+    clean-up created.  masks bool [n, H, W], boxes i32 [n, 4] -> (masks, boxes, keep indices into the input, changed flags of the kept)."""
+    if len(masks) == 0:
+        return masks, boxes_xyxy, np.zeros(0, np.int64), np.zeros(0, bool)
+    new, scores = [], []
+    for m in masks:
+        m1, ch1 = remove_small_regions(m, min_area, "holes")
+        m2, ch2 = remove_small_regions(m1, min_area, "islands")
+        new.append(m2)
+        scores.append(0.0 if (ch1 or ch2) else 1.0)
+    new = np.stack(new)
+    nb = np.zeros((len(new), 4), np.int32)                                         # batched_mask_to_box: [x0, y0, x1, y1] inclusive, zeros if empty
+    for i, m in enumerate(new):
+        ys, xs = np.nonzero(m)
+        if len(ys):
+            nb[i] = (xs.min(), ys.min(), xs.max(), ys.max())
+    scores = np.asarray(scores, np.float32)
+    keep = box_nms(nb.astype(np.float32), scores, nms_thresh)
+    out_boxes = boxes_xyxy.copy()
+    changed = scores == 0.0
+    out_boxes[changed] = nb[changed]                                               # only recalculated for masks that changed (as upstream)
+    return new[keep], out_boxes[keep], keep, changed[keep]
+
+
 class HipSam2AutomaticMaskGenerator:
     def __init__(self, image_encoder, decoder, points_per_side: int = 32, pred_iou_thresh: float = 0.8,
                  stability_score_thresh: float = 0.95, stability_score_offset: float = 1.0, mask_threshold: float = 0.0,
                  box_nms_thresh: float = 0.7, min_mask_region_area: int = 0, use_m2m: bool = False, **unused):
-        if min_mask_region_area > 0 or use_m2m:
-            raise NotImplementedError("min_mask_region_area > 0 (cv2 connected components) and use_m2m are not built; "
-                                      "the reference runs SAM2 with 0 / False (segment_utils.py:300-303)")
+        if use_m2m:
+            raise NotImplementedError("use_m2m is not built; the reference runs SAM2 with False (segment_utils.py:300-303)")
+        self.min_mask_region_area = int(min_mask_region_area)        # > 0: host clean-up of the kept masks (segment_utils.py:283,300: SAM1 100, SAM2 0)
         self.encoder, self.decoder = image_encoder, decoder
         self.points_per_side = points_per_side
         self.pred_iou_thresh, self.stability_score_thresh = pred_iou_thresh, stability_score_thresh
@@ -129,8 +177,19 @@ class HipSam2AutomaticMaskGenerator:
                 d_sel = torch.from_numpy(sel.astype(np.int32)).to(logits.device, non_blocking=True)
                 L.check(lib.ovo_amg_binarize(L.ptr(logits), L.ptr(d_sel), len(sel), lh, lw, H, W, float(self.mask_threshold), L.ptr(masks),
                                              L.stream()))
-        return {"masks": masks, "predicted_iou": iou_h[sel], "stability_score": stab[sel], "boxes_xyxy": boxes[keep],
-                "area": st[sel, 2].copy(), "point_index": sel // nm, "index": sel}
+        out = {"masks": masks, "predicted_iou": iou_h[sel], "stability_score": stab[sel], "boxes_xyxy": boxes[keep],
+               "area": st[sel, 2].copy(), "point_index": sel // nm, "index": sel}
+        if self.min_mask_region_area > 0 and len(sel):
+            # small disconnected regions and holes (generate(): `if self.min_mask_region_area > 0: postprocess_small_regions(...)`): a host pass over
+            # the few dozen kept masks -- one device sync; not on the reference's SAM2 path (min_mask_region_area 0)
+            with torch.cuda.stream(h["stream"]):
+                host = masks.cpu().numpy().astype(bool)
+                new, nboxes, keep2, changed = postprocess_small_regions(host, out["boxes_xyxy"], self.min_mask_region_area, self.box_nms_thresh)
+                out = {k: (v[keep2] if k != "masks" else v) for k, v in out.items()}
+                out["boxes_xyxy"] = nboxes
+                out["area"] = np.where(changed, new.reshape(len(new), -1).sum(1), out["area"]).astype(out["area"].dtype)
+                out["masks"] = torch.from_numpy(new.astype(np.uint8)).to(logits.device)
+        return out
 
     def generate_device(self, image) -> Dict[str, Any]:
         """image u8 [H, W, 3] (numpy or device tensor) -> dict(masks u8 [n, H, W] on the GPU, predicted_iou f32 [n],

@@ -166,6 +166,38 @@ def test_automatic_mask_generator_end_to_end():
     assert seg_map.dtype == torch.int32 and bmaps.dtype == torch.bool and seg_map.is_cuda
 
 
+def test_generator_small_region_cleanup():
+    """`min_mask_region_area > 0` (segment_utils.py:283,300: the SAM1 default is 100) through the whole generator: the kept masks are what
+    `postprocess_small_regions` makes of the masks the same generator keeps with the clean-up off (tests/test_amg_small_regions.py checks
+    that function against a flood fill), records stay aligned, no kept mask has an island or a hole below the threshold."""
+    from scipy import ndimage
+    from ovo_amd import synthetic as syn
+    from ovo_amd.entities.mask_generator import MaskGenerator
+    from ovo_amd.entities.sam_amg import postprocess_small_regions
+    cfg = {"sam_encoder": "hiera_test256", "sam_decoder": "sam2_small", "points_per_side": 6, "nms_iou_th": 0.0, "stability_score_th": 0.0,
+           "nms_score_th": 0.2, "nms_inner_th": 0.5, "seed": 1}
+    img = syn.render_rgb(144, 192, 2)
+    off = MaskGenerator(cfg, None, device=DEV).mask_generator
+    on = MaskGenerator(dict(cfg, min_mask_region_area=60), None, device=DEV).mask_generator
+    for g in (off, on):
+        g.box_nms_thresh, g.pred_iou_thresh = 1.0, -1.0            # random weights give masks with identical boxes: box NMS would eat them all
+    a, b = off.generate_device(img), on.generate_device(img)
+    assert on.min_mask_region_area == 60 and len(a["masks"]) >= 3
+    masks, boxes, keep, changed = postprocess_small_regions(a["masks"].cpu().numpy().astype(bool), a["boxes_xyxy"], 60, 1.0)
+    got = b["masks"].cpu().numpy().astype(bool)
+    assert got.shape == masks.shape and np.array_equal(got, masks) and np.array_equal(b["boxes_xyxy"], boxes)
+    np.testing.assert_array_equal(b["predicted_iou"], a["predicted_iou"][keep])
+    np.testing.assert_array_equal(b["point_index"], a["point_index"][keep])
+    assert np.array_equal(b["area"][changed], got[changed].reshape(int(changed.sum()), -1).sum(1))
+    eight = np.ones((3, 3), bool)
+    for m in got:
+        for work in (m, ~m):
+            lab, n = ndimage.label(work, structure=eight)
+            sizes = np.bincount(lab.reshape(-1), minlength=n + 1)[1:]
+            assert n <= 1 or sizes.min() >= 60 or (work is m and n == 1), sizes
+    print(f"small-region clean-up: {len(a['masks'])} -> {len(got)} masks, {int(changed.sum())} changed")
+
+
 def test_full_size_generator_feeds_tracking_640x480():
     """Row f1 at the benchmark's size: hiera_b+ encoder @1024^2 + the full SAM2 decoder on a 16 x 16 click grid (768 candidates) on a
     640 x 480 frame, generator filters, box NMS, mask NMS and seg-map painting -- against the oracle post-processing of the device's own
