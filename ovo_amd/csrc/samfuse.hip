@@ -11,6 +11,8 @@
 //   * k_up1_ln      : ConvTranspose2d(2x2, s2) + skip + LayerNorm2d + GELU -> bf16 [P, 2s, 2s, C1]   (output_upscaling.0-2)
 //   * k_up2_masks   : ConvTranspose2d(2x2, s2) + skip + GELU + hyper-network product -> mask logits  (output_upscaling.3-4 + hypernets)
 // Reference path: sam2 MaskDecoder.predict_masks / TwoWayAttentionBlock, reached at segment_utils.py:291-308, mask_generator.py:113.
+#include <stdlib.h>
+
 #include "skinny.h"
 
 namespace {
@@ -129,6 +131,7 @@ struct Up1Args {
     const float *bias, *feat, *gamma, *beta; float eps;
     int P, s;
     uint16_t *out;
+    int lut;                    // 1: GELU through the LDS table (gemm_common.h: gelu_lut; round 5), 0: the packed polynomial (OVO_SAM_GELU_POLY)
 };
 template <int K, int C1, int NTHREADS>
 __global__ void __launch_bounds__(NTHREADS) k_up1_ln(Up1Args a) {
@@ -136,7 +139,9 @@ __global__ void __launch_bounds__(NTHREADS) k_up1_ln(Up1Args a) {
     using S = Skinny<K, N>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *gs = (float *)(smem + S::W_BYTES), *bs = gs + C1, *cs = bs + C1;
+    const float2 *lut = a.lut ? (const float2 *)(cs + C1) : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    if (lut) ovo_gemm_detail::gelu_lut_fill((float2 *)lut, tid, NTHREADS);
     S::load_w(smem, a.W, K, tid, NTHREADS);
     for (int i = tid; i < C1; i += NTHREADS) { gs[i] = a.gamma[i]; bs[i] = a.beta[i]; cs[i] = a.bias[i]; }
     __syncthreads();
@@ -179,7 +184,10 @@ __global__ void __launch_bounds__(NTHREADS) k_up1_ln(Up1Args a) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const f32x4 v = acc[g * JPG + jj + h] * rstd * *(const f32x4 *)(gl + (jj + h) * 16) + *(const f32x4 *)(bl + (jj + h) * 16);
-                    const f32x2 lo = gelu2(f32x2{v[0], v[1]}), hi = gelu2(f32x2{v[2], v[3]});
+                    f32x2 lo, hi;
+                    if (lut) { lo = f32x2{ovo_gemm_detail::gelu_lut(v[0], lut), ovo_gemm_detail::gelu_lut(v[1], lut)};
+                               hi = f32x2{ovo_gemm_detail::gelu_lut(v[2], lut), ovo_gemm_detail::gelu_lut(v[3], lut)}; }
+                    else { lo = gelu2(f32x2{v[0], v[1]}); hi = gelu2(f32x2{v[2], v[3]}); }
                     o16[h] = make_uint2(pack2(lo.x, lo.y), pack2(hi.x, hi.y));
                 }
                 store_pair16(a.out + pix * C1 + jj * 16, fq, o16[0], o16[1]);
@@ -196,6 +204,7 @@ struct Up2Args {
     const float *bias, *feat, *hyper;
     int n_mask, first, n_out, P, s2;
     float *out;
+    int lut;                    // as Up1Args
 };
 template <int K, int C2>
 __global__ void __launch_bounds__(512, 4) k_up2_masks(Up2Args a) {
@@ -203,7 +212,9 @@ __global__ void __launch_bounds__(512, 4) k_up2_masks(Up2Args a) {
     using S = Skinny<K, N>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *cs = (float *)(smem + S::W_BYTES);
+    const float2 *lut = a.lut ? (const float2 *)(cs + C2) : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    if (lut) ovo_gemm_detail::gelu_lut_fill((float2 *)lut, tid, 512);
     S::load_w(smem, a.W, K, tid, 512);
     for (int i = tid; i < C2; i += 512) cs[i] = a.bias[i];
     __syncthreads();
@@ -238,7 +249,10 @@ __global__ void __launch_bounds__(512, 4) k_up2_masks(Up2Args a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = acc[g * JPG + jj];
-                const f32x2 lo = gelu2(f32x2{v[0], v[1]}), hi = gelu2(f32x2{v[2], v[3]});
+                f32x2 lo, hi;
+                if (lut) { lo = f32x2{ovo_gemm_detail::gelu_lut(v[0], lut), ovo_gemm_detail::gelu_lut(v[1], lut)};
+                           hi = f32x2{ovo_gemm_detail::gelu_lut(v[2], lut), ovo_gemm_detail::gelu_lut(v[3], lut)}; }
+                else { lo = gelu2(f32x2{v[0], v[1]}); hi = gelu2(f32x2{v[2], v[3]}); }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) part[g][i] += (h[i][0] * lo.x + h[i][1] * lo.y) + (h[i][2] * hi.x + h[i][3] * hi.y);
             }
@@ -411,6 +425,13 @@ __global__ void __launch_bounds__(NTHREADS, NTHREADS == 512 ? 4 : 1) k_skinny_li
     }
 }
 
+// GELU of the two upscaling kernels: the table in LDS (default) or the packed polynomial (OVO_SAM_GELU_POLY=1; measurement)
+int sam_gelu_lut() {
+    static int lut = getenv("OVO_SAM_GELU_POLY") == nullptr;
+    if (ovo_knobs_dynamic()) lut = getenv("OVO_SAM_GELU_POLY") == nullptr;
+    return lut;
+}
+
 template <typename KernelT>
 int set_lds(KernelT k, size_t lds, const char *who) {
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -458,11 +479,12 @@ extern "C" int ovo_sam_up1_ln(const void *A, const void *W, const float *bias, c
     Up1Args a;
     a.A = (const uint16_t *)A; a.W = (const uint16_t *)W; a.bias = bias; a.feat = feat; a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.P = (int)P; a.s = s; a.out = (uint16_t *)out;
+    a.lut = sam_gelu_lut();
     const int blocks = (int)((P * s * s + 15) / 16);
     hipStream_t st = (hipStream_t)stream;
 #define GO(KK, CC, NTH, WGS)                                                                                     \
     {                                                                                                            \
-        const size_t lds = (size_t)4 * CC * KK * 2 + 3 * CC * sizeof(float);                                     \
+        const size_t lds = (size_t)4 * CC * KK * 2 + 3 * CC * sizeof(float) + ovo_gemm_detail::GELU_LUT_BYTES;   \
         static bool done = false;                                                                                \
         if (!done) { if (int rc = set_lds(k_up1_ln<KK, CC, NTH>, lds, __func__)) return rc; done = true; }       \
         const int wpb = NTH / 64, grid = blocks < WGS * wpb ? (blocks + wpb - 1) / wpb : WGS;                    \
@@ -485,11 +507,12 @@ extern "C" int ovo_sam_up2_masks(const void *A, const void *W, const float *bias
     Up2Args a;
     a.A = (const uint16_t *)A; a.W = (const uint16_t *)W; a.bias = bias; a.feat = feat; a.hyper = hyper; a.n_mask = n_mask; a.first = first;
     a.n_out = n_mask - first; a.P = (int)P; a.s2 = s2; a.out = out;
+    a.lut = sam_gelu_lut();
     const int blocks = (int)((P * s2 * s2 + 15) / 16), grid = blocks < 512 * 8 ? (blocks + 7) / 8 : 512;
     hipStream_t st = (hipStream_t)stream;
 #define GO(KK, CC)                                                                                           \
     {                                                                                                        \
-        const size_t lds = (size_t)4 * CC * KK * 2 + CC * sizeof(float);                                     \
+        const size_t lds = (size_t)4 * CC * KK * 2 + CC * sizeof(float) + ovo_gemm_detail::GELU_LUT_BYTES;   \
         static bool done = false;                                                                            \
         if (!done) { if (int rc = set_lds(k_up2_masks<KK, CC>, lds, __func__)) return rc; done = true; }     \
         k_up2_masks<KK, CC><<<grid, 512, lds, st>>>(a);                                                      \
