@@ -473,6 +473,13 @@ typedef struct {
 } ovo_hiera_weights_t;
 
 size_t ovo_hiera_workspace_bytes(const ovo_hiera_config_t *cfg, int B);
+/* Hiera's patch embedding alone (sam2 `PatchEmbed`: Conv2d(3, E, 7, stride 4, padding 3) + the windowed position embedding; the first
+ * step of SAM2's image encoder, mask_generator.py:113) as a direct convolution on the f32 image, no im2col matrix (ABI v10):
+ *   x[b, oy * S/4 + ox, :] = conv(images[b])[:, oy, ox] + bias + pos[oy * S/4 + ox, :]
+ * images f32 [B, 3, S, S]; patch_w bf16 [E, ldw], column (c * 7 + ky) * 7 + kx, ldw >= 147; bias f32 [E]; pos f32 [(S/4)^2, E]; x f32 out.
+ * E in {96, 112, 144} and S % 128 == 0, else OVO_E_UNSUPPORTED (ovo_hiera_forward then runs ovo_im2col + ovo_gemm itself). */
+int ovo_hiera_patch_embed(const float *images, int B, int S, int E, const void *patch_w, int ldw, const float *bias, const float *pos,
+                          float *x, ovo_stream_t stream);
 /* images f32 [B, 3, S, S], already resized + normalised. */
 int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *w, const float *images, int B,
                       float *feat0, float *feat1, float *feat2, void *ws, size_t ws_bytes, ovo_stream_t stream);

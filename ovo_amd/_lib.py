@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libovo_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 E_UNSUPPORTED = -3          # OVO_E_UNSUPPORTED: the entry point does not cover this shape; the caller takes its general path
 
 
@@ -211,6 +211,7 @@ _SIGNATURES = {
     "ovo_vit_forward": (_I32, [C.POINTER(VitConfig), C.POINTER(VitWeights), _P, _I32, _P, _P, _SZ, _P]),
     "ovo_hiera_workspace_bytes": (_SZ, [C.POINTER(HieraConfig), _I32]),
     "ovo_hiera_forward": (_I32, [C.POINTER(HieraConfig), C.POINTER(HieraWeights), _P, _I32, _P, _P, _P, _P, _SZ, _P]),
+    "ovo_hiera_patch_embed": (_I32, [_P, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -335,6 +335,166 @@ int gemm_from_f32(const float *x, const Grid &g, int d, int kp, const float *gam
     return ovo_gemm(&q, s);
 }
 
+// ---- patch embedding as a direct 7 x 7 / stride-4 convolution (round 5) ----
+// x[b, (oy, ox), :] = conv7x7s4p3(image[b]) + bias + pos[(oy, ox), :], f32, straight from the f32 image: no im2col matrix (302 MB written and read back
+// per 12 frames at 1024^2) and no per-image GEMM launches.  A workgroup (8 waves, one output row each) walks over tiles of 8 x 32 output positions: a tile's 35 x 131 x 3 input
+// pixels go to LDS as bf16 (the rounding the im2col pass applied; float4 loads from the 16-byte aligned column 3 on), the weights [E, 192] once
+// per workgroup, re-ordered while they are copied so that a K-step of 32 is four (channel, ky) rows of 8 columns each -- the pixel left of the
+// window (a zero weight) and the 7 of kx: a lane's 8 consecutive k of the MFMA's B operand are then 8 consecutive pixels of one input row
+// starting at an 8-byte aligned LDS address -- two ds_read_b64 -- and of its A operand 16 bytes of a weight row.  out^T = W . patches^T, so a
+// lane ends up with 4 consecutive channels of one token: bias + position embedding + store are float4.
+// Bound by the 4 E bytes per token it writes (352 MB per 12 frames of hiera_b+).
+constexpr int PE_TH = 8, PE_TW = 32, PE_IH = 4 * PE_TH + 3, PE_RS = 136, PE_WS = 200;
+template <int NT>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_patch_embed7(const float *__restrict__ img, int S, const uint16_t *__restrict__ w, int ldw,
+                                                      const float *__restrict__ bias, const float *__restrict__ pos, float *__restrict__ out, int B,
+                                                      int n_tiles) {
+    using namespace ovo_gemm_detail;
+    constexpr int E = 16 * NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pe_lds[];
+    uint16_t *s_img = (uint16_t *)pe_lds;                               // [3 * PE_IH][PE_RS]: input column x of the tile sits at index x - x_first + 1
+    uint16_t *s_w = s_img + 3 * PE_IH * PE_RS;                          // [E][PE_WS]: k' = (channel * 7 + ky) * 8 + (kx + 1)
+    const int S4 = S >> 2, tiles_x = S4 / PE_TW;
+    for (int i = threadIdx.x; i < E * 24; i += 512) {                   // one (channel, ky) row of one output channel per thread: 7 weights
+        const int e = i / 24, r = i - 24 * e;
+        uint4 p = make_uint4(0u, 0u, 0u, 0u);
+        if (r < 21) {
+            const uint16_t *q = w + (long long)e * ldw + 7 * r;
+            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4], w5 = q[5], w6 = q[6];
+            p.x = w0 << 16; p.y = w1 | (w2 << 16); p.z = w3 | (w4 << 16); p.w = w5 | (w6 << 16);
+        }
+        *(uint4 *)(s_w + e * PE_WS + 8 * r) = p;
+    }
+    for (int i = threadIdx.x; i < 3 * PE_IH; i += 512) s_img[i * PE_RS] = 0;     // index 0 of every row: multiplied by the zero weight
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l16 = lane & 15;
+    constexpr int NV = (3 * PE_IH * 32 + 511) / 512;
+    float4 v[NV];
+    float h;
+    // a tile's pixels: columns 3 .. 130 of each row are 32 aligned float4, columns 0 .. 2 (left halo) scalars -- into registers, one tile ahead
+    auto load_tile = [&](int t) {                                       // (branch-free: clamped addresses, then a select -- seven loads in flight)
+        const int b = t % B, tt = t / B;
+        const int oy0 = (tt / tiles_x) * PE_TH, ox0 = (tt % tiles_x) * PE_TW;
+        const int y_first = 4 * oy0 - 3, x_first = 4 * ox0 - 3;
+        const float *src = img + (long long)b * 3 * S * S;
+        const float *col0 = src + 4 * ox0 + 4 * (threadIdx.x & 31);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            int row = (threadIdx.x >> 5) + 16 * j;
+            if (row > 3 * PE_IH - 1) row = 3 * PE_IH - 1;
+            const int c = row / PE_IH, y = y_first + (row - c * PE_IH);
+            const int yc = y < 0 ? 0 : (y > S - 1 ? S - 1 : y);
+            const float4 u = *(const float4 *)(col0 + (c * S + yc) * S);
+            const bool ok = y == yc;
+            v[j].x = ok ? u.x : 0.f; v[j].y = ok ? u.y : 0.f; v[j].z = ok ? u.z : 0.f; v[j].w = ok ? u.w : 0.f;
+        }
+        {
+            int row = threadIdx.x / 3;
+            const int col = threadIdx.x - 3 * row;
+            if (row > 3 * PE_IH - 1) row = 3 * PE_IH - 1;
+            const int c = row / PE_IH, y = y_first + (row - c * PE_IH), x = x_first + col;
+            const int yc = y < 0 ? 0 : (y > S - 1 ? S - 1 : y), xc = x < 0 ? 0 : x;
+            const float u = src[(c * S + yc) * S + xc];
+            h = (y == yc && x == xc) ? u : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) load_tile(blockIdx.x);
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int b = t % B, tt = t / B;                                // the images sharing a tile's position-embedding rows run side by side
+        const int oy0 = (tt / tiles_x) * PE_TH, ox0 = (tt % tiles_x) * PE_TW;
+        __syncthreads();                                                // the previous tile's products have read s_img
+        // accumulators start at bias + position embedding: the loads fly while the tile is written to LDS
+        // lane: channels 16 n + 4 g .. + 3 of token (oy0 + wave, ox0 + 16 m + l16): a wave owns one output row of the tile
+        f32x4 acc[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const long long tok = (long long)(oy0 + wave) * S4 + ox0 + 16 * m + l16;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = *(const f32x4 *)(pos + tok * E + 16 * n + 4 * g);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int row = (threadIdx.x >> 5) + 16 * j;
+            if (16 * j + 15 < 3 * PE_IH || row < 3 * PE_IH) {
+                uint2 p;
+                p.x = f2bf(v[j].x) | ((uint32_t)f2bf(v[j].y) << 16); p.y = f2bf(v[j].z) | ((uint32_t)f2bf(v[j].w) << 16);
+                *(uint2 *)(s_img + row * PE_RS + 4 + 4 * (threadIdx.x & 31)) = p;
+            }
+        }
+        {
+            const int i = threadIdx.x, row = i / 3, col = i - 3 * row;
+            if (row < 3 * PE_IH) s_img[row * PE_RS + 1 + col] = f2bf(h);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const f32x4 bb = *(const f32x4 *)(bias + 16 * n + 4 * g);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m][n] += bb;
+        }
+        if (t + (int)gridDim.x < n_tiles) load_tile(t + gridDim.x);    // the next tile's pixels fly under this tile's products and stores
+#pragma unroll 1                                                       // (unrolled, the scheduler hoists all 6 steps' fragments)
+        for (int s = 0; s < 6; ++s) {
+            int r = 4 * s + g;
+            if (r > 20) r = 20;                                         // rows 21-23: zero weights, any finite pixels
+            const int c = r / 7, ky = r - 7 * c;
+            bf16x8 pb[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int oy = wave, ox = 16 * m + l16;
+                const uint2 *q = (const uint2 *)(s_img + (c * PE_IH + 4 * oy + ky) * PE_RS + 4 * ox);
+                const uint2 lo = q[0], hi = q[1];
+                uint4 u; u.x = lo.x; u.y = lo.y; u.z = hi.x; u.w = hi.y;
+                pb[m] = *(const bf16x8 *)&u;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bf16x8 wa = *(const bf16x8 *)(s_w + (16 * n + l16) * PE_WS + 32 * s + 8 * g);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m][n] = Mfma<bf16x8>::run(wa, pb[m], acc[m][n]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const long long tok = (long long)(oy0 + wave) * S4 + ox0 + 16 * m + l16;
+            float *dst = out + ((long long)b * S4 * S4 + tok) * E;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                float4 o;
+                o.x = acc[m][n][0]; o.y = acc[m][n][1]; o.z = acc[m][n][2]; o.w = acc[m][n][3];
+                *(float4 *)(dst + 16 * n + 4 * g) = o;
+            }
+        }
+    }
+}
+
+template <int NT>
+int launch_patch_embed7(const float *img, int S, const void *w, int ldw, const float *bias, const float *pos, float *out, int B, hipStream_t s) {
+    const size_t lds = (size_t)(3 * PE_IH * PE_RS + 16 * NT * PE_WS) * 2;
+    static bool set = false;
+    if (!set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_patch_embed7<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { ovo_set_error("ovo_hiera_forward: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
+        set = true;
+    }
+    const int S4 = S / 4, n_tiles = B * (S4 / PE_TH) * (S4 / PE_TW);
+    k_patch_embed7<NT><<<n_tiles < 512 ? n_tiles : 512, 512, lds, s>>>(img, S, (const uint16_t *)w, ldw, bias, pos, out, B, n_tiles);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+// E = 96 (hiera_t / s), 112 (b+), 144 (l); anything else (or a grid that does not tile by 8 x 32) keeps the im2col + GEMM form
+int patch_embed_direct(const float *img, int S, int E, const void *w, int ldw, const float *bias, const float *pos, float *out, int B, hipStream_t s) {
+    static const bool off_once = getenv("OVO_HIERA_PATCH_GEMM") != nullptr;               // measurement / tests: the im2col + GEMM form
+    if (ovo_knobs_dynamic() ? getenv("OVO_HIERA_PATCH_GEMM") != nullptr : off_once) return OVO_E_UNSUPPORTED;
+    if (S % 128 != 0 || ldw < 147) return OVO_E_UNSUPPORTED;
+    switch (E) {
+        case 96: return launch_patch_embed7<6>(img, S, w, ldw, bias, pos, out, B, s);
+        case 112: return launch_patch_embed7<7>(img, S, w, ldw, bias, pos, out, B, s);
+        case 144: return launch_patch_embed7<9>(img, S, w, ldw, bias, pos, out, B, s);
+        default: return OVO_E_UNSUPPORTED;
+    }
+}
+
 }  // namespace
 
 #define TRY(call)                        \
@@ -351,6 +511,13 @@ size_t ovo_hiera_workspace_bytes(const ovo_hiera_config_t *cfg, int B) {
     Plan p;
     if (make_plan(*cfg, p) != 0) return 0;
     return carve(*cfg, p, B, nullptr).bytes;
+}
+
+int ovo_hiera_patch_embed(const float *images, int B, int S, int E, const void *patch_w, int ldw, const float *bias, const float *pos,
+                          float *x, ovo_stream_t stream) {
+    OVO_REQUIRE(images && patch_w && bias && pos && x && B > 0 && S > 0 && E > 0, "bad argument");
+    OVO_REQUIRE((long long)B * (S / 4) * (S / 4) < (1ll << 31) / 256, "too many tokens for one launch");
+    return patch_embed_direct(images, S, E, patch_w, ldw, bias, pos, x, B, (hipStream_t)stream);
 }
 
 int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *w, const float *images, int B, float *feat0,
@@ -371,10 +538,14 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
     const long long T0 = (long long)S4 * S4;
 
     // patch embedding (+ position embedding through the GEMM epilogue), one image at a time (pos has no batch dim)
-    TRY(ovo_im2col(images, B, 3, c.image_size, c.image_size, 7, 4, 3, k.col, 192, stream));
-    for (int b = 0; b < B; ++b)
-        TRY(gemm(k.col + (size_t)b * T0 * 192, 192, w->patch_w, 192, w->patch_b, k.x + (size_t)b * T0 * c.dims[0], c.dims[0], 0, w->pos,
-                 c.dims[0], T0, c.dims[0], 192, 0, stream));
+    const int pe_rc = patch_embed_direct(images, c.image_size, c.dims[0], w->patch_w, 192, w->patch_b, w->pos, k.x, B, hs);
+    if (pe_rc == OVO_E_UNSUPPORTED) {
+        TRY(ovo_im2col(images, B, 3, c.image_size, c.image_size, 7, 4, 3, k.col, 192, stream));
+        for (int b = 0; b < B; ++b)
+            TRY(gemm(k.col + (size_t)b * T0 * 192, 192, w->patch_w, 192, w->patch_b, k.x + (size_t)b * T0 * c.dims[0], c.dims[0], 0, w->pos,
+                     c.dims[0], T0, c.dims[0], 192, 0, stream));
+    } else
+        TRY(pe_rc);
 
     float *x = k.x, *spare = k.xr;
     long long att_rows = -1;

@@ -122,3 +122,44 @@ def test_flops_accounting_matches_the_launched_work(card):
     model = spec.flops_per_image()
     print(f"{card}: launched {launched / 1e9:.1f} GFLOP, flops_per_image {model / 1e9:.1f} GFLOP")
     assert abs(launched - model) / model < 0.03
+
+
+@pytest.mark.parametrize("E,S,B", [(112, 1024, 2), (96, 256, 3), (144, 128, 1)])
+def test_patch_embed_direct_conv_vs_torch(E, S, B):
+    """`ovo_hiera_patch_embed` (round 5: the 7 x 7 / stride-4 patch convolution straight from the f32 image, bias and position embedding in its
+    epilogue) against torch's fp32 Conv2d on the same bf16-rounded image and weights: the products are exact in f32, only the summation order
+    differs -> 1e-5 of the output scale.  Edge tiles (zero padding on all four sides) are part of every case."""
+    import ctypes as C
+    from ovo_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(E + S)
+    img = torch.randn(B, 3, S, S, generator=g)
+    w = torch.randn(E, 3, 7, 7, generator=g) * 0.05
+    bias, pos = torch.randn(E, generator=g), torch.randn((S // 4) ** 2, E, generator=g)
+    wp = torch.zeros(E, 192)
+    wp[:, :147] = w.reshape(E, -1)
+    d_img, d_w, d_b, d_p = img.to(DEV), wp.to(torch.bfloat16).to(DEV), bias.to(DEV), pos.to(DEV)
+    out = torch.empty(B, (S // 4) ** 2, E, device=DEV)
+    L.check(lib.ovo_hiera_patch_embed(L.ptr(d_img), B, S, E, L.ptr(d_w), 192, L.ptr(d_b), L.ptr(d_p), L.ptr(out), L.stream()))
+    ref = torch.nn.functional.conv2d(img.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), bias, stride=4, padding=3)
+    ref = ref.permute(0, 2, 3, 1).reshape(B, -1, E) + pos[None]
+    err = (out.cpu() - ref).abs().max().item()
+    print(f"E={E} S={S} B={B}: max |err| = {err:.3e} (output rms {ref.pow(2).mean().sqrt():.2f})")
+    assert err < 2e-5 * ref.abs().max().item()
+
+
+def test_patch_embed_direct_equals_im2col_gemm_forward(monkeypatch):
+    """The whole hiera_b+ forward with the direct patch convolution against the im2col + GEMM form (OVO_HIERA_PATCH_GEMM=1): the first layer's
+    f32 sums differ in their last bit or two, which re-rolls a few bf16 roundings downstream -- inside the noise both carry against the oracle
+    (measured rms difference / rms 1.4-1.8e-3 at the stage-1 level, 3.6-3.8e-3 behind stage 3's sixteen blocks; each is 5-7e-3 from the oracle)."""
+    from ovo_amd.encoders.hiera import SPECS, HipHiera, random_state
+    spec = SPECS["hiera_b+"]
+    enc = HipHiera(spec, random_state(spec, seed=5), device=DEV)
+    x = torch.randn(1, 3, spec.image_size, spec.image_size, generator=torch.Generator().manual_seed(2)).to(DEV)
+    a = [f.clone() for f in enc.forward(x)]
+    monkeypatch.setenv("OVO_HIERA_PATCH_GEMM", "1")
+    b = [f.clone() for f in enc.forward(x)]
+    for i, (u, v) in enumerate(zip(a, b)):
+        er = _rel_rms(u.cpu(), v.cpu())
+        print(f"level {i}: rms difference / rms = {er:.3e}")
+        assert er < 8e-3
