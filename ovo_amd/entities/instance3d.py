@@ -84,6 +84,25 @@ class Instance3D:
         self.add_points_ids(points_ids)
         self.add_top_kf(kf_id, area)
 
+    def observe(self, kf_id: int, area: int) -> None:
+        """`update([], kf_id, area)` for the tracking loop (one call per matched mask and keyframe, ovo.py:262-266): the same state changes as
+        add_keyframes + add_top_kf with the usual case -- a keyframe this instance has not been seen in, a heap that is not full -- in line."""
+        k = self.kfs_ids
+        if not k or (k[-1] != kf_id and kf_id not in k):
+            k.append(kf_id)
+            if self.n_top_kf <= 0:
+                self._pending_kfs.append(kf_id)
+        top = self._top_area
+        if kf_id not in top and len(self._top_kf) < self.n_top_kf:
+            entry = (area, kf_id)
+            heapq.heappush(self._top_kf, entry)
+            top[kf_id] = area
+            bisect.insort(self._top_sorted, entry)
+            self._pending_kfs.append(kf_id)
+            self.to_update = True
+        else:
+            self.add_top_kf(kf_id, area)
+
     def add_points_ids(self, points_ids) -> None:
         self.points_ids.extend(points_ids)
 

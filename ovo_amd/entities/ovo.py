@@ -156,11 +156,13 @@ class OVO:
         pend["frame"] = (frame_id, image)
         return pend
 
-    def detect_and_track_finish(self, pend: Optional[Dict[str, Any]]):
+    def detect_and_track_finish(self, pend: Optional[Dict[str, Any]], want_maps: bool = True):
+        """`want_maps=False` (a keyframe another rank owns, pipeline.py): the kept binary maps -- read only by the descriptor extraction of the
+        keyframe's owner -- are not gathered; the queued keyframe carries None in their place."""
         if pend is None:
             return None
         frame_id, image = pend["frame"]
-        matched, binary_maps, n_matched, updated = self.track_finish(pend)
+        matched, binary_maps, n_matched, updated = self.track_finish(pend, want_maps)
         self.keyframes_queue.append([matched, binary_maps, image, self.kf_id])
         self.kf_id += 1
         return updated
@@ -276,9 +278,9 @@ class OVO:
         self._track_pending.append(pend)
         return pend
 
-    def track_finish(self, pend: Dict[str, Any]):
+    def track_finish(self, pend: Dict[str, Any], want_maps: bool = True):
         """Wait for the keyframe's result block and do the host bookkeeping of ovo.py:255-324 on it (instances, top-k heaps, kept mask
-        rows).  Returns what `_match_and_track_instances` returns."""
+        rows).  Returns what `_match_and_track_instances` returns (`want_maps=False`: None instead of the kept binary maps)."""
         if not self._track_pending or self._track_pending[0] is not pend:
             raise L.OvoHipError("track_finish: keyframes must be finished in the order they were launched")
         res = self._track_ring.wait(pend["seq"])
@@ -294,19 +296,24 @@ class OVO:
         n, n_matched, next_after = int(res[1]), int(res[3]), int(res[4])
         table = res[8:8 + 6 * n_masks].reshape(n_masks, 6).tolist()
         track_th = self.config["track_th"]
+        objects = self.objects
         matched_info: Dict[int, List[Tuple[int, int]]] = {}
         for m, (n_pts, n_assigned, mode_id, area, target, _) in enumerate(table):
             if n_pts <= track_th:
                 continue
             if n_assigned > track_th:
-                self.objects[mode_id].update([], kf_id, area)
-                matched_info.setdefault(mode_id, []).append((m, area))
+                objects[mode_id].observe(kf_id, area)
+                hits = matched_info.get(mode_id)
+                if hits is None:
+                    matched_info[mode_id] = [(m, area)]
+                else:
+                    hits.append((m, area))
             elif n_pts - n_assigned > track_th:
                 new_id = self.next_ins_id
                 self.next_ins_id += 1
                 if target != new_id:
                     raise L.OvoHipError(f"instance ids diverged between host and device ({target} vs {new_id})")
-                self.objects[new_id] = Instance3D(new_id, kf_id=kf_id, points_ids=[], mask_area=area, bank=self.bank)
+                objects[new_id] = Instance3D(new_id, kf_id=kf_id, points_ids=[], mask_area=area, bank=self.bank)
                 matched_info[new_id] = [(m, area)]
         if next_after != self.next_ins_id:
             raise L.OvoHipError(f"next instance id diverged between host and device ({next_after} vs {self.next_ins_id})")
@@ -322,7 +329,7 @@ class OVO:
                     mask_rows[m] = len(matched_ins_ids)
                 matched_ins_ids.append(ins_id)
                 keep_rows.append(first)
-        kept = L.gather_rows(binary_maps, keep_rows)
+        kept = L.gather_rows(binary_maps, keep_rows) if want_maps else None
         slam = pend["slam"]
         updated = pend["ins"] if slam is None else slam._ins[:n]
         self.last_point_seg, self.last_mask_rows, self.last_n_points = pend["point_seg"][:n], mask_rows, n
@@ -493,7 +500,8 @@ class OVO:
                 return None
             if len(rows) != len(matched_ins_ids):
                 matched_ins_ids = [matched_ins_ids[j] for j in rows]
-                binary_maps = binary_maps[torch.tensor(rows, device=binary_maps.device)]
+                if binary_maps is not None:                      # (None: a keyframe whose descriptors another rank extracts)
+                    binary_maps = binary_maps[torch.tensor(rows, device=binary_maps.device)]
         self._planned_kfs.add(kf_id)
         updates = self._planned_updates(matched_ins_ids)
         return {"kf_id": kf_id, "matched_ins_ids": matched_ins_ids, "binary_maps": binary_maps, "image": image, "updates": updates}

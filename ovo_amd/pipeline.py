@@ -362,8 +362,8 @@ class FramePipeline:
                     and all(self.ovo._native_ok(f.masks) for f in nxt):
                 self.masks.frames.update({f.index: f for f in nxt})
                 self._chains[nxt[0].index] = self._launch_chains(nxt, ratio)
-            for p in pend:
-                self.ovo.detect_and_track_finish(p)                # (assignment happened in place in the mapper's buffer)
+            for k, p in enumerate(pend):                           # (assignment happened in place in the mapper's buffer; only the owner of a
+                self.ovo.detect_and_track_finish(p, want_maps=(k == self.rank))     # keyframe reads its kept binary maps: `_extract_clip` below)
                 plans.append(self.ovo._plan_semantic_info() if len(self.ovo.keyframes_queue) > 0 else None)
                 segs.append((self.ovo.last_point_seg, self.ovo.last_mask_rows))
             # the map's size after this round: from the round's last map step (a keyframe without masks reports none through the tracker,
