@@ -588,10 +588,24 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
             if (rc == OVO_OK) q_pooled = true;
             else if (rc != OVO_E_UNSUPPORTED) return rc;
         }
-        if (!q_pooled)
-            TRY(gemm_from_f32(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, 1, k.h, h_done, L.qkv_w, L.qkv_b, k.qkv, 3 * dout, 2, 3 * dout, 0, stream));
         const long long n_win = (long long)B * g.nwh * g.nww;
         const int tk = g.wh * g.ww, tq = p.pool[i] ? tk / 4 : tk;
+        // K-padding columns of the attention output must be zero; the attention kernels only write the real ones, so they STAY zero from block to
+        // block while rows x row width do not change (the blocks of one stage): one fill per layout instead of one per block (3 of 5 for hiera_b+)
+        if (kout != dout && (att_rows != (long long)n_win * tq || att_kout != kout)) {
+            OVO_HIP(hipMemsetAsync(k.att, 0, (size_t)n_win * tq * kout * 2, hs));
+            att_rows = (long long)n_win * tq; att_kout = kout;
+        } else if (kout == dout) {
+            att_rows = -1;                                       // every column written: the next padded layout starts from a fresh fill
+        }
+        // stage 1 of hiera_b+ (round 5): LayerNorm -> QKV -> window attention in one pass over x, q | k | v never written (winattn.hip)
+        int fused_attn = OVO_E_UNSUPPORTED;
+        if (!p.pool[i] && din == dout && g.ws > 0 && !h_done && cfg->q_prescaled)
+            fused_attn = ovo_gemm_detail::win_attn_launch(x, B, H, H, g.ws, dout, p.heads[i], L.ln1_g, L.ln1_b, c.ln_eps, L.qkv_w, kin, L.qkv_b, k.att, kout, hs);
+        if (fused_attn != OVO_OK && fused_attn != OVO_E_UNSUPPORTED) return fused_attn;
+        if (fused_attn == OVO_E_UNSUPPORTED) {
+        if (!q_pooled)
+            TRY(gemm_from_f32(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, 1, k.h, h_done, L.qkv_w, L.qkv_b, k.qkv, 3 * dout, 2, 3 * dout, 0, stream));
         ovo_attention_t a = {};
         a.k = k.qkv + dout; a.v = k.qkv + 2 * dout; a.o = k.att;
         a.k_sb = a.v_sb = (int64_t)tk * 3 * dout; a.k_sh = a.v_sh = hd; a.k_st = a.v_st = 3 * dout;
@@ -606,17 +620,10 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         } else {
             a.q = k.qkv; a.q_sb = a.k_sb; a.q_sh = hd; a.q_st = 3 * dout;
         }
-        // K-padding columns of the attention output must be zero; the attention kernel only writes the real ones, so they STAY zero from block to
-        // block while rows x row width do not change (the blocks of one stage): one fill per layout instead of one per block (3 of 5 for hiera_b+)
-        if (kout != dout && (att_rows != (long long)n_win * tq || att_kout != kout)) {
-            OVO_HIP(hipMemsetAsync(k.att, 0, (size_t)n_win * tq * kout * 2, hs));
-            att_rows = (long long)n_win * tq; att_kout = kout;
-        } else if (kout == dout) {
-            att_rows = -1;                                       // every column written: the next padded layout starts from a fresh fill
-        }
         a.o_sb = (int64_t)tq * kout; a.o_sh = hd; a.o_st = kout;
         a.B = (int)n_win; a.H = p.heads[i]; a.Tq = tq; a.Tk = tk; a.hd = hd; a.scale = cfg->q_prescaled ? 0.0f : 1.0f / sqrtf((float)hd);
         TRY(ovo_attention(&a, stream));
+        }
         // output projection; its epilogue also takes the rows from window order (pooled window size) back to spatial order and
         // adds the residual (ovo_gemm_unwindow; k_unwindow_add was a pass of its own).  In place: same-dim blocks add onto x; at a
         // stage change the old x is dead (only LN1 read it) and the pooled skip lives in `spare`, so the smaller new stream is

@@ -1,0 +1,41 @@
+"""Hiera stage-1 attention half up to the output projection at the bench's 12-frame group: `ovo_window_attention_f32` (one launch) against the
+three launches it replaces, timed through two whole forwards (OVO_HIERA_NO_WINATTN=1 vs default) and alone.
+usage: python tools/winattn_bench.py [frames]"""
+import os, sys
+os.environ.setdefault("OVO_KNOBS_DYNAMIC", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ovo_amd import _lib as L
+from ovo_amd.encoders.hiera import SPECS, HipHiera
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+dev = torch.device("cuda", 0)
+lib = L.load()
+H = W = 256; C = 112
+x = torch.randn(B, H, W, C, device=dev)
+g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+w = (torch.randn(3 * C, 128, device=dev) * 0.1).to(torch.bfloat16); w[:, C:] = 0
+bias = torch.zeros(3 * C, device=dev)
+n_win = B * 32 * 32
+att = torch.zeros(n_win * 64, 128, dtype=torch.bfloat16, device=dev)
+
+def timed(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a_.record()
+    for _ in range(reps): fn()
+    b_.record(); torch.cuda.synchronize()
+    return 1e3 * a_.elapsed_time(b_) / reps
+
+def fused():
+    L.check(lib.ovo_window_attention_f32(L.ptr(x), B, H, W, 8, C, 2, L.ptr(g), L.ptr(b), 1e-6, L.ptr(w), 128, L.ptr(bias), L.ptr(att), 128, L.stream()))
+t = timed(fused)
+alg = B * H * W * C * (4 + 2)
+print(f"B={B}: fused LN + QKV + 8x8 window attention {t:.1f} us = {alg / t / 1e6:.2f} TB/s of algorithmic bytes (x in, attention out)")
+enc = HipHiera(SPECS["hiera_b+"], None, dev, 0)
+img = torch.randn(B, 3, 1024, 1024, device=dev)
+t_on = timed(lambda: enc.forward(img), 5)
+os.environ["OVO_HIERA_NO_WINATTN"] = "1"
+t_off = timed(lambda: enc.forward(img), 5)
+del os.environ["OVO_HIERA_NO_WINATTN"]
+print(f"hiera_b+ forward of {B} frames: {t_on / 1e3:.3f} ms with the fused stage-1 attention, {t_off / 1e3:.3f} ms with the three launches ({(t_off - t_on) / 2:.0f} us per stage-1 block)")
