@@ -280,15 +280,17 @@ int ovo_gemm_f32a(const ovo_gemm_t *g, const ovo_window_t *win, const float *x, 
  * (192, 192), (144, 192)) or rows < 16384: run ovo_gemm_f32a + ovo_gemm then (ovo_hiera_forward does exactly that). */
 int ovo_mlp_f32(float *x, int64_t rows, int d, const float *ln_g, const float *ln_b, float eps, const void *w1, int64_t ldw1,
                 const float *b1, int hidden, const void *w2, int64_t ldw2, const float *b2, ovo_stream_t stream);
-/* The attention half of a Hiera stage-1 block up to its output projection in ONE launch (sam2 `MultiScaleAttention` on windowed tokens,
- * reached at mask_generator.py:113; ABI v10): per 8 x 8 window and head
+/* The attention half of a Hiera block of 8 x 8 windows up to its output projection without the q | k | v tensor (sam2 `MultiScaleAttention` on
+ * windowed tokens, reached at mask_generator.py:113; ABI v10): per window and head
  *     att[window-major row, head * hd + :] = softmax(q k^T) v,    q | k | v = LayerNorm(x; ln_g, ln_b, eps) . Wqkv^T + b
- * x f32 [B, H, W, d] (spatial order); qkv_w bf16 [3 d, ldw >= 128] (columns >= d zero; the q rows and q bias carry log2(e) / sqrt(head_dim):
- * the kernel takes exp2 of the scores as they are); att bf16 out [B (H/8)(W/8) 64, ld_att] -- columns [0, d) written, the rest untouched.
- * The q | k | v tensor never reaches memory.  OVO_E_UNSUPPORTED -- nothing launched -- unless d = 112, heads = 2, window = 8, H % 8 == W % 8 == 0
- * and >= 2048 windows: run ovo_gemm_f32a + ovo_attention then (ovo_hiera_forward does exactly that). */
-int ovo_window_attention_f32(const float *x, int B, int H, int W, int window, int d, int heads, const float *ln_g, const float *ln_b, float eps,
-                             const void *qkv_w, int64_t ldw, const float *qkv_b, void *att, int ld_att, ovo_stream_t stream);
+ * x f32 [B, H, W, d] (spatial order); qkv_w bf16 [3 d_out, ldw >= 128] (columns >= d zero; the q rows and q bias carry log2(e) / sqrt(head_dim):
+ * the kernel takes exp2 of the scores as they are); att bf16 out [B (H/8)(W/8) 64, ld_att] -- columns [0, d_out) written, the rest untouched.
+ * pool = 1 (the stage-change block, q_stride 2): q is 2 x 2 max-pooled inside the window before the scores; att has 16 rows per window.
+ * One launch per pair of heads.  OVO_E_UNSUPPORTED -- nothing launched -- unless d = 112, window = 8, H % 8 == W % 8 == 0, >= 512 windows and
+ * (d_out, heads, pool) = (112, 2, 0) or (224, 4, 1): run ovo_gemm_f32a + ovo_attention then (ovo_hiera_forward does exactly that). */
+int ovo_window_attention_f32(const float *x, int B, int H, int W, int window, int d, int d_out, int heads, int pool, const float *ln_g,
+                             const float *ln_b, float eps, const void *qkv_w, int64_t ldw, const float *qkv_b, void *att, int ld_att,
+                             ovo_stream_t stream);
 /* The large-vocabulary query (BASELINE.json config 5) with the argmax FUSED into the GEMM epilogue: per row and wave one
  * 64-bit atomicMax on (order-preserving bits of the score << 32 | ~column) into best u64[M] (ZERO on entry; columns >=
  * n_valid -- vocabulary padding -- never win).  store_scores = 0 never writes the score matrix at all (g->C may be NULL).

@@ -190,7 +190,7 @@ _SIGNATURES = {
     "ovo_global_patch_filter": (_I32, [_P, _P, _I32, _I32, _I32, _F32, _P, _P]),
     "ovo_scale_rows_bf16": (_I32, [_P, _P, _I32, _I32, _P, _P]),
     "ovo_mlp_f32": (_I32, [_P, _I64, _I32, _P, _P, _F32, _P, _I64, _P, _I32, _P, _I64, _P, _P]),
-    "ovo_window_attention_f32": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _F32, _P, _I64, _P, _P, _I32, _P]),
+    "ovo_window_attention_f32": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _F32, _P, _I64, _P, _P, _I32, _P]),
     "ovo_l2_normalize_rows": (_I32, [_P, _I64, _I32, _P, _P]),
     "ovo_cast_f32": (_I32, [_P, _I64, _P, _I32, _P]),
     "ovo_row_epilogue": (_I32, [_P, _I64, _I32, _P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _P]),

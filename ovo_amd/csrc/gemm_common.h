@@ -258,9 +258,10 @@ int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *
 int mlp_stream_launch(float *x, long long rows, int d, const float *ln_g, const float *ln_b, float eps, const void *w1, long long ldw1, const float *b1,
                       int hid, const void *w2, long long ldw2, const float *b2, hipStream_t s);
 
-// att bf16 [windows x 64, ld_att] (window-major rows) = per-window, per-head softmax(q k^T) v of q | k | v = LayerNorm(x) . Wqkv^T + b, straight from the
-// f32 token grid x [B, H, W, d] in ONE launch (winattn.hip); OVO_E_UNSUPPORTED (nothing launched) unless d = 112, 2 heads, 8 x 8 windows, >= 2048 windows
-int win_attn_launch(const float *x, int B, int H, int W, int ws, int d, int heads, const float *ln_g, const float *ln_b, float eps, const void *qkv_w,
-                    long long ldw, const float *qkv_b, void *att, int ld_att, hipStream_t s);
+// att bf16 [windows x 64 (16 with `pool`), ld_att] (window-major rows) = per-window, per-head softmax(q k^T) v of q | k | v = LayerNorm(x) . Wqkv^T + b, straight
+// from the f32 token grid x [B, H, W, d] (winattn.hip; one launch per pair of heads); OVO_E_UNSUPPORTED (nothing launched) unless d = 112, 8 x 8 windows,
+// >= 512 windows and (d_out, heads, pool) = (112, 2, 0) or (224, 4, 1: queries 2 x 2 max-pooled inside the window)
+int win_attn_launch(const float *x, int B, int H, int W, int ws, int d, int d_out, int heads, int pool, const float *ln_g, const float *ln_b, float eps,
+                    const void *qkv_w, long long ldw, const float *qkv_b, void *att, int ld_att, hipStream_t s);
 
 }  // namespace ovo_gemm_detail

@@ -577,6 +577,24 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
             }
             residual = spare;
         }
+        const long long n_win = (long long)B * g.nwh * g.nww;
+        const int tk = g.wh * g.ww, tq = p.pool[i] ? tk / 4 : tk;
+        // K-padding columns of the attention output must be zero; the attention kernels only write the real ones, so they STAY zero from block to
+        // block while rows x row width do not change (the blocks of one stage): one fill per layout instead of one per block (3 of 5 for hiera_b+)
+        if (kout != dout && (att_rows != (long long)n_win * tq || att_kout != kout)) {
+            OVO_HIP(hipMemsetAsync(k.att, 0, (size_t)n_win * tq * kout * 2, hs));
+            att_rows = (long long)n_win * tq; att_kout = kout;
+        } else if (kout == dout) {
+            att_rows = -1;                                       // every column written: the next padded layout starts from a fresh fill
+        }
+        // stage 1 of hiera_b+ and the stage-change block after it (round 5): LayerNorm -> QKV (-> 2 x 2 pool of q) -> window attention in one pass over x
+        // per pair of heads, q | k | v never written (winattn.hip)
+        int fused_attn = OVO_E_UNSUPPORTED;
+        if (g.ws > 0 && !h_done && cfg->q_prescaled)
+            fused_attn = ovo_gemm_detail::win_attn_launch(x, B, H, H, g.ws, din, dout, p.heads[i], p.pool[i] ? 1 : 0, L.ln1_g, L.ln1_b, c.ln_eps, L.qkv_w, kin,
+                                                          L.qkv_b, k.att, kout, hs);
+        if (fused_attn != OVO_OK && fused_attn != OVO_E_UNSUPPORTED) return fused_attn;
+        if (fused_attn == OVO_E_UNSUPPORTED) {
         // QKV; at a stage change the q columns are pooled 2 x 2 in the product's epilogue where the streaming GEMM runs it (else k_qpool below)
         bool q_pooled = false;
         if (p.pool[i] && g.ws > 0 && !h_done) {
@@ -588,22 +606,6 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
             if (rc == OVO_OK) q_pooled = true;
             else if (rc != OVO_E_UNSUPPORTED) return rc;
         }
-        const long long n_win = (long long)B * g.nwh * g.nww;
-        const int tk = g.wh * g.ww, tq = p.pool[i] ? tk / 4 : tk;
-        // K-padding columns of the attention output must be zero; the attention kernels only write the real ones, so they STAY zero from block to
-        // block while rows x row width do not change (the blocks of one stage): one fill per layout instead of one per block (3 of 5 for hiera_b+)
-        if (kout != dout && (att_rows != (long long)n_win * tq || att_kout != kout)) {
-            OVO_HIP(hipMemsetAsync(k.att, 0, (size_t)n_win * tq * kout * 2, hs));
-            att_rows = (long long)n_win * tq; att_kout = kout;
-        } else if (kout == dout) {
-            att_rows = -1;                                       // every column written: the next padded layout starts from a fresh fill
-        }
-        // stage 1 of hiera_b+ (round 5): LayerNorm -> QKV -> window attention in one pass over x, q | k | v never written (winattn.hip)
-        int fused_attn = OVO_E_UNSUPPORTED;
-        if (!p.pool[i] && din == dout && g.ws > 0 && !h_done && cfg->q_prescaled)
-            fused_attn = ovo_gemm_detail::win_attn_launch(x, B, H, H, g.ws, dout, p.heads[i], L.ln1_g, L.ln1_b, c.ln_eps, L.qkv_w, kin, L.qkv_b, k.att, kout, hs);
-        if (fused_attn != OVO_OK && fused_attn != OVO_E_UNSUPPORTED) return fused_attn;
-        if (fused_attn == OVO_E_UNSUPPORTED) {
         if (!q_pooled)
             TRY(gemm_from_f32(x, g, din, kin, L.ln1_g, L.ln1_b, c.ln_eps, 1, k.h, h_done, L.qkv_w, L.qkv_b, k.qkv, 3 * dout, 2, 3 * dout, 0, stream));
         ovo_attention_t a = {};

@@ -15,7 +15,8 @@
 //          of Wqkv carry log2(e) / sqrt(head_dim), ovo_hiera_config_t.q_prescaled), packed  ->  B operand of  O^T
 //     O^T (rows = head dim, column = query): 4 consecutive channels of one token per lane -> one 8-byte store.
 // head_dim 56 is walked as 4 tiles of 16: the weights sit in LDS as (q | k | v, head) blocks of 64 rows whose last 8 (and their bias) are zeros.
-// hiera_b+ stage 1 only (C = 112, 2 heads, 8 x 8 windows, no query pooling): at C = 224 the weights (301 KB) do not fit LDS.
+// hiera_b+: the two stage-1 blocks (C = 112, 2 heads, 8 x 8 windows) and the stage-change block that follows them (112 -> 224 channels, 4 heads, queries
+// pooled 2 x 2: k_win_attn112<true>, two passes of two heads).  From stage 2 on (C = 224) the weights (301 KB) do not fit LDS.
 // Reference: sam2 MultiScaleBlock / MultiScaleAttention inside the image encoder, reached at mask_generator.py:113.
 #include <stdlib.h>
 
@@ -38,6 +39,7 @@ struct WinAttnArgs {
     const uint16_t *w; long long ldw; const float *bias;
     uint16_t *att; int ld_att;
     int n_win, nwh, nww;
+    int part_rows, head0;          // rows between the q | k | v parts of Wqkv (= output width: 112, or 224 at the stage change); first head of this pass
 };
 
 __device__ __forceinline__ uint32_t pk2(float a, float b) {       // v_cvt_pk_bf16_f32 (RNE)
@@ -66,6 +68,15 @@ __device__ __forceinline__ float quad_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// xor-1 / xor-8 partners inside a row of 16 lanes on the DPP path (quad_perm [1, 0, 3, 2]; row_ror 8)
+__device__ __forceinline__ float pool_max4(float v) {
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xf, 0xf, true)));
+    return fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x128, 0xf, 0xf, true)));
+}
+
+// POOL: the stage-change block (sam2 MultiScaleBlock with q_stride 2): q is 2 x 2 max-pooled over the window's 8 x 8 tokens before the scores -- 16 queries
+// per window attend to its 64 keys, att rows = window x 16 pooled positions.  Its projection is twice as wide (4 heads): two passes of two heads each.
+template <bool POOL>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_win_attn112(WinAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *s_bias = (float *)(smem + LDS_W), *s_g = s_bias + NROW, *s_b = s_g + KP;
@@ -73,12 +84,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int id = tid; id < NROW * CPR; id += 512) {              // weights: 16-byte chunk c of LDS row n at chunk (c ^ (n & 15)) of the row
         const int n = id >> 4, c = id & 15, blk = n >> 6, r = n & 63;             // blk = part * NH + head
         uint4 u = make_uint4(0u, 0u, 0u, 0u);
-        if (r < HD) u = *(const uint4 *)(a.w + (long long)((blk >> 1) * C + (blk & 1) * HD + r) * a.ldw + c * 8);
+        if (r < HD) u = *(const uint4 *)(a.w + (long long)((blk >> 1) * a.part_rows + (a.head0 + (blk & 1)) * HD + r) * a.ldw + c * 8);
         *(uint4 *)(smem + (n * CPR + (c ^ (n & 15))) * 16) = u;
     }
     for (int n = tid; n < NROW; n += 512) {
         const int blk = n >> 6, r = n & 63;
-        s_bias[n] = (a.bias && r < HD) ? a.bias[(blk >> 1) * C + (blk & 1) * HD + r] : 0.f;
+        s_bias[n] = (a.bias && r < HD) ? a.bias[(blk >> 1) * a.part_rows + (a.head0 + (blk & 1)) * HD + r] : 0.f;
     }
     for (int i = tid; i < KP; i += 512) { s_g[i] = i < C ? a.ln_g[i] : 0.f; s_b[i] = i < C ? a.ln_b[i] : 0.f; }
     __syncthreads();
@@ -158,8 +169,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                         for (int t = 0; t < 4; ++t) acc[t] = Mfma<bf16x8>::run(w, xf[t][ks], acc[t]);
                     }
+                    if (POOL && which == 1) {
+                        // token tile t = window rows 2 t, 2 t + 1: the pool cell (t, px) is lanes l16 in {2 px, 2 px + 1, 8 + 2 px, 9 + 2 px}; pooled query
+                        // 4 t + px of the window goes to lane l16 = 4 t + px of the ONE query tile
+                        f32x4 r = acc[0];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float m = __shfl(pool_max4(acc[t][j]), (lane & 48) | ((l16 & 3) << 1), 64);
+                                if (t == 0 || (l16 >> 2) == t) r[j] = m;
+                            }
+                        acc[0] = r;
+                    }
+#pragma unroll
+                    for (int t = 0; t < ((POOL && which == 1) ? 1 : 4); ++t) {
                         uint4 &d = which == 0 ? ka[t][ht >> 1] : qb[t][ht >> 1];
                         if (ht & 1) { d.z = pk2(acc[t][0], acc[t][1]); d.w = pk2(acc[t][2], acc[t][3]); }
                         else { d.x = pk2(acc[t][0], acc[t][1]); d.y = pk2(acc[t][2], acc[t][3]); }
@@ -184,7 +208,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             // ---- one query tile at a time: scores, softmax over the keys, output
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < (POOL ? 1 : 4); ++q) {
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 f32x4 s[4];
 #pragma unroll
@@ -205,7 +229,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const float inv = __builtin_amdgcn_rcpf(quad_sum(sum));
                 const bf16x8 p0 = frag(pk2(s[0][0], s[0][1]), pk2(s[0][2], s[0][3]), pk2(s[1][0], s[1][1]), pk2(s[1][2], s[1][3]));
                 const bf16x8 p1 = frag(pk2(s[2][0], s[2][1]), pk2(s[2][2], s[2][3]), pk2(s[3][0], s[3][1]), pk2(s[3][2], s[3][3]));
-                uint16_t *dst = a.att + ((long long)win * WT + 16 * q + l16) * a.ld_att + h * HD + 4 * g;
+                uint16_t *dst = a.att + ((long long)win * (POOL ? 16 : WT) + 16 * q + l16) * a.ld_att + (a.head0 + h) * HD + 4 * g;
                 f32x4 o[4];
 #pragma unroll
                 for (int ht = 0; ht < 4; ++ht) o[ht] = Mfma<bf16x8>::run(*(const bf16x8 *)&va[ht][0], p0, zero);
@@ -223,33 +247,40 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 namespace ovo_gemm_detail {
 
-int win_attn_launch(const float *x, int B, int H, int W, int ws, int d, int heads, const float *ln_g, const float *ln_b, float eps, const void *qkv_w,
-                    long long ldw, const float *qkv_b, void *att, int ld_att, hipStream_t s) {
+int win_attn_launch(const float *x, int B, int H, int W, int ws, int d, int d_out, int heads, int pool, const float *ln_g, const float *ln_b, float eps,
+                    const void *qkv_w, long long ldw, const float *qkv_b, void *att, int ld_att, hipStream_t s) {
     static const bool off_once = getenv("OVO_HIERA_NO_WINATTN") != nullptr;                // measurement / tests: the three-launch form
     if (ovo_knobs_dynamic() ? getenv("OVO_HIERA_NO_WINATTN") != nullptr : off_once) return OVO_E_UNSUPPORTED;
-    if (d != C || heads != NH || ws != 8 || H % 8 != 0 || W % 8 != 0 || ldw < KP || ld_att < C || ld_att % 4 != 0) return OVO_E_UNSUPPORTED;
+    const bool plain = !pool && d_out == C && heads == NH, change = pool && d_out == 2 * C && heads == 2 * NH;
+    if (d != C || !(plain || change) || ws != 8 || H % 8 != 0 || W % 8 != 0 || ldw < KP || ld_att < d_out || ld_att % 4 != 0) return OVO_E_UNSUPPORTED;
     if ((((uintptr_t)x | (uintptr_t)qkv_w) & 15) != 0 || ((uintptr_t)att & 7) != 0 || ldw % 8 != 0) return OVO_E_UNSUPPORTED;
     const long long n_win = (long long)B * (H / 8) * (W / 8);
-    if (n_win < 512 || n_win >= (1ll << 31) / WT) return OVO_E_UNSUPPORTED;                // (short streams: the weight copy per workgroup would dominate)
+    if (n_win < 512 || n_win >= (1ll << 31) / WT) return OVO_E_UNSUPPORTED;                 // (short streams: the weight copy per workgroup would dominate)
     static bool set = false;
     if (!set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_win_attn112, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void *)k_win_attn112<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_win_attn112<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) { ovo_set_error("win_attn_launch: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
         set = true;
     }
     WinAttnArgs a;
     a.x = x; a.B = B; a.H = H; a.W = W; a.ln_g = ln_g; a.ln_b = ln_b; a.eps = eps;
     a.w = (const uint16_t *)qkv_w; a.ldw = ldw; a.bias = qkv_b; a.att = (uint16_t *)att; a.ld_att = ld_att;
-    a.n_win = (int)n_win; a.nwh = H / 8; a.nww = W / 8;
-    k_win_attn112<<<256, 512, LDS_BYTES, s>>>(a);
+    a.n_win = (int)n_win; a.nwh = H / 8; a.nww = W / 8; a.part_rows = d_out;
+    for (int h0 = 0; h0 < heads; h0 += NH) {                       // two heads per pass (their weights fill LDS)
+        a.head0 = h0;
+        if (pool) k_win_attn112<true><<<256, 512, LDS_BYTES, s>>>(a);
+        else k_win_attn112<false><<<256, 512, LDS_BYTES, s>>>(a);
+    }
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }
 
 }  // namespace ovo_gemm_detail
 
-extern "C" int ovo_window_attention_f32(const float *x, int B, int H, int W, int window, int d, int heads, const float *ln_g, const float *ln_b, float eps,
-                                        const void *qkv_w, int64_t ldw, const float *qkv_b, void *att, int ld_att, ovo_stream_t stream) {
+extern "C" int ovo_window_attention_f32(const float *x, int B, int H, int W, int window, int d, int d_out, int heads, int pool, const float *ln_g,
+                                        const float *ln_b, float eps, const void *qkv_w, int64_t ldw, const float *qkv_b, void *att, int ld_att,
+                                        ovo_stream_t stream) {
     OVO_REQUIRE(x && ln_g && ln_b && qkv_w && att && B > 0 && H > 0 && W > 0, "bad argument");
-    return ovo_gemm_detail::win_attn_launch(x, B, H, W, window, d, heads, ln_g, ln_b, eps, qkv_w, ldw, qkv_b, att, ld_att, (hipStream_t)stream);
+    return ovo_gemm_detail::win_attn_launch(x, B, H, W, window, d, d_out, heads, pool, ln_g, ln_b, eps, qkv_w, ldw, qkv_b, att, ld_att, (hipStream_t)stream);
 }

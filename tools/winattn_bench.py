@@ -28,14 +28,21 @@ def timed(fn, reps=20):
     return 1e3 * a_.elapsed_time(b_) / reps
 
 def fused():
-    L.check(lib.ovo_window_attention_f32(L.ptr(x), B, H, W, 8, C, 2, L.ptr(g), L.ptr(b), 1e-6, L.ptr(w), 128, L.ptr(bias), L.ptr(att), 128, L.stream()))
+    L.check(lib.ovo_window_attention_f32(L.ptr(x), B, H, W, 8, C, C, 2, 0, L.ptr(g), L.ptr(b), 1e-6, L.ptr(w), 128, L.ptr(bias), L.ptr(att), 128, L.stream()))
 t = timed(fused)
 alg = B * H * W * C * (4 + 2)
 print(f"B={B}: fused LN + QKV + 8x8 window attention {t:.1f} us = {alg / t / 1e6:.2f} TB/s of algorithmic bytes (x in, attention out)")
+w4 = (torch.randn(6 * C, 128, device=dev) * 0.1).to(torch.bfloat16); w4[:, C:] = 0
+bias4 = torch.zeros(6 * C, device=dev)
+att4 = torch.zeros(n_win * 16, 256, dtype=torch.bfloat16, device=dev)
+def fused_pool():
+    L.check(lib.ovo_window_attention_f32(L.ptr(x), B, H, W, 8, C, 2 * C, 4, 1, L.ptr(g), L.ptr(b), 1e-6, L.ptr(w4), 128, L.ptr(bias4), L.ptr(att4), 256, L.stream()))
+t = timed(fused_pool)
+print(f"B={B}: stage-change block (4 heads, q pooled 2 x 2, two passes) {t:.1f} us")
 enc = HipHiera(SPECS["hiera_b+"], None, dev, 0)
 img = torch.randn(B, 3, 1024, 1024, device=dev)
 t_on = timed(lambda: enc.forward(img), 5)
 os.environ["OVO_HIERA_NO_WINATTN"] = "1"
 t_off = timed(lambda: enc.forward(img), 5)
 del os.environ["OVO_HIERA_NO_WINATTN"]
-print(f"hiera_b+ forward of {B} frames: {t_on / 1e3:.3f} ms with the fused stage-1 attention, {t_off / 1e3:.3f} ms with the three launches ({(t_off - t_on) / 2:.0f} us per stage-1 block)")
+print(f"hiera_b+ forward of {B} frames: {t_on / 1e3:.3f} ms with the fused window attention (stage 1 + stage change), {t_off / 1e3:.3f} ms with the three launches ({(t_off - t_on) / 3:.0f} us per fused block, 3 blocks)")
