@@ -280,14 +280,15 @@ int ovo_gemm_f32a(const ovo_gemm_t *g, const ovo_window_t *win, const float *x, 
  * (192, 192), (144, 192)) or rows < 16384: run ovo_gemm_f32a + ovo_gemm then (ovo_hiera_forward does exactly that). */
 int ovo_mlp_f32(float *x, int64_t rows, int d, const float *ln_g, const float *ln_b, float eps, const void *w1, int64_t ldw1,
                 const float *b1, int hidden, const void *w2, int64_t ldw2, const float *b2, ovo_stream_t stream);
-/* The attention half of a Hiera block of 8 x 8 windows up to its output projection without the q | k | v tensor (sam2 `MultiScaleAttention` on
+/* The attention half of a Hiera block of 8 x 8 (4 x 4) windows up to its output projection without the q | k | v tensor (sam2 `MultiScaleAttention` on
  * windowed tokens, reached at mask_generator.py:113; ABI v10): per window and head
  *     att[window-major row, head * hd + :] = softmax(q k^T) v,    q | k | v = LayerNorm(x; ln_g, ln_b, eps) . Wqkv^T + b
- * x f32 [B, H, W, d] (spatial order); qkv_w bf16 [3 d_out, ldw >= 128] (columns >= d zero; the q rows and q bias carry log2(e) / sqrt(head_dim):
- * the kernel takes exp2 of the scores as they are); att bf16 out [B (H/8)(W/8) 64, ld_att] -- columns [0, d_out) written, the rest untouched.
+ * x f32 [B, H, W, d] (spatial order); qkv_w bf16 [3 d_out, ldw >= d rounded up to 128] (columns >= d zero; the q rows and q bias carry log2(e) / sqrt(head_dim):
+ * the kernel takes exp2 of the scores as they are); att bf16 out [windows x window^2, ld_att] -- columns [0, d_out) written, the rest untouched.
  * pool = 1 (the stage-change block, q_stride 2): q is 2 x 2 max-pooled inside the window before the scores; att has 16 rows per window.
- * One launch per pair of heads.  OVO_E_UNSUPPORTED -- nothing launched -- unless d = 112, window = 8, H % 8 == W % 8 == 0, >= 512 windows and
- * (d_out, heads, pool) = (112, 2, 0) or (224, 4, 1): run ovo_gemm_f32a + ovo_attention then (ovo_hiera_forward does exactly that). */
+ * One launch per pair of heads.  OVO_E_UNSUPPORTED -- nothing launched -- unless H % window == W % window == 0, >= 512 windows and
+ * (window, d, d_out, heads, pool) = (8, 112, 112, 2, 0), (8, 112, 224, 4, 1) or (4, 224, 224, 4, 0; ldw >= 224, an even
+ * number >= 2048 of windows): run ovo_gemm_f32a + ovo_attention then (ovo_hiera_forward does exactly that). */
 int ovo_window_attention_f32(const float *x, int B, int H, int W, int window, int d, int d_out, int heads, int pool, const float *ln_g,
                              const float *ln_b, float eps, const void *qkv_w, int64_t ldw, const float *qkv_b, void *att, int ld_att,
                              ovo_stream_t stream);

@@ -243,6 +243,137 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
+
+// ---- C = 224 (hiera_b+ stage 2, blocks after the stage change): 4 heads of 56, 4 x 4 windows --------------------------------------------------------
+// The same chain with a window = ONE 16-token tile: a wave takes two windows (32 tokens x 224 channels) at a time; scores are one 16 x 16 tile per window
+// and head, and O^T = V^T . P^T has a reduction of 16 keys: v_mfma_f32_16x16x16_bf16, whose operand layout (4 consecutive k per lane) is the 16 x 16
+// accumulator layout itself.  The weights of TWO heads fill LDS (336 rows x 448 bytes, row pitch 464: 16 consecutive rows start 13 x 16-byte chunks
+// apart mod 16 -> conflict-free without a swizzle), so a block is two passes over x; blocks of 56 rows cannot be padded to 64 here (178 KB): head-dim
+// tile 3 selects zeros for its rows / columns beyond 56.
+namespace c224 {
+constexpr int C2 = 224, KS2 = 7, ROWS = 3 * NH * HD, PITCH = 464, NW = 8;
+constexpr int LDS2_W = ROWS * PITCH, LDS2_BYTES = LDS2_W + ROWS * 4 + 2 * C2 * 4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) k_win_attn224(WinAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *s_bias = (float *)(smem + LDS2_W), *s_g = s_bias + ROWS, *s_b = s_g + C2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    for (int id = tid; id < ROWS * 28; id += 64 * NW) {
+        const int n = id / 28, c = id - 28 * n, blk = n / HD, r = n - blk * HD;            // blk = part * NH + head of the pass
+        *(uint4 *)(smem + n * PITCH + c * 16) = *(const uint4 *)(a.w + (long long)((blk >> 1) * a.part_rows + (a.head0 + (blk & 1)) * HD + r) * a.ldw + c * 8);
+    }
+    for (int n = tid; n < ROWS; n += 64 * NW) {
+        const int blk = n / HD, r = n - blk * HD;
+        s_bias[n] = a.bias ? a.bias[(blk >> 1) * a.part_rows + (a.head0 + (blk & 1)) * HD + r] : 0.f;
+    }
+    for (int i = tid; i < C2; i += 64 * NW) { s_g[i] = a.ln_g[i]; s_b[i] = a.ln_b[i]; }
+    __syncthreads();
+    auto wfrag = [&](int row, int ks, bool valid) -> bf16x8 {
+        uint4 u = *(const uint4 *)(smem + row * PITCH + (ks * 4 + g) * 16);
+        if (!valid) u = make_uint4(0u, 0u, 0u, 0u);
+        return *(const bf16x8 *)&u;
+    };
+    const int n_task = a.n_win >> 1;                             // (the launcher requires an even number of windows)
+    for (int task = blockIdx.x * NW + wave; task < n_task; task += gridDim.x * NW) {
+        // ---- phase 1: two windows' rows (lane: token l16 of window t, 8 channels of group g per K-step), LayerNorm, bf16 fragments
+        bf16x8 xf[2][KS2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                            // (one window at a time: 56 registers of f32 rows beside the fragments)
+            f32x4 v[KS2][2];
+            const int win = 2 * task + t, per = a.nwh * a.nww, b = win / per, wr = win - b * per, wy = wr / a.nww, wx = wr - wy * a.nww;
+            const float *xr = a.x + (((long long)b * a.H + wy * 4 + (l16 >> 2)) * a.W + wx * 4 + (l16 & 3)) * C2 + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) { v[ks][0] = *(const f32x4 *)(xr + 32 * ks); v[ks][1] = *(const f32x4 *)(xr + 32 * ks + 4); }
+            f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) s2 += (v[ks][0].lo + v[ks][0].hi) + (v[ks][1].lo + v[ks][1].hi);
+            const float mean = quad_sum(s2.x + s2.y) * (1.0f / C2);
+            f32x2 q2 = {0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    v[ks][h] -= mean;
+                    q2 += v[ks][h].lo * v[ks][h].lo + v[ks][h].hi * v[ks][h].hi;
+                }
+            const float rstd = rsqrtf(quad_sum(q2.x + q2.y) * (1.0f / C2) + a.eps);
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                const int c0 = 32 * ks + 8 * g;
+                const f32x4 g0 = *(const f32x4 *)(s_g + c0), g1 = *(const f32x4 *)(s_g + c0 + 4);
+                const f32x4 b0 = *(const f32x4 *)(s_b + c0), b1 = *(const f32x4 *)(s_b + c0 + 4);
+                const f32x4 y0 = v[ks][0] * rstd * g0 + b0, y1 = v[ks][1] * rstd * g1 + b1;
+                xf[t][ks] = frag(pk2(y0[0], y0[1]), pk2(y0[2], y0[3]), pk2(y1[0], y1[1]), pk2(y1[2], y1[3]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- phase 2: per head of the pass
+#pragma unroll 1
+        for (int h = 0; h < NH; ++h) {
+            uint4 ka[2][2], qb[2][2];        // [window][K-step over head dim]: A / B fragments of S^T
+            uint2 va[4][2];                  // [head-dim tile][window]: A fragment (16 keys) of O^T
+            const int rq = h * HD, rk = (NH + h) * HD, rvv = (2 * NH + h) * HD;
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                const bool rv = ht < 3 || l16 < 8, cv = ht < 3 || g < 2;       // this lane's weight row / its 4 accumulator rows are real head dims
+#pragma unroll
+                for (int which = 0; which < 2; ++which) {        // K^T, then Q^T tiles (rows = head dim 16 ht + 4 g + j, column = token l16 of window t)
+                    const int r0 = (which == 0 ? rk : rq) + 16 * ht;
+                    f32x4 bb = *(const f32x4 *)(s_bias + r0 + 4 * g);
+                    if (!cv) bb = (f32x4)(0.f);
+                    f32x4 acc[2] = {bb, bb};
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks) {
+                        const bf16x8 w = wfrag(r0 + l16, ks, rv);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) acc[t] = Mfma<bf16x8>::run(w, xf[t][ks], acc[t]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        uint4 &d = which == 0 ? ka[t][ht >> 1] : qb[t][ht >> 1];
+                        if (ht & 1) { d.z = pk2(acc[t][0], acc[t][1]); d.w = pk2(acc[t][2], acc[t][3]); }
+                        else { d.x = pk2(acc[t][0], acc[t][1]); d.y = pk2(acc[t][2], acc[t][3]); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);            // (keeps the next tile's seven weight reads from being hoisted over this one: registers)
+                }
+                {   // V tiles (rows = key 4 g + j of window t, column = head dim 16 ht + l16)
+                    const float bv = rv ? s_bias[rvv + 16 * ht + l16] : 0.f;
+                    const f32x4 bb = {bv, bv, bv, bv};
+                    f32x4 acc[2] = {bb, bb};
+#pragma unroll
+                    for (int ks = 0; ks < KS2; ++ks) {
+                        const bf16x8 w = wfrag(rvv + 16 * ht + l16, ks, rv);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) acc[t] = Mfma<bf16x8>::run(xf[t][ks], w, acc[t]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) va[ht][t] = make_uint2(pk2(acc[t][0], acc[t][1]), pk2(acc[t][2], acc[t][3]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                        // one window: 16 x 16 scores, softmax over its 16 keys, output
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                f32x4 s = Mfma<bf16x8>::run(*(const bf16x8 *)&ka[t][0], *(const bf16x8 *)&qb[t][0], zero);
+                s = Mfma<bf16x8>::run(*(const bf16x8 *)&ka[t][1], *(const bf16x8 *)&qb[t][1], s);
+                const float mx = quad_max(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] = __builtin_amdgcn_exp2f(s[j] - mx);
+                const float inv = __builtin_amdgcn_rcpf(quad_sum((s[0] + s[1]) + (s[2] + s[3])));
+                const uint2 pp = make_uint2(pk2(s[0], s[1]), pk2(s[2], s[3]));
+                uint16_t *dst = a.att + ((long long)(2 * task + t) * 16 + l16) * a.ld_att + (a.head0 + h) * HD + 4 * g;
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht) {
+                    const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*(const bf16x4 *)&va[ht][t], *(const bf16x4 *)&pp, zero, 0, 0, 0);
+                    if (ht < 3 || g < 2) *(uint2 *)(dst + 16 * ht) = make_uint2(pk2(o[0] * inv, o[1] * inv), pk2(o[2] * inv, o[3] * inv));
+                }
+            }
+        }
+    }
+}
+}  // namespace c224
+
 }  // namespace
 
 namespace ovo_gemm_detail {
@@ -251,9 +382,29 @@ int win_attn_launch(const float *x, int B, int H, int W, int ws, int d, int d_ou
                     const void *qkv_w, long long ldw, const float *qkv_b, void *att, int ld_att, hipStream_t s) {
     static const bool off_once = getenv("OVO_HIERA_NO_WINATTN") != nullptr;                // measurement / tests: the three-launch form
     if (ovo_knobs_dynamic() ? getenv("OVO_HIERA_NO_WINATTN") != nullptr : off_once) return OVO_E_UNSUPPORTED;
+    if ((((uintptr_t)x | (uintptr_t)qkv_w) & 15) != 0 || ((uintptr_t)att & 7) != 0 || ldw % 8 != 0 || ld_att < d_out || ld_att % 4 != 0) return OVO_E_UNSUPPORTED;
+    if (d == c224::C2 && d_out == d && heads == 2 * NH && !pool && ws == 4 && H % 4 == 0 && W % 4 == 0 && ldw >= c224::C2) {     // stage 2: 4 x 4 windows
+        const long long n_win = (long long)B * (H / 4) * (W / 4);
+        if (n_win < 2048 || n_win % 2 != 0 || n_win >= (1ll << 31) / 16) return OVO_E_UNSUPPORTED;
+        static bool set2 = false;
+        if (!set2) {
+            hipError_t e = hipFuncSetAttribute((const void *)c224::k_win_attn224, hipFuncAttributeMaxDynamicSharedMemorySize, c224::LDS2_BYTES);
+            if (e != hipSuccess) { ovo_set_error("win_attn_launch: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
+            set2 = true;
+        }
+        WinAttnArgs a;
+        a.x = x; a.B = B; a.H = H; a.W = W; a.ln_g = ln_g; a.ln_b = ln_b; a.eps = eps;
+        a.w = (const uint16_t *)qkv_w; a.ldw = ldw; a.bias = qkv_b; a.att = (uint16_t *)att; a.ld_att = ld_att;
+        a.n_win = (int)n_win; a.nwh = H / 4; a.nww = W / 4; a.part_rows = d_out;
+        for (int h0 = 0; h0 < heads; h0 += NH) {
+            a.head0 = h0;
+            c224::k_win_attn224<<<256, 64 * c224::NW, c224::LDS2_BYTES, s>>>(a);
+        }
+        OVO_CHECK_LAUNCH();
+        return OVO_OK;
+    }
     const bool plain = !pool && d_out == C && heads == NH, change = pool && d_out == 2 * C && heads == 2 * NH;
-    if (d != C || !(plain || change) || ws != 8 || H % 8 != 0 || W % 8 != 0 || ldw < KP || ld_att < d_out || ld_att % 4 != 0) return OVO_E_UNSUPPORTED;
-    if ((((uintptr_t)x | (uintptr_t)qkv_w) & 15) != 0 || ((uintptr_t)att & 7) != 0 || ldw % 8 != 0) return OVO_E_UNSUPPORTED;
+    if (d != C || !(plain || change) || ws != 8 || H % 8 != 0 || W % 8 != 0 || ldw < KP) return OVO_E_UNSUPPORTED;
     const long long n_win = (long long)B * (H / 8) * (W / 8);
     if (n_win < 512 || n_win >= (1ll << 31) / WT) return OVO_E_UNSUPPORTED;                 // (short streams: the weight copy per workgroup would dominate)
     static bool set = false;

@@ -165,39 +165,42 @@ def test_patch_embed_direct_equals_im2col_gemm_forward(monkeypatch):
         assert er < 8e-3
 
 
-@pytest.mark.parametrize("pool", [0, 1])
-def test_window_attention_fused_vs_torch(pool):
-    """`ovo_window_attention_f32` (round 5: LayerNorm -> QKV -> 8 x 8 window attention of a Hiera block in one launch per pair of heads, q | k | v in
-    registers; pool = 1: the stage-change block, 4 heads, queries 2 x 2 max-pooled inside the window) against torch with the kernel's rounding points
-    (LayerNorm output, q | k | v, the softmax numerators and the output in bf16; f32 sums).  What is left is summation order and the rounding of
-    values that sit on a bf16 boundary: measured max 2.5e-2 / rms 2e-4 of the output rms."""
+@pytest.mark.parametrize("case", ["stage1", "stage_change", "stage2"])
+def test_window_attention_fused_vs_torch(case):
+    """`ovo_window_attention_f32` (round 5: LayerNorm -> QKV -> window attention of a Hiera block in one launch per pair of heads, q | k | v in
+    registers; "stage_change": 4 heads, queries 2 x 2 max-pooled inside the 8 x 8 window; "stage2": 224 channels, 4 heads, 4 x 4 windows) against torch
+    with the kernel's rounding points (LayerNorm output, q | k | v, the softmax numerators and the output in bf16; f32 sums).  What is left is summation
+    order and the rounding of values that sit on a bf16 boundary: measured max 2.5e-2 / rms 2e-4 of the output rms."""
     import math
     from ovo_amd import _lib as L
     lib = L.load()
-    B, H, W, C, HD = 2, 256, 256, 112, 56
-    NH, CO = (4, 224) if pool else (2, 112)
-    g = torch.Generator().manual_seed(3 + pool)
+    HD = 56
+    B, H, W, C, CO, NH, ws, pool = {"stage1": (2, 256, 256, 112, 112, 2, 8, 0), "stage_change": (2, 256, 256, 112, 224, 4, 8, 1),
+                                    "stage2": (2, 128, 128, 224, 224, 4, 4, 0)}[case]
+    kp = 128 if C == 112 else 256
+    g = torch.Generator().manual_seed(3 + len(case))
     x = (torch.randn(B, H, W, C, generator=g) * 1.5 + 0.3)
     ln_g, ln_b = 1.0 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
     w = torch.randn(3 * CO, C, generator=g) * (C ** -0.5)
     bias = 0.2 * torch.randn(3 * CO, generator=g)
     w[:CO] *= math.log2(math.e) / math.sqrt(HD)                  # the q rows carry log2(e) / sqrt(head_dim)
     bias[:CO] *= math.log2(math.e) / math.sqrt(HD)
-    wp = torch.zeros(3 * CO, 128)
+    wp = torch.zeros(3 * CO, kp)
     wp[:, :C] = w
     w16 = wp.to(torch.bfloat16)
-    n_win, tq, ld = B * (H // 8) * (W // 8), (16 if pool else 64), 256
+    n_win, tk, ld = B * (H // ws) * (W // ws), ws * ws, 256
+    tq = tk // 4 if pool else tk
     att = torch.full((n_win * tq, ld), 7.0, dtype=torch.bfloat16, device=DEV)
     d = [t.to(DEV) for t in (x, ln_g, ln_b, w16, bias)]
-    L.check(lib.ovo_window_attention_f32(L.ptr(d[0]), B, H, W, 8, C, CO, NH, pool, L.ptr(d[1]), L.ptr(d[2]), 1e-6, L.ptr(d[3]), 128, L.ptr(d[4]), L.ptr(att),
+    L.check(lib.ovo_window_attention_f32(L.ptr(d[0]), B, H, W, ws, C, CO, NH, pool, L.ptr(d[1]), L.ptr(d[2]), 1e-6, L.ptr(d[3]), kp, L.ptr(d[4]), L.ptr(att),
                                          ld, L.stream()))
     out = att.float().cpu()
     assert (out[:, CO:] == 7.0).all()                            # the padding columns are not touched
     r16 = lambda t: t.to(torch.bfloat16).float()
     xn = r16(torch.nn.functional.layer_norm(x, (C,), ln_g, ln_b, 1e-6))
-    xw = xn.reshape(B, H // 8, 8, W // 8, 8, C).permute(0, 1, 3, 2, 4, 5).reshape(n_win, 64, C)
-    qkv = r16(xw @ w16[:, :C].float().T + bias).reshape(n_win, 64, 3, NH, HD)
-    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))           # [n_win, NH, 64, HD]
+    xw = xn.reshape(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(n_win, tk, C)
+    qkv = r16(xw @ w16[:, :C].float().T + bias).reshape(n_win, tk, 3, NH, HD)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))           # [n_win, NH, tk, HD]
     if pool:                                                     # 2 x 2 max-pool of q over the window's 8 x 8 tokens (sam2 do_pool on q)
         q = q.reshape(n_win, NH, 4, 2, 4, 2, HD).amax(dim=(3, 5)).reshape(n_win, NH, 16, HD)
     s = q @ k.transpose(-1, -2)
@@ -205,8 +208,10 @@ def test_window_attention_fused_vs_torch(pool):
     ref = r16((r16(p) @ v) / p.sum(-1, keepdim=True)).permute(0, 2, 1, 3).reshape(n_win * tq, CO)
     err = (out[:, :CO] - ref).abs()
     rms = ref.pow(2).mean().sqrt().item()
-    print(f"pool={pool}: max |err| / rms = {err.max().item() / rms:.3e}, rms err / rms = {err.pow(2).mean().sqrt().item() / rms:.3e}")
-    assert err.max().item() < 4e-2 * rms and err.pow(2).mean().sqrt().item() < 3e-3 * rms
+    print(f"{case}: max |err| / rms = {err.max().item() / rms:.3e}, rms err / rms = {err.pow(2).mean().sqrt().item() / rms:.3e}")
+    # (the maximum is a handful of values whose inputs sat on a bf16 rounding boundary -- q, k, v or a softmax numerator one step apart; the rms is the
+    # bound that moves when something is wrong: measured 2.0-2.2e-4)
+    assert err.max().item() < 8e-2 * rms and err.pow(2).mean().sqrt().item() < 1e-3 * rms
 
 
 def test_window_attention_fused_equals_three_launch_forward(monkeypatch):

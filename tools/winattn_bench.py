@@ -39,10 +39,19 @@ def fused_pool():
     L.check(lib.ovo_window_attention_f32(L.ptr(x), B, H, W, 8, C, 2 * C, 4, 1, L.ptr(g), L.ptr(b), 1e-6, L.ptr(w4), 128, L.ptr(bias4), L.ptr(att4), 256, L.stream()))
 t = timed(fused_pool)
 print(f"B={B}: stage-change block (4 heads, q pooled 2 x 2, two passes) {t:.1f} us")
+x2 = torch.randn(B, 128, 128, 224, device=dev)
+g2, b2 = torch.ones(224, device=dev), torch.zeros(224, device=dev)
+w2 = (torch.randn(3 * 224, 256, device=dev) * 0.1).to(torch.bfloat16); w2[:, 224:] = 0
+bias2 = torch.zeros(3 * 224, device=dev)
+att2 = torch.zeros(B * 128 * 128, 256, dtype=torch.bfloat16, device=dev)
+def fused_s2():
+    L.check(lib.ovo_window_attention_f32(L.ptr(x2), B, 128, 128, 4, 224, 224, 4, 0, L.ptr(g2), L.ptr(b2), 1e-6, L.ptr(w2), 256, L.ptr(bias2), L.ptr(att2), 256, L.stream()))
+t = timed(fused_s2)
+print(f"B={B}: stage-2 block (224 channels, 4 heads, 4 x 4 windows, two passes) {t:.1f} us")
 enc = HipHiera(SPECS["hiera_b+"], None, dev, 0)
 img = torch.randn(B, 3, 1024, 1024, device=dev)
 t_on = timed(lambda: enc.forward(img), 5)
 os.environ["OVO_HIERA_NO_WINATTN"] = "1"
 t_off = timed(lambda: enc.forward(img), 5)
 del os.environ["OVO_HIERA_NO_WINATTN"]
-print(f"hiera_b+ forward of {B} frames: {t_on / 1e3:.3f} ms with the fused window attention (stage 1 + stage change), {t_off / 1e3:.3f} ms with the three launches ({(t_off - t_on) / 3:.0f} us per fused block, 3 blocks)")
+print(f"hiera_b+ forward of {B} frames: {t_on / 1e3:.3f} ms with the fused window attention (stages 1-2), {t_off / 1e3:.3f} ms with the three launches ({(t_off - t_on) / 5:.0f} us per fused block, 5 blocks)")
