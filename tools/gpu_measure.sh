@@ -26,6 +26,9 @@ timeout 600 python tools/vit_bench.py > $OUT/vit_bench.txt 2>&1
 timeout 300 python tools/attn_bench.py > $OUT/attn_bench.txt 2>&1
 timeout 300 python tools/scatter_bench.py > $OUT/scatter_bench.txt 2>&1; timeout 300 python tools/scatter_bench.py 5000000 768 60000 >> $OUT/scatter_bench.txt 2>&1
 RBS=0 timeout 300 python tools/mlp_bench.py > $OUT/mlp_bench.txt 2>&1
+timeout 300 python tools/winattn_bench.py 12 > $OUT/winattn_bench.txt 2>&1
+(timeout 300 python tools/patch_embed_bench.py 12; timeout 300 python tools/patch_embed_bench.py 1) > $OUT/patch_embed_bench.txt 2>&1
+timeout 300 python tools/round_host.py 8 > $OUT/round_host.txt 2>&1
 # BASELINE configs[3]'s process layout on ONE GPU over gloo (8 ranks, 5 M-point map): executes rings, staging and shards at world 8; not a scaling number
 (export OVO_FORCE_DEVICE=0 OVO_DIST_BACKEND=gloo; timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 8 --steps 8 --warmup 2 --map-points 5000000 --no-cpu-baseline --no-roofline --dense-merge none 2>&1 | tail -1) > $OUT/bench_world8_one_gpu_5m.json
 cd /tmp
@@ -34,6 +37,8 @@ timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OU
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- python $R/tools/pmc_calib.py > $OUT/calib_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- python $R/tools/pmc_calib.py > $OUT/calib_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/wa_fetch -- python $R/tools/winattn_bench.py 12 > $OUT/wa_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/wa_write -- python $R/tools/winattn_bench.py 12 > $OUT/wa_write.log 2>&1
 DEC_ONLY=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/amg_prof -- python $R/tools/amg_bench.py 16 > $OUT/amg_prof.log 2>&1
 ITERS=5 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/geom_stats -- python $R/tools/geom_bench.py 10000000 > $OUT/geom_stats.log 2>&1
 ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/geom_fetch -- python $R/tools/geom_bench.py 10000000 > $OUT/geom_fetch.log 2>&1
@@ -42,6 +47,7 @@ ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INS
 cd $R
 python tools/pmc_traffic.py --fetch-dir $OUT/pmc_fetch --write-dir $OUT/pmc_write --calib-fetch-dir $OUT/calib_fetch --calib-write-dir $OUT/calib_write --out $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
 python tools/pmc_traffic.py --fetch-dir $OUT/geom_fetch --write-dir $OUT/geom_write --out $OUT/geom_10m_pmc_traffic.json > $OUT/geom_pmc.log 2>&1
+python tools/pmc_traffic.py --fetch-dir $OUT/wa_fetch --write-dir $OUT/wa_write --out $OUT/winattn_pmc_traffic.json > $OUT/wa_pmc.log 2>&1
 python tools/sq_counters.py $OUT/geom_sq > $OUT/geom_10m_sq_counters.txt 2>&1
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/bench_n1_kernel_stats.csv
 python tools/kstats_region.py $OUT/prof $OUT/bench_n1_timed_region_kernel_stats.csv $OUT/bench_n1_isolated_pass_kernel_stats.csv > $OUT/kstats_region.log 2>&1
