@@ -18,6 +18,16 @@
 // hiera_b+: the two stage-1 blocks (C = 112, 2 heads, 8 x 8 windows) and the stage-change block that follows them (112 -> 224 channels, 4 heads, queries
 // pooled 2 x 2: k_win_attn112<true>, two passes of two heads).  From stage 2 on (C = 224) the weights (301 KB) do not fit LDS.
 // Reference: sam2 MultiScaleBlock / MultiScaleAttention inside the image encoder, reached at mask_generator.py:113.
+//
+// Measured on the way (12 frames, stage 1; profiles/r05c_winattn_bench.txt has the final numbers):
+//   * first form (unpadded 56-row blocks with selects, zero-initialised accumulators + bias adds, Q^T per query tile, scalar LayerNorm math): 250 us =
+//     load phase 92 us (alone: x in at 3.8 TB/s) + product phase 160 us (alone) -- the two waves of a SIMD run in step and the phases do not overlap;
+//   * 64-row zero-padded blocks (no selects), bias as the accumulators' initial value, fragments kept as whole uint4 (no v_mov in front of the MFMAs),
+//     LayerNorm on explicit f32 pairs (v_pk_*, 340 v_mov gone), Q^T for all four query tiles per weight read: 214 us;
+//   * quad reductions on v_permlane16/32_swap instead of ds_bpermute: 202 us;
+//   * a start stagger of 10-40 us between the two waves of a SIMD: no effect (214-225 us);
+//   * one wave per SIMD (512 registers) with the next window requested as soon as LayerNorm frees this one's 128 registers: 245 us -- the product
+//     phase of a single wave per SIMD is a serial dependency chain (~20 us per window), two waves per SIMD hide more of it than the prefetch does.
 #include <stdlib.h>
 
 #include "gemm_common.h"
