@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     extern __shared__ __attribute__((aligned(16))) unsigned char pe_lds[];
     uint16_t *s_img = (uint16_t *)pe_lds;                               // [3 * PE_IH][PE_RS]: input column x of the tile sits at index x - x_first + 1
     uint16_t *s_w = s_img + 3 * PE_IH * PE_RS;                          // [E][PE_WS]: k' = (channel * 7 + ky) * 8 + (kx + 1)
-    const int S4 = S >> 2, tiles_x = S4 / PE_TW;
+    const int S4 = S >> 2, tiles_x = S4 / PE_TW, n_pos = tiles_x * (S4 / PE_TH);
     for (int i = threadIdx.x; i < E * 24; i += 512) {                   // one (channel, ky) row of one output channel per thread: 7 weights
         const int e = i / 24, r = i - 24 * e;
         uint4 p = make_uint4(0u, 0u, 0u, 0u);
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     float h;
     // a tile's pixels: columns 3 .. 130 of each row are 32 aligned float4, columns 0 .. 2 (left halo) scalars -- into registers, one tile ahead
     auto load_tile = [&](int t) {                                       // (branch-free: clamped addresses, then a select -- seven loads in flight)
-        const int b = t % B, tt = t / B;
+        const int tt = t % n_pos, b = t / n_pos;
         const int oy0 = (tt / tiles_x) * PE_TH, ox0 = (tt % tiles_x) * PE_TW;
         const int y_first = 4 * oy0 - 3, x_first = 4 * ox0 - 3;
         const float *src = img + (long long)b * 3 * S * S;
@@ -399,7 +399,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     };
     if ((int)blockIdx.x < n_tiles) load_tile(blockIdx.x);
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const int b = t % B, tt = t / B;                                // the images sharing a tile's position-embedding rows run side by side
+        // task t = (image, tile position), position fastest: a workgroup's tasks are gridDim.x apart, so with the grid a multiple of the positions
+        // per image it keeps ONE position and walks through the images -- the tile's position-embedding rows come from its own L1 / L2 after the first
+        // (image-fastest, the twelve readers of a position sat on different XCDs: PMC fetch 591 MB per launch for 151 MB of pixels + 29 MB of table;
+        // the launch time did not move, 193 -> 191 us: it is bound by its 352 MB of stores)
+        const int tt = t % n_pos, b = t / n_pos;
         const int oy0 = (tt / tiles_x) * PE_TH, ox0 = (tt % tiles_x) * PE_TW;
         __syncthreads();                                                // the previous tile's products have read s_img
         // accumulators start at bias + position embedding: the loads fly while the tile is written to LDS

@@ -24,7 +24,7 @@ cam = G.make_camera(corners, torch.linalg.inv(pose), Kt, 0.05, h, w)
 ITERS = int(os.environ.get("ITERS", "10"))
 
 def timed(fn):
-    for _ in range(2): fn()
+    for _ in range(10): fn()                      # (2 warm-up launches left clock ramp / first-touch cost in the first row of a fresh process: 130 vs 24 us)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     for _ in range(ITERS): fn()
