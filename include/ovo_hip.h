@@ -288,7 +288,7 @@ int ovo_mlp_f32(float *x, int64_t rows, int d, const float *ln_g, const float *l
  * pool = 1 (the stage-change block, q_stride 2): q is 2 x 2 max-pooled inside the window before the scores; att has 16 rows per window.
  * One launch per pair of heads.  OVO_E_UNSUPPORTED -- nothing launched -- unless H % window == W % window == 0, >= 512 windows and
  * (window, d, d_out, heads, pool) = (8, 112, 112, 2, 0), (8, 112, 224, 4, 1) or (4, 224, 224, 4, 0; ldw >= 224, an even
- * number >= 2048 of windows): run ovo_gemm_f32a + ovo_attention then (ovo_hiera_forward does exactly that). */
+ * number >= 512 of windows): run ovo_gemm_f32a + ovo_attention then (ovo_hiera_forward does exactly that). */
 int ovo_window_attention_f32(const float *x, int B, int H, int W, int window, int d, int d_out, int heads, int pool, const float *ln_g,
                              const float *ln_b, float eps, const void *qkv_w, int64_t ldw, const float *qkv_b, void *att, int ld_att,
                              ovo_stream_t stream);

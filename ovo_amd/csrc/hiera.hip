@@ -481,7 +481,14 @@ int launch_patch_embed7(const float *img, int S, const void *w, int ldw, const f
         set = true;
     }
     const int S4 = S / 4, n_tiles = B * (S4 / PE_TH) * (S4 / PE_TW);
+    const bool prof = ovo_prof_enabled();
+    if (prof) {
+        const double tok = (double)B * S4 * S4;
+        ovo_prof_begin(8, 2.0 * tok * 147.0 * 16 * NT, s); ovo_prof_shape((int)tok, 16 * NT, 147); ovo_prof_flags(1 | 2 | 256);
+        ovo_prof_bytes(12.0 * B * S * S + 4.0 * 16 * NT * (tok + (double)S4 * S4));
+    }
     k_patch_embed7<NT><<<n_tiles < 512 ? n_tiles : 512, 512, lds, s>>>(img, S, (const uint16_t *)w, ldw, bias, pos, out, B, n_tiles);
+    if (prof) ovo_prof_end(s);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

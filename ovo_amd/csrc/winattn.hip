@@ -395,7 +395,7 @@ int win_attn_launch(const float *x, int B, int H, int W, int ws, int d, int d_ou
     if ((((uintptr_t)x | (uintptr_t)qkv_w) & 15) != 0 || ((uintptr_t)att & 7) != 0 || ldw % 8 != 0 || ld_att < d_out || ld_att % 4 != 0) return OVO_E_UNSUPPORTED;
     if (d == c224::C2 && d_out == d && heads == 2 * NH && !pool && ws == 4 && H % 4 == 0 && W % 4 == 0 && ldw >= c224::C2) {     // stage 2: 4 x 4 windows
         const long long n_win = (long long)B * (H / 4) * (W / 4);
-        if (n_win < 2048 || n_win % 2 != 0 || n_win >= (1ll << 31) / 16) return OVO_E_UNSUPPORTED;
+        if (n_win < 512 || n_win % 2 != 0 || n_win >= (1ll << 31) / 16) return OVO_E_UNSUPPORTED;
         static bool set2 = false;
         if (!set2) {
             hipError_t e = hipFuncSetAttribute((const void *)c224::k_win_attn224, hipFuncAttributeMaxDynamicSharedMemorySize, c224::LDS2_BYTES);
@@ -406,10 +406,17 @@ int win_attn_launch(const float *x, int B, int H, int W, int ws, int d, int d_ou
         a.x = x; a.B = B; a.H = H; a.W = W; a.ln_g = ln_g; a.ln_b = ln_b; a.eps = eps;
         a.w = (const uint16_t *)qkv_w; a.ldw = ldw; a.bias = qkv_b; a.att = (uint16_t *)att; a.ld_att = ld_att;
         a.n_win = (int)n_win; a.nwh = H / 4; a.nww = W / 4; a.part_rows = d_out;
+        // (the event profiler books the pair of passes as one streaming-family launch: QKV product + scores + P . V flops; bytes = x in, attention out)
+        const bool prof = ovo_prof_enabled();
+        if (prof) {
+            ovo_prof_begin(8, 2.0 * n_win * 16.0 * d * 3.0 * d_out + 4.0 * n_win * heads * 16.0 * 16.0 * HD, s);
+            ovo_prof_shape((int)(n_win * 16), 3 * d_out, d); ovo_prof_flags(32 | 64); ovo_prof_bytes((double)n_win * 16.0 * (4.0 * d + 2.0 * d_out));
+        }
         for (int h0 = 0; h0 < heads; h0 += NH) {
             a.head0 = h0;
             c224::k_win_attn224<<<256, 64 * c224::NW, c224::LDS2_BYTES, s>>>(a);
         }
+        if (prof) ovo_prof_end(s);
         OVO_CHECK_LAUNCH();
         return OVO_OK;
     }
@@ -428,11 +435,18 @@ int win_attn_launch(const float *x, int B, int H, int W, int ws, int d, int d_ou
     a.x = x; a.B = B; a.H = H; a.W = W; a.ln_g = ln_g; a.ln_b = ln_b; a.eps = eps;
     a.w = (const uint16_t *)qkv_w; a.ldw = ldw; a.bias = qkv_b; a.att = (uint16_t *)att; a.ld_att = ld_att;
     a.n_win = (int)n_win; a.nwh = H / 8; a.nww = W / 8; a.part_rows = d_out;
+    const bool prof = ovo_prof_enabled();
+    if (prof) {
+        const double tq = pool ? 16.0 : 64.0;
+        ovo_prof_begin(8, 2.0 * n_win * 64.0 * d * 3.0 * d_out + 4.0 * n_win * heads * tq * 64.0 * HD, s);
+        ovo_prof_shape((int)(n_win * 64), 3 * d_out, d); ovo_prof_flags(32 | 64); ovo_prof_bytes((double)n_win * (64.0 * 4.0 * d + tq * 2.0 * d_out));
+    }
     for (int h0 = 0; h0 < heads; h0 += NH) {                       // two heads per pass (their weights fill LDS)
         a.head0 = h0;
         if (pool) k_win_attn112<true><<<256, 512, LDS_BYTES, s>>>(a);
         else k_win_attn112<false><<<256, 512, LDS_BYTES, s>>>(a);
     }
+    if (prof) ovo_prof_end(s);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }
