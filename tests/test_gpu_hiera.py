@@ -228,3 +228,41 @@ def test_window_attention_fused_equals_three_launch_forward(monkeypatch):
         er = _rel_rms(u.cpu(), v.cpu())
         print(f"level {i}: rms difference / rms = {er:.3e}")
         assert 0 < er < 8e-3
+
+
+def test_fused_hiera_kernels_are_deterministic():
+    """The fused stage-1/2 kernels at the bench's full 12-frame size, launched repeatedly: every output bit-identical to the first launch (the fused
+    MLP kernel once had a two-workgroup form that was not, `test_fused_mlp_stream_is_deterministic`; these kernels have no cross-wave hand-over after
+    the weights are in LDS, and this test holds them to it)."""
+    from ovo_amd import _lib as L
+    lib = L.load()
+    B = 12
+    g = torch.Generator().manual_seed(11)
+    for (H, C, CO, NH, ws, pool, kp) in ((256, 112, 112, 2, 8, 0, 128), (256, 112, 224, 4, 8, 1, 128), (128, 224, 224, 4, 4, 0, 256)):
+        x = torch.randn(B, H, H, C, generator=g).to(DEV)
+        ln_g, ln_b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        w = torch.zeros(3 * CO, kp)
+        w[:, :C] = torch.randn(3 * CO, C, generator=g) * 0.1
+        w16, bias = w.to(torch.bfloat16).to(DEV), (0.1 * torch.randn(3 * CO, generator=g)).to(DEV)
+        n_win, tq = B * (H // ws) ** 2, (ws * ws // 4 if pool else ws * ws)
+        outs = []
+        for rep in range(20):
+            att = torch.zeros((n_win * tq, 256), dtype=torch.bfloat16, device=DEV)
+            L.check(lib.ovo_window_attention_f32(L.ptr(x), B, H, H, ws, C, CO, NH, pool, L.ptr(ln_g), L.ptr(ln_b), 1e-6, L.ptr(w16), kp, L.ptr(bias), L.ptr(att),
+                                                 256, L.stream()))
+            outs.append(att)
+        torch.cuda.synchronize()
+        bad = sum(int(not torch.equal(outs[0], o)) for o in outs[1:])
+        assert bad == 0, f"window attention ({C} -> {CO}, pool {pool}): {bad} of 19 repeats differ"
+    S, E = 1024, 112
+    img = torch.randn(B, 3, S, S, generator=g).to(DEV)
+    wp = torch.zeros(E, 192)
+    wp[:, :147] = torch.randn(E, 147, generator=g) * 0.05
+    d_w, d_b, d_p = wp.to(torch.bfloat16).to(DEV), torch.randn(E, generator=g).to(DEV), torch.randn((S // 4) ** 2, E, generator=g).to(DEV)
+    outs = []
+    for rep in range(6):
+        out = torch.empty(B, (S // 4) ** 2, E, device=DEV)
+        L.check(lib.ovo_hiera_patch_embed(L.ptr(img), B, S, E, L.ptr(d_w), 192, L.ptr(d_b), L.ptr(d_p), L.ptr(out), L.stream()))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
