@@ -349,6 +349,11 @@ int ovo_resize_normalize(const void *src, int src_dtype, int C, int H, int W, in
 int ovo_resize_window_normalize(const void *src, int src_dtype, int C, int H, int W, int y0, int x0, int ch, int cw, float *out,
                                 int oh, int ow, int virt_h, int virt_w, int top, int left, int filter, float scale,
                                 const float *mean3_host, const float *std3_host, ovo_stream_t stream);
+/* ovo_resize_normalize for n_src source images of one size / layout x n_crop crops each in ONE launch (ABI v10): out image i * n_crop + k
+ * (f32 [C, oh, ow] each, contiguous) = crop k (crops_host[4 k ..] = y0, x0, h, w) of source i.  srcs_host / crops_host are HOST arrays. */
+int ovo_resize_normalize_batch(const void *const *srcs_host, int n_src, int src_dtype, int C, int H, int W, const int32_t *crops_host, int n_crop,
+                               float *out, int oh, int ow, int antialias, float scale, const float *mean3_host, const float *std3_host,
+                               ovo_stream_t stream);
 
 /* ---- a14: per-mask crops of the crop-mode descriptors (segment_utils.py:29-41 segmap2segimg, :43-94, :118-172) ----
  * ovo_mask_boxes: masks u8 [n, H, W] -> boxes i32 [n, 4] = (x, y, w, h) with the reference's w = x_max - x_min,

@@ -181,6 +181,7 @@ _SIGNATURES = {
     "ovo_im2col": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "ovo_resize_normalize": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _F32,
                                     C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
+    "ovo_resize_normalize_batch": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _I32, _I32, _F32, _P, _P, _P]),
     "ovo_resize_window_normalize": (_I32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _F32,
                                            C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "ovo_rope_qk": (_I32, [_P, _I32, _I32, _I32, _I32, _P, _P, _I32, _P]),

@@ -212,7 +212,7 @@ __device__ __forceinline__ void aa_taps(const ResizeArgs &a, int ymin, int xmin,
 }
 
 #define OVO_RS_TAPS 10                                  // taps per axis held in registers: down-scaling up to ~4.5x; beyond that the generic loop
-__global__ void __launch_bounds__(256) k_resize_norm(ResizeArgs a, float *__restrict__ out) {
+__device__ __forceinline__ void resize_norm_body(const ResizeArgs &a, float *__restrict__ out) {
     const int wx_ = blockIdx.x * 64 + (threadIdx.x & 63), wy_ = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (wx_ >= a.ow || wy_ >= a.oh) return;
     const int ox = wx_ + a.left, oy = wy_ + a.top;     // position in the virtual vh x vw output
@@ -262,6 +262,17 @@ __global__ void __launch_bounds__(256) k_resize_norm(ResizeArgs a, float *__rest
         }
     }
     for (int c = 0; c < a.C; ++c) out[((long long)c * a.oh + wy_) * a.ow + wx_] = (v[c] * a.scale - a.mean[c]) / a.std[c];
+}
+__global__ void __launch_bounds__(256) k_resize_norm(ResizeArgs a, float *__restrict__ out) { resize_norm_body(a, out); }
+
+// Several (source image, crop) pairs of one geometry in ONE launch (blockIdx.z): the look-ahead encoders resize 12 frames x 2 TextRegion crops and 12 SAM2
+// inputs per group -- 36 launches of 12-18 us each, most of it launch ramp for 0.3 M output pixels.  Same body, same arithmetic per pixel.
+constexpr int RESIZE_BATCH_MAX = 64;
+struct ResizeBatch { const void *src[RESIZE_BATCH_MAX]; int y0[RESIZE_BATCH_MAX], x0[RESIZE_BATCH_MAX], ch[RESIZE_BATCH_MAX], cw[RESIZE_BATCH_MAX]; };
+__global__ void __launch_bounds__(256) k_resize_norm_batch(ResizeArgs a, ResizeBatch b, float *__restrict__ out) {
+    const int z = blockIdx.z;
+    a.src = b.src[z]; a.y0 = b.y0[z]; a.x0 = b.x0[z]; a.ch = b.ch[z]; a.cw = b.cw[z];
+    resize_norm_body(a, out + (long long)z * a.C * a.oh * a.ow);
 }
 
 // ---- a14: per-mask crops for the crop-mode descriptors (segment_utils.py:29-41, 118-170) ----
@@ -589,6 +600,36 @@ int ovo_resize_normalize(const void *src, int src_dtype, int C, int H, int W, in
                          ovo_stream_t stream) {
     return ovo_resize_window_normalize(src, src_dtype, C, H, W, y0, x0, ch, cw, out, oh, ow, oh, ow, 0, 0, antialias, scale, mean3_host,
                                        std3_host, stream);
+}
+
+int ovo_resize_normalize_batch(const void *const *srcs_host, int n_src, int src_dtype, int C, int H, int W, const int32_t *crops_host, int n_crop, float *out,
+                               int oh, int ow, int antialias, float scale, const float *mean3_host, const float *std3_host, ovo_stream_t stream) {
+    OVO_REQUIRE(srcs_host && crops_host && out && n_src > 0 && n_crop > 0, "null / empty argument");
+    OVO_REQUIRE(src_dtype == 0 || src_dtype == 3 || src_dtype == 4, "src_dtype: 0 = f32 [C,H,W], 3 = u8 [C,H,W], 4 = u8 [H,W,C]");
+    OVO_REQUIRE(C >= 1 && C <= 4 && oh > 0 && ow > 0 && antialias >= 0 && antialias <= 2, "bad shape");
+    ResizeArgs a;
+    a.src = nullptr; a.src_u8 = src_dtype >= 3; a.hwc = src_dtype == 4; a.C = C; a.H = H; a.W = W; a.y0 = a.x0 = 0; a.ch = H; a.cw = W;
+    a.oh = oh; a.ow = ow; a.aa = antialias; a.scale = scale; a.vh = oh; a.vw = ow; a.top = 0; a.left = 0;
+    for (int c = 0; c < 4; ++c) { a.mean[c] = mean3_host && c < C ? mean3_host[c] : 0.f; a.std[c] = std3_host && c < C ? std3_host[c] : 1.f; }
+    for (int k = 0; k < n_crop; ++k) {
+        const int32_t *r = crops_host + 4 * k;
+        OVO_REQUIRE(r[2] > 0 && r[3] > 0 && r[0] >= 0 && r[1] >= 0 && r[0] + r[2] <= H && r[1] + r[3] <= W, "crop outside the image");
+    }
+    // output image i * n_crop + k = crop k of source i; as many launches of up to RESIZE_BATCH_MAX pairs as it takes
+    const int total = n_src * n_crop;
+    for (int z0 = 0; z0 < total; z0 += RESIZE_BATCH_MAX) {
+        const int nz = total - z0 < RESIZE_BATCH_MAX ? total - z0 : RESIZE_BATCH_MAX;
+        ResizeBatch b;
+        for (int z = 0; z < nz; ++z) {
+            const int i = (z0 + z) / n_crop, k = (z0 + z) % n_crop;
+            OVO_REQUIRE(srcs_host[i], "null source image");
+            b.src[z] = srcs_host[i]; b.y0[z] = crops_host[4 * k]; b.x0[z] = crops_host[4 * k + 1]; b.ch[z] = crops_host[4 * k + 2]; b.cw[z] = crops_host[4 * k + 3];
+        }
+        dim3 grid((ow + 63) / 64, (oh + 3) / 4, nz);
+        k_resize_norm_batch<<<grid, 256, 0, (hipStream_t)stream>>>(a, b, out + (long long)z0 * C * oh * ow);
+    }
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
 }
 
 int ovo_mask_boxes(const uint8_t *masks, int n, int H, int W, int32_t *boxes_xywh, ovo_stream_t stream) {

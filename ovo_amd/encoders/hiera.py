@@ -212,6 +212,26 @@ class HipHiera:
                                               mean, std, L.stream()))
         return out
 
+    def preprocess_batch(self, images, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`preprocess` of several frames -> f32 [len(images), 3, S, S]; frames of one size / layout as ONE launch (`ovo_resize_normalize_batch`)."""
+        s = self.spec.image_size
+        imgs = [L.dev(im, im.dtype, "image") for im in images]
+        first = imgs[0]
+        if out is None:
+            out = torch.empty((len(imgs), 3, s, s), dtype=torch.float32, device=first.device)
+        if not all(im.dtype == first.dtype and im.shape == first.shape for im in imgs) or first.dtype not in (torch.uint8, torch.float32):
+            for k, im in enumerate(imgs):
+                self.preprocess(im, out=out[k:k + 1])
+            return out
+        hwc = first.dtype == torch.uint8 and first.shape[-1] == 3 and first.shape[0] != 3
+        h, w = (first.shape[0], first.shape[1]) if hwc else (first.shape[1], first.shape[2])
+        mean, std = (C.c_float * 3)(*IMAGENET_MEAN), (C.c_float * 3)(*IMAGENET_STD)
+        srcs = (C.c_void_p * len(imgs))(*[im.data_ptr() for im in imgs])
+        rect = (C.c_int32 * 4)(0, 0, h, w)
+        L.check(L.load().ovo_resize_normalize_batch(srcs, len(imgs), 4 if hwc else L.DTYPE_CODE[first.dtype], 3, h, w, rect, 1, L.ptr(out), s, s, 1,
+                                                    1.0 / 255.0 if first.dtype == torch.uint8 else 1.0, mean, std, L.stream()))
+        return out
+
     def forward(self, images: torch.Tensor):
         """images f32 [B, 3, S, S] -> (feat0 [B,S/4,S/4,c0], feat1 [B,S/8,S/8,c1], feat2 [B,S/16,S/16,fpn_dim]) NHWC f32."""
         s = self.spec

@@ -304,6 +304,31 @@ class HipViT:
                                              s.image_size, s.image_size, int(antialias), float(scale), mean, std, L.stream()))
         return out
 
+    def preprocess_batch(self, images: Sequence[torch.Tensor], crops: Optional[Sequence[Tuple[int, int, int, int]]] = None, scale: float = 1.0,
+                         antialias: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`preprocess` of SEVERAL frames (MI355X extension: the look-ahead encoders take a group of keyframes): out[i * len(crops) + k] = crop k of
+        image i.  Frames of one size / layout go down as ONE launch (`ovo_resize_normalize_batch`); anything else frame by frame.  Same arithmetic."""
+        s = self.spec
+        imgs = [L.dev(im, im.dtype, "image") for im in images]
+        first = imgs[0]
+        same = all(im.dtype == first.dtype and im.shape == first.shape and im.device == first.device for im in imgs) and first.dtype in (torch.uint8, torch.float32)
+        hwc = first.dtype == torch.uint8 and first.shape[-1] == 3 and first.shape[0] != 3
+        h, w = (first.shape[0], first.shape[1]) if hwc else (first.shape[1], first.shape[2])
+        crops = list(crops) if crops is not None else [(0, 0, h, w)]
+        nc = len(crops)
+        if out is None:
+            out = torch.empty((len(imgs) * nc, 3, s.image_size, s.image_size), dtype=torch.float32, device=first.device)
+        if not same:
+            for i, im in enumerate(imgs):
+                self.preprocess(im, crops, scale, antialias, out=out[i * nc:(i + 1) * nc])
+            return out
+        mean, std = (C.c_float * 3)(*s.mean), (C.c_float * 3)(*s.std)
+        srcs = (C.c_void_p * len(imgs))(*[im.data_ptr() for im in imgs])
+        rects = (C.c_int32 * (4 * nc))(*[int(v) for r in crops for v in r])
+        L.check(L.load().ovo_resize_normalize_batch(srcs, len(imgs), 4 if hwc else L.DTYPE_CODE[first.dtype], 3, h, w, rects, nc, L.ptr(out), s.image_size,
+                                                    s.image_size, int(antialias), float(scale), mean, std, L.stream()))
+        return out
+
     def clip_window(self, h: int, w: int) -> Tuple[int, int, int, int]:
         """(virt_h, virt_w, top, left) of the card's open_clip transform on an h x w image: torchvision `Resize(S)` puts the shorter side
         at S and the longer at int(S * long / short); `CenterCrop(S)` starts at int(round((size - S) / 2)).  "squash": (S, S, 0, 0)."""

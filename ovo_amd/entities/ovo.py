@@ -643,9 +643,12 @@ class OVO:
         for ev in ready:                                          # the images' uploads, when they are still in flight (resident images:
             side.wait_event(ev)                                   # nothing to wait for -- and no wait on the caller's stream, whose queue
         with torch.cuda.stream(side):                             # holds the previous keyframes' tails this forward should overlap)
-            for k, image in enumerate(images):
-                src = image if image.dtype == torch.uint8 and image.is_contiguous() else image.permute(2, 0, 1).contiguous()     # HWC u8: read in place
-                tr.vlm.preprocess(src, crops, scale=1.0 / 255.0, out=slot["batch"][k * nc:(k + 1) * nc])
+            srcs = [image if image.dtype == torch.uint8 and image.is_contiguous() else image.permute(2, 0, 1).contiguous() for image in images]   # HWC u8: read in place
+            if hasattr(tr.vlm, "preprocess_batch"):                # every frame's crops in one launch
+                tr.vlm.preprocess_batch(srcs, crops, scale=1.0 / 255.0, out=slot["batch"][:n])
+            else:
+                for k, src in enumerate(srcs):
+                    tr.vlm.preprocess(src, crops, scale=1.0 / 255.0, out=slot["batch"][k * nc:(k + 1) * nc])
             tr.vlm.forward(slot["batch"][:n], tokens=True, out=slot["tokens"][:n])
             done = torch.cuda.Event()
             done.record(side)

@@ -266,8 +266,7 @@ class FramePipeline:
                 s = self.sam.spec.image_size
                 if self._sam_in is None or self._sam_in.shape[0] < len(group):
                     self._sam_in = torch.empty((len(group), 3, s, s), dtype=torch.float32, device=self.device)
-                for k, g in enumerate(group):
-                    self.sam.preprocess(_hwc(g.rgb), out=self._sam_in[k:k + 1])      # the HWC frame is read in place
+                self.sam.preprocess_batch([_hwc(g.rgb) for g in group], out=self._sam_in[:len(group)])      # the HWC frames are read in place, one launch
                 self.sam_out = self.sam.forward(self._sam_in[:len(group)])
                 for k, g in enumerate(group):                      # a frame's features = slice k of the batched output
                     self._sam_by_frame[g.index] = (self.sam_out, k)

@@ -1042,3 +1042,23 @@ def test_textregion_full_size_640x480_vs_oracle():
     err = np.abs(out[ok] - ref[ok]).max()
     print(f"TextRegion 640x480 / PE-L/14-336 / 32 masks: max |unit descriptor error| = {err:.2e}")
     assert err <= 1e-3
+
+
+def test_batched_preprocess_equals_per_image():
+    """`ovo_resize_normalize_batch` (round 5: every frame x crop of an encoder look-ahead group in one launch) against the per-image launches: the same
+    kernel body per pixel -> bit-identical, for the ViT's TextRegion crops (antialiased down-scaling, HWC u8 frames read in place) and SAM2's 1024^2 input."""
+    from ovo_amd.encoders.hiera import SPECS as HS, HipHiera
+    from ovo_amd.encoders.vit import SPECS as VS, HipViT
+    g = torch.Generator().manual_seed(5)
+    frames = [torch.randint(0, 256, (480, 640, 3), generator=g, dtype=torch.uint8).to(DEV) for _ in range(5)]
+    vit = HipViT(VS["PE-Core-L14-336"], None, DEV, 0)
+    crops = [(0, 0, 480, 640), (72, 152, 336, 336)]
+    one = torch.cat([vit.preprocess(f, crops, scale=1.0 / 255.0) for f in frames])
+    many = vit.preprocess_batch(frames, crops, scale=1.0 / 255.0)
+    assert many.shape == one.shape and torch.equal(one, many)
+    chw = [f.permute(2, 0, 1).contiguous() for f in frames]             # CHW u8 path
+    assert torch.equal(torch.cat([vit.preprocess(f, crops, scale=1.0 / 255.0) for f in chw]), vit.preprocess_batch(chw, crops, scale=1.0 / 255.0))
+    sam = HipHiera(HS["hiera_test"], None, DEV, 0)
+    assert torch.equal(torch.cat([sam.preprocess(f) for f in frames]), sam.preprocess_batch(frames))
+    mixed = frames[:2] + [frames[2][:240].contiguous()]                  # frames of different sizes: the per-image path
+    assert torch.equal(torch.cat([sam.preprocess(f) for f in mixed]), sam.preprocess_batch(mixed))
