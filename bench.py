@@ -53,8 +53,10 @@ def parse():
     ap.add_argument("--map-points", type=int, default=1_000_000)
     ap.add_argument("--texts", type=int, default=10)
     ap.add_argument("--no-dense", action="store_true", help="skip the dense per-point accumulate / query")
-    ap.add_argument("--encoder-batch", type=int, default=int(os.environ.get("OVO_ENCODER_BATCH", "12")),
-                    help="keyframes (per GPU) whose SAM2 / ViT forwards run as ONE batched forward each (encoder look-ahead; 1 = per frame). "
+    ap.add_argument("--encoder-batch", type=int, default=int(os.environ.get("OVO_ENCODER_BATCH", "14")),
+                    help="keyframes (per GPU) whose SAM2 / ViT forwards run as ONE batched forward each (encoder look-ahead; 1 = per frame; 14 keyframes = "
+                         "28 crops x 577 tokens = 16 156 rows make every ViT product a whole number of 256-CU rounds of 256 x 256 tiles: +1 % over 12, "
+                         "profiles/r05c_encoder_batch_sweep.txt). "
                          "The reference defers a keyframe's descriptors by kf_queue_delay = 10 keyframes (ovo.yaml:53), so results do not change")
     ap.add_argument("--sam-full", action="store_true", help="not the headline workload: also run SAM2's mask decoder on a 16x16 click grid and the "
                     "automatic-mask-generator filters every frame (SURVEY.md f1); tracking still consumes the synthetic masks, because "
