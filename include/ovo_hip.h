@@ -258,6 +258,13 @@ typedef struct {
     int32_t B, H, W, wh, ww;
 } ovo_window_t;
 int ovo_gemm_unwindow(const ovo_gemm_t *g, const ovo_window_t *win, ovo_stream_t stream);
+/* ovo_gemm (win == NULL) / ovo_gemm_unwindow with f32 output that ALSO writes the LayerNorm of every result row (ABI v10):
+ *   C[row] = A . W^T + bias (+ add);   ln_out bf16 [C rows, ld_ln] = LayerNorm(C[row]; ln_g, ln_b, eps)
+ * -- Hiera stage 3's attention output projection + residual with the block's norm2 (the A operand of its MLP) taken from the accumulators: a workgroup
+ * owns whole rows.  OVO_E_UNSUPPORTED -- nothing launched -- unless N = 448, K % 64 == 0, bf16 operands, f32 C, no activation (then ovo_gemm_unwindow +
+ * ovo_gemm_f32a, which ovo_hiera_forward chains itself). */
+int ovo_gemm_rowln(const ovo_gemm_t *g, const ovo_window_t *win, const float *ln_g, const float *ln_b, float eps, void *ln_out, int64_t ld_ln,
+                   ovo_stream_t stream);
 /* ovo_gemm whose A operand is the f32 residual stream itself (Hiera stages 1-2 inside SAM2AutomaticMaskGenerator.generate,
  * mask_generator.py:113; no reference counterpart -- there LayerNorm and the linear layer are two modules): g->A is ignored,
  * product row m reads x[src(m), 0..d) -- src(m) = m, or with `win` the SPATIAL token of window-major row m (a padding row

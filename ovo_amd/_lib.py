@@ -173,6 +173,7 @@ _SIGNATURES = {
     "ovo_gemm_rope": (_I32, [C.POINTER(Gemm), C.POINTER(Rope), _P]),
     "ovo_gemm_periodic": (_I32, [C.POINTER(Gemm), _I64, _P]),
     "ovo_gemm_unwindow": (_I32, [C.POINTER(Gemm), C.POINTER(Window), _P]),
+    "ovo_gemm_rowln": (_I32, [C.POINTER(Gemm), C.POINTER(Window), _P, _P, _F32, _P, _I64, _P]),
     "ovo_gemm_f32a": (_I32, [C.POINTER(Gemm), C.POINTER(Window), _P, C.c_int, _P, _P, C.c_float, C.c_int, C.c_int, _P]),
     "ovo_decode_best": (_I32, [_P, _I64, _F32, _P, _P, _P]),
     "ovo_attention": (_I32, [C.POINTER(Attention), _P]),

@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
         md[i] = m < g.M ? row_dest(g, m) : -1;
     }
     auto fetch_epilogue = [&]() {
+        if constexpr (BN == 448) return;             // the full-row tile reads bias / residual in its epilogue (168 registers of prefetch do not fit beside 112 of accumulators)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn0 + j * 16 + fq * 4;
@@ -220,6 +221,65 @@ __global__ void __launch_bounds__(64 * NW) k_gemm(GemmArgs g) {
         }
     }
     };
+    if constexpr (BN == 448) {
+        // ---- full-row epilogue: C (f32) = acc + bias (+ residual), then LayerNorm of the row -> rln_out (bf16).  A row's 448 columns sit in two waves
+        // (wave & 1: columns 0..223 / 224..447) x 4 lanes (fq) x 14 tiles: in-lane sums, two xor-shuffles, one exchange through LDS per statistic.
+        bool ok[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm0 + i * 16 + fr;
+            ok[i] = m < g.M && md[i] >= 0;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = wn0 + j * 16 + fq * 4;
+                f32x4 v = acc[i][j] * g.alpha;
+                if (g.bias) v += *(const f32x4 *)(g.bias + n);
+                if (g.add && ok[i]) v += *(const f32x4 *)(g.add + add_row(g, m, md[i]) * g.ld_add + n);
+                acc[i][j] = v;
+                if (ok[i]) *(f32x4 *)((float *)g.C + md[i] * g.ldc + n) = v;
+            }
+        }
+        float *red = (float *)smem;                                // [BM][2]; the ring's stages are dead once every wave is past its last product
+        float mean[TM], rstd[TM];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) s += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            if (fq == 0) red[(wm0 + i * 16 + fr) * 2 + (wave & 1)] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) mean[i] = (red[(wm0 + i * 16 + fr) * 2] + red[(wm0 + i * 16 + fr) * 2 + 1]) * (1.0f / 448.0f);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] -= mean[i];
+                q += (acc[i][j][0] * acc[i][j][0] + acc[i][j][1] * acc[i][j][1]) + (acc[i][j][2] * acc[i][j][2] + acc[i][j][3] * acc[i][j][3]);
+            }
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            if (fq == 0) red[(wm0 + i * 16 + fr) * 2 + (wave & 1)] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) rstd[i] = rsqrtf((red[(wm0 + i * 16 + fr) * 2] + red[(wm0 + i * 16 + fr) * 2 + 1]) * (1.0f / 448.0f) + g.rln_eps);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = wn0 + j * 16 + fq * 4;
+            const f32x4 ga = *(const f32x4 *)(g.rln_g + n), be = *(const f32x4 *)(g.rln_b + n);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const f32x4 y = acc[i][j] * rstd[i] * ga + be;
+                if (ok[i]) *(uint2 *)(g.rln_out + md[i] * g.rln_ld + n) = make_uint2(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]));
+            }
+        }
+        return;
+    }
     const bool simple = !g.best && !g.rope_cos;
     if (simple && g.out_dtype != 0 && !g.add && g.act == 0) epilogue(std::integral_constant<int, 0>{});
     else if (simple && g.out_dtype != 0 && !g.add && g.act == 1) epilogue(std::integral_constant<int, 1>{});
@@ -382,8 +442,9 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
 
 }  // namespace
 
+struct RowLn { const float *g, *b; float eps; void *out; long long ld; };
 static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, int n_valid, ovo_stream_t stream, const ovo_rope_t *rope = nullptr,
-                      const ovo_window_t *win = nullptr, long long add_rows = 0) {
+                      const ovo_window_t *win = nullptr, long long add_rows = 0, const RowLn *rln = nullptr) {
     OVO_REQUIRE(p, "null descriptor");
     OVO_REQUIRE(p->M >= 0 && p->N > 0 && p->K > 0, "bad shape");
     if (p->M == 0) return OVO_OK;
@@ -403,6 +464,7 @@ static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, 
     g.best = best; g.store = store; g.n_valid = n_valid; g.add_rows = (int)add_rows; g.strip = 0;
     g.rope_cos = g.rope_sin = nullptr; g.rope_T = 1; g.rope_hd = 4; g.rope_cols = 0; g.rope_t0 = 0;
     g.ln_x = g.ln_g = g.ln_b = nullptr; g.ln_eps = 0.f; g.ln_d = 0; g.ln_mode = 0; g.pool_ww = 0; g.qpool_out = nullptr; g.qpool_cols = 0;
+    g.rln_g = g.rln_b = nullptr; g.rln_eps = 0.f; g.rln_out = nullptr; g.rln_ld = 0;
     g.dbg = 0; g.slab16 = 0; g.rope_lds = 0; g.stamps = nullptr; g.win_per = 0; g.win_ww = g.win_wh = g.win_nww = g.win_nwin = 1; g.win_H = g.win_W = 0;
     if (win) {
         OVO_REQUIRE(win->B > 0 && win->H > 0 && win->W > 0 && win->wh > 0 && win->ww > 0, "bad window descriptor");
@@ -414,6 +476,16 @@ static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, 
         OVO_REQUIRE(rope->cos && rope->sin && rope->T > 0 && rope->hd > 0 && rope->hd % 4 == 0 && rope->cols % rope->hd == 0 && rope->cols <= p->N &&
                     rope->t0 >= 0 && (((uintptr_t)rope->cos | (uintptr_t)rope->sin) & 15) == 0, "bad rope descriptor");
         g.rope_cos = rope->cos; g.rope_sin = rope->sin; g.rope_T = rope->T; g.rope_hd = rope->hd; g.rope_cols = rope->cols; g.rope_t0 = rope->t0;
+    }
+    if (rln) {                                                   // full-row tile + LayerNorm of the result (Hiera stage 3's projection + norm2)
+        if (p->N != 448 || p->K % 64 != 0 || p->out_dtype != 0 || p->in_dtype != 2 || p->act != 0 || p->alpha != 1.0f || add_rows != 0) return OVO_E_UNSUPPORTED;
+        OVO_REQUIRE(rln->g && rln->b && rln->out && rln->ld >= 448 && rln->ld % 4 == 0 && ((uintptr_t)rln->out & 7) == 0 &&
+                    (((uintptr_t)rln->g | (uintptr_t)rln->b) & 15) == 0, "bad row-LayerNorm operands");
+        g.rln_g = rln->g; g.rln_b = rln->b; g.rln_eps = rln->eps; g.rln_out = (uint16_t *)rln->out; g.rln_ld = rln->ld;
+        const int rc = launch<128, 448, 64, bf16x8, 8, 2>(g, (hipStream_t)stream);
+        if (rc != OVO_OK) return rc;
+        OVO_CHECK_LAUNCH();
+        return OVO_OK;
     }
     const int rc = p->in_dtype == 2 ? dispatch<bf16x8>(g, (hipStream_t)stream) : dispatch<f16x8>(g, (hipStream_t)stream);
     if (rc != OVO_OK) return rc;
@@ -435,6 +507,16 @@ extern "C" int ovo_gemm_rope(const ovo_gemm_t *p, const ovo_rope_t *rope, ovo_st
 extern "C" int ovo_gemm_unwindow(const ovo_gemm_t *p, const ovo_window_t *win, ovo_stream_t stream) {
     OVO_REQUIRE(win, "null window descriptor");
     return gemm_entry(p, nullptr, 1, 0, stream, nullptr, win);
+}
+
+int ovo_gemm_detail::gemm_unwindow_rowln(const ovo_gemm_t *p, const ovo_window_t *win, const float *ln_g, const float *ln_b, float eps, void *ln_out,
+                                         long long ld_ln, ovo_stream_t stream) {
+    const RowLn r = {ln_g, ln_b, eps, ln_out, ld_ln};
+    return gemm_entry(p, nullptr, 1, 0, stream, nullptr, win, 0, &r);
+}
+extern "C" int ovo_gemm_rowln(const ovo_gemm_t *p, const ovo_window_t *win, const float *ln_g, const float *ln_b, float eps, void *ln_out, int64_t ld_ln,
+                              ovo_stream_t stream) {
+    return ovo_gemm_detail::gemm_unwindow_rowln(p, win, ln_g, ln_b, eps, ln_out, ld_ln, stream);
 }
 
 // ovo_gemm whose `add` operand is periodic in the rows: product row m adds add[m % add_rows] (a per-pixel constant shared by every prompt of

@@ -43,6 +43,9 @@ struct GemmArgs {
     int tail_wait;             // gemm8p: 1 = a wave waits for its epilogue stores before it ends (OVO_8P_TAILWAIT, measurement)
     int rope_lds;              // k_gemm8p: the rotary epilogue stages its table slice in LDS (OVO_8P_ROPE_LDS)
     int slab16;                // k_gemm8p: 2-byte outputs cross the epilogue's LDS slab already rounded (OVO_8P_NO_SLAB16: the f32 slab)
+    // k_gemm<128, 448> (gemm.hip, round 5): a workgroup owns whole rows (N = 448 = BN), so after the f32 result (+ residual) is stored the LayerNorm of the
+    // rows that FOLLOWS the product in Hiera stage 3 (norm2 before the MLP) is taken from the accumulators: rln_out bf16 [C rows, rln_ld] = LN(C row)
+    const float *rln_g, *rln_b; float rln_eps; uint16_t *rln_out; long long rln_ld;
     int dbg;                   // tools/ only (OVO_8P_DEBUG): 1 = leave before anything, 2 = leave after the prologue, 4 = no epilogue, 8 = epilogue without the 2-byte stores
     unsigned long long *stamps;   // tools/ only (OVO_8P_STAMPS = address of u64[tiles][4]): s_memrealtime at start / K-loop / epilogue / end
 };
@@ -257,6 +260,11 @@ int gemm_f32a_stream(const ovo_gemm_t *p, const ovo_window_t *win, const float *
 // widths have no instantiation or rows < 16384 (nothing launched: the caller runs the two products)
 int mlp_stream_launch(float *x, long long rows, int d, const float *ln_g, const float *ln_b, float eps, const void *w1, long long ldw1, const float *b1,
                       int hid, const void *w2, long long ldw2, const float *b2, hipStream_t s);
+
+// ovo_gemm_unwindow (f32 C += residual, rows re-ordered from window order) that ALSO writes ln_out bf16 [C rows, ld_ln] = LayerNorm(C row; g, b, eps): the
+// full-row tile of gemm.hip.  OVO_E_UNSUPPORTED (nothing launched) unless N = 448, K % 64 == 0, f32 output
+int gemm_unwindow_rowln(const ovo_gemm_t *p, const ovo_window_t *win, const float *ln_g, const float *ln_b, float eps, void *ln_out, long long ld_ln,
+                        ovo_stream_t stream);
 
 // att bf16 [windows x 64 (16 with `pool`), ld_att] (window-major rows) = per-window, per-head softmax(q k^T) v of q | k | v = LayerNorm(x) . Wqkv^T + b, straight
 // from the f32 token grid x [B, H, W, d] (winattn.hip; one launch per pair of heads); OVO_E_UNSUPPORTED (nothing launched) unless d = 112, 8 x 8 windows,

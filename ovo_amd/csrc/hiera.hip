@@ -642,12 +642,24 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         // stage change the old x is dead (only LN1 read it) and the pooled skip lives in `spare`, so the smaller new stream is
         // written over the old buffer.
         const Grid go = make_grid(B, Ho, Ho, p.ws[i] > 0 ? (p.pool[i] ? p.ws[i] / 2 : p.ws[i]) : 0);
+        bool ln2_done = false;
         {
             ovo_gemm_t og;
             og.A = k.att; og.lda = kout; og.W = L.out_w; og.ldw = kout; og.bias = L.out_b; og.C = x; og.ldc = dout; og.add = residual; og.ld_add = dout;
             og.M = (int)(n_win * tq); og.N = dout; og.K = kout; og.in_dtype = 2; og.out_dtype = 0; og.act = 0; og.alpha = 1.0f;
             const ovo_window_t ow = {go.B, go.H, go.W, go.wh, go.ww};
-            TRY(ovo_gemm_unwindow(&og, &ow, stream));
+            // stage 3 (N = 448), OPT-IN (OVO_HIERA_PROJ_LN=1): a full-row 128 x 448 tile, norm2 of the result rows from its accumulators straight into k.h, the
+            // MLP below then skips its LayerNorm pass.  MEASURED AND LEFT OFF (tools/rowln_bench.py, profiles/r05c_rowln_bench.txt): 87 us against 64 (128 x 64
+            // tiles) + 28 (LayerNorm pass) alone, but 25 us per block SLOWER inside the forward (15.97 vs 15.57 ms per 12 frames): one 512-thread workgroup
+            // per CU with a two-stage ring of 72 KB K-tiles does not overlap its neighbours the way the small tiles and the copy-rate LayerNorm pass do.
+            static const bool rowln_once = getenv("OVO_HIERA_PROJ_LN") != nullptr;
+            const bool rowln = ovo_knobs_dynamic() ? getenv("OVO_HIERA_PROJ_LN") != nullptr : rowln_once;
+            int rc = OVO_E_UNSUPPORTED;
+            if (rowln && dout == 448 && kout == dout)
+                rc = ovo_gemm_detail::gemm_unwindow_rowln(&og, &ow, L.ln2_g, L.ln2_b, c.ln_eps, k.h, kout, stream);
+            if (rc == OVO_OK) ln2_done = true;
+            else if (rc != OVO_E_UNSUPPORTED) return rc;
+            else TRY(ovo_gemm_unwindow(&og, &ow, stream));
         }
         // MLP
         const Grid gi = make_grid(B, Ho, Ho, 0);
@@ -668,7 +680,7 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         for (long long r0 = fused == OVO_OK ? tok_out : 0; r0 < tok_out; r0 += chunk_rows) {
             const long long nr = tok_out - r0 < chunk_rows ? tok_out - r0 : chunk_rows;
             const Grid gc = chunk_rows == tok_out ? gi : make_grid(1, (int)nr, 1, 0);
-            bool hd = chunk_rows == tok_out ? h_done : false;
+            bool hd = chunk_rows == tok_out ? (h_done || ln2_done) : false;
             float *xc = x + r0 * dout;
             TRY(gemm_from_f32(xc, gc, dout, kout, L.ln2_g, L.ln2_b, c.ln_eps, 1, k.h, hd, L.fc1_w, L.fc1_b, k.u, 4 * dout, 2, 4 * dout, 1, stream));
             TRY(gemm(k.u, 4 * dout, L.fc2_w, 4 * dout, L.fc2_b, xc, dout, 0, xc, dout, nr, dout, 4 * dout, 0, stream));

@@ -266,3 +266,56 @@ def test_fused_hiera_kernels_are_deterministic():
         outs.append(out)
     torch.cuda.synchronize()
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+@pytest.mark.parametrize("windowed", [True, False])
+def test_projection_with_rowwise_layernorm_vs_torch(windowed):
+    """`ovo_gemm_rowln` (round 5: Hiera stage 3's attention output projection + residual on a full-row tile, the block's norm2 taken from the accumulators):
+    C against torch's f32 product of the same bf16 operands (summation order only) and ln_out against LayerNorm of the C the kernel itself wrote (the
+    statistics' summation order and one bf16 rounding)."""
+    import ctypes as C
+    from ovo_amd import _lib as L
+    lib = L.load()
+    B, H, ws, N, K = 2, 64, 14, 448, 448
+    g = torch.Generator().manual_seed(9)
+    nw = -(-H // ws)
+    M = B * nw * nw * ws * ws if windowed else B * H * H
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias, x = torch.randn(N, generator=g) * 0.1, torch.randn(B * H * H, N, generator=g)
+    ln_g, ln_b = 1.0 + 0.2 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    d_A, d_W, d_bias, d_x, d_g, d_b = (t.to(DEV) for t in (A, W, bias, x.clone(), ln_g, ln_b))
+    h = torch.full((B * H * H, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    q = L.Gemm()
+    q.A, q.lda, q.W, q.ldw, q.bias, q.C, q.ldc, q.add, q.ld_add = d_A.data_ptr(), K, d_W.data_ptr(), K, d_bias.data_ptr(), d_x.data_ptr(), N, d_x.data_ptr(), N
+    q.M, q.N, q.K, q.in_dtype, q.out_dtype, q.act, q.alpha = M, N, K, 2, 0, 0, 1.0
+    win = L.Window(B, H, H, ws, ws) if windowed else None
+    L.check(lib.ovo_gemm_rowln(C.byref(q), C.byref(win) if windowed else None, L.ptr(d_g), L.ptr(d_b), 1e-6, L.ptr(h), N, L.stream()))
+    prod = A.float() @ W.float().T + bias
+    if windowed:                                                 # window-major product rows -> spatial rows; padding positions dropped
+        prod = prod.reshape(B, nw, nw, ws, ws, N).permute(0, 1, 3, 2, 4, 5).reshape(B, nw * ws, nw * ws, N)[:, :H, :H].reshape(B * H * H, N)
+    ref = x + prod
+    out = d_x.cpu()
+    err = (out - ref).abs().max().item()
+    ln_ref = torch.nn.functional.layer_norm(out, (N,), ln_g, ln_b, 1e-6)
+    e_ln = (h.float().cpu() - ln_ref).abs()
+    print(f"windowed={windowed}: C max |err| {err:.2e}; LN max |err| {e_ln.max().item():.2e} (one bf16 step at |y| ~ 4 is 1.6e-2)")
+    assert err < 2e-5 * ref.abs().max().item() + 1e-5
+    assert (e_ln <= 2.0 ** -8 * ln_ref.abs() + 1e-4).all()
+
+
+def test_forward_with_the_rowwise_layernorm_projection(monkeypatch):
+    """The opt-in stage-3 form (OVO_HIERA_PROJ_LN=1: projection + residual + norm2 on the full-row tile) against the default forward: the same values
+    up to the statistics' summation order."""
+    from ovo_amd.encoders.hiera import SPECS, HipHiera, random_state
+    spec = SPECS["hiera_b+"]
+    enc = HipHiera(spec, random_state(spec, seed=5), device=DEV)
+    x = torch.randn(1, 3, spec.image_size, spec.image_size, generator=torch.Generator().manual_seed(2)).to(DEV)
+    a = [f.clone() for f in enc.forward(x)]
+    monkeypatch.setenv("OVO_HIERA_PROJ_LN", "1")
+    b = [f.clone() for f in enc.forward(x)]
+    for i, (u, v) in enumerate(zip(a, b)):
+        er = _rel_rms(u.cpu(), v.cpu())
+        print(f"level {i}: rms difference / rms = {er:.3e}")
+        assert er < 8e-3
+    assert _rel_rms(a[2].cpu(), b[2].cpu()) > 0                  # (the knob took effect: stage 3 feeds level 2)
