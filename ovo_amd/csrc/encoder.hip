@@ -177,6 +177,22 @@ __device__ __forceinline__ float src_px(const ResizeArgs &a, int c, int y, int x
     const long long i = a.hwc ? ((long long)(a.y0 + y) * a.W + (a.x0 + x)) * a.C + c : ((long long)c * a.H + (a.y0 + y)) * a.W + (a.x0 + x);
     return a.src_u8 ? (float)((const uint8_t *)a.src)[i] : ((const float *)a.src)[i];
 }
+// all channels of one source pixel.  An interleaved u8 frame (the camera frame as it arrives) keeps a pixel's 3 channels in consecutive bytes: ONE unaligned
+// 4-byte load instead of three byte loads -- the resize kernels are bound by their gather instructions (27 byte loads per output pixel of SAM2's 1024^2
+// input, ~60 for a TextRegion crop), not by arithmetic.  The very last pixel of the frame would read one byte past the buffer: it takes the byte loads.
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+__device__ __forceinline__ void src_px_all(const ResizeArgs &a, int y, int x, float (&v)[4]) {
+    if (a.hwc && a.src_u8 && a.C == 3) {
+        const long long i = ((long long)(a.y0 + y) * a.W + (a.x0 + x)) * 3;
+        const uint8_t *p = (const uint8_t *)a.src + i;
+        if (i + 4 <= (long long)a.H * a.W * 3) {
+            const uint32_t w = *(const u32_unaligned *)p;
+            v[0] = (float)(w & 0xffu); v[1] = (float)((w >> 8) & 0xffu); v[2] = (float)((w >> 16) & 0xffu);
+        } else { v[0] = (float)p[0]; v[1] = (float)p[1]; v[2] = (float)p[2]; }
+        return;
+    }
+    for (int c = 0; c < a.C; ++c) v[c] = src_px(a, c, y, x);
+}
 __device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
 // Keys cubic with a = -0.5: the kernel of torch's antialiased bicubic (_upsample_bicubic2d_aa; the plain bicubic uses -0.75)
 __device__ __forceinline__ float cubic_aa(float x) {
@@ -205,7 +221,9 @@ __device__ __forceinline__ void aa_taps(const ResizeArgs &a, int ymin, int xmin,
 #pragma unroll
         for (int ix = 0; ix < T; ++ix) {
             if (ix >= nx) break;
-            for (int c = 0; c < a.C; ++c) rowacc[c] += wx[ix] * src_px(a, c, ymin + iy, xmin + ix);
+            float px[4];
+            src_px_all(a, ymin + iy, xmin + ix, px);
+            for (int c = 0; c < a.C; ++c) rowacc[c] += wx[ix] * px[c];
         }
         for (int c = 0; c < a.C; ++c) v[c] += wy[iy] * rowacc[c];
     }
@@ -224,9 +242,10 @@ __device__ __forceinline__ void resize_norm_body(const ResizeArgs &a, float *__r
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = y0 + (y0 < a.ch - 1 ? 1 : 0), x1 = x0 + (x0 < a.cw - 1 ? 1 : 0);
         const float ly = fy - (float)y0, lx = fx - (float)x0;
+        float p00[4], p01[4], p10[4], p11[4];
+        src_px_all(a, y0, x0, p00); src_px_all(a, y0, x1, p01); src_px_all(a, y1, x0, p10); src_px_all(a, y1, x1, p11);
         for (int c = 0; c < a.C; ++c)
-            v[c] = (1.f - ly) * ((1.f - lx) * src_px(a, c, y0, x0) + lx * src_px(a, c, y0, x1)) +
-                   ly * ((1.f - lx) * src_px(a, c, y1, x0) + lx * src_px(a, c, y1, x1));
+            v[c] = (1.f - ly) * ((1.f - lx) * p00[c] + lx * p01[c]) + ly * ((1.f - lx) * p10[c] + lx * p11[c]);
     } else {                                            // torch _upsample_bilinear2d_aa / _upsample_bicubic2d_aa (separable triangle / cubic filter)
         const float half = a.aa == 2 ? 2.f : 1.f;       // interp_size / 2
         const float supy = (sy >= 1.f ? sy : 1.f) * half, supx = (sx >= 1.f ? sx : 1.f) * half;
