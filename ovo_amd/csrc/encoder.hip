@@ -294,6 +294,78 @@ __global__ void __launch_bounds__(256) k_resize_norm_batch(ResizeArgs a, ResizeB
     resize_norm_body(a, out + (long long)z * a.C * a.oh * a.ow);
 }
 
+// The two resizes every keyframe pays -- an interleaved u8 camera frame (3 channels) through the antialiased triangle filter to SAM2's 1024^2 (3 taps per
+// axis) and to the TextRegion crops' 336^2 (<= 6) -- without the generic kernel's control flow: T taps per axis held in registers, taps beyond the filter's
+// support carry a ZERO weight and a clamped address instead of a branch (x + 0 * p = x: the sums are the generic kernel's, bit for bit), the source layout
+// and filter are compile-time.  The generic body (run-time layout / filter / tap-count branches around every tap, tap arrays in scratch) spent ~1000
+// instructions per output pixel: the two launches of a 14-frame group 419 + 122 us.
+template <int T>
+__global__ void __launch_bounds__(256) k_resize_tri_hwc3(ResizeArgs a, ResizeBatch b, float *__restrict__ out) {
+    const int z = blockIdx.z;
+    const uint8_t *src = (const uint8_t *)b.src[z];
+    const int y0c = b.y0[z], x0c = b.x0[z], ch = b.ch[z], cw = b.cw[z];
+    const int wx_ = blockIdx.x * 64 + (threadIdx.x & 63), wy_ = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (wx_ >= a.ow || wy_ >= a.oh) return;
+    const int ox = wx_ + a.left, oy = wy_ + a.top;
+    const float sy = (float)ch / (float)a.vh, sx = (float)cw / (float)a.vw;
+    const float supy = sy >= 1.f ? sy : 1.f, supx = sx >= 1.f ? sx : 1.f;
+    const float ivy = sy >= 1.f ? 1.f / sy : 1.f, ivx = sx >= 1.f ? 1.f / sx : 1.f;
+    const float cy = sy * ((float)oy + 0.5f), cx = sx * ((float)ox + 0.5f);
+    int ymin = (int)(cy - supy + 0.5f); ymin = ymin < 0 ? 0 : ymin;
+    int ymax = (int)(cy + supy + 0.5f); ymax = ymax > ch ? ch : ymax;
+    int xmin = (int)(cx - supx + 0.5f); xmin = xmin < 0 ? 0 : xmin;
+    int xmax = (int)(cx + supx + 0.5f); xmax = xmax > cw ? cw : xmax;
+    float wy[T], wx[T], wy_tot = 0.f, wx_tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        wy[i] = ymin + i < ymax ? tri(((float)(ymin + i) - cy + 0.5f) * ivy) : 0.f;
+        wx[i] = xmin + i < xmax ? tri(((float)(xmin + i) - cx + 0.5f) * ivx) : 0.f;
+        wy_tot += wy[i]; wx_tot += wx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i) { wy[i] = wy[i] / wy_tot; wx[i] = wx[i] / wx_tot; }
+    const long long last = (long long)a.H * a.W * 3 - 4;          // byte offset up to which a 4-byte load stays inside the frame
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int iy = 0; iy < T; ++iy) {
+        int y = ymin + iy; y = y < ch - 1 ? y : ch - 1;
+        const long long row = (long long)(y0c + y) * a.W + x0c;
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+        for (int ix = 0; ix < T; ++ix) {
+            int x = xmin + ix; x = x < cw - 1 ? x : cw - 1;
+            const long long off = (row + x) * 3;
+            uint32_t w;
+            if (off <= last) w = *(const u32_unaligned *)(src + off);
+            else w = (uint32_t)src[off] | ((uint32_t)src[off + 1] << 8) | ((uint32_t)src[off + 2] << 16);
+            r0 += wx[ix] * (float)(w & 0xffu); r1 += wx[ix] * (float)((w >> 8) & 0xffu); r2 += wx[ix] * (float)((w >> 16) & 0xffu);
+        }
+        v0 += wy[iy] * r0; v1 += wy[iy] * r1; v2 += wy[iy] * r2;
+    }
+    float *o = out + (long long)z * 3 * a.oh * a.ow + (long long)wy_ * a.ow + wx_;
+    const long long plane = (long long)a.oh * a.ow;
+    o[0] = (v0 * a.scale - a.mean[0]) / a.std[0];
+    o[plane] = (v1 * a.scale - a.mean[1]) / a.std[1];
+    o[2 * plane] = (v2 * a.scale - a.mean[2]) / a.std[2];
+}
+// taps per axis the triangle filter can reach for a crop of ch x cw pixels resized to vh x vw (the generic kernel's own bound)
+inline int resize_tap_bound(int ch, int cw, int vh, int vw) {
+    const float sy = (float)ch / (float)vh, sx = (float)cw / (float)vw;
+    const float supy = sy >= 1.f ? sy : 1.f, supx = sx >= 1.f ? sx : 1.f;
+    return (int)(2.f * (supy > supx ? supy : supx)) + 1;
+}
+// one launch over nz (source, crop) pairs: the fast kernel when it covers them, else the generic one
+inline void launch_resize_batch(const ResizeArgs &a, const ResizeBatch &b, int nz, float *out, hipStream_t s) {
+    dim3 grid((a.ow + 63) / 64, (a.oh + 3) / 4, nz);
+    int bound = 0;
+    for (int z = 0; z < nz; ++z) { const int t = resize_tap_bound(b.ch[z], b.cw[z], a.vh, a.vw); bound = t > bound ? t : bound; }
+    static const bool generic_once = getenv("OVO_RESIZE_GENERIC") != nullptr;              // measurement / tests
+    const bool generic = ovo_knobs_dynamic() ? getenv("OVO_RESIZE_GENERIC") != nullptr : generic_once;
+    if (!generic && a.hwc && a.src_u8 && a.C == 3 && a.aa == 1 && bound <= 3) k_resize_tri_hwc3<3><<<grid, 256, 0, s>>>(a, b, out);
+    else if (!generic && a.hwc && a.src_u8 && a.C == 3 && a.aa == 1 && bound <= 6) k_resize_tri_hwc3<6><<<grid, 256, 0, s>>>(a, b, out);
+    else k_resize_norm_batch<<<grid, 256, 0, s>>>(a, b, out);
+}
+
 // ---- a14: per-mask crops for the crop-mode descriptors (segment_utils.py:29-41, 118-170) ----
 // k_mask_boxes: XYXY box of every mask (inclusive max edges) -> XYWH with the reference's w = x2 - x1, h = y2 - y1 (the last
 // column / row is NOT part of the crop: segment_utils.py:88-94 subtracts inclusive edges); empty mask -> 0,0,0,0.
@@ -608,8 +680,14 @@ int ovo_resize_window_normalize(const void *src, int src_dtype, int C, int H, in
     a.oh = oh; a.ow = ow; a.aa = filter; a.scale = scale;
     a.vh = virt_h; a.vw = virt_w; a.top = top; a.left = left;
     for (int c = 0; c < 4; ++c) { a.mean[c] = mean3_host && c < C ? mean3_host[c] : 0.f; a.std[c] = std3_host && c < C ? std3_host[c] : 1.f; }
-    dim3 grid((ow + 63) / 64, (oh + 3) / 4);
-    k_resize_norm<<<grid, 256, 0, (hipStream_t)stream>>>(a, out);
+    if (a.hwc && a.src_u8 && C == 3 && filter == 1) {               // the camera-frame case: the branch-free kernel (a batch of one)
+        ResizeBatch b;
+        b.src[0] = src; b.y0[0] = y0; b.x0[0] = x0; b.ch[0] = ch; b.cw[0] = cw;
+        launch_resize_batch(a, b, 1, out, (hipStream_t)stream);
+    } else {
+        dim3 grid((ow + 63) / 64, (oh + 3) / 4);
+        k_resize_norm<<<grid, 256, 0, (hipStream_t)stream>>>(a, out);
+    }
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }
@@ -644,8 +722,7 @@ int ovo_resize_normalize_batch(const void *const *srcs_host, int n_src, int src_
             OVO_REQUIRE(srcs_host[i], "null source image");
             b.src[z] = srcs_host[i]; b.y0[z] = crops_host[4 * k]; b.x0[z] = crops_host[4 * k + 1]; b.ch[z] = crops_host[4 * k + 2]; b.cw[z] = crops_host[4 * k + 3];
         }
-        dim3 grid((ow + 63) / 64, (oh + 3) / 4, nz);
-        k_resize_norm_batch<<<grid, 256, 0, (hipStream_t)stream>>>(a, b, out + (long long)z0 * C * oh * ow);
+        launch_resize_batch(a, b, nz, out + (long long)z0 * C * oh * ow, (hipStream_t)stream);
     }
     OVO_CHECK_LAUNCH();
     return OVO_OK;

@@ -1062,3 +1062,21 @@ def test_batched_preprocess_equals_per_image():
     assert torch.equal(torch.cat([sam.preprocess(f) for f in frames]), sam.preprocess_batch(frames))
     mixed = frames[:2] + [frames[2][:240].contiguous()]                  # frames of different sizes: the per-image path
     assert torch.equal(torch.cat([sam.preprocess(f) for f in mixed]), sam.preprocess_batch(mixed))
+
+
+def test_fast_resize_kernel_equals_generic_kernel(monkeypatch):
+    """The branch-free resize of an interleaved u8 frame (`k_resize_tri_hwc3<3 / 6>`: taps beyond the filter's support carry a zero weight instead of a
+    branch) against the generic kernel (OVO_RESIZE_GENERIC=1): bit-identical, for SAM2's up-scaling (3 taps), the TextRegion crops (<= 6 taps; a crop
+    touching the frame's last pixel: the 4-byte load's edge case) and a single-image call."""
+    from ovo_amd.encoders.hiera import SPECS as HS, HipHiera
+    from ovo_amd.encoders.vit import SPECS as VS, HipViT
+    g = torch.Generator().manual_seed(6)
+    frames = [torch.randint(0, 256, (480, 640, 3), generator=g, dtype=torch.uint8).to(DEV) for _ in range(3)]
+    vit = HipViT(VS["PE-Core-L14-336"], None, DEV, 0)
+    sam = HipHiera(HS["hiera_test"], None, DEV, 0)
+    crops = [(0, 0, 480, 640), (72, 152, 336, 336), (144, 304, 336, 336), (0, 0, 480, 320)]       # the third ends at the frame's last pixel
+    fast = (vit.preprocess_batch(frames, crops, scale=1.0 / 255.0), sam.preprocess_batch(frames), vit.preprocess(frames[0], crops[:2], scale=1.0 / 255.0))
+    monkeypatch.setenv("OVO_RESIZE_GENERIC", "1")
+    slow = (vit.preprocess_batch(frames, crops, scale=1.0 / 255.0), sam.preprocess_batch(frames), vit.preprocess(frames[0], crops[:2], scale=1.0 / 255.0))
+    for a, b in zip(fast, slow):
+        assert torch.equal(a, b), f"max |difference| {(a - b).abs().max().item():.3e}"
