@@ -29,6 +29,7 @@ RBS=0 timeout 300 python tools/mlp_bench.py > $OUT/mlp_bench.txt 2>&1
 timeout 300 python tools/winattn_bench.py 12 > $OUT/winattn_bench.txt 2>&1
 (timeout 300 python tools/patch_embed_bench.py 12; timeout 300 python tools/patch_embed_bench.py 1) > $OUT/patch_embed_bench.txt 2>&1
 timeout 300 python tools/round_host.py 8 > $OUT/round_host.txt 2>&1
+timeout 300 python tools/resize_batch_bench.py > $OUT/resize_batch_bench_now.txt 2>&1
 # BASELINE configs[3]'s process layout on ONE GPU over gloo (8 ranks, 5 M-point map): executes rings, staging and shards at world 8; not a scaling number
 (export OVO_FORCE_DEVICE=0 OVO_DIST_BACKEND=gloo; timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 8 --steps 8 --warmup 2 --map-points 5000000 --no-cpu-baseline --no-roofline --dense-merge none 2>&1 | tail -1) > $OUT/bench_world8_one_gpu_5m.json
 cd /tmp
