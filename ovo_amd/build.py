@@ -61,7 +61,7 @@ def build(force: bool = False, verbose: bool = True, gemm_debug: bool = False, e
     `experimental` (--experimental): also compiles the two forms that lost their measurements -- the persistent 256 x 128 GEMM (gemm8q.hip,
     OVO_GEMM_TILE=256x128p) and the one-launch round chain (k_round_chain, OVO_ROUND_CHAIN=1); their parity tests skip without it."""
     if gemm_debug:
-        for f in ("gemm8p.hip", "gemm8q.hip"):
+        for f in ("gemm8p.hip", "gemm8q.hip", "mlp_stream.hip"):
             EXTRA[f] = EXTRA.get(f, []) + ["-DOVO_GEMM_DEBUG"]
     if experimental:                                   # kernels that were measured and lost (persistent 256 x 128 GEMM, one-launch round chain)
         for f in ("gemm8q.hip", "geometry.hip"):

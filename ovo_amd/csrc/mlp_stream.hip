@@ -35,7 +35,12 @@ struct MlpArgs {
     const uint16_t *w1; long long ldw1; const float *b1;
     const uint16_t *w2; long long ldw2; const float *b2;
     int dbg;                       // OVO_MLP_DBG (diagnosis): 1 = a barrier after every chunk's products, 2 = wait for every DMA right after its issue
-};
+    // tools/ builds only (python -m ovo_amd.build --force --gemm-debug, tools/mlp_race.py): 4 / 8 = compare the chunk's weights IN LDS with their global
+    // source right after the barrier / after the chunk's products (pieces brought in by ANOTHER wave), 16 = ~2000 idle cycles between the barrier and the
+    // first fragment read, 32 = every wave reads its own pieces back before it enters the barrier, 64 = pad the workgroup's LDS so that only one fits a CU,
+    // 128 = the next chunk's DMA is issued AFTER this chunk's products (nothing in flight under them)
+    unsigned *dbg_out;             // [0] mismatching pieces, [1] of them equal to the chunk that was in the buffer before (c - 2), [2] workgroups with a
+};                                 // non-zero LDS base, [3] records, then {blockIdx, chunk << 16 | piece, LDS_ALLOC register, when} per record
 
 // K1 = padded input width (multiple of 32 >= D), D = model width, HID = hidden width, RB = 16-row blocks per wave, RI = row blocks that share one
 // read of the weight fragments (RB / RI passes over a chunk's fragments: more rows per chunk amortise its barrier and DMA wait, registers bound RI)
@@ -102,6 +107,34 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
         if (g.dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
+#ifdef OVO_GEMM_DEBUG
+    const unsigned lds_alloc = __builtin_amdgcn_s_getreg((31 << 11) | 6);           // HW_REG_LDS_ALLOC: base [7:0], size [20:12] (granules)
+    if (g.dbg_out && tid == 0 && (lds_alloc & 0xff)) atomicAdd(g.dbg_out + 2, 1u);
+    // the 16-byte piece `id` of chunk `chunk` as the DMA fetches it (the set-up above, for any piece -- here: one another wave brought in)
+    auto piece_src = [&](int id, int chunk) -> const uint4 * {
+        if (id < P1) { const int q = id / CPR1, c = (id % CPR1) ^ S1::swz(q); return (const uint4 *)(g.w1 + ((long long)chunk * HC + unit_of(q)) * g.ldw1 + c * 8); }
+        const int n = (id - P1) / CPR2, c = ((id - P1) % CPR2) ^ S2::swz(n);
+        return (const uint4 *)(g.w2 + (long long)n * g.ldw2 + (long long)chunk * HC + c * 8);
+    };
+    auto verify = [&](int c, int par, unsigned when) {
+        if (!g.dbg_out) return;
+        for (int p = 0; p < PPT; ++p) {
+            const int id = p * NTHREADS + ((tid + 64) % NTHREADS);                    // the next wave's piece
+            if (id >= PIECES) continue;
+            const uint4 have = *(const uint4 *)(smem + par * BUF + id * 16), want = *piece_src(id, c);
+            if (have.x != want.x || have.y != want.y || have.z != want.z || have.w != want.w) {
+                atomicAdd(g.dbg_out + 0, 1u);
+                if (c >= 2) { const uint4 old = *piece_src(id, c - 2); if (have.x == old.x && have.y == old.y && have.z == old.z && have.w == old.w) atomicAdd(g.dbg_out + 1, 1u); }
+                const unsigned at = atomicAdd(g.dbg_out + 3, 1u);
+                if (at < 200) { unsigned *r = g.dbg_out + 8 + at * 4; r[0] = blockIdx.x; r[1] = ((unsigned)c << 16) | (unsigned)id; r[2] = lds_alloc; r[3] = when; }
+            }
+        }
+    };
+    const bool late_dma = (g.dbg & 128) != 0;
+#else
+    auto verify = [](int, int, unsigned) {};
+    constexpr bool late_dma = false;
+#endif
     const long long blocks = (g.rows + 15) / 16, groups = (blocks + WPB * RB - 1) / (WPB * RB);
     for (long long grp = blockIdx.x; grp < groups; grp += n_slots) {
         // (all waves of the workgroup run the same number of chunk iterations: the barriers below are workgroup-wide even for a wave without rows)
@@ -164,11 +197,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
         auto chunk_body = [&](auto PAR_, int c) {
             constexpr int PAR = decltype(PAR_)::value;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of chunk c have landed ...
+#ifdef OVO_GEMM_DEBUG
+            if (g.dbg & 32) {                                        // (diagnosis) ... and the wave has read its last one back
+                const uint4 v = *(const uint4 *)(smem + PAR * BUF + (((PPT - 1) * NTHREADS + tid) < PIECES ? ((PPT - 1) * NTHREADS + tid) : tid) * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(v.x) : "memory");
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();                                         // ... and everybody's: chunk c is in buffer PAR; every wave is done with buffer PAR ^ 1
             __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < NCH) dma(c + 1, std::integral_constant<int, PAR ^ 1>{});
+            if (c + 1 < NCH && !late_dma) dma(c + 1, std::integral_constant<int, PAR ^ 1>{});
             __builtin_amdgcn_sched_barrier(0);
+#ifdef OVO_GEMM_DEBUG
+            if (g.dbg & 16) { const unsigned long long t0 = __builtin_amdgcn_s_memtime(); while (__builtin_amdgcn_s_memtime() - t0 < 2000ull) {} }
+            if (g.dbg & 4) verify(c, PAR, 0u);
+#endif
             const char *w1 = smem + PAR * BUF, *w2 = w1 + W1_BYTES;
             static_assert(RB % RI == 0, "row blocks per fragment pass");
 #pragma unroll
@@ -233,6 +276,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
                     }
                 }
             }
+#ifdef OVO_GEMM_DEBUG
+            if (g.dbg & 8) verify(c, PAR, 1u);
+#endif
+            if (c + 1 < NCH && late_dma) dma(c + 1, std::integral_constant<int, PAR ^ 1>{});
             if (g.dbg & 1) __syncthreads();
         };
         {
@@ -281,7 +328,14 @@ int launch_mlp(const MlpArgs &g, hipStream_t s) {
     // profiler kind 8 (the streaming GEMMs): flops of both products; algorithmic bytes = the stream in and out + the weights
     if (prof) { ovo_prof_begin(8, 2.0 * (double)g.rows * HID * (double)(K1 + D), s); ovo_prof_shape((int)g.rows, HID, K1); ovo_prof_flags(1 | 2 | 4 | 64);
                 ovo_prof_bytes(8.0 * (double)g.rows * D + 2.0 * HID * (K1 + D)); }
-    k_mlp_stream<K1, D, HID, RB, RI, NTHREADS, POLY, HC><<<slots, NTHREADS, lds, s>>>(g, slots);
+    size_t lds_launch = lds;
+#ifdef OVO_GEMM_DEBUG
+    if ((g.dbg & 64) && lds_all < 84 * 1024) {                      // one workgroup per CU whatever its size: pad the dynamic LDS past half a CU's
+        lds_launch = lds + (84 * 1024 - lds_all);
+        (void)hipFuncSetAttribute((const void *)k_mlp_stream<K1, D, HID, RB, RI, NTHREADS, POLY, HC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch);
+    }
+#endif
+    k_mlp_stream<K1, D, HID, RB, RI, NTHREADS, POLY, HC><<<slots, NTHREADS, lds_launch, s>>>(g, slots);
     if (prof) ovo_prof_end(s);
     return OVO_OK;
 }
@@ -304,6 +358,10 @@ int mlp_stream_launch(float *x, long long rows, int d, const float *ln_g, const 
     static int dbg_env = getenv("OVO_MLP_DBG") ? atoi(getenv("OVO_MLP_DBG")) : 0;                  // diagnosis (tools/mlp_stress.py)
     if (ovo_knobs_dynamic()) dbg_env = getenv("OVO_MLP_DBG") ? atoi(getenv("OVO_MLP_DBG")) : 0;
     g.dbg = dbg_env;
+    g.dbg_out = nullptr;
+#ifdef OVO_GEMM_DEBUG        // the record buffer's ADDRESS comes from the environment: never in a production build
+    g.dbg_out = getenv("OVO_MLP_DBG_OUT") ? (unsigned *)strtoull(getenv("OVO_MLP_DBG_OUT"), nullptr, 0) : nullptr;
+#endif
     g.w1 = (const uint16_t *)w1; g.ldw1 = ldw1; g.b1 = b1; g.w2 = (const uint16_t *)w2; g.ldw2 = ldw2; g.b2 = b2;
     const int k1 = (int)ldw1;
     // GELU: the table in LDS (gemm_common.h: gelu_lut), as the two-launch path.  The packed polynomial (OVO_MLP_GELU_POLY=1) measured SLOWER here --

@@ -1,0 +1,64 @@
+"""Diagnosis of the non-deterministic two-workgroups-per-CU variant of k_mlp_stream (mlp_stream.hip).  Needs a debug build:
+    python -m ovo_amd.build --force --gemm-debug && python tools/mlp_race.py
+Variant 2 (two 256-thread workgroups per CU) at 786 432 rows fails in every launch; each run below changes ONE thing (OVO_MLP_DBG bits, see MlpArgs) and
+reports launches that differ from the production variant's output, the weights found WRONG IN LDS by the in-kernel check (pieces another wave brought in,
+compared with their global source right after the barrier / after the chunk's products), and the LDS base of the workgroups that saw them."""
+import os, sys
+os.environ["OVO_KNOBS_DYNAMIC"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ovo_amd import _lib as L
+DEV = "cuda:0"
+lib = L.load()
+rows, d, k1 = int(os.environ.get("ROWS", 786432)), 112, 128
+hid = 4 * d
+g = torch.Generator().manual_seed(rows + d)
+x0 = (torch.randn(rows, d, generator=g) * 2 + 0.5).to(DEV)
+gamma, beta = (torch.randn(d, generator=g) * 0.5 + 1).to(DEV), (torch.randn(d, generator=g) * 0.1).to(DEV)
+w1 = torch.zeros(hid, k1, dtype=torch.bfloat16, device=DEV)
+w1[:, :d] = (torch.randn(hid, d, generator=g) * d ** -0.5).to(DEV, torch.bfloat16)
+w2 = (torch.randn(d, hid, generator=g) * hid ** -0.5).to(DEV, torch.bfloat16)
+b1, b2 = torch.randn(hid, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+out = torch.zeros(8 + 4 * 200, dtype=torch.int32, device=DEV)
+os.environ["OVO_MLP_DBG_OUT"] = str(out.data_ptr())
+def call(xf):
+    rc = lib.ovo_mlp_f32(xf.data_ptr(), rows, d, gamma.data_ptr(), beta.data_ptr(), 1e-6, w1.data_ptr(), k1, b1.data_ptr(), hid, w2.data_ptr(), hid, b2.data_ptr(), L.stream())
+    assert rc == 0, rc
+os.environ["OVO_MLP_RB"], os.environ["OVO_MLP_DBG"] = "1", "0"
+ref = x0.clone(); call(ref); torch.cuda.synchronize()
+def run(variant, dbg, what, iters=12):
+    os.environ["OVO_MLP_RB"], os.environ["OVO_MLP_DBG"] = str(variant), str(dbg)
+    out.zero_()
+    bad, blocks = 0, 0
+    for it in range(iters):
+        xf = x0.clone(); call(xf); torch.cuda.synchronize()
+        if not torch.equal(xf, ref):
+            bad += 1
+            blocks += int(((xf - ref).abs().amax(1) > 0).view(-1, 16).any(1).sum())
+    h = out.cpu().tolist()
+    print(f"variant {variant} dbg {dbg:3d} {what:78s}: {bad:2d} of {iters} launches differ ({blocks} row blocks); LDS check: {h[0]} wrong pieces, {h[1]} = the buffer's "
+          f"previous chunk; workgroup launches with a non-zero LDS base {h[2]}")
+    recs = [(h[8 + 4 * i], h[9 + 4 * i] >> 16, h[9 + 4 * i] & 0xffff, h[10 + 4 * i] & 0xff, (h[10 + 4 * i] >> 12) & 0x1ff, h[11 + 4 * i]) for i in range(min(h[3], 200))]
+    if recs:
+        print("      first records (workgroup, chunk, piece, LDS base granules, LDS size granules, 0 = after the barrier / 1 = after the products):", recs[:10])
+        print("      workgroups < 256:", sum(r[0] < 256 for r in recs), " >= 256:", sum(r[0] >= 256 for r in recs), " base == 0:", sum(r[3] == 0 for r in recs), " pieces < P1 (W1):",
+              sum(r[2] < 1024 for r in recs), " chunks:", sorted(set(r[1] for r in recs)))
+    sys.stdout.flush()
+run(1, 0, "production: ONE 512-thread workgroup per CU")
+run(1, 4 + 8, "  + LDS check")
+run(2, 0, "TWO 256-thread workgroups per CU")
+run(2, 4, "  + LDS check after the barrier")
+run(2, 8, "  + LDS check after the products")
+run(2, 64, "  padded to one workgroup per CU")
+run(2, 64 + 4 + 8, "  padded + both LDS checks")
+run(2, 16, "  + ~2000 idle cycles between the barrier and the first fragment read")
+run(2, 16 + 4, "  + idle cycles + LDS check after them")
+run(2, 32, "  + every wave reads its last piece back before it enters the barrier")
+run(2, 32 + 4, "  + read-back + LDS check")
+run(2, 128, "  next chunk's DMA issued AFTER this chunk's products")
+run(2, 128 + 4 + 8, "  late DMA + both LDS checks")
+run(2, 2, "  wait for every DMA right after its issue")
+run(2, 2 + 4 + 8, "  wait at issue + both LDS checks")
+run(2, 1, "  + a barrier after every chunk's products")
+run(3, 0, "variant 3 (4 row blocks per wave)")
+run(3, 4 + 8, "variant 3 + both LDS checks")
