@@ -260,7 +260,9 @@ def profile_pass(pipe, feed, rounds, lib):
             "attention_tflops": round(work[1] / (ms[1] * 1e-3) / 1e12, 1) if ms[1] > 0 else 0.0,
             "track_project_ms_per_frame": round(ms[2] / steps / max(pipe.world, 1), 4),
             "track_project_gbs": round(work[2] / (ms[2] * 1e-3) / 1e9, 1) if ms[2] > 0 else 0.0,
-            # the dense scatter-reduce fusion (fusion.hip: scan + apply launches of one keyframe): algorithmic bytes = hits x (8 D + 12) + 2 n
+            # the dense scatter-reduce fusion of one keyframe.  Round 6 (fusion.hip: k_scatter_query): ONE launch from the tracking pass's hit list that also
+            # re-queries the changed rows (what was scan + apply + ovo_similarity_rows); algorithmic bytes = changed rows x (8 D + 12)
+            "scatter_form": "fused accumulate + re-query (ovo_scatter_accum_query)" if getattr(pipe.ovo, "hit_shard", None) is not None else "scan + apply (+ separate query launch)",
             "scatter_accum_us": round(1e3 * ms[9] / max(n[9], 1), 2), "scatter_accum_mb": round(work[9] / max(n[9], 1) / 1e6, 1),
             "scatter_accum_gbs": round(work[9] / (ms[9] * 1e-3) / 1e9, 1) if ms[9] > 0 else 0.0,
             "hbm_peak_gbs": HBM_PEAK_GBS}

@@ -175,6 +175,17 @@ int ovo_scatter_accum_touched(const int16_t *point_seg, int64_t n, const int32_t
                               const float *desc, int D, float *acc, int32_t *cnt, int32_t *touched, int32_t *n_touched,
                               int32_t *n_next, int shard_rank, int shard_count, int shard_block, ovo_stream_t stream);
 
+/* The dense fusion of one keyframe AND the re-query of the rows it changed in one launch (ABI 11): for every listed row whose mask has a
+ * descriptor, acc[row] += desc[mask_row[point_seg[point]]], cnt[row] += 1, then (T != NULL) out_cls / out_conf[row] = the class and confidence
+ * ovo_similarity would give the updated row (same arithmetic: bit-identical).  hits / n_hits: the list ovo_track_step_t.hits receives (local
+ * row numbers under sharding; n_hits is read on the device, max_hits only sizes the launch).  This is ovo_scatter_accum_touched followed by
+ * ovo_similarity_rows (instance3d.py:9-21 generalised per point; clip_utils.py:10-19) without the scan over point_seg and without reading
+ * the rows twice.  OVO_E_UNSUPPORTED (nothing launched): Q > 16 or the text rows exceed 96 KB -- run the two calls. */
+int ovo_scatter_accum_query(const int32_t *hits, const int32_t *n_hits, int64_t max_hits, const int16_t *point_seg, const int32_t *mask_row,
+                            int n_masks, const float *desc, int D, float *acc, int32_t *cnt, int shard_rank, int shard_count, int shard_block,
+                            const float *T, int Q, int siglip, float logit_scale, float logit_bias, float th, int64_t *out_cls,
+                            float *out_conf, ovo_stream_t stream);
+
 /* ---- a21 + a22: similarity query (clip_utils.py:10-19, ovo.py:487-491) ---------------------------
  * S[i,q] = row_scale(i) * sum_k F[i,k] T[q,k];  siglip: S = sigmoid(S * exp(logit_scale) + logit_bias).
  * F is f32 or f16 ([n,D], feat_dtype 0 = f32, 1 = f16, 2 = bf16); T f32[Q,D].
@@ -646,6 +657,12 @@ typedef struct {
     int32_t *next_ins; int32_t next_ins_host;
     int64_t n_upper;
     int32_t *result_host; int32_t seq;
+    /* ABI 11: the points this keyframe's masks cover (point_seg >= 0), listed by the tracking pass itself -- the row list of
+     * ovo_scatter_accum_query, so that the dense fusion needs no scan over point_seg.  hits i32[>= n_upper + the frame's new points] (any
+     * order), n_hits i32[1] (zeroed by the step); NULL: no list.  hit_shard_count > 1: only points of block-cyclic shard hit_shard_rank
+     * (blocks of hit_shard_block points, a power of two) are listed, as LOCAL row numbers (the map of ovo_scatter_accum_touched). */
+    int32_t *hits; int32_t *n_hits;
+    int32_t hit_shard_rank, hit_shard_count, hit_shard_block;
 } ovo_track_step_t;
 size_t ovo_track_workspace_bytes(int n_masks, int hist_cols);
 int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream);

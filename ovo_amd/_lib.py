@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libovo_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 E_UNSUPPORTED = -3          # OVO_E_UNSUPPORTED: the entry point does not cover this shape; the caller takes its general path
 
 
@@ -116,7 +116,8 @@ class TrackStep(C.Structure):
     _fields_ = [("map", MapRef), ("depth", _P), ("filter_depth", C.c_int32), ("depth_scratch", _P), ("cam", Camera), ("ratio", Ratio),
                 ("seg_map", _P), ("seg_h", C.c_int32), ("seg_w", C.c_int32), ("masks", _P), ("n_masks", C.c_int32), ("pixels", _I64),
                 ("point_seg", _P), ("ws", _P), ("ws_bytes", _SZ), ("hist_cols", C.c_int32), ("track_th", C.c_int32),
-                ("next_ins", _P), ("next_ins_host", C.c_int32), ("n_upper", _I64), ("result_host", _P), ("seq", C.c_int32)]
+                ("next_ins", _P), ("next_ins_host", C.c_int32), ("n_upper", _I64), ("result_host", _P), ("seq", C.c_int32),
+                ("hits", _P), ("n_hits", _P), ("hit_shard_rank", C.c_int32), ("hit_shard_count", C.c_int32), ("hit_shard_block", C.c_int32)]
 
 
 class RoundChain(C.Structure):
@@ -159,6 +160,7 @@ _SIGNATURES = {
     "ovo_similarity": (_I32, [_P, _I32, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P, _P]),
     "ovo_similarity_rows": (_I32, [_P, _I32, _P, _P, _I64, _I32, _P, _I32, _P, _I32, _F32, _F32, _F32, _P, _P, _P]),
     "ovo_scatter_accum_touched": (_I32, [_P, _I64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
+    "ovo_scatter_accum_query": (_I32, [_P, _P, _I64, _P, _P, _I32, _P, _I32, _P, _P, _I32, _I32, _I32, _P, _I32, _I32, _F32, _F32, _F32, _P, _P, _P]),
     "ovo_mask_boxes": (_I32, [_P, _I32, _I32, _I32, _P, _P]),
     "ovo_mask_crops": (_I32, [_P, _I32, _I32, _I32, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "ovo_row_argmax": (_I32, [_P, _I64, _I32, _I32, _F32, _F32, _F32, _P, _P, _P]),

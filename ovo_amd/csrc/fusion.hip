@@ -215,6 +215,122 @@ __global__ void __launch_bounds__(256) k_scatter_apply(const int32_t *__restrict
     }
 }
 
+// ---- round 6: the dense fusion of one keyframe and the re-query of the rows it changed in ONE pass, from the tracking pass's own hit list --------------
+// ovo_scatter_accum_touched + ovo_similarity_rows were three launches per keyframe: the scan (33 us to find, in 2.6 MB of point_seg, the points
+// k_track_project had just had in registers), the apply (read + write of every hit row) and the query (the same rows read a third time).  Here a wave owns
+// 16 hits: lane (rr, g) streams row rr's 16-byte pieces k0 + 4 g and k0 + 16 + 4 g (two instructions cover a row's 128-byte line, as k_similarity_mfma's
+// f32 loader), adds the descriptor row's pieces (L2-resident: <= 128 rows), stores the sums and feeds them straight to the exact-f32 MFMA
+// (v_mfma_f32_16x16x4_f32) against the text rows in LDS -- the SAME instruction sequence per row as k_similarity_mfma<0>, so class / confidence are
+// bit-identical to querying the stored row afterwards (tests/test_gpu_features.py::test_scatter_query_fused_vs_two_passes), and the accumulator row is the
+// x + y of k_scatter_apply.  HBM bytes per hit: 2 D 4 (row in and out) instead of 3 D 4 + the scan.
+typedef __attribute__((ext_vector_type(4))) float sq_f32x4;
+__global__ void __launch_bounds__(512) k_scatter_query(const int32_t *__restrict__ hits, const int32_t *__restrict__ n_hits,
+                                                       const int16_t *__restrict__ point_seg, const int32_t *__restrict__ mask_row, int n_masks,
+                                                       const float *__restrict__ desc, int D, float *__restrict__ acc, int32_t *__restrict__ cnt,
+                                                       int shard_rank, int shard_count, int block_log2, const float *__restrict__ T, int Q, int siglip,
+                                                       float scale_exp, float bias, float th, long long *__restrict__ out_cls, float *__restrict__ out_conf,
+                                                       int32_t *__restrict__ n_live) {
+    extern __shared__ __attribute__((aligned(16))) float sT[];                      // [Q <= 16][D]
+    const int lane = threadIdx.x & 63, rr = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6, WPB = blockDim.x >> 6;
+    const int count = *n_hits;
+    const int groups = (count + 15) >> 4;
+    if ((int)blockIdx.x >= groups) return;                                          // (workgroup-uniform: before the barrier below)
+    if (T) {
+        for (int i = threadIdx.x * 4; i < Q * D; i += blockDim.x * 4) *(float4 *)(sT + i) = *(const float4 *)(T + i);
+        __syncthreads();
+    }
+    const float *tq = sT + (rr < Q ? rr : Q - 1) * D;
+    const int D32 = D & ~31;
+    // groups are dealt wave-slot-major: slot w of every workgroup before slot w + 1 of any, so a short list still spreads over all CUs
+    for (int grp = wv * gridDim.x + blockIdx.x; grp < groups; grp += WPB * gridDim.x) {
+        const int c = grp * 16 + rr;
+        int li = 0, row = -1;
+        if (c < count) {
+            li = hits[c];
+            int64_t i = li;
+            if (shard_count > 1) {
+                const int64_t lb = (int64_t)li >> block_log2;
+                i = ((lb * shard_count + shard_rank) << block_log2) | (li & ((1 << block_log2) - 1));
+            }
+            const int sgm = point_seg[i];
+            if (sgm >= 0 && sgm < n_masks) row = mask_row[sgm];
+        }
+        const bool live = row >= 0;
+        const unsigned long long lm = __ballot(live);
+        if (!lm) continue;
+        if (n_live && lane == 0) atomicAdd(n_live, (int)__popcll(lm & 0xffffull));   // (profiled passes only: rows really changed)
+        float *ap = acc + (int64_t)li * D + g * 4;
+        const float *dp = desc + (int64_t)(live ? row : 0) * D + g * 4;
+        sq_f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int k0 = 0; k0 < D32; k0 += 32) {
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+            if (live) {
+                a0 = *(const float4 *)(ap + k0); a1 = *(const float4 *)(ap + k0 + 16);
+                const float4 d0 = *(const float4 *)(dp + k0), d1 = *(const float4 *)(dp + k0 + 16);
+                a0.x += d0.x; a0.y += d0.y; a0.z += d0.z; a0.w += d0.w;
+                a1.x += d1.x; a1.y += d1.y; a1.z += d1.z; a1.w += d1.w;
+                __builtin_nontemporal_store(sq_f32x4{a0.x, a0.y, a0.z, a0.w}, (sq_f32x4 *)(ap + k0));
+                __builtin_nontemporal_store(sq_f32x4{a1.x, a1.y, a1.z, a1.w}, (sq_f32x4 *)(ap + k0 + 16));
+            }
+            if (T) {
+                const float4 t0 = *(const float4 *)(tq + k0 + g * 4), t1 = *(const float4 *)(tq + k0 + 16 + g * 4);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.x, a0.x, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.y, a0.y, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.z, a0.z, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.w, a0.w, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.x, a1.x, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.y, a1.y, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.z, a1.z, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.w, a1.w, s, 0, 0, 0);
+            }
+        }
+        if (D32 < D) {                                                               // one 16-wide tail step
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) {
+                a0 = *(const float4 *)(ap + D32);
+                const float4 d0 = *(const float4 *)(dp + D32);
+                a0.x += d0.x; a0.y += d0.y; a0.z += d0.z; a0.w += d0.w;
+                *(float4 *)(ap + D32) = a0;
+            }
+            if (T) {
+                const float4 t0 = *(const float4 *)(tq + D32 + g * 4);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.x, a0.x, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.y, a0.y, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.z, a0.z, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.w, a0.w, s, 0, 0, 0);
+            }
+        }
+        int cn = 0;
+        if (live) { cn = cnt[li] + 1; }
+        __builtin_amdgcn_wave_barrier();
+        if (live && g == 0) cnt[li] = cn;                                            // (the four lanes of a row read the same old count above)
+        if (!T) continue;
+        // lane (row rr, g): s[r] = S[4 g + r][row] -- the finish of k_similarity_mfma (mean = sum / count, first maximum, threshold)
+        const float rs = cn > 0 ? 1.0f / (float)cn : 0.f;
+        float best = -3.0e38f;
+        int arg = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = 4 * g + r;
+            float v = s[r] * rs;
+            if (siglip) v = 1.0f / (1.0f + __expf(-(v * scale_exp + bias)));
+            if (q < Q && v > best) { best = v; arg = q; }
+        }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oa = __shfl_xor(arg, o, 64);
+            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+        }
+        if (g == 0 && live) {
+            if (best <= th) { best = 0.f; arg = -1; }
+            out_conf[li] = best;
+            out_cls[li] = arg;
+        }
+    }
+}
+
 int launch_scatter(const int16_t *point_seg, int64_t n, const int32_t *mask_row, int n_masks, const float *desc, int D, float *acc, int32_t *cnt,
                    int32_t *touched, int32_t *n_touched, int32_t *n_next, int shard_rank, int shard_count, int block_log2, hipStream_t s) {
     const int nv = (D / 4 + 63) / 64;
@@ -270,6 +386,51 @@ int ovo_scatter_accum_touched(const int16_t *point_seg, int64_t n, const int32_t
     OVO_REQUIRE(point_seg && mask_row && desc && acc && cnt && (touched == nullptr) == (n_touched == nullptr), "null pointer");
     OVO_REQUIRE((((uintptr_t)desc | (uintptr_t)acc) & 15) == 0 && D % 4 == 0, "acc/desc must be 16-byte aligned, D % 4 == 0");
     launch_scatter(point_seg, n, mask_row, n_masks, desc, D, acc, cnt, touched, n_touched, n_next, shard_rank, shard_count, block_log2, (hipStream_t)stream);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+
+// ovo_scatter_accum_touched + ovo_similarity_rows in one launch, driven by the hit list of the tracking pass (ovo_track_step_t.hits; ABI 11).
+// hits[0 .. *n_hits) name the (local) rows whose point_seg >= 0; rows whose mask has no descriptor (mask_row < 0) are skipped.  T == NULL: accumulate only.
+int ovo_scatter_accum_query(const int32_t *hits, const int32_t *n_hits, int64_t max_hits, const int16_t *point_seg, const int32_t *mask_row, int n_masks,
+                            const float *desc, int D, float *acc, int32_t *cnt, int shard_rank, int shard_count, int shard_block,
+                            const float *T, int Q, int siglip, float logit_scale, float logit_bias, float th, int64_t *out_cls, float *out_conf,
+                            ovo_stream_t stream) {
+    OVO_REQUIRE(max_hits >= 0 && D > 0 && n_masks > 0, "bad argument");
+    OVO_REQUIRE(shard_count >= 1 && shard_rank >= 0 && shard_rank < shard_count && shard_block > 0 && (shard_block & (shard_block - 1)) == 0,
+                "bad shard description (shard_block must be a power of two)");
+    if (max_hits == 0) return OVO_OK;
+    OVO_REQUIRE(hits && n_hits && point_seg && mask_row && desc && acc && cnt, "null pointer");
+    OVO_REQUIRE((((uintptr_t)desc | (uintptr_t)acc) & 15) == 0 && D % 16 == 0, "acc/desc must be 16-byte aligned, D % 16 == 0");
+    size_t lds = 0;
+    if (T) {
+        OVO_REQUIRE(Q > 0 && out_cls && out_conf, "query without outputs");
+        if (Q > 16 || (size_t)Q * D * sizeof(float) > 96 * 1024) return OVO_E_UNSUPPORTED;       // the caller runs the two passes
+        OVO_REQUIRE(((uintptr_t)T & 15) == 0, "T must be 16-byte aligned");
+        lds = (size_t)Q * D * sizeof(float);
+    }
+    int block_log2 = 0;
+    while ((1 << block_log2) < shard_block) ++block_log2;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (lds > 64 * 1024 && !attr_done) {
+        OVO_HIP(hipFuncSetAttribute((const void *)k_scatter_query, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_done = true;
+    }
+    const int64_t groups = (max_hits + 15) / 16;
+    const int grid = (int)(groups < 256 ? groups : 256);
+    const bool prof = ovo_prof_enabled();
+    int32_t *n_live = nullptr;
+    if (prof) {                                                  // rows really changed (listed rows whose mask has a descriptor): counted by the kernel itself
+        static int32_t *live_ring = nullptr;
+        static unsigned live_at = 0;
+        if (!live_ring && hipMalloc((void **)&live_ring, 4096 * sizeof(int32_t)) != hipSuccess) live_ring = nullptr;
+        if (live_ring) { n_live = live_ring + (live_at++ & 4095); OVO_HIP(hipMemsetAsync(n_live, 0, sizeof(int32_t), s)); }
+        ovo_prof_begin(9, 0.0, s);                               // bytes follow from that count, read back after the end event (ovo_prof_count)
+    }
+    k_scatter_query<<<grid, 512, lds, s>>>(hits, n_hits, point_seg, mask_row, n_masks, desc, D, acc, cnt, shard_rank, shard_count, block_log2, T, Q, siglip,
+                                           expf(logit_scale), logit_bias, th, (long long *)out_cls, out_conf, n_live);
+    if (prof) { ovo_prof_end(s); ovo_prof_count(n_live, 2.0 * D * 4.0 + 12.0, 0.0, s); }      // per changed row: the row read + written, its list entry, its segment id, cnt
     OVO_CHECK_LAUNCH();
     return OVO_OK;
 }

@@ -325,14 +325,20 @@ __device__ __forceinline__ void wq_push(WaveQueue &q, int &tail, bool keep, floa
     tail += (int)__popcll(m);
 }
 
+// The points a keyframe's masks cover (seg >= 0), listed while the tracking pass still has them in registers (round 6): the dense scatter-reduce used to
+// find them again with a scan over point_seg (k_scatter_scan: 33 us for 2.6 MB, launch + latency).  hits == NULL: no list.  shard_count > 1: only the
+// points of this rank's block-cyclic shard are listed, as LOCAL row numbers (the map of ovo_scatter_accum_touched).
+struct HitSink { int32_t *hits; int32_t *n_hits; int shard_rank, shard_count, block_log2; };
+
 // The chain of one batch of survivors (lane < count active): project, depth-test, colour-frame remap, seg lookup, vote.
 __device__ __forceinline__ void track_batch(const WaveQueue &q, int head, int count, const ovo_camera_t &cam, const float *__restrict__ depth,
                                             const int32_t *__restrict__ point_ins, const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
                                             const ovo_ratio_t &ratio, int16_t *__restrict__ point_seg, int32_t *__restrict__ hist, int n_masks,
-                                            int hist_cols, long long &n_match) {
+                                            int hist_cols, long long &n_match, const HitSink &sink) {
     const int lane = threadIdx.x & 63;
     int cell = 0;
     bool vote = false;
+    int hit_row = -1;
     if (lane < count) {
         const int slot = (head + lane) & 255;
         const float x = q.x[slot], y = q.y[slot], z = q.z[slot];
@@ -354,11 +360,25 @@ __device__ __forceinline__ void track_batch(const WaveQueue &q, int head, int co
                 if (ins + 1 >= hist_cols) ins = -1;   // never taken: the host sizes hist_cols > max id + 1
                 cell = seg * hist_cols + (ins < 0 ? 0 : ins + 1);
                 vote = true;
+                hit_row = (int)i;
+                if (sink.shard_count > 1) {
+                    const int64_t blk = i >> sink.block_log2;
+                    hit_row = blk % sink.shard_count == sink.shard_rank ? (int)(((blk / sink.shard_count) << sink.block_log2) | (i & ((1ll << sink.block_log2) - 1))) : -1;
+                }
             }
         }
         point_seg[i] = (int16_t)seg;
     }
     wave_hist_add(hist, cell, vote);
+    if (sink.hits) {                                                // one atomic per batch of 64 survivors
+        const unsigned long long m = __ballot(hit_row >= 0);
+        if (m) {
+            int at = 0;
+            if (lane == 0) at = atomicAdd(sink.n_hits, (int)__popcll(m));
+            at = __shfl(at, 0, 64);
+            if (hit_row >= 0) sink.hits[at + (int)__popcll(m & ((1ull << lane) - 1ull))] = hit_row;
+        }
+    }
 }
 
 __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const int32_t *__restrict__ point_ins,
@@ -366,7 +386,7 @@ __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const in
                                   const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
                                   ovo_ratio_t ratio, int16_t *__restrict__ point_seg,
                                   int32_t *__restrict__ hist, int n_masks, int hist_cols,
-                                  unsigned long long *__restrict__ counters) {
+                                  unsigned long long *__restrict__ counters, const HitSink &sink) {
     __shared__ WaveQueue s_q[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     WaveQueue &q = s_q[wave];
@@ -389,7 +409,7 @@ __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const in
             wq_push(q, tail, in, px[k], py[k], pz[k], (int)i);
             __builtin_amdgcn_wave_barrier();                        // the ring is private to the wave: LDS operations of one wave stay in order
             if (tail - head >= 64) {                                // at most 63 + 64 queued: the 256-slot ring never wraps onto live entries
-                track_batch(q, head, 64, cam, depth, point_ins, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, n_match);
+                track_batch(q, head, 64, cam, depth, point_ins, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, n_match, sink);
                 head += 64; n_in += 1;
                 __builtin_amdgcn_wave_barrier();
             }
@@ -397,7 +417,7 @@ __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const in
     }
     if (tail - head > 0) {
         n_in += lane < tail - head;
-        track_batch(q, head, tail - head, cam, depth, point_ins, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, n_match);
+        track_batch(q, head, tail - head, cam, depth, point_ins, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, n_match, sink);
     }
     // the two counters: wave reduction, then across the workgroup's waves through LDS -> one atomic pair per workgroup
     // (every wave of the grid adding to the same two addresses serialises in the L2 atomic unit: 16k same-address atomics)
@@ -425,9 +445,9 @@ __global__ void __launch_bounds__(256) k_track_project(const float *__restrict__
                                                        const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
                                                        ovo_ratio_t ratio, int16_t *__restrict__ point_seg,
                                                        int32_t *__restrict__ hist, int n_masks, int hist_cols,
-                                                       unsigned long long *__restrict__ counters, const long long *__restrict__ n_dev) {
+                                                       unsigned long long *__restrict__ counters, const long long *__restrict__ n_dev, HitSink sink) {
     if (n_dev) n = *n_dev;                                         // device-resident map size (ovo_track_step): no host round trip
-    dev_track_project(this_block(), pts, point_ins, n, cam, depth, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, counters);
+    dev_track_project(this_block(), pts, point_ins, n, cam, depth, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, counters, sink);
 }
 
 // ---- a6: per-mask statistics ----
@@ -880,9 +900,10 @@ __global__ void __launch_bounds__(256) k_fuse_publish(uint4 *__restrict__ masks,
 //   k_vote_decide
 //   k_kf_finish    workgroup ranges: in-place assignment | mask fusion; the last one publishes the result block
 constexpr int CHAIN_MAX_MASKS_V = 1024;
-struct KfZero { uint4 *a; long long a16; uint4 *b; long long b16; };
+struct KfZero { uint4 *a; long long a16; uint4 *b; long long b16; int32_t *c; };
 __global__ void __launch_bounds__(256) k_kf_zero(KfZero z) {
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+    if (z.c && i0 == 0) *z.c = 0;                                  // the keyframe's hit counter
     for (long long i = i0; i < z.a16; i += step) z.a[i] = make_uint4(0, 0, 0, 0);
     for (long long i = i0; i < z.b16; i += step) z.b[i] = make_uint4(0, 0, 0, 0);
 }
@@ -1100,7 +1121,7 @@ __global__ void __launch_bounds__(256) k_round_chain(const ChainKf *__restrict__
         // ---- pass F: cull / project / depth-test / seg lookup / votes over the whole map (ovo.py:208-222)
         if (kf.do_track && n_now > 0)
             dev_track_project(b, kf.xyz, kf.ins, n_now, kf.cam, kf.filter ? kf.depth_f : kf.depth_t, kf.seg_map, kf.seg_h, kf.seg_w, kf.ratio,
-                              kf.point_seg, kf.hist, kf.n_masks, kf.hist_cols, kf.counters);
+                              kf.point_seg, kf.hist, kf.n_masks, kf.hist_cols, kf.counters, HitSink{nullptr, nullptr, 0, 1, 0});
         grid_sync(gb, gen);                                                                                       // 6
         // ---- pass G: per-mask vote statistics, then the decisions in mask order (ovo.py:255-282)
         if (kf.do_track)
@@ -1210,7 +1231,7 @@ int ovo_track_project(const float *pts, const int32_t *point_ins, int64_t n, con
     if (prof) ovo_prof_begin(2, 14.0 * (double)n, s);          // 12 B xyz read + 2 B mask id written per map point
     k_track_project<<<ovo_grid(n, 256, TRACK_GRID_CAP), 256, 0, s>>>(pts, point_ins, n, *cam, depth, seg_map, seg_h, seg_w, ratio,
                                                       point_seg, hist, n_masks, hist_cols,
-                                                      (unsigned long long *)counters, nullptr);
+                                                      (unsigned long long *)counters, nullptr, HitSink{nullptr, nullptr, 0, 1, 0});
     if (prof) ovo_prof_end(s);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
@@ -1323,6 +1344,22 @@ int ovo_map_step(const ovo_map_step_t *a, ovo_stream_t stream) {
     return OVO_OK;
 }
 
+// the hit list of a tracking step (ovo_track_step_t.hits; ABI 11), validated
+static int make_sink(const ovo_track_step_t *t, HitSink &sink) {
+    sink = HitSink{nullptr, nullptr, 0, 1, 0};
+    if (!t->hits) return OVO_OK;
+    OVO_REQUIRE(t->n_hits, "hits without n_hits");
+    const int count = t->hit_shard_count < 1 ? 1 : t->hit_shard_count;
+    OVO_REQUIRE(t->hit_shard_rank >= 0 && t->hit_shard_rank < count, "bad hit shard rank");
+    int block_log2 = 0;
+    if (count > 1) {
+        OVO_REQUIRE(t->hit_shard_block > 0 && (t->hit_shard_block & (t->hit_shard_block - 1)) == 0, "hit_shard_block must be a power of two");
+        while ((1 << block_log2) < t->hit_shard_block) ++block_log2;
+    }
+    sink = HitSink{t->hits, t->n_hits, t->hit_shard_rank, count, block_log2};
+    return OVO_OK;
+}
+
 int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream) {
     OVO_REQUIRE(a && a->depth && a->seg_map && a->point_seg && a->ws && a->map.state && a->next_ins, "null argument");
     OVO_REQUIRE(a->n_upper == 0 || (a->map.xyz && a->map.ins), "null map");
@@ -1340,6 +1377,9 @@ int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream) {
     int32_t *res = dst + nm;
     const size_t zero_bytes = (size_t)((char *)dst - (char *)hist);
     OVO_HIP(hipMemsetAsync(hist, 0, zero_bytes, s));
+    HitSink sink;
+    { const int rc = make_sink(a, sink); if (rc != OVO_OK) return rc; }
+    if (sink.hits) OVO_HIP(hipMemsetAsync(sink.n_hits, 0, sizeof(int32_t), s));
     const bool known = a->map.n >= 0;
     const long long *n_dev = known ? nullptr : (const long long *)a->map.state;
     const float *depth = a->depth;
@@ -1354,7 +1394,7 @@ int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream) {
         const bool prof = ovo_prof_enabled();
         if (prof) ovo_prof_begin(2, 14.0 * (double)n_grid, s);
         k_track_project<<<ovo_grid(n_grid, 256, TRACK_GRID_CAP), 256, 0, s>>>(a->map.xyz, a->map.ins, known ? a->map.n : 0, a->cam, depth, a->seg_map, a->seg_h,
-                                                           a->seg_w, a->ratio, a->point_seg, hist, nm, a->hist_cols, counters, n_dev);
+                                                           a->seg_w, a->ratio, a->point_seg, hist, nm, a->hist_cols, counters, n_dev, sink);
         if (prof) ovo_prof_end(s);
     }
     const int64_t seg_pixels = (int64_t)a->seg_h * a->seg_w;
@@ -1423,6 +1463,7 @@ int ovo_round_chain(ovo_round_chain_t *ctx, const ovo_map_step_t *maps, const ov
         }
         if (c.do_track) {
             if (t->n_masks > CHAIN_MAX_MASKS) { ovo_set_error("ovo_round_chain: more than %d masks", CHAIN_MAX_MASKS); return OVO_E_UNSUPPORTED; }
+            if (t->hits) { ovo_set_error("ovo_round_chain: no hit list in the one-launch form"); return OVO_E_UNSUPPORTED; }
             OVO_REQUIRE(t->depth && t->seg_map && t->point_seg && t->ws && t->next_ins && t->hist_cols >= 1, "bad track step");
             OVO_REQUIRE(t->ws_bytes >= ovo_track_workspace_bytes(t->n_masks, t->hist_cols), "workspace too small");
             OVO_REQUIRE(!t->masks || (t->pixels > 0 && t->pixels % 16 == 0 && ((uintptr_t)t->masks & 15) == 0), "masks: pixels must be a multiple of 16");
@@ -1485,7 +1526,9 @@ int ovo_keyframe_step(const ovo_map_step_t *a, const ovo_track_step_t *t, ovo_st
     const size_t zero_bytes = ((size_t)((char *)dst - (char *)hist) + 15) & ~(size_t)15;        // (dst / res are rewritten by the decisions anyway)
     // ---- 1: zero
     KfZero z;
-    z.a = (uint4 *)a->explained; z.a16 = (long long)((size_t)a->h * a->w / 16); z.b = (uint4 *)hist; z.b16 = (long long)(zero_bytes / 16);
+    HitSink sink;
+    { const int rc = make_sink(t, sink); if (rc != OVO_OK) return rc; }
+    z.a = (uint4 *)a->explained; z.a16 = (long long)((size_t)a->h * a->w / 16); z.b = (uint4 *)hist; z.b16 = (long long)(zero_bytes / 16); z.c = sink.n_hits;
     k_kf_zero<<<64, 256, 0, s>>>(z);
     // ---- 2: the three independent first passes
     const bool known = a->map.n >= 0;
@@ -1521,7 +1564,7 @@ int ovo_keyframe_step(const ovo_map_step_t *a, const ovo_track_step_t *t, ovo_st
     const bool prof = ovo_prof_enabled();
     if (prof) ovo_prof_begin(2, 14.0 * (double)n_grid, s);
     k_track_project<<<ovo_grid(n_grid, 256, TRACK_GRID_CAP), 256, 0, s>>>(t->map.xyz, t->map.ins, 0, t->cam, depth, t->seg_map, t->seg_h, t->seg_w, t->ratio, t->point_seg, hist, nm,
-                                                       t->hist_cols, counters, (const long long *)t->map.state);
+                                                       t->hist_cols, counters, (const long long *)t->map.state, sink);
     if (prof) ovo_prof_end(s);
     // ---- 6: vote statistics + decisions
     Decide d;

@@ -193,6 +193,26 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int j = 0; j < NT2; ++j) acc2[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef OVO_GEMM_DEBUG
+        // (diagnosis, dbg & 256) per row block: a hash of the LayerNorm-ed fragments, of every chunk's hidden fragments and of the FC2 accumulators, to be
+        // compared with another variant's run on the host (tools/mlp_race.py): WHICH intermediate of a wrong row block is wrong first
+        auto wave_xor = [&](unsigned h) { for (int o = 1; o < 64; o <<= 1) h ^= (unsigned)__shfl_xor((int)h, o, 64); return h; };
+        auto hash8 = [&](const bf16x8 &v, unsigned h) { const uint4 u = *(const uint4 *)&v; return (h * 16777619u) ^ (u.x + 3u * u.y + 5u * u.z + 7u * u.w + (unsigned)lane * 2654435761u); };
+        unsigned *hash_out = (g.dbg_out && (g.dbg & 256)) ? g.dbg_out + 8 + 800 : nullptr;
+        constexpr int HW = 2 + NCH;                                  // words per row block: af, chunk 0 .. NCH - 1, acc2
+        if (hash_out) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                unsigned h = 0;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) h = hash8(af[rb][ks], h);
+                h = wave_xor(h);
+                const long long b = (grp * WPB + wave) * RB + rb;
+                if (lane == 0 && b < blocks) hash_out[b * HW] = h;
+            }
+        }
+        unsigned hh[RB];
+#endif
 
         auto chunk_body = [&](auto PAR_, int c) {
             constexpr int PAR = decltype(PAR_)::value;
@@ -214,6 +234,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
 #endif
             const char *w1 = smem + PAR * BUF, *w2 = w1 + W1_BYTES;
             static_assert(RB % RI == 0, "row blocks per fragment pass");
+#ifdef OVO_GEMM_DEBUG
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) hh[rb] = 0;
+#endif
 #pragma unroll
             for (int r0 = 0; r0 < RB; r0 += RI) {
                 // one FC2 k-step (32 hidden units = two FC1 column tiles) at a time: FC1 tiles 2 kp, 2 kp + 1 over all of K1, bias + table GELU + bf16 --
@@ -256,6 +280,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
                             }
                         }
                         hf[ri] = *(const bf16x8 *)pk;
+#ifdef OVO_GEMM_DEBUG
+                        if (hash_out) hh[r0 + ri] = hash8(hf[ri], hh[r0 + ri]);
+#endif
                     }
                     // FC2 partial, k-step kp: acc2[r0 + ri][j] += H . W2[:, chunk]^T
                     constexpr int JG = 4;                            // fragments per read group (the last group takes what is left)
@@ -278,6 +305,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
             }
 #ifdef OVO_GEMM_DEBUG
             if (g.dbg & 8) verify(c, PAR, 1u);
+            if (hash_out) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const unsigned h = wave_xor(hh[rb]);
+                    const long long b = (grp * WPB + wave) * RB + rb;
+                    if (lane == 0 && b < blocks) hash_out[b * HW + 1 + c] = h;
+                }
+            }
 #endif
             if (c + 1 < NCH && late_dma) dma(c + 1, std::integral_constant<int, PAR ^ 1>{});
             if (g.dbg & 1) __syncthreads();
@@ -290,6 +325,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
             }
             if (c < NCH) chunk_body(std::integral_constant<int, 0>{}, c);
         }
+#ifdef OVO_GEMM_DEBUG
+        if (hash_out) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                unsigned h = 0;
+#pragma unroll
+                for (int j = 0; j < NT2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h = (h * 16777619u) ^ (__float_as_uint(acc2[rb][j][e]) + (unsigned)lane * 2654435761u);
+                h = wave_xor(h);
+                const long long b = (grp * WPB + wave) * RB + rb;
+                if (lane == 0 && b < blocks) hash_out[b * HW + 1 + NCH] = h;
+            }
+        }
+#endif
         // ---- epilogue: + b2 + residual, f32 rows in place (4 lanes x 16 B = 64 contiguous bytes per row and instruction)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {

@@ -96,6 +96,10 @@ class OVO:
         self.kf_id = 0
         self.last_point_seg: Optional[torch.Tensor] = None     # i16[N] mask id per map point of the last keyframe
         self.last_mask_rows: Optional[List[int]] = None
+        # (rank, world, block) of the dense accumulators' point shards: the tracking chain then lists the points its masks cover (`ovo_track_step_t.hits`)
+        # for `ovo_scatter_accum_query`; None: no list.  `last_hits` = (hits i32[...], pointer of the device-side count) of the last keyframe, or None
+        self.hit_shard: Optional[Tuple[int, int, int]] = None
+        self.last_hits = None
         # native keyframe chain (`ovo_track_step`): the next instance id also lives on the device; results arrive in pinned blocks
         self._track_pending: deque = deque()
         self._track_ring = None
@@ -248,6 +252,11 @@ class OVO:
         a.track_th = int(self.config["track_th"])
         point_seg = torch.empty((max(int(a.n_upper), 1) + 0xfffff) & ~0xfffff, dtype=torch.int16, device=dev)    # 1 Mi-point steps: the allocator re-uses blocks
         a.point_seg = point_seg.data_ptr()
+        hits = None
+        if self.hit_shard is not None:                            # the list and, behind it, its device-side count (zeroed by the step itself)
+            hits = torch.empty(point_seg.numel() + 4, dtype=torch.int32, device=dev)
+            a.hits, a.n_hits = hits.data_ptr(), hits[point_seg.numel():].data_ptr()
+            a.hit_shard_rank, a.hit_shard_count, a.hit_shard_block = self.hit_shard
         a.ws_bytes = lib.ovo_track_workspace_bytes(n_masks, a.hist_cols)
         ws = getattr(self, "_track_ws", None)
         if ws is None or ws.numel() < a.ws_bytes or ws.device != point_seg.device:
@@ -273,7 +282,7 @@ class OVO:
             L.check(lib.ovo_track_step(L.C.byref(a), L.C.c_void_p(stream.cuda_stream)))
             done = torch.cuda.Event()
             done.record(stream)
-        pend = {"seq": seq, "n_masks": n_masks, "point_seg": point_seg, "binary_maps": binary_maps, "ins": ins_view, "slam": slam,
+        pend = {"seq": seq, "n_masks": n_masks, "point_seg": point_seg, "hits": hits, "binary_maps": binary_maps, "ins": ins_view, "slam": slam,
                 "keep": (depth, seg_map, ws), "done": done, "step": a if defer else None}
         self._track_pending.append(pend)
         return pend
@@ -291,6 +300,8 @@ class OVO:
             cur = torch.cuda.current_stream()                      # allocated on the chain's stream: tell the allocator about the second user
             cur.wait_event(pend["done"])
             pend["point_seg"].record_stream(cur)
+            if pend["hits"] is not None:
+                pend["hits"].record_stream(cur)
             pend["binary_maps"].record_stream(cur)
         kf_id, n_masks = self.kf_id, pend["n_masks"]
         n, n_matched, next_after = int(res[1]), int(res[3]), int(res[4])
@@ -333,6 +344,7 @@ class OVO:
         slam = pend["slam"]
         updated = pend["ins"] if slam is None else slam._ins[:n]
         self.last_point_seg, self.last_mask_rows, self.last_n_points = pend["point_seg"][:n], mask_rows, n
+        self.last_hits = pend["hits"]
         return matched_ins_ids, kept, n_matched, updated
 
     def _match_and_track_instances_host(self, frame_data, map_data, c2w, seg_map: torch.Tensor, binary_maps: torch.Tensor):
@@ -409,6 +421,7 @@ class OVO:
 
         matched_ins_ids, binary_maps, mask_rows = self._fuse_masks_with_same_ins_id(binary_maps, matched_info, kf_id)
         self.last_point_seg, self.last_mask_rows = point_seg, mask_rows
+        self.last_hits = None
 
         if self.debug_info:
             ins_maps = torch.full(tuple(seg_map.shape), -1, dtype=torch.int32, device=dev)     # == image.shape[:2] (ovo.py:277)

@@ -192,6 +192,10 @@ class FramePipeline:
                 self.touched = torch.empty(self.rows_local, dtype=torch.int32, device=self.device)
                 self.n_touched = torch.zeros(2, dtype=torch.int32, device=self.device)     # two counters, used alternately
                 self._touch_parity = 0
+                # round 6: the tracking chain lists the points its masks cover and ONE launch accumulates and re-queries them (`ovo_scatter_accum_query`);
+                # the scan + apply + query launches above remain for keyframes tracked on the host path and for OVO_NO_FUSED_SCATTER=1
+                if not os.environ.get("OVO_NO_FUSED_SCATTER") and n_text <= 16 and n_text * self.D * 4 <= 96 * 1024:
+                    self.ovo.hit_shard = (self.rank, self.world, self.SHARD_BLOCK)
         self.last: Dict[str, object] = {}
         # Masks from this rank's OWN generator (SAM2 end to end, or an injected `mask_source(frame) -> (seg_map, masks)`): the owner of a
         # keyframe produces them, `parallel.share_masks` carries them bit-packed to the replicas, which track with exactly those bits.
@@ -364,7 +368,7 @@ class FramePipeline:
             for k, p in enumerate(pend):                           # (assignment happened in place in the mapper's buffer; only the owner of a
                 self.ovo.detect_and_track_finish(p, want_maps=(k == self.rank))     # keyframe reads its kept binary maps: `_extract_clip` below)
                 plans.append(self.ovo._plan_semantic_info() if len(self.ovo.keyframes_queue) > 0 else None)
-                segs.append((self.ovo.last_point_seg, self.ovo.last_mask_rows))
+                segs.append((self.ovo.last_point_seg, self.ovo.last_mask_rows, self.ovo.last_hits))
             # the map's size after this round: from the round's last map step (a keyframe without masks reports none through the tracker,
             # and a pre-queued NEXT round may already have moved the mapper's own count past it)
             seq = self._round_seq.pop(group[0].index, 0)
@@ -379,7 +383,7 @@ class FramePipeline:
                 if updated is not None:
                     self.slam.update_pcd_obj_ids(updated)
                 plans.append(self.ovo._plan_semantic_info() if len(self.ovo.keyframes_queue) > 0 else None)
-                segs.append((self.ovo.last_point_seg, self.ovo.last_mask_rows))
+                segs.append((self.ovo.last_point_seg, self.ovo.last_mask_rows, self.ovo.last_hits))
             n = self.slam._n
         # ---- descriptors of the keyframe this rank owns, then the round's one exchange
         plan = plans[self.rank]
@@ -409,12 +413,19 @@ class FramePipeline:
         live = [k for k, (p, d) in enumerate(zip(plans, descs)) if p is not None and self.dense and d.shape[0] > 0]
         all_rows = torch.tensor([r for k in live for r in segs[k][1]], dtype=torch.int32).to(self.device, non_blocking=True) if live else None
         row_off = 0
-        for k, (p, d, (point_seg, mask_rows)) in enumerate(zip(plans, descs, segs)):
+        for k, (p, d, (point_seg, mask_rows, hits)) in enumerate(zip(plans, descs, segs)):
             if p is None:
                 continue
             if self.dense and d.shape[0] > 0:
                 rows = all_rows[row_off:row_off + len(mask_rows)]
                 row_off += len(mask_rows)
+                if hits is not None and self.incremental_query:    # one launch: accumulate the listed rows and re-evaluate exactly them
+                    n_list = hits.numel() - 4
+                    L.check(lib.ovo_scatter_accum_query(L.ptr(hits), hits[n_list:].data_ptr(), min(point_seg.shape[0], self.rows_local), L.ptr(point_seg),
+                                                        L.ptr(rows), rows.shape[0], L.ptr(d), self.D, L.ptr(self.acc), L.ptr(self.cnt), self.rank, self.world,
+                                                        self.SHARD_BLOCK, L.ptr(self.texts), self.texts.shape[0], 0, 0.0, 0.0, 0.0,
+                                                        L.ptr(self.dense_cls), L.ptr(self.dense_conf), L.stream()))
+                    continue
                 touched, n_cur, n_nxt = None, None, None
                 if self.incremental_query:
                     k = self._touch_parity

@@ -186,6 +186,58 @@ def test_scatter_accum_linearity():
     assert np.array_equal(acc.cpu().numpy(), ref)              # x + x is exact
     assert np.array_equal(cnt.cpu().numpy(), 2 * hit.astype(np.int32))
 
+@pytest.mark.parametrize("D,Q,shards", [(1024, 10, 1), (768, 16, 1), (400, 1, 1), (1024, 10, 4), (48, 3, 2)])
+def test_scatter_query_fused_vs_two_passes(D, Q, shards):
+    """ovo_scatter_accum_query (one launch from a hit list: accumulate + re-query) against ovo_scatter_accum_touched + ovo_similarity_rows through the
+    C ABI: accumulators, counts, classes and confidences bit-identical; rows whose mask has no descriptor stay untouched; D % 32 == 16 tail."""
+    from ovo_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(D + Q)
+    n, n_masks, blk = 70_003, 40, 256
+    seg = rng.integers(-2, n_masks + 3, n).astype(np.int16)       # ids >= n_masks: masks the tracker does not know (skipped)
+    mask_row = np.where(np.arange(n_masks) % 7 == 0, -1, rng.permutation(n_masks)).astype(np.int32)
+    desc = rng.standard_normal((n_masks, D)).astype(np.float32)
+    texts = rng.standard_normal((Q, D)).astype(np.float32)
+    texts /= np.linalg.norm(texts, axis=1, keepdims=True)
+    d_seg, d_row, d_desc, d_T = _t(seg), _t(mask_row), _t(desc), _t(texts)
+    for rank in range(shards):
+        nb = -(-n // blk)
+        rows_local = -(-nb // shards) * blk if shards > 1 else n
+        acc0 = torch.from_numpy(rng.standard_normal((rows_local, D)).astype(np.float32)).to(DEV)
+        cnt0 = torch.from_numpy(rng.integers(0, 5, rows_local).astype(np.int32)).to(DEV)
+        # the list the tracking pass would emit: every point with a segment id of this keyframe (also those whose mask has no descriptor), shuffled
+        i = np.nonzero((seg >= 0) & (seg < n_masks))[0]
+        if shards > 1:
+            i = i[(i // blk) % shards == rank]
+            local = (i // blk // shards) * blk + i % blk
+        else:
+            local = i
+        hits = _t(rng.permutation(local).astype(np.int32))
+        n_hits = torch.tensor([hits.numel()], dtype=torch.int32, device=DEV)
+        out = []
+        for fused in (True, False):
+            acc, cnt = acc0.clone(), cnt0.clone()
+            cls = torch.full((rows_local,), -7, dtype=torch.int64, device=DEV)
+            conf = torch.full((rows_local,), -7.0, dtype=torch.float32, device=DEV)
+            if fused:
+                L.check(lib.ovo_scatter_accum_query(L.ptr(hits), L.ptr(n_hits), n, L.ptr(d_seg), L.ptr(d_row), n_masks, L.ptr(d_desc), D, L.ptr(acc), L.ptr(cnt),
+                                                    rank, shards, blk, L.ptr(d_T), Q, 0, 0.0, 0.0, 0.05, L.ptr(cls), L.ptr(conf), L.stream()))
+            else:
+                touched = torch.empty(rows_local, dtype=torch.int32, device=DEV)
+                n_t = torch.zeros(2, dtype=torch.int32, device=DEV)
+                L.check(lib.ovo_scatter_accum_touched(L.ptr(d_seg), n, L.ptr(d_row), n_masks, L.ptr(d_desc), D, L.ptr(acc), L.ptr(cnt), L.ptr(touched),
+                                                      n_t.data_ptr(), n_t[1:].data_ptr(), rank, shards, blk, L.stream()))
+                L.check(lib.ovo_similarity_rows(L.ptr(acc), 0, L.ptr(touched), n_t.data_ptr(), rows_local, D, L.ptr(d_T), Q, L.ptr(cnt), 0, 0.0, 0.0, 0.05,
+                                                L.ptr(cls), L.ptr(conf), L.stream())) if D % 16 == 0 else None
+            out.append((acc, cnt, cls, conf))
+        (a1, c1, k1, f1), (a2, c2, k2, f2) = out
+        assert torch.equal(a1, a2) and torch.equal(c1, c2)
+        assert torch.equal(k1, k2) and torch.equal(f1, f2)
+        changed = (c1 != cnt0)
+        assert int(changed.sum()) > 0 and int((k1 != -7).sum()) == int(changed.sum())
+        live = mask_row[seg[i]] >= 0
+        assert int(changed.sum()) == int(live.sum())
+
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_mask_nms_golden(tag):

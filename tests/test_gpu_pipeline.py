@@ -103,25 +103,65 @@ def test_shared_identical_crops_do_not_change_results():
         assert (da is None and db is None) or torch.equal(torch.nan_to_num(da, nan=7.0), torch.nan_to_num(db, nan=7.0))
 
 
-def test_incremental_dense_query_equals_full_requery():
-    """The resident dense class / confidence map, patched only for the rows a keyframe's scatter pass touched (ovo_scatter_accum_touched
-    -> ovo_similarity_rows), against a full re-query of every row after every keyframe: equal bit for bit, and the touched set is a
-    small part of the map."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_incremental_dense_query_equals_full_requery(fused, monkeypatch):
+    """The resident dense class / confidence map, patched only for the rows a keyframe changed -- in one launch from the tracking pass's hit list
+    (`ovo_scatter_accum_query`, round 6) or as ovo_scatter_accum_touched -> ovo_similarity_rows --, against a full re-query of every row after
+    every keyframe: equal bit for bit, and the touched set is a small part of the map.  The hit list itself = the points with point_seg >= 0."""
     from ovo_amd.pipeline import FramePipeline, synthetic_frames
     from ovo_amd.utils import clip_utils
+    if not fused:
+        monkeypatch.setenv("OVO_NO_FUSED_SCATTER", "1")
     pipe = FramePipeline(DEV, vit_card="tiny-pe", sam_card=None, n_map=60_000, n_text=7, scale=0.35, extra_capacity=200_000, track_th=40)
-    assert pipe.incremental_query
+    assert pipe.incremental_query and (pipe.ovo.hit_shard is not None) == fused
     frames = synthetic_frames(5, DEV, scale=0.35, n_masks_grid=(3, 4), n_blobs=4)
-    fractions = []
+    fractions, accs = [], []
     for f in frames:
         out = pipe.step(f)
         n = out["n_points"]
         _, cls, conf = clip_utils.similarity(pipe.acc[:n], pipe.texts, cnt=pipe.cnt[:n], want_sim=False, want_argmax=True)
         assert torch.equal(out["dense_cls"], cls) and torch.equal(out["dense_conf"], conf)
-        touched = int(pipe.n_touched[pipe._touch_parity ^ 1].item())
-        assert touched == int((pipe.ovo.last_point_seg >= 0).sum().item()) or touched <= n      # every matched point of a kept mask, once
+        matched = torch.nonzero(pipe.ovo.last_point_seg >= 0).flatten()
+        if fused:
+            hits = pipe.ovo.last_hits
+            touched = int(hits[-4].item())
+            assert torch.equal(torch.sort(hits[:touched].long()).values, matched)          # every matched point, once, in any order
+        else:
+            touched = int(pipe.n_touched[pipe._touch_parity ^ 1].item())
+            assert touched == matched.numel() or touched <= n                               # every matched point of a kept mask, once
         fractions.append(touched / n)
+        accs.append((pipe.acc[:n].clone(), pipe.cnt[:n].clone()))
     assert (out["dense_cls"] >= 0).any() and max(fractions) > 0 and max(fractions) < 0.6
+    return accs
+
+
+def test_fused_scatter_query_accumulators_equal_the_three_launch_path(monkeypatch):
+    """Same frames through both forms: the dense accumulators and counts are identical after every keyframe."""
+    a = test_incremental_dense_query_equals_full_requery(True, monkeypatch)
+    b = test_incremental_dense_query_equals_full_requery(False, monkeypatch)
+    for (xa, ca), (xb, cb) in zip(a, b):
+        assert torch.equal(xa, xb) and torch.equal(ca, cb)
+    assert float(a[-1][0].abs().sum()) > 0
+
+
+def test_hit_list_of_a_point_shard():
+    """hit_shard_count = 3: the tracking pass lists only the points of this rank's block-cyclic shard, as local rows (`emulate` = rank 1 of 3)."""
+    from ovo_amd.pipeline import FramePipeline, synthetic_frames
+    pipe = FramePipeline(DEV, vit_card="tiny-pe", sam_card=None, n_map=60_000, n_text=7, scale=0.35, extra_capacity=200_000, track_th=40, emulate=(1, 3))
+    assert pipe.ovo.hit_shard == (1, 3, pipe.SHARD_BLOCK)
+    frames = synthetic_frames(6, DEV, scale=0.35, n_masks_grid=(3, 4), n_blobs=4)
+    seen = 0
+    for r in range(2):
+        pipe.step_round(frames[3 * r:3 * r + 3], frames[3 * r + 3:])
+        seg, hits = pipe.ovo.last_point_seg, pipe.ovo.last_hits               # the round's LAST keyframe
+        i = torch.nonzero(seg >= 0).flatten()
+        blk = i // pipe.SHARD_BLOCK
+        mine = i[blk % 3 == 1]
+        local = (blk[blk % 3 == 1] // 3) * pipe.SHARD_BLOCK + mine % pipe.SHARD_BLOCK
+        n = int(hits[-4].item())
+        assert torch.equal(torch.sort(hits[:n].long()).values, torch.sort(local).values)
+        seen += n
+    assert seen > 0
 
 
 def test_keyframe_without_descriptors_releases_its_lookahead_slot():

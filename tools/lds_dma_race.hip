@@ -29,7 +29,7 @@ constexpr int PIECES = 1920;                   // 16-byte pieces per chunk = 30 
 constexpr int BUF = PIECES * 16;
 
 template <int NTHREADS>
-__global__ void __launch_bounds__(NTHREADS) k_race(Args a, int n_slots) {
+__global__ void __launch_bounds__(NTHREADS, 512 / NTHREADS) k_race(Args a, int n_slots) {     // (<= 256 VGPRs: two 256-thread workgroups fit a CU)
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PPT = (PIECES + NTHREADS - 1) / NTHREADS;
@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(NTHREADS) k_race(Args a, int n_slots) {
             }
             const char *cur = smem + PAR * BUF;
             // every wave reads every piece, the pieces the OTHER waves brought in first (the last pieces issued are read first)
+#pragma unroll 2
             for (int k = PIECES / 64 - 1; k >= 0; --k) {
                 const int piece = ((k + wave * 7) % (PIECES / 64)) * 64 + lane;
                 const u32x4 v = *(const u32x4 *)(cur + piece * 16);

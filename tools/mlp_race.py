@@ -19,7 +19,9 @@ w1 = torch.zeros(hid, k1, dtype=torch.bfloat16, device=DEV)
 w1[:, :d] = (torch.randn(hid, d, generator=g) * d ** -0.5).to(DEV, torch.bfloat16)
 w2 = (torch.randn(d, hid, generator=g) * hid ** -0.5).to(DEV, torch.bfloat16)
 b1, b2 = torch.randn(hid, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
-out = torch.zeros(8 + 4 * 200, dtype=torch.int32, device=DEV)
+NB = (rows + 15) // 16
+HW = 2 + hid // 64
+out = torch.zeros(8 + 4 * 200 + HW * NB, dtype=torch.int32, device=DEV)
 os.environ["OVO_MLP_DBG_OUT"] = str(out.data_ptr())
 def call(xf):
     rc = lib.ovo_mlp_f32(xf.data_ptr(), rows, d, gamma.data_ptr(), beta.data_ptr(), 1e-6, w1.data_ptr(), k1, b1.data_ptr(), hid, w2.data_ptr(), hid, b2.data_ptr(), L.stream())
@@ -44,6 +46,34 @@ def run(variant, dbg, what, iters=12):
         print("      workgroups < 256:", sum(r[0] < 256 for r in recs), " >= 256:", sum(r[0] >= 256 for r in recs), " base == 0:", sum(r[3] == 0 for r in recs), " pieces < P1 (W1):",
               sum(r[2] < 1024 for r in recs), " chunks:", sorted(set(r[1] for r in recs)))
     sys.stdout.flush()
+def stages(variant, dbg, iters=8):
+    """Per row block: hashes of the LayerNorm-ed fragments, every chunk's hidden fragments and the FC2 accumulators (dbg & 256), against variant 1's."""
+    os.environ["OVO_MLP_RB"], os.environ["OVO_MLP_DBG"] = "1", "256"
+    out.zero_(); xf = x0.clone(); call(xf); torch.cuda.synchronize()
+    want = out[808:].view(NB, HW).clone()
+    assert torch.equal(xf, ref)
+    os.environ["OVO_MLP_RB"], os.environ["OVO_MLP_DBG"] = str(variant), str(dbg | 256)
+    names = ["LN fragments"] + [f"hidden chunk {c}" for c in range(HW - 2)] + ["FC2 accumulators"]
+    first = {}
+    n_bad_out, n_hash_only = 0, 0
+    for it in range(iters):
+        out.zero_(); xf = x0.clone(); call(xf); torch.cuda.synchronize()
+        got = out[808:].view(NB, HW)
+        bad_out = ((xf - ref).abs().amax(1) > 0).view(-1, 16).any(1)
+        bad_hash = (got != want)
+        for b in torch.nonzero(bad_out | bad_hash.any(1)).flatten().tolist():
+            st = torch.nonzero(bad_hash[b]).flatten().tolist()
+            key = names[st[0]] if st else "none (only the stored rows differ)"
+            first[key] = first.get(key, 0) + 1
+            n_bad_out += int(bad_out[b]); n_hash_only += int(not bad_out[b])
+            if sum(first.values()) <= 6:
+                print(f"      launch {it} row block {b} (workgroup slot {(b // (4 * 2)) % 512 if variant == 2 else -1}): output wrong {bool(bad_out[b])}; stages that differ: {[names[k] for k in st]}")
+    print(f"variant {variant} dbg {dbg}: wrong row blocks {n_bad_out} (+{n_hash_only} with a wrong hash but right output) in {iters} launches; FIRST wrong stage: {first}")
+    sys.stdout.flush()
+if os.environ.get("STAGES", "1") != "0":
+    stages(2, 0); stages(2, 2); stages(2, 128); stages(3, 0)
+if os.environ.get("STAGES") == "only":
+    sys.exit(0)
 run(1, 0, "production: ONE 512-thread workgroup per CU")
 run(1, 4 + 8, "  + LDS check")
 run(2, 0, "TWO 256-thread workgroups per CU")
