@@ -681,7 +681,7 @@ int ovo_resize_window_normalize(const void *src, int src_dtype, int C, int H, in
     a.vh = virt_h; a.vw = virt_w; a.top = top; a.left = left;
     for (int c = 0; c < 4; ++c) { a.mean[c] = mean3_host && c < C ? mean3_host[c] : 0.f; a.std[c] = std3_host && c < C ? std3_host[c] : 1.f; }
     if (a.hwc && a.src_u8 && C == 3 && filter == 1) {               // the camera-frame case: the branch-free kernel (a batch of one)
-        ResizeBatch b;
+        ResizeBatch b = {};
         b.src[0] = src; b.y0[0] = y0; b.x0[0] = x0; b.ch[0] = ch; b.cw[0] = cw;
         launch_resize_batch(a, b, 1, out, (hipStream_t)stream);
     } else {

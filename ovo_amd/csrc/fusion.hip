@@ -262,27 +262,57 @@ __global__ void __launch_bounds__(512) k_scatter_query(const int32_t *__restrict
         float *ap = acc + (int64_t)li * D + g * 4;
         const float *dp = desc + (int64_t)(live ? row : 0) * D + g * 4;
         sq_f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int k0 = 0; k0 < D32; k0 += 32) {
-            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-            if (live) {
-                a0 = *(const float4 *)(ap + k0); a1 = *(const float4 *)(ap + k0 + 16);
-                const float4 d0 = *(const float4 *)(dp + k0), d1 = *(const float4 *)(dp + k0 + 16);
+        // One 32-column step = two 16-byte pieces of the row (+ the descriptor's); a BLOCK of U steps is fetched whole before its first add, and the
+        // next block is in flight while this one is added, stored and multiplied: 2 x 2 U KB of accumulator rows per wave on their way at any time
+        // (the first form met every load four instructions later: 78 us for 200 MB; ~1500 waves is all a keyframe's hits give).
+        constexpr int U = 4;
+        auto fetch = [&](float4 (&a)[2 * U], float4 (&d)[2 * U], int k0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (live && k0 + 32 * u < D32) {
+                    a[2 * u] = *(const float4 *)(ap + k0 + 32 * u); a[2 * u + 1] = *(const float4 *)(ap + k0 + 32 * u + 16);
+                    d[2 * u] = *(const float4 *)(dp + k0 + 32 * u); d[2 * u + 1] = *(const float4 *)(dp + k0 + 32 * u + 16);
+                } else {
+                    a[2 * u] = a[2 * u + 1] = d[2 * u] = d[2 * u + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        auto finish = [&](float4 (&a)[2 * U], float4 (&d)[2 * U], int k0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 32 * u;
+                if (k >= D32) break;
+                float4 a0 = a[2 * u], a1 = a[2 * u + 1];
+                const float4 d0 = d[2 * u], d1 = d[2 * u + 1];
                 a0.x += d0.x; a0.y += d0.y; a0.z += d0.z; a0.w += d0.w;
                 a1.x += d1.x; a1.y += d1.y; a1.z += d1.z; a1.w += d1.w;
-                __builtin_nontemporal_store(sq_f32x4{a0.x, a0.y, a0.z, a0.w}, (sq_f32x4 *)(ap + k0));
-                __builtin_nontemporal_store(sq_f32x4{a1.x, a1.y, a1.z, a1.w}, (sq_f32x4 *)(ap + k0 + 16));
+                if (live) {
+                    __builtin_nontemporal_store(sq_f32x4{a0.x, a0.y, a0.z, a0.w}, (sq_f32x4 *)(ap + k));
+                    __builtin_nontemporal_store(sq_f32x4{a1.x, a1.y, a1.z, a1.w}, (sq_f32x4 *)(ap + k + 16));
+                }
+                if (T) {
+                    const float4 t0 = *(const float4 *)(tq + k + g * 4), t1 = *(const float4 *)(tq + k + 16 + g * 4);
+                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.x, a0.x, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.y, a0.y, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.z, a0.z, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.w, a0.w, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.x, a1.x, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.y, a1.y, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.z, a1.z, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.w, a1.w, s, 0, 0, 0);
+                }
             }
-            if (T) {
-                const float4 t0 = *(const float4 *)(tq + k0 + g * 4), t1 = *(const float4 *)(tq + k0 + 16 + g * 4);
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.x, a0.x, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.y, a0.y, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.z, a0.z, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.w, a0.w, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.x, a1.x, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.y, a1.y, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.z, a1.z, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.w, a1.w, s, 0, 0, 0);
+        };
+        {
+            float4 xa[2 * U], xd[2 * U], ya[2 * U], yd[2 * U];
+            fetch(xa, xd, 0);
+            for (int k0 = 0; k0 < D32; k0 += 64 * U) {                                 // two blocks per trip: static buffer roles
+                if (k0 + 32 * U < D32) fetch(ya, yd, k0 + 32 * U);
+                finish(xa, xd, k0);
+                if (k0 + 32 * U < D32) {
+                    if (k0 + 64 * U < D32) fetch(xa, xd, k0 + 64 * U);
+                    finish(ya, yd, k0 + 32 * U);
+                }
             }
         }
         if (D32 < D) {                                                               // one 16-wide tail step

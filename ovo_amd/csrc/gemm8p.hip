@@ -381,6 +381,41 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                 if constexpr (KIND == 3) { v[0] += addv.x; v[1] += addv.y; v[2] += addv.z; v[3] += addv.w; }
             }
         };
+        // KIND 3 (f32 output += f32 residual: the ViT's / Hiera's out-projection and FC2), round 6: the residual rows of a pass are FETCHED AHEAD -- pass 0's
+        // before the slab is written (the loads fly under the slab write and the workgroup barrier before it), pass 1's before pass 0's rows are finished
+        // (under its slab reads, arithmetic and stores).  In the row loop below a lane met its residual load four rows at a time: 16 dependent
+        // load -> add -> store groups of ~1.5 us each per pass were the +17 us this epilogue cost over the plain one.  Same
+        // arithmetic in the same order: bit-identical (tests/test_gpu_encoder.py).  g.add_ahead = 0 (OVO_8P_ADD_AHEAD=0): the loop loads as before.
+        constexpr int LPR3 = WTN / 4, RPI3 = 64 / LPR3, NIT3 = HM / RPI3, NG3 = NIT3 / 2;      // a pass = two groups of NG3 row instructions
+        float4 ahead_a[KIND == 3 ? NG3 : 1], ahead_b[KIND == 3 ? NG3 : 1];                     // two groups in flight (a third would spill: 128 accumulators are live)
+        const bool use_ahead = KIND == 3 && g.add_ahead;
+        auto fetch_ahead = [&](float4 (&buf)[KIND == 3 ? NG3 : 1], int grp) {                  // grp 0 .. 3: pass grp / 2, its first / second half
+            if constexpr (KIND == 3) {
+                const int mw = m0 + wr * WTM + (grp >> 1) * HM, n = n0 + wc * WTN + (lane % LPR3) * 4;
+#pragma unroll
+                for (int k = 0; k < NG3; ++k) {
+                    const int m = mw + ((grp & 1) * NG3 + k) * RPI3 + lane / LPR3;
+                    const long long md = (m < g.M && n < g.N) ? row_dest(g, m) : -1;
+                    buf[k] = md >= 0 ? *(const float4 *)(g.add + add_row(g, m, md) * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        auto rows_ahead = [&](const float4 (&buf)[KIND == 3 ? NG3 : 1], int grp, float4 bias) {
+            if constexpr (KIND == 3) {
+                const int mw = m0 + wr * WTM + (grp >> 1) * HM, c = (lane % LPR3) * 4, n = n0 + wc * WTN + c;
+#pragma unroll
+                for (int k = 0; k < NG3; ++k) {
+                    const int r = ((grp & 1) * NG3 + k) * RPI3 + lane / LPR3, m = mw + r;
+                    const f32x4 a = *(const f32x4 *)(slab + r * ROWB + c * 4);
+                    const long long md = (m < g.M && n < g.N) ? row_dest(g, m) : -1;
+                    if (md < 0) continue;
+                    float v[4] = {a[0], a[1], a[2], a[3]};
+                    mathk(0, 0, n, v, bias, buf[k]);
+                    { const f32x4 vv = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(vv, (f32x4 *)((float *)g.C + md * g.ldc + n)); }
+                }
+            }
+        };
+        if (use_ahead) fetch_ahead(ahead_a, 0);
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -390,6 +425,15 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     *(f32x4 *)(slab + (i * RT + lrow) * ROWB + (j * CS + lcol) * 4) = piece(pass * (NI / 2) + i, j);
             OVO_FENCE();
             const int mw = m0 + wr * WTM + pass * HM, nw = n0 + wc * WTN;
+            if (KIND == 3 && use_ahead) {
+                const int n = nw + (lane % LPR3) * 4;
+                const float4 bias = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pass == 0) fetch_ahead(ahead_b, 1);            // (64 accumulators just died in the slab)
+                rows_ahead(ahead_a, 2 * pass, bias);
+                if (pass == 0) fetch_ahead(ahead_a, 2);
+                rows_ahead(ahead_b, 2 * pass + 1, bias);
+                if (pass == 0) fetch_ahead(ahead_b, 3);
+            } else
             if (KIND == 3 || (KIND < 0 && g.out_dtype == 0)) {                       // f32 rows: 16 lanes x 16 bytes per row, 4 rows per instruction
                 constexpr int LPR = WTN / 4, RPI = 64 / LPR;
                 const int c = (lane % LPR) * 4, n = nw + c;
@@ -615,6 +659,9 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     static int gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     if (ovo_knobs_dynamic()) gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     g.gelu_lut = !gelu_poly;
+    static int add_ahead = getenv("OVO_8P_ADD_AHEAD") ? atoi(getenv("OVO_8P_ADD_AHEAD")) : 1;      // (0: the residual epilogue loads inside its row loop, as until round 5)
+    if (ovo_knobs_dynamic()) add_ahead = getenv("OVO_8P_ADD_AHEAD") ? atoi(getenv("OVO_8P_ADD_AHEAD")) : 1;
+    g.add_ahead = add_ahead;
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;
     constexpr size_t ring = 2 * (size_t)(BM + BN) * 128;                                  // two K-tile buffers

@@ -43,6 +43,7 @@ struct GemmArgs {
     int tail_wait;             // gemm8p: 1 = a wave waits for its epilogue stores before it ends (OVO_8P_TAILWAIT, measurement)
     int rope_lds;              // k_gemm8p: the rotary epilogue stages its table slice in LDS (OVO_8P_ROPE_LDS)
     int slab16;                // k_gemm8p: 2-byte outputs cross the epilogue's LDS slab already rounded (OVO_8P_NO_SLAB16: the f32 slab)
+    int add_ahead;             // k_gemm8p: the f32-residual epilogue fetches a pass's residual rows ahead of its slab round trip (OVO_8P_ADD_AHEAD)
     // k_gemm<128, 448> (gemm.hip, round 5): a workgroup owns whole rows (N = 448 = BN), so after the f32 result (+ residual) is stored the LayerNorm of the
     // rows that FOLLOWS the product in Hiera stage 3 (norm2 before the MLP) is taken from the accumulators: rln_out bf16 [C rows, rln_ld] = LN(C row)
     const float *rln_g, *rln_b; float rln_eps; uint16_t *rln_out; long long rln_ld;
@@ -267,8 +268,9 @@ int gemm_unwindow_rowln(const ovo_gemm_t *p, const ovo_window_t *win, const floa
                         ovo_stream_t stream);
 
 // att bf16 [windows x 64 (16 with `pool`), ld_att] (window-major rows) = per-window, per-head softmax(q k^T) v of q | k | v = LayerNorm(x) . Wqkv^T + b, straight
-// from the f32 token grid x [B, H, W, d] (winattn.hip; one launch per pair of heads); OVO_E_UNSUPPORTED (nothing launched) unless d = 112, 8 x 8 windows,
-// >= 512 windows and (d_out, heads, pool) = (112, 2, 0) or (224, 4, 1: queries 2 x 2 max-pooled inside the window)
+// from the f32 token grid x [B, H, W, d] (winattn.hip; one launch per pair of heads); OVO_E_UNSUPPORTED (nothing launched) unless >= 512 windows and
+// d = 112 with 8 x 8 windows and (d_out, heads, pool) = (112, 2, 0) or (224, 4, 1: queries 2 x 2 max-pooled inside the window), or d = d_out = 224 with
+// 4 x 4 windows and 4 heads (k_win_attn224; the same contract as ovo_hip.h's ovo_win_attn)
 int win_attn_launch(const float *x, int B, int H, int W, int ws, int d, int d_out, int heads, int pool, const float *ln_g, const float *ln_b, float eps,
                     const void *qkv_w, long long ldw, const float *qkv_b, void *att, int ld_att, hipStream_t s);
 

@@ -680,9 +680,9 @@ int ovo_hiera_forward(const ovo_hiera_config_t *cfg, const ovo_hiera_weights_t *
         for (long long r0 = fused == OVO_OK ? tok_out : 0; r0 < tok_out; r0 += chunk_rows) {
             const long long nr = tok_out - r0 < chunk_rows ? tok_out - r0 : chunk_rows;
             const Grid gc = chunk_rows == tok_out ? gi : make_grid(1, (int)nr, 1, 0);
-            bool hd = chunk_rows == tok_out ? (h_done || ln2_done) : false;
+            bool h_ready = chunk_rows == tok_out ? (h_done || ln2_done) : false;      // (a chunked pass re-normalises its rows: ln2_done is for the one-pass form only)
             float *xc = x + r0 * dout;
-            TRY(gemm_from_f32(xc, gc, dout, kout, L.ln2_g, L.ln2_b, c.ln_eps, 1, k.h, hd, L.fc1_w, L.fc1_b, k.u, 4 * dout, 2, 4 * dout, 1, stream));
+            TRY(gemm_from_f32(xc, gc, dout, kout, L.ln2_g, L.ln2_b, c.ln_eps, 1, k.h, h_ready, L.fc1_w, L.fc1_b, k.u, 4 * dout, 2, 4 * dout, 1, stream));
             TRY(gemm(k.u, 4 * dout, L.fc2_w, 4 * dout, L.fc2_b, xc, dout, 0, xc, dout, nr, dout, 4 * dout, 0, stream));
         }
         h_done = false;

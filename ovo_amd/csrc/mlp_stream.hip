@@ -143,6 +143,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
         // ---- this wave's rows: LayerNorm in the load (two-pass statistics over the 4 lanes (fr, 0..3) that hold a row), bf16 A fragments
         bf16x8 af[RB][KS1];
         long long row[RB];
+#ifdef OVO_GEMM_DEBUG
+        unsigned pre_h[RB][3];                                       // (diagnosis) hashes of the raw x values, of (mean, rstd) and of the gamma / beta values as read
+#endif
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const long long b = (grp * WPB + wave) * RB + rb;
@@ -175,6 +178,20 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
             }
             q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
             const float rstd = rsqrtf(q / (float)D + g.eps);
+#ifdef OVO_GEMM_DEBUG
+            {
+                unsigned hx = 0, ht = 0;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int d0 = (ks * 4 + fq) * 8;
+                        hx = (hx * 16777619u) ^ (__float_as_uint(xv[ks][e]) + (unsigned)lane * 2654435761u);
+                        ht = (ht * 16777619u) ^ (__float_as_uint(lg[d0 + e]) + 3u * __float_as_uint(lb[d0 + e]) + (unsigned)lane * 2654435761u);
+                    }
+                pre_h[rb][0] = hx; pre_h[rb][1] = __float_as_uint(mean) * 31u + __float_as_uint(rstd) + (unsigned)lane * 2654435761u; pre_h[rb][2] = ht;
+            }
+#endif
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
                 const int d0 = (ks * 4 + fq) * 8;
@@ -199,7 +216,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
         auto wave_xor = [&](unsigned h) { for (int o = 1; o < 64; o <<= 1) h ^= (unsigned)__shfl_xor((int)h, o, 64); return h; };
         auto hash8 = [&](const bf16x8 &v, unsigned h) { const uint4 u = *(const uint4 *)&v; return (h * 16777619u) ^ (u.x + 3u * u.y + 5u * u.z + 7u * u.w + (unsigned)lane * 2654435761u); };
         unsigned *hash_out = (g.dbg_out && (g.dbg & 256)) ? g.dbg_out + 8 + 800 : nullptr;
-        constexpr int HW = 2 + NCH;                                  // words per row block: af, chunk 0 .. NCH - 1, acc2
+        constexpr int HW = 5 + NCH;                                  // words per row block: x, (mean, rstd), gamma / beta, af, chunk 0 .. NCH - 1, acc2
         if (hash_out) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -208,7 +225,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
                 for (int ks = 0; ks < KS1; ++ks) h = hash8(af[rb][ks], h);
                 h = wave_xor(h);
                 const long long b = (grp * WPB + wave) * RB + rb;
-                if (lane == 0 && b < blocks) hash_out[b * HW] = h;
+                const unsigned h0 = wave_xor(pre_h[rb][0]), h1 = wave_xor(pre_h[rb][1]), h2 = wave_xor(pre_h[rb][2]);
+                if (lane == 0 && b < blocks) { hash_out[b * HW] = h0; hash_out[b * HW + 1] = h1; hash_out[b * HW + 2] = h2; hash_out[b * HW + 3] = h; }
             }
         }
         unsigned hh[RB];
@@ -310,7 +328,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
                 for (int rb = 0; rb < RB; ++rb) {
                     const unsigned h = wave_xor(hh[rb]);
                     const long long b = (grp * WPB + wave) * RB + rb;
-                    if (lane == 0 && b < blocks) hash_out[b * HW + 1 + c] = h;
+                    if (lane == 0 && b < blocks) hash_out[b * HW + 4 + c] = h;
                 }
             }
 #endif
@@ -336,7 +354,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
                     for (int e = 0; e < 4; ++e) h = (h * 16777619u) ^ (__float_as_uint(acc2[rb][j][e]) + (unsigned)lane * 2654435761u);
                 h = wave_xor(h);
                 const long long b = (grp * WPB + wave) * RB + rb;
-                if (lane == 0 && b < blocks) hash_out[b * HW + 1 + NCH] = h;
+                if (lane == 0 && b < blocks) hash_out[b * HW + 4 + NCH] = h;
             }
         }
 #endif
@@ -363,22 +381,25 @@ int launch_mlp(const MlpArgs &g, hipStream_t s) {
     constexpr size_t lds = 2 * (size_t)(HC * K1 * 2 + D * HC * 2);                                   // dynamic: the weight buffers
     constexpr size_t lds_all = lds + (size_t)(HID + D + 2 * K1) * sizeof(float) + GELU_LUT_BYTES + 64;   // + the static tables
     static_assert(lds_all <= 160 * 1024, "LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_mlp_stream<K1, D, HID, RB, RI, NTHREADS, POLY, HC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { ovo_set_error("ovo_mlp_stream: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
-        attr_done = true;
-    }
     // 8 waves per CU (2 per SIMD, up to 256 VGPRs each): ONE workgroup of 512 threads (the diagnosis variants: two of 256 when their LDS fits
     // twice).  Each workgroup walks row groups blockIdx.x, + slots, ...
     constexpr int PER_CU = (NTHREADS <= 256 && 2 * lds_all + 2048 <= 160 * 1024) ? 2 : 1;
+    // The one-workgroup form is PINNED to one workgroup per CU by its LDS request: padded past half of the CU's 160 KB, a second workgroup
+    // can never become resident beside it, whatever register count a later compiler lands at and whatever else runs on the other streams.
+    constexpr size_t lds_pinned = (PER_CU == 1 && lds_all < 82 * 1024) ? lds + (82 * 1024 - lds_all) : lds;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_mlp_stream<K1, D, HID, RB, RI, NTHREADS, POLY, HC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pinned);
+        if (e != hipSuccess) { ovo_set_error("ovo_mlp_stream: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
+        attr_done = true;
+    }
     const long long blocks = (g.rows + 15) / 16, groups = (blocks + (NTHREADS / 64) * RB - 1) / ((NTHREADS / 64) * RB);
     const int slots = (int)(groups < 256 * PER_CU ? groups : 256 * PER_CU);
     const bool prof = ovo_prof_enabled();
     // profiler kind 8 (the streaming GEMMs): flops of both products; algorithmic bytes = the stream in and out + the weights
     if (prof) { ovo_prof_begin(8, 2.0 * (double)g.rows * HID * (double)(K1 + D), s); ovo_prof_shape((int)g.rows, HID, K1); ovo_prof_flags(1 | 2 | 4 | 64);
                 ovo_prof_bytes(8.0 * (double)g.rows * D + 2.0 * HID * (K1 + D)); }
-    size_t lds_launch = lds;
+    size_t lds_launch = lds_pinned;
 #ifdef OVO_GEMM_DEBUG
     if ((g.dbg & 64) && lds_all < 84 * 1024) {                      // one workgroup per CU whatever its size: pad the dynamic LDS past half a CU's
         lds_launch = lds + (84 * 1024 - lds_all);

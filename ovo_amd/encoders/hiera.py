@@ -219,7 +219,7 @@ class HipHiera:
         first = imgs[0]
         if out is None:
             out = torch.empty((len(imgs), 3, s, s), dtype=torch.float32, device=first.device)
-        if not all(im.dtype == first.dtype and im.shape == first.shape for im in imgs) or first.dtype not in (torch.uint8, torch.float32):
+        if not all(im.dtype == first.dtype and im.shape == first.shape and im.device == first.device for im in imgs) or first.dtype not in (torch.uint8, torch.float32):
             for k, im in enumerate(imgs):
                 self.preprocess(im, out=out[k:k + 1])
             return out

@@ -314,13 +314,14 @@ class HipViT:
         same = all(im.dtype == first.dtype and im.shape == first.shape and im.device == first.device for im in imgs) and first.dtype in (torch.uint8, torch.float32)
         hwc = first.dtype == torch.uint8 and first.shape[-1] == 3 and first.shape[0] != 3
         h, w = (first.shape[0], first.shape[1]) if hwc else (first.shape[1], first.shape[2])
-        crops = list(crops) if crops is not None else [(0, 0, h, w)]
+        given = list(crops) if crops is not None else None          # (None stays None in the frame-by-frame path: every frame's OWN extent)
+        crops = given if given is not None else [(0, 0, h, w)]
         nc = len(crops)
         if out is None:
             out = torch.empty((len(imgs) * nc, 3, s.image_size, s.image_size), dtype=torch.float32, device=first.device)
         if not same:
             for i, im in enumerate(imgs):
-                self.preprocess(im, crops, scale, antialias, out=out[i * nc:(i + 1) * nc])
+                self.preprocess(im, given, scale, antialias, out=out[i * nc:(i + 1) * nc])
             return out
         mean, std = (C.c_float * 3)(*s.mean), (C.c_float * 3)(*s.std)
         srcs = (C.c_void_p * len(imgs))(*[im.data_ptr() for im in imgs])

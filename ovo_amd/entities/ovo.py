@@ -685,6 +685,8 @@ class OVO:
     @_timed("t_clip")
     def _extract_clip(self, image: np.ndarray, binary_maps: torch.Tensor) -> torch.Tensor:
         """Reference: ovo.py:427-437 -- but the descriptors stay on the GPU."""
+        if binary_maps is None:                                   # (pipeline.py: a keyframe another rank owns is tracked with want_maps=False)
+            raise L.OvoHipError("_extract_clip: this keyframe's binary maps were not kept (track_finish(want_maps=False)): only its owner pools it")
         hit = self._prefetched_batch.pop(id(image), None)
         if hit is not None and hit[0] is image:                  # tokens from a batched look-ahead forward
             _, feats, done, slot = hit

@@ -20,7 +20,7 @@ w1[:, :d] = (torch.randn(hid, d, generator=g) * d ** -0.5).to(DEV, torch.bfloat1
 w2 = (torch.randn(d, hid, generator=g) * hid ** -0.5).to(DEV, torch.bfloat16)
 b1, b2 = torch.randn(hid, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
 NB = (rows + 15) // 16
-HW = 2 + hid // 64
+HW = 5 + hid // 64
 out = torch.zeros(8 + 4 * 200 + HW * NB, dtype=torch.int32, device=DEV)
 os.environ["OVO_MLP_DBG_OUT"] = str(out.data_ptr())
 def call(xf):
@@ -53,7 +53,7 @@ def stages(variant, dbg, iters=8):
     want = out[808:].view(NB, HW).clone()
     assert torch.equal(xf, ref)
     os.environ["OVO_MLP_RB"], os.environ["OVO_MLP_DBG"] = str(variant), str(dbg | 256)
-    names = ["LN fragments"] + [f"hidden chunk {c}" for c in range(HW - 2)] + ["FC2 accumulators"]
+    names = ["x as loaded", "mean / rstd", "gamma / beta as read from LDS", "LN fragments"] + [f"hidden chunk {c}" for c in range(HW - 5)] + ["FC2 accumulators"]
     first = {}
     n_bad_out, n_hash_only = 0, 0
     for it in range(iters):
@@ -67,7 +67,7 @@ def stages(variant, dbg, iters=8):
             first[key] = first.get(key, 0) + 1
             n_bad_out += int(bad_out[b]); n_hash_only += int(not bad_out[b])
             if sum(first.values()) <= 6:
-                print(f"      launch {it} row block {b} (workgroup slot {(b // (4 * 2)) % 512 if variant == 2 else -1}): output wrong {bool(bad_out[b])}; stages that differ: {[names[k] for k in st]}")
+                print(f"      launch {it} row block {b} (workgroup slot {(b // (4 * 2)) % 512 if variant == 2 else -1}): output wrong {bool(bad_out[b])}; stages that differ: {[names[k] for k in st][:5]}")
     print(f"variant {variant} dbg {dbg}: wrong row blocks {n_bad_out} (+{n_hash_only} with a wrong hash but right output) in {iters} launches; FIRST wrong stage: {first}")
     sys.stdout.flush()
 if os.environ.get("STAGES", "1") != "0":
