@@ -218,19 +218,26 @@ __global__ void __launch_bounds__(256) k_scatter_apply(const int32_t *__restrict
 // ---- round 6: the dense fusion of one keyframe and the re-query of the rows it changed in ONE pass, from the tracking pass's own hit list --------------
 // ovo_scatter_accum_touched + ovo_similarity_rows were three launches per keyframe: the scan (33 us to find, in 2.6 MB of point_seg, the points
 // k_track_project had just had in registers), the apply (read + write of every hit row) and the query (the same rows read a third time).  Here a wave owns
-// 16 hits: lane (rr, g) streams row rr's 16-byte pieces k0 + 4 g and k0 + 16 + 4 g (two instructions cover a row's 128-byte line, as k_similarity_mfma's
-// f32 loader), adds the descriptor row's pieces (L2-resident: <= 128 rows), stores the sums and feeds them straight to the exact-f32 MFMA
-// (v_mfma_f32_16x16x4_f32) against the text rows in LDS -- the SAME instruction sequence per row as k_similarity_mfma<0>, so class / confidence are
-// bit-identical to querying the stored row afterwards (tests/test_gpu_features.py::test_scatter_query_fused_vs_two_passes), and the accumulator row is the
-// x + y of k_scatter_apply.  HBM bytes per hit: 2 D 4 (row in and out) instead of 3 D 4 + the scan.
+// 16 hits and walks their rows in steps of 32 columns:
+//   * MEMORY side, "load layout": lane l handles piece l & 7 (16 bytes) of row l >> 3 and of row 8 + (l >> 3) -- a wave instruction covers 8 rows x one whole
+//     128-byte line; accumulator pieces + descriptor pieces (L2-resident: <= 128 rows) are added in that layout and stored back as whole lines
+//     (non-temporal).  (First form, measured: the lanes loaded straight in the MFMA's layout, 64 bytes per row and instruction, as k_similarity_mfma's f32
+//     loader -- 78.6 us for 200 MB in the bench's isolated pass = 2.4 TB/s, whether 2 or 8 steps were in flight: half-line requests, not latency.)
+//   * ARITHMETIC side: the sums cross a 2 KB per-wave LDS slab (XOR-swizzled 16-byte pieces, conflict-free both ways) into the layout of the exact-f32 MFMA
+//     (v_mfma_f32_16x16x4_f32; lane (rr, g) holds columns k0 + 4 g .. and k0 + 16 + 4 g .. of row rr) against the text rows in LDS -- the SAME instruction
+//     sequence per row as k_similarity_mfma<0>, so class / confidence are bit-identical to querying the stored row afterwards
+//     (tests/test_gpu_features.py::test_scatter_query_fused_vs_two_passes), and the accumulator row is the x + y of k_scatter_apply.
+// HBM bytes per hit: 2 D 4 (row in and out) instead of 3 D 4 + the scan.
 typedef __attribute__((ext_vector_type(4))) float sq_f32x4;
+constexpr int SQ_WAVES = 8, SQ_SLAB = 2048;                          // waves per workgroup; bytes of one staging slab (16 rows x 128 B), two per wave
 __global__ void __launch_bounds__(512) k_scatter_query(const int32_t *__restrict__ hits, const int32_t *__restrict__ n_hits,
                                                        const int16_t *__restrict__ point_seg, const int32_t *__restrict__ mask_row, int n_masks,
                                                        const float *__restrict__ desc, int D, float *__restrict__ acc, int32_t *__restrict__ cnt,
                                                        int shard_rank, int shard_count, int block_log2, const float *__restrict__ T, int Q, int siglip,
                                                        float scale_exp, float bias, float th, long long *__restrict__ out_cls, float *__restrict__ out_conf,
                                                        int32_t *__restrict__ n_live) {
-    extern __shared__ __attribute__((aligned(16))) float sT[];                      // [Q <= 16][D]
+    extern __shared__ __attribute__((aligned(16))) char sq_smem[];                  // staging slabs [8 waves][2][2 KB], then the text rows [Q <= 16][D]
+    float *sT = (float *)(sq_smem + SQ_WAVES * 2 * SQ_SLAB);
     const int lane = threadIdx.x & 63, rr = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6, WPB = blockDim.x >> 6;
     const int count = *n_hits;
     const int groups = (count + 15) >> 4;
@@ -241,6 +248,11 @@ __global__ void __launch_bounds__(512) k_scatter_query(const int32_t *__restrict
     }
     const float *tq = sT + (rr < Q ? rr : Q - 1) * D;
     const int D32 = D & ~31;
+    char *slab = sq_smem + wv * 2 * SQ_SLAB;
+    // load layout: rows ra = l >> 3 and rb = 8 + ra, piece pc = l & 7;  slab address of (row, piece) = row * 128 + ((piece ^ ((row >> 1) & 7)) << 4)
+    const int ra = lane >> 3, rb = 8 + ra, pc = lane & 7;
+    const int wr_a = ra * 128 + ((pc ^ ((ra >> 1) & 7)) << 4), wr_b = rb * 128 + ((pc ^ ((rb >> 1) & 7)) << 4);
+    const int rd_0 = rr * 128 + ((g ^ ((rr >> 1) & 7)) << 4), rd_1 = rr * 128 + (((4 + g) ^ ((rr >> 1) & 7)) << 4);
     // groups are dealt wave-slot-major: slot w of every workgroup before slot w + 1 of any, so a short list still spreads over all CUs
     for (int grp = wv * gridDim.x + blockIdx.x; grp < groups; grp += WPB * gridDim.x) {
         const int c = grp * 16 + rr;
@@ -259,47 +271,52 @@ __global__ void __launch_bounds__(512) k_scatter_query(const int32_t *__restrict
         const unsigned long long lm = __ballot(live);
         if (!lm) continue;
         if (n_live && lane == 0) atomicAdd(n_live, (int)__popcll(lm & 0xffffull));   // (profiled passes only: rows really changed)
-        float *ap = acc + (int64_t)li * D + g * 4;
-        const float *dp = desc + (int64_t)(live ? row : 0) * D + g * 4;
+        // the two rows this lane moves (lanes 0 .. 15 hold candidates 0 .. 15)
+        const int li_a = __shfl(li, ra, 64), li_b = __shfl(li, rb, 64), row_a = __shfl(row, ra, 64), row_b = __shfl(row, rb, 64);
+        const bool live_a = row_a >= 0, live_b = row_b >= 0;
+        float *ap_a = acc + (int64_t)li_a * D + pc * 4, *ap_b = acc + (int64_t)li_b * D + pc * 4;
+        const float *dp_a = desc + (int64_t)(live_a ? row_a : 0) * D + pc * 4, *dp_b = desc + (int64_t)(live_b ? row_b : 0) * D + pc * 4;
         sq_f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        // One 32-column step = two 16-byte pieces of the row (+ the descriptor's); a BLOCK of U steps is fetched whole before its first add, and the
-        // next block is in flight while this one is added, stored and multiplied: 2 x 2 U KB of accumulator rows per wave on their way at any time
-        // (the first form met every load four instructions later: 78 us for 200 MB; ~1500 waves is all a keyframe's hits give).
+        // A BLOCK of U steps is fetched whole before its first add, and the next block is in flight while this one is added, stored and multiplied
         constexpr int U = 4;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         auto fetch = [&](float4 (&a)[2 * U], float4 (&d)[2 * U], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (live && k0 + 32 * u < D32) {
-                    a[2 * u] = *(const float4 *)(ap + k0 + 32 * u); a[2 * u + 1] = *(const float4 *)(ap + k0 + 32 * u + 16);
-                    d[2 * u] = *(const float4 *)(dp + k0 + 32 * u); d[2 * u + 1] = *(const float4 *)(dp + k0 + 32 * u + 16);
-                } else {
-                    a[2 * u] = a[2 * u + 1] = d[2 * u] = d[2 * u + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                const bool in = k0 + 32 * u < D32;
+                a[2 * u] = (in && live_a) ? *(const float4 *)(ap_a + k0 + 32 * u) : z4;
+                a[2 * u + 1] = (in && live_b) ? *(const float4 *)(ap_b + k0 + 32 * u) : z4;
+                d[2 * u] = (in && live_a) ? *(const float4 *)(dp_a + k0 + 32 * u) : z4;
+                d[2 * u + 1] = (in && live_b) ? *(const float4 *)(dp_b + k0 + 32 * u) : z4;
             }
+        };
+        auto mfma8 = [&](int k, const sq_f32x4 &a0, const sq_f32x4 &a1) {
+            const float4 t0 = *(const float4 *)(tq + k + g * 4), t1 = *(const float4 *)(tq + k + 16 + g * 4);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.x, a0[0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.y, a0[1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.z, a0[2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.w, a0[3], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.x, a1[0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.y, a1[1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.z, a1[2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.w, a1[3], s, 0, 0, 0);
         };
         auto finish = [&](float4 (&a)[2 * U], float4 (&d)[2 * U], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int k = k0 + 32 * u;
                 if (k >= D32) break;
-                float4 a0 = a[2 * u], a1 = a[2 * u + 1];
-                const float4 d0 = d[2 * u], d1 = d[2 * u + 1];
-                a0.x += d0.x; a0.y += d0.y; a0.z += d0.z; a0.w += d0.w;
-                a1.x += d1.x; a1.y += d1.y; a1.z += d1.z; a1.w += d1.w;
-                if (live) {
-                    __builtin_nontemporal_store(sq_f32x4{a0.x, a0.y, a0.z, a0.w}, (sq_f32x4 *)(ap + k));
-                    __builtin_nontemporal_store(sq_f32x4{a1.x, a1.y, a1.z, a1.w}, (sq_f32x4 *)(ap + k + 16));
-                }
+                const sq_f32x4 xa = {a[2 * u].x + d[2 * u].x, a[2 * u].y + d[2 * u].y, a[2 * u].z + d[2 * u].z, a[2 * u].w + d[2 * u].w};
+                const sq_f32x4 xb = {a[2 * u + 1].x + d[2 * u + 1].x, a[2 * u + 1].y + d[2 * u + 1].y, a[2 * u + 1].z + d[2 * u + 1].z, a[2 * u + 1].w + d[2 * u + 1].w};
+                if (live_a) __builtin_nontemporal_store(xa, (sq_f32x4 *)(ap_a + k));
+                if (live_b) __builtin_nontemporal_store(xb, (sq_f32x4 *)(ap_b + k));
                 if (T) {
-                    const float4 t0 = *(const float4 *)(tq + k + g * 4), t1 = *(const float4 *)(tq + k + 16 + g * 4);
-                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.x, a0.x, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.y, a0.y, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.z, a0.z, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.w, a0.w, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.x, a1.x, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.y, a1.y, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.z, a1.z, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.w, a1.w, s, 0, 0, 0);
+                    char *sl = slab + (u & 1) * SQ_SLAB;                                 // (the step before last read the other slab: same wave, LDS in order)
+                    *(sq_f32x4 *)(sl + wr_a) = xa;
+                    *(sq_f32x4 *)(sl + wr_b) = xb;
+                    __builtin_amdgcn_wave_barrier();
+                    const sq_f32x4 a0 = *(const sq_f32x4 *)(sl + rd_0), a1 = *(const sq_f32x4 *)(sl + rd_1);
+                    mfma8(k, a0, a1);
                 }
             }
         };
@@ -315,20 +332,22 @@ __global__ void __launch_bounds__(512) k_scatter_query(const int32_t *__restrict
                 }
             }
         }
-        if (D32 < D) {                                                               // one 16-wide tail step
-            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live) {
-                a0 = *(const float4 *)(ap + D32);
-                const float4 d0 = *(const float4 *)(dp + D32);
-                a0.x += d0.x; a0.y += d0.y; a0.z += d0.z; a0.w += d0.w;
-                *(float4 *)(ap + D32) = a0;
+        if (D32 < D) {                                                               // one 16-wide tail step: pieces 0 .. 3 of every row
+            sq_f32x4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa;
+            if (pc < 4) {
+                if (live_a) { const float4 v = *(const float4 *)(ap_a + D32), w = *(const float4 *)(dp_a + D32); xa = sq_f32x4{v.x + w.x, v.y + w.y, v.z + w.z, v.w + w.w}; *(sq_f32x4 *)(ap_a + D32) = xa; }
+                if (live_b) { const float4 v = *(const float4 *)(ap_b + D32), w = *(const float4 *)(dp_b + D32); xb = sq_f32x4{v.x + w.x, v.y + w.y, v.z + w.z, v.w + w.w}; *(sq_f32x4 *)(ap_b + D32) = xb; }
             }
             if (T) {
+                *(sq_f32x4 *)(slab + wr_a) = xa;
+                *(sq_f32x4 *)(slab + wr_b) = xb;
+                __builtin_amdgcn_wave_barrier();
+                const sq_f32x4 a0 = *(const sq_f32x4 *)(slab + rd_0);
                 const float4 t0 = *(const float4 *)(tq + D32 + g * 4);
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.x, a0.x, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.y, a0.y, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.z, a0.z, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.w, a0.w, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.x, a0[0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.y, a0[1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.z, a0[2], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(t0.w, a0[3], s, 0, 0, 0);
             }
         }
         int cn = 0;
@@ -437,14 +456,14 @@ int ovo_scatter_accum_query(const int32_t *hits, const int32_t *n_hits, int64_t 
         OVO_REQUIRE(Q > 0 && out_cls && out_conf, "query without outputs");
         if (Q > 16 || (size_t)Q * D * sizeof(float) > 96 * 1024) return OVO_E_UNSUPPORTED;       // the caller runs the two passes
         OVO_REQUIRE(((uintptr_t)T & 15) == 0, "T must be 16-byte aligned");
-        lds = (size_t)Q * D * sizeof(float);
+        lds = (size_t)Q * D * sizeof(float) + SQ_WAVES * 2 * SQ_SLAB;
     }
     int block_log2 = 0;
     while ((1 << block_log2) < shard_block) ++block_log2;
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
-        OVO_HIP(hipFuncSetAttribute((const void *)k_scatter_query, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        OVO_HIP(hipFuncSetAttribute((const void *)k_scatter_query, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024 + SQ_WAVES * 2 * SQ_SLAB));
         attr_done = true;
     }
     const int64_t groups = (max_hits + 15) / 16;

@@ -292,7 +292,10 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
         // 15 000 instructions of straight-line code: the 256 x 256 tile's epilogue ran out of the instruction cache and LOST 7 us): 0 plain, 1 table GELU.
         // (Rotary stays with the row-layout loop below: in this layout its 64 table loads per lane cover 16 rows x 64 bytes per instruction, and the ViT's
         // QKV measured 114.9 us -- 117.8 with all of a column tile's table rows fetched ahead of their arithmetic -- against 101-103.)
-        const int kind16 = (g.out_dtype != 0 && !g.add && g.slab16) ? ((g.act == 0 && !g.rope_cos) ? 0 : ((g.act == 1 && lut && !g.rope_cos) ? 1 : -1)) : -1;
+        // (2 = plain + the fused per-row argmax, round 6: the large-vocabulary query WITH its scores -- BASELINE configs[4] names "cosine scores within 1e-3
+        // fp16" -- stored 8 bytes per lane straight from the accumulators (16 rows x 32 bytes per instruction: 4.08 ms for 1.25 M x 768 x 1000, a third of the
+        // copy rate).  The row maximum is taken from the f32 values exactly as the unstaged form takes it; the scores then leave through the rounded slab.)
+        const int kind16 = (g.out_dtype != 0 && !g.add && g.slab16) ? ((g.act == 0 && !g.rope_cos) ? (g.best ? 2 : 0) : ((g.act == 1 && lut && !g.rope_cos && !g.best) ? 1 : -1)) : -1;
         OVO_BARRIER();                                    // every wave's LDS-DMA has landed and every fragment read is done: LDS is free
         if (kind16 >= 0) {
             // 2-byte outputs without a residual: bias / activation / rotary are applied in the accumulator layout (a lane's 4 consecutive columns) and the
@@ -313,6 +316,8 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                 constexpr int KIND = decltype(KIND_)::value;
                 static_for<0, NI>([&](auto I_) {
                     constexpr int i = decltype(I_)::value;
+                    float row_mx = -3.0e38f;
+                    int row_arg = 0x7fffffff;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         const f32x4 pc = piece(i, j);
@@ -324,14 +329,25 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = gelu_lut(v[r], lut);
                         }
+                        if (KIND == 2) {                                                 // first maximum over ascending columns, as finish4's running pair
+                            const int n = nw + j * CS + lcol;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (n + r < g.n_valid && v[r] > row_mx) { row_mx = v[r]; row_arg = n + r; }
+                        }
                         uint2 p;
                         if (g.out_dtype == 2) { p.x = pack_bf16(v[0], v[1]); p.y = pack_bf16(v[2], v[3]); }
                         else { p.x = pack_f16(v[0], v[1]); p.y = pack_f16(v[2], v[3]); }
                         *(uint2 *)(slab + (i * RT + lrow) * RB2 + (j * CS + lcol) * 2) = p;
                     }
+                    if constexpr (KIND == 2 && MF == 16) {
+                        const int m = m0 + wr * WTM + i * RT + lrow;
+                        if (m < g.M) finish_best(g, m, fq, row_mx, row_arg);
+                    }
                 });
             };
             if (kind16 == 0) write_all(std::integral_constant<int, 0>{});
+            else if (kind16 == 2) write_all(std::integral_constant<int, 2>{});
             else write_all(std::integral_constant<int, 1>{});
             OVO_FENCE();
             const int q = lane >> 3, c = (lane & 7) * 8, n = nw + c;
@@ -381,41 +397,9 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                 if constexpr (KIND == 3) { v[0] += addv.x; v[1] += addv.y; v[2] += addv.z; v[3] += addv.w; }
             }
         };
-        // KIND 3 (f32 output += f32 residual: the ViT's / Hiera's out-projection and FC2), round 6: the residual rows of a pass are FETCHED AHEAD -- pass 0's
-        // before the slab is written (the loads fly under the slab write and the workgroup barrier before it), pass 1's before pass 0's rows are finished
-        // (under its slab reads, arithmetic and stores).  In the row loop below a lane met its residual load four rows at a time: 16 dependent
-        // load -> add -> store groups of ~1.5 us each per pass were the +17 us this epilogue cost over the plain one.  Same
-        // arithmetic in the same order: bit-identical (tests/test_gpu_encoder.py).  g.add_ahead = 0 (OVO_8P_ADD_AHEAD=0): the loop loads as before.
-        constexpr int LPR3 = WTN / 4, RPI3 = 64 / LPR3, NIT3 = HM / RPI3, NG3 = NIT3 / 2;      // a pass = two groups of NG3 row instructions
-        float4 ahead_a[KIND == 3 ? NG3 : 1], ahead_b[KIND == 3 ? NG3 : 1];                     // two groups in flight (a third would spill: 128 accumulators are live)
-        const bool use_ahead = KIND == 3 && g.add_ahead;
-        auto fetch_ahead = [&](float4 (&buf)[KIND == 3 ? NG3 : 1], int grp) {                  // grp 0 .. 3: pass grp / 2, its first / second half
-            if constexpr (KIND == 3) {
-                const int mw = m0 + wr * WTM + (grp >> 1) * HM, n = n0 + wc * WTN + (lane % LPR3) * 4;
-#pragma unroll
-                for (int k = 0; k < NG3; ++k) {
-                    const int m = mw + ((grp & 1) * NG3 + k) * RPI3 + lane / LPR3;
-                    const long long md = (m < g.M && n < g.N) ? row_dest(g, m) : -1;
-                    buf[k] = md >= 0 ? *(const float4 *)(g.add + add_row(g, m, md) * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        };
-        auto rows_ahead = [&](const float4 (&buf)[KIND == 3 ? NG3 : 1], int grp, float4 bias) {
-            if constexpr (KIND == 3) {
-                const int mw = m0 + wr * WTM + (grp >> 1) * HM, c = (lane % LPR3) * 4, n = n0 + wc * WTN + c;
-#pragma unroll
-                for (int k = 0; k < NG3; ++k) {
-                    const int r = ((grp & 1) * NG3 + k) * RPI3 + lane / LPR3, m = mw + r;
-                    const f32x4 a = *(const f32x4 *)(slab + r * ROWB + c * 4);
-                    const long long md = (m < g.M && n < g.N) ? row_dest(g, m) : -1;
-                    if (md < 0) continue;
-                    float v[4] = {a[0], a[1], a[2], a[3]};
-                    mathk(0, 0, n, v, bias, buf[k]);
-                    { const f32x4 vv = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(vv, (f32x4 *)((float *)g.C + md * g.ldc + n)); }
-                }
-            }
-        };
-        if (use_ahead) fetch_ahead(ahead_a, 0);
+        // (measured and dropped, round 6: KIND 3's residual rows FETCHED AHEAD of the slab round trip -- two groups of 8 row instructions in flight, pass 1's
+        //  issued under pass 0's rows; 252 VGPRs, no spill, bit-identical.  (16156, 1024, 1024) + f32 residual 52.3 vs 52.4 us, (16156, 1024, 4096) 110.5 vs
+        //  108.6, bench 439.7 vs 442.4 frames/s (profiles/r06_gemm_addahead.txt): the +17 us of this epilogue is the 113 MB it moves, not its load latency.)
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -425,15 +409,6 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     *(f32x4 *)(slab + (i * RT + lrow) * ROWB + (j * CS + lcol) * 4) = piece(pass * (NI / 2) + i, j);
             OVO_FENCE();
             const int mw = m0 + wr * WTM + pass * HM, nw = n0 + wc * WTN;
-            if (KIND == 3 && use_ahead) {
-                const int n = nw + (lane % LPR3) * 4;
-                const float4 bias = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pass == 0) fetch_ahead(ahead_b, 1);            // (64 accumulators just died in the slab)
-                rows_ahead(ahead_a, 2 * pass, bias);
-                if (pass == 0) fetch_ahead(ahead_a, 2);
-                rows_ahead(ahead_b, 2 * pass + 1, bias);
-                if (pass == 0) fetch_ahead(ahead_b, 3);
-            } else
             if (KIND == 3 || (KIND < 0 && g.out_dtype == 0)) {                       // f32 rows: 16 lanes x 16 bytes per row, 4 rows per instruction
                 constexpr int LPR = WTN / 4, RPI = 64 / LPR;
                 const int c = (lane % LPR) * 4, n = nw + c;
@@ -659,9 +634,6 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     static int gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     if (ovo_knobs_dynamic()) gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     g.gelu_lut = !gelu_poly;
-    static int add_ahead = getenv("OVO_8P_ADD_AHEAD") ? atoi(getenv("OVO_8P_ADD_AHEAD")) : 1;      // (0: the residual epilogue loads inside its row loop, as until round 5)
-    if (ovo_knobs_dynamic()) add_ahead = getenv("OVO_8P_ADD_AHEAD") ? atoi(getenv("OVO_8P_ADD_AHEAD")) : 1;
-    g.add_ahead = add_ahead;
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;
     constexpr size_t ring = 2 * (size_t)(BM + BN) * 128;                                  // two K-tile buffers
@@ -696,7 +668,12 @@ int launch8p(const GemmArgs &g, hipStream_t s) {
     // OVO_8P_MFMA32 = 1: the 32 x 32 x 16 MFMA K-loop for the staged epilogues (bf16; measured against the 16 x 16 x 32 loop in profiles/r05*_gemm_mfma32.txt)
     static int mf32 = getenv("OVO_8P_MFMA32") ? atoi(getenv("OVO_8P_MFMA32")) : OVO_8P_MFMA32_DEFAULT;
     if (ovo_knobs_dynamic()) mf32 = getenv("OVO_8P_MFMA32") ? atoi(getenv("OVO_8P_MFMA32")) : OVO_8P_MFMA32_DEFAULT;
-    if (g.best) return launch8p_<BM, BN, WARPS_M, VT, false>(g, s);
+    // the fused argmax: straight from the accumulators -- unless the scores are stored too as plain 2-byte rows, which leave through the staged epilogue
+    static int best_staged = getenv("OVO_8P_BEST_STAGED") ? atoi(getenv("OVO_8P_BEST_STAGED")) : 1;
+    if (ovo_knobs_dynamic()) best_staged = getenv("OVO_8P_BEST_STAGED") ? atoi(getenv("OVO_8P_BEST_STAGED")) : 1;
+    if (g.best && !(best_staged && g.store && g.out_dtype != 0 && !g.add && !g.act && !g.rope_cos && g.win_per <= 0 && BN / (8 / WARPS_M) == 64 && !getenv("OVO_8P_NO_SLAB16")))
+        return launch8p_<BM, BN, WARPS_M, VT, false>(g, s);
+    if (g.best) return launch8p_<BM, BN, WARPS_M, VT, true>(g, s);
     if constexpr (std::is_same<VT, bf16x8>::value) {
         if (mf32) return launch8p_<BM, BN, WARPS_M, VT, true, 32>(g, s);
     }

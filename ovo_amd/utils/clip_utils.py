@@ -18,11 +18,13 @@ _DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 def similarity(img_embed: torch.Tensor, txt_embeds: torch.Tensor, *, siglip: bool = False, logit_scale: float = 0.0,
                logit_bias: float = 0.0, cnt: Optional[torch.Tensor] = None, want_sim: bool = True,
-               want_argmax: bool = False, th: float = 0.0) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
+               want_argmax: bool = False, th: float = 0.0, sim_dtype: Optional[torch.dtype] = None) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
     """S = img_embed @ txt_embeds.T (+ SigLIP epilogue, + 1/cnt row scale, + fused argmax/threshold).
 
     img_embed [N, D] f32 / f16 / bf16 on the GPU, txt_embeds [Q, D].  Returns (S f32[N,Q] | None,
-    classes i64[N] | None, conf f32[N] | None)."""
+    classes i64[N] | None, conf f32[N] | None).  `sim_dtype` (MI355X extension; default f32 as the reference's tensor): torch.float16 /
+    bfloat16 scores -- BASELINE.json configs[4] asks for the cosine scores "within 1e-3 fp16": half the bytes of the N x Q write, and in the
+    large-vocabulary form they leave the GEMM through its staged epilogue (whole 128-byte row segments) with the argmax still fused."""
     if img_embed.dtype not in _DTYPE_CODE:
         raise L.OvoHipError(f"unsupported descriptor dtype {img_embed.dtype}")
     feats = L.dev(img_embed, img_embed.dtype, "img_embed")
@@ -34,20 +36,20 @@ def similarity(img_embed: torch.Tensor, txt_embeds: torch.Tensor, *, siglip: boo
     cls = torch.empty(n, dtype=torch.int64, device=feats.device) if want_argmax else None
     conf = torch.empty(n, dtype=torch.float32, device=feats.device) if want_argmax else None
     if q >= LARGE_VOCABULARY and feats.dtype != torch.float32 and cnt is None and d % 32 == 0 and n > 0:
-        return _similarity_large(feats, txt, siglip, logit_scale, logit_bias, th, cls, conf, want_sim)
+        return _similarity_large(feats, txt, siglip, logit_scale, logit_bias, th, cls, conf, want_sim, sim_dtype or torch.float32)
     sim = torch.empty((n, q), dtype=torch.float32, device=feats.device) if want_sim else None
     if cnt is not None:
         cnt = L.dev(cnt, torch.int32, "cnt")
     L.check(L.load().ovo_similarity(L.ptr(feats), _DTYPE_CODE[feats.dtype], n, d, L.ptr(txt), q, L.ptr(cnt), int(siglip),
                                     float(logit_scale), float(logit_bias), float(th), L.ptr(sim), L.ptr(cls), L.ptr(conf),
                                     L.stream()))
-    return sim, cls, conf
+    return (sim if (sim is None or sim_dtype in (None, torch.float32)) else sim.to(sim_dtype)), cls, conf
 
 
 LARGE_VOCABULARY = 64     # from here on the f16/bf16 score matrix is an MFMA GEMM (BASELINE.json config 5: 1k texts)
 
 
-def _similarity_large(feats, txt, siglip, logit_scale, logit_bias, th, cls, conf, want_sim=True):
+def _similarity_large(feats, txt, siglip, logit_scale, logit_bias, th, cls, conf, want_sim=True, sim_dtype=torch.float32):
     """S = F . T^T on the MFMA GEMM (inputs in F's 16-bit dtype, fp32 accumulation), SigLIP as the GEMM's own epilogue
     (alpha = exp(scale), bias, sigmoid), and the argmax FUSED into that epilogue (`ovo_gemm_argmax`): the score matrix is
     written only when the caller wants it -- 5 GB at 1.25 M points x 1000 texts.  The vocabulary is zero-padded to a
@@ -61,13 +63,15 @@ def _similarity_large(feats, txt, siglip, logit_scale, logit_bias, th, cls, conf
         txt = torch.cat([txt, torch.zeros((qp - q, d), dtype=txt.dtype, device=txt.device)]).contiguous()
     t16 = torch.empty((qp, d), dtype=feats.dtype, device=feats.device)
     L.check(lib.ovo_cast_f32(L.ptr(txt), qp * d, L.ptr(t16), _DTYPE_CODE[feats.dtype], L.stream()))
-    sim = torch.empty((n, qp), dtype=torch.float32, device=feats.device) if want_sim else None
+    if sim_dtype not in _DTYPE_CODE:
+        raise L.OvoHipError(f"unsupported score dtype {sim_dtype}")
+    sim = torch.empty((n, qp), dtype=sim_dtype, device=feats.device) if want_sim else None
     bias = torch.full((qp,), float(logit_bias), dtype=torch.float32, device=feats.device) if siglip else None
     g = L.Gemm()
     g.A, g.lda, g.W, g.ldw, g.bias = feats.data_ptr(), d, t16.data_ptr(), d, L.ptr(bias)
     g.C, g.ldc, g.add, g.ld_add = L.ptr(sim), qp, None, 0
     g.M, g.N, g.K = n, qp, d
-    g.in_dtype, g.out_dtype, g.act, g.alpha = _DTYPE_CODE[feats.dtype], 0, (4 if siglip else 0), (math.exp(logit_scale) if siglip else 1.0)
+    g.in_dtype, g.out_dtype, g.act, g.alpha = _DTYPE_CODE[feats.dtype], _DTYPE_CODE[sim_dtype], (4 if siglip else 0), (math.exp(logit_scale) if siglip else 1.0)
     if cls is not None:
         best = torch.zeros(n, dtype=torch.int64, device=feats.device)         # u64 (score, ~column) keys
         L.check(lib.ovo_gemm_argmax(L.C.byref(g), L.ptr(best), int(want_sim), q, L.stream()))

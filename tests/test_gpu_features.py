@@ -238,6 +238,28 @@ def test_scatter_query_fused_vs_two_passes(D, Q, shards):
         live = mask_row[seg[i]] >= 0
         assert int(changed.sum()) == int(live.sum())
 
+@pytest.mark.parametrize("q,dt", [(1000, torch.float16), (130, torch.bfloat16), (64, torch.float16)])
+def test_large_vocabulary_scores_in_16_bits_with_fused_argmax(q, dt, monkeypatch):
+    """BASELINE configs[4] with the scores it names (fp16): the 16-bit score matrix leaves the GEMM through the staged epilogue with the argmax still
+    fused (round 6).  Classes / confidences equal the f32-score run's exactly (the maximum is taken before the rounding), the 16-bit scores are the
+    rounded f32 scores, and the unstaged form (OVO_8P_BEST_STAGED=0) stores the same bits."""
+    from ovo_amd.utils import clip_utils as CU
+    monkeypatch.setenv("OVO_KNOBS_DYNAMIC", "1")
+    g = torch.Generator(device=DEV).manual_seed(q)
+    n, d = 70_001, 768
+    F = torch.nn.functional.normalize(torch.randn((n, d), generator=g, device=DEV), dim=1).to(dt)
+    T = torch.nn.functional.normalize(torch.randn((q, d), generator=g, device=DEV), dim=1)
+    s32, c32, f32 = CU.similarity(F, T, want_argmax=True)
+    s16, c16, f16 = CU.similarity(F, T, want_argmax=True, sim_dtype=dt)
+    assert s16.dtype == dt and s16.shape == (n, q)
+    assert torch.equal(c16, c32) and torch.equal(f16, f32)
+    assert torch.equal(s16, s32.to(dt))
+    monkeypatch.setenv("OVO_8P_BEST_STAGED", "0")
+    s16b, c16b, f16b = CU.similarity(F, T, want_argmax=True, sim_dtype=dt)
+    assert torch.equal(s16b, s16) and torch.equal(c16b, c16) and torch.equal(f16b, f16)
+    ref = F.float() @ T.to(dt).float().t()
+    assert float((s16.float() - ref).abs().max()) < 1e-3 * (1 if dt == torch.float16 else 4)
+
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_mask_nms_golden(tag):

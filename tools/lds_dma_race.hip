@@ -22,7 +22,7 @@
 struct Args {
     const uint32_t *src;      // [chunks][PIECES][4]
     uint32_t *err;            // [0] mismatching pieces, [1] stale (chunk - 2), [2] early (chunk + 2), [3] other, [4..] first records {chunk, piece, seen0, seen2}
-    int chunks, groups, delay, readback, filler, mode;
+    int chunks, groups, delay, readback, filler, mode, perm_rounds;
 };
 
 constexpr int PIECES = 1920;                   // 16-byte pieces per chunk = 30 KB, as k_mlp_stream<128, 112, 448>
@@ -46,7 +46,21 @@ __global__ void __launch_bounds__(NTHREADS, 512 / NTHREADS) k_race(Args a, int n
         if (a.mode & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-    uint32_t bad = 0, stale = 0, early = 0;
+    uint32_t bad = 0, stale = 0, early = 0, bad_perm = 0;
+    // mode & 4 / 8: a ds_bpermute_b32 self-check (what __shfl_xor compiles to: the LDS crossbar, no LDS memory) while LDS-DMA writes are landing on this CU --
+    // 4: right after this wave's own DMA issue, 8: between the barrier and the DMA issue (only OTHER waves' / workgroups' DMA can be in flight)
+    auto perm_check = [&](int rounds, unsigned salt) {
+        for (int it = 0; it < rounds; ++it) {
+            const unsigned v = (unsigned)lane * 2654435761u + salt + (unsigned)it * 40503u;
+            unsigned r = v;
+            r += (unsigned)__shfl_xor((int)r, 16, 64);
+            r += (unsigned)__shfl_xor((int)r, 32, 64);
+            const unsigned l0 = lane & 15;
+            unsigned want = 0;
+            for (int k = 0; k < 4; ++k) want += (l0 + 16u * k) * 2654435761u + salt + (unsigned)it * 40503u;
+            if (r != want) ++bad_perm;
+        }
+    };
     const unsigned lds_alloc = __builtin_amdgcn_s_getreg((31 << 11) | 6);           // HW_REG_LDS_ALLOC: base [7:0], size [20:12] (granules)
     if (tid == 0 && (lds_alloc & 0xff)) atomicAdd(a.err + 5, 1u);
     if (tid == 0 && blockIdx.x == n_slots - 1) a.err[6] = lds_alloc;
@@ -63,8 +77,10 @@ __global__ void __launch_bounds__(NTHREADS, 512 / NTHREADS) k_race(Args a, int n
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
+            if (a.mode & 8) perm_check(a.perm_rounds, (unsigned)c * 977u + blockIdx.x);
             if (c + 1 < a.chunks) dma(c + 1, std::integral_constant<int, PAR ^ 1>{});
             __builtin_amdgcn_sched_barrier(0);
+            if (a.mode & 4) perm_check(a.perm_rounds, (unsigned)c * 977u + blockIdx.x);
             if (a.delay > 0) {
                 const unsigned long long t0 = __builtin_amdgcn_s_memtime();
                 while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)a.delay) {}
@@ -94,7 +110,7 @@ __global__ void __launch_bounds__(NTHREADS, 512 / NTHREADS) k_race(Args a, int n
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, acc, 0, 0, 0);
                     }
                 }
-                if (acc[0] == 12345.678f) a.err[7] = 1;
+                if (acc[0] == 12345.678f) a.err[6] = 1;
             }
         };
         int c = 0;
@@ -104,8 +120,28 @@ __global__ void __launch_bounds__(NTHREADS, 512 / NTHREADS) k_race(Args a, int n
         }
         if (c < a.chunks) body(std::integral_constant<int, 0>{}, c);
     }
+    if (bad_perm) atomicAdd(a.err + 7, bad_perm);
     if (bad) { atomicAdd(a.err + 0, bad); atomicAdd(a.err + 1, stale); atomicAdd(a.err + 2, early); atomicAdd(a.err + 3, bad - stale - early); }
 #endif
+}
+
+// A kernel with NO LDS-DMA and no LDS memory at all: ds_bpermute_b32 self-checks in a loop (a LayerNorm's wave reduction).  Launched on a second stream
+// beside k_race: its waves share CUs with the DMA kernel's workgroups when registers allow.
+__global__ void __launch_bounds__(256) k_perm_only(uint32_t *err, int rounds) {
+    const int lane = threadIdx.x & 63;
+    uint32_t bad = 0;
+    for (int it = 0; it < rounds; ++it) {
+        const unsigned salt = blockIdx.x * 7919u + (unsigned)it * 40503u;
+        const unsigned v = (unsigned)lane * 2654435761u + salt;
+        unsigned r = v;
+        r += (unsigned)__shfl_xor((int)r, 16, 64);
+        r += (unsigned)__shfl_xor((int)r, 32, 64);
+        unsigned want = 0;
+        for (int k = 0; k < 4; ++k) want += ((lane & 15) + 16u * k) * 2654435761u + salt;
+        if (r != want) ++bad;
+    }
+    if (bad) atomicAdd(err, bad);
+    if (threadIdx.x == 0) atomicAdd(err + 1, 1u);
 }
 
 template <int NTHREADS>
@@ -129,8 +165,8 @@ static void run(const Args &a0, int per_cu, int launches, const char *tag) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     uint32_t h[1024];
     CK(hipMemcpy(h, a.err, 4096, hipMemcpyDeviceToHost));
-    printf("%-46s threads %3d per_cu %d (occupancy %d) delay %4d readback %d filler %d mode %d : %8u bad pieces (stale %u, early %u, other %u) in %d launches, %.1f us each; workgroups with a non-zero LDS base %u (LDS_ALLOC of the last: %08x)\n",
-           tag, NTHREADS, per_cu, occ, a.delay, a.readback, a.filler, a.mode, h[0], h[1], h[2], h[3], launches, 1e3 * ms / launches, h[5], h[6]);
+    printf("%-46s threads %3d per_cu %d (occupancy %d) delay %4d readback %d filler %d mode %2d : %8u WRONG ds_bpermute results; %8u bad pieces (stale %u, early %u, other %u) in %d launches, %.1f us each; workgroups with a non-zero LDS base %u (LDS_ALLOC of the last: %08x)\n",
+           tag, NTHREADS, per_cu, occ, a.delay, a.readback, a.filler, a.mode, h[7], h[0], h[1], h[2], h[3], launches, 1e3 * ms / launches, h[5], h[6]);
     const uint32_t n = h[4] < 8 ? h[4] : 8;
     for (uint32_t i = 0; i < n; ++i)
         printf("      chunk %u piece %u (wave %u): word0 %08x chunk word %u\n", h[8 + i * 4], h[8 + i * 4 + 1] & 0xffffff, h[8 + i * 4 + 1] >> 24, h[8 + i * 4 + 2], h[8 + i * 4 + 3]);
@@ -165,11 +201,41 @@ int main(int argc, char **argv) {
         {256, 2, 2000, 0, 4, 0, "  + 2000 cycles"},
         {256, 2, 0, 1, 4, 0, "  + read-back of own pieces before the barrier"},
         {256, 2, 0, 0, 4, 2, "  + wait for every DMA at its issue"},
+        {512, 1, 0, 0, 4, 4, "ONE workgroup/CU, bpermute checks after own DMA issue"},
+        {512, 1, 0, 0, 4, 8, "ONE workgroup/CU, bpermute checks before own DMA issue"},
+        {256, 1, 0, 0, 4, 4, "ONE 256-thread workgroup/CU, checks after own DMA issue"},
+        {256, 2, 0, 0, 4, 4, "TWO workgroups/CU, bpermute checks after own DMA issue"},
+        {256, 2, 0, 0, 4, 8, "TWO workgroups/CU, checks before own DMA issue (others' DMA only)"},
+        {256, 2, 0, 0, 4, 10, "TWO workgroups/CU, no DMA in flight under the checks of its own workgroup"},
     };
+    a.perm_rounds = 64;
     for (const Cfg &c : cfgs) {
         a.delay = c.delay; a.readback = c.readback; a.filler = c.filler; a.mode = c.mode;
         if (c.threads == 512) run<512>(a, c.per_cu, launches, c.tag);
         else run<256>(a, c.per_cu, launches, c.tag);
+    }
+    // ---- two different kernels on two streams: the DMA kernel (one 512-thread workgroup per CU, 60 KB of LDS, <= 256 VGPRs) and the checker (no LDS)
+    {
+        hipStream_t s1, s2;
+        CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+        uint32_t *perr;
+        CK(hipMalloc(&perr, 64));
+        for (int with_dma = 1; with_dma >= 0; --with_dma) {
+            CK(hipMemset(perr, 0, 64)); CK(hipMemset(a.err, 0, 4096));
+            a.delay = 0; a.readback = 0; a.filler = 4; a.mode = 0;
+            const size_t lds = 2 * (size_t)BUF;
+            CK(hipFuncSetAttribute((const void *)k_race<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CK(hipDeviceSynchronize());
+            for (int l = 0; l < launches; ++l) {
+                if (with_dma) k_race<256><<<256, 256, lds, s1>>>(a, 256);
+                k_perm_only<<<4096, 256, 0, s2>>>(perr, 20000);
+            }
+            CK(hipDeviceSynchronize());
+            uint32_t h[16];
+            CK(hipMemcpy(h, perr, 64, hipMemcpyDeviceToHost));
+            printf("two kernels on two streams: bpermute-only kernel %s the LDS-DMA kernel: %u WRONG ds_bpermute results in %u workgroups x 4 waves x 20000 checks\n",
+                   with_dma ? "BESIDE" : "WITHOUT", h[0], h[1]);
+        }
     }
     return 0;
 }

@@ -18,17 +18,18 @@ for s0 in range(0, n, 1 << 20):                                  # in slices: no
     F[s0:s0 + (1 << 20)] = torch.nn.functional.normalize(torch.randn(min(1 << 20, n - s0), d, device="cuda"), dim=1).half()
 T = torch.nn.functional.normalize(torch.randn(q, d, device="cuda"), dim=1)
 flops = 2.0 * n * q * d
-cases = ((True, "scores + classes", n * d * 2 + n * q * 4 + n * 20), (False, "classes only    ", (n * d + 8 * n) * 2))
+cases = ((True, "f32 scores + classes", n * d * 2 + n * q * 4 + n * 20, None), (True, "f16 scores + classes", n * d * 2 + n * q * 2 + n * 20, torch.float16),
+         (False, "classes only        ", (n * d + 8 * n) * 2, None))
 if n * q * 4 > 20e9:
-    cases = cases[1:]                                             # the 40 GB score matrix of the full map is never wanted: classes only
-for want_sim, label, bytes_ in cases:
+    cases = cases[2:]                                             # the 40 GB score matrix of the full map is never wanted: classes only
+for want_sim, label, bytes_, sdt in cases:
     for _ in range(2):
-        clip_utils.similarity(F, T, want_argmax=True, want_sim=want_sim)
+        clip_utils.similarity(F, T, want_argmax=True, want_sim=want_sim, sim_dtype=sdt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 5
     for _ in range(reps):
-        sim, cls, conf = clip_utils.similarity(F, T, want_argmax=True, want_sim=want_sim)
+        sim, cls, conf = clip_utils.similarity(F, T, want_argmax=True, want_sim=want_sim, sim_dtype=sdt)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
     print(f"query {n} x {d} f16  x  {q} texts, {label}: {ms:.2f} ms   {flops / ms / 1e9:.0f} TFLOP/s   {bytes_ / ms / 1e6:.0f} GB/s algorithmic   "
