@@ -1,6 +1,8 @@
 // fusion.hip -- multi-view descriptor fusion (instance form) and dense per-point scatter-accumulate.
 #include <float.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -274,20 +276,21 @@ __global__ void __launch_bounds__(512) k_scatter_query(const int32_t *__restrict
         // the two rows this lane moves (lanes 0 .. 15 hold candidates 0 .. 15)
         const int li_a = __shfl(li, ra, 64), li_b = __shfl(li, rb, 64), row_a = __shfl(row, ra, 64), row_b = __shfl(row, rb, 64);
         const bool live_a = row_a >= 0, live_b = row_b >= 0;
-        float *ap_a = acc + (int64_t)li_a * D + pc * 4, *ap_b = acc + (int64_t)li_b * D + pc * 4;
+        // (rows that are not live read row 0 of both tables -- an unconditional 16-byte load -- and store nothing: with the load inside a select the compiler
+        //  made four guarded dword loads of each, 75 us per launch)
+        float *ap_a = acc + (int64_t)(live_a ? li_a : 0) * D + pc * 4, *ap_b = acc + (int64_t)(live_b ? li_b : 0) * D + pc * 4;
         const float *dp_a = desc + (int64_t)(live_a ? row_a : 0) * D + pc * 4, *dp_b = desc + (int64_t)(live_b ? row_b : 0) * D + pc * 4;
         sq_f32x4 s = {0.f, 0.f, 0.f, 0.f};
         // A BLOCK of U steps is fetched whole before its first add, and the next block is in flight while this one is added, stored and multiplied
         constexpr int U = 4;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         auto fetch = [&](float4 (&a)[2 * U], float4 (&d)[2 * U], int k0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const bool in = k0 + 32 * u < D32;
-                a[2 * u] = (in && live_a) ? *(const float4 *)(ap_a + k0 + 32 * u) : z4;
-                a[2 * u + 1] = (in && live_b) ? *(const float4 *)(ap_b + k0 + 32 * u) : z4;
-                d[2 * u] = (in && live_a) ? *(const float4 *)(dp_a + k0 + 32 * u) : z4;
-                d[2 * u + 1] = (in && live_b) ? *(const float4 *)(dp_b + k0 + 32 * u) : z4;
+                const int k = k0 + 32 * u < D32 ? k0 + 32 * u : 0;                       // (steps past the row: re-read its start, never used)
+                a[2 * u] = *(const float4 *)(ap_a + k);
+                a[2 * u + 1] = *(const float4 *)(ap_b + k);
+                d[2 * u] = *(const float4 *)(dp_a + k);
+                d[2 * u + 1] = *(const float4 *)(dp_b + k);
             }
         };
         auto mfma8 = [&](int k, const sq_f32x4 &a0, const sq_f32x4 &a1) {
@@ -301,15 +304,18 @@ __global__ void __launch_bounds__(512) k_scatter_query(const int32_t *__restrict
             s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.z, a1[2], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_16x16x4f32(t1.w, a1[3], s, 0, 0, 0);
         };
-        auto finish = [&](float4 (&a)[2 * U], float4 (&d)[2 * U], int k0) {
+        // ALL: every one of the wave's 16 rows is live (the usual case) -- its stores are unconditional.  A store under a per-lane condition is a basic
+        // block of its own, and the wait-count pass then drains EVERYTHING in flight (s_waitcnt vmcnt(0)) before it: the next block's loads with it.
+        auto finish = [&](auto ALL_, float4 (&a)[2 * U], float4 (&d)[2 * U], int k0) {
+            constexpr bool ALL = decltype(ALL_)::value;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int k = k0 + 32 * u;
                 if (k >= D32) break;
                 const sq_f32x4 xa = {a[2 * u].x + d[2 * u].x, a[2 * u].y + d[2 * u].y, a[2 * u].z + d[2 * u].z, a[2 * u].w + d[2 * u].w};
                 const sq_f32x4 xb = {a[2 * u + 1].x + d[2 * u + 1].x, a[2 * u + 1].y + d[2 * u + 1].y, a[2 * u + 1].z + d[2 * u + 1].z, a[2 * u + 1].w + d[2 * u + 1].w};
-                if (live_a) __builtin_nontemporal_store(xa, (sq_f32x4 *)(ap_a + k));
-                if (live_b) __builtin_nontemporal_store(xb, (sq_f32x4 *)(ap_b + k));
+                if (ALL || live_a) __builtin_nontemporal_store(xa, (sq_f32x4 *)(ap_a + k));
+                if (ALL || live_b) __builtin_nontemporal_store(xb, (sq_f32x4 *)(ap_b + k));
                 if (T) {
                     char *sl = slab + (u & 1) * SQ_SLAB;                                 // (the step before last read the other slab: same wave, LDS in order)
                     *(sq_f32x4 *)(sl + wr_a) = xa;
@@ -320,18 +326,18 @@ __global__ void __launch_bounds__(512) k_scatter_query(const int32_t *__restrict
                 }
             }
         };
-        {
+        auto walk = [&](auto ALL_) {
             float4 xa[2 * U], xd[2 * U], ya[2 * U], yd[2 * U];
             fetch(xa, xd, 0);
             for (int k0 = 0; k0 < D32; k0 += 64 * U) {                                 // two blocks per trip: static buffer roles
-                if (k0 + 32 * U < D32) fetch(ya, yd, k0 + 32 * U);
-                finish(xa, xd, k0);
-                if (k0 + 32 * U < D32) {
-                    if (k0 + 64 * U < D32) fetch(xa, xd, k0 + 64 * U);
-                    finish(ya, yd, k0 + 32 * U);
-                }
+                fetch(ya, yd, k0 + 32 * U);                                            // (past the row's end: a re-read of its start, never used)
+                finish(ALL_, xa, xd, k0);
+                fetch(xa, xd, k0 + 64 * U);
+                finish(ALL_, ya, yd, k0 + 32 * U);
             }
-        }
+        };
+        if ((lm & 0xffffull) == 0xffffull) walk(std::integral_constant<bool, true>{});
+        else walk(std::integral_constant<bool, false>{});
         if (D32 < D) {                                                               // one 16-wide tail step: pieces 0 .. 3 of every row
             sq_f32x4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa;
             if (pc < 4) {

@@ -426,7 +426,9 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     const float4 addv = (KIND == 3 || g.add) ? *(const float4 *)(g.add + add_row(g, m, md) * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                     float v[4] = {a[0], a[1], a[2], a[3]};
                     mathk(tk, nh, n, v, bias, addv);
-                    { const f32x4 vv = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(vv, (f32x4 *)((float *)g.C + md * g.ldc + n)); }
+                    { const f32x4 vv = {v[0], v[1], v[2], v[3]};
+                      if (g.res_plain) *(f32x4 *)((float *)g.C + md * g.ldc + n) = vv;        // (OVO_8P_RES_PLAIN=1, measurement: the f32 stream kept in the caches for the LayerNorm that follows)
+                      else __builtin_nontemporal_store(vv, (f32x4 *)((float *)g.C + md * g.ldc + n)); }
                 }
             } else {                                      // 2-byte rows: 8 lanes x 16 bytes per row, 8 rows per instruction
                 constexpr int LPR = WTN / 8, RPI = 64 / LPR;
@@ -634,6 +636,9 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     static int gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     if (ovo_knobs_dynamic()) gelu_poly = getenv("OVO_GELU_POLY") != nullptr;
     g.gelu_lut = !gelu_poly;
+    static int res_plain = getenv("OVO_8P_RES_PLAIN") ? atoi(getenv("OVO_8P_RES_PLAIN")) : 0;
+    if (ovo_knobs_dynamic()) res_plain = getenv("OVO_8P_RES_PLAIN") ? atoi(getenv("OVO_8P_RES_PLAIN")) : 0;
+    g.res_plain = res_plain;
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;
     constexpr size_t ring = 2 * (size_t)(BM + BN) * 128;                                  // two K-tile buffers

@@ -43,6 +43,7 @@ struct GemmArgs {
     int tail_wait;             // gemm8p: 1 = a wave waits for its epilogue stores before it ends (OVO_8P_TAILWAIT, measurement)
     int rope_lds;              // k_gemm8p: the rotary epilogue stages its table slice in LDS (OVO_8P_ROPE_LDS)
     int slab16;                // k_gemm8p: 2-byte outputs cross the epilogue's LDS slab already rounded (OVO_8P_NO_SLAB16: the f32 slab)
+    int res_plain;             // k_gemm8p: the f32 + residual epilogue stores with the default cache policy instead of non-temporal (OVO_8P_RES_PLAIN, measurement)
     // k_gemm<128, 448> (gemm.hip, round 5): a workgroup owns whole rows (N = 448 = BN), so after the f32 result (+ residual) is stored the LayerNorm of the
     // rows that FOLLOWS the product in Hiera stage 3 (norm2 before the MLP) is taken from the accumulators: rln_out bf16 [C rows, rln_ld] = LN(C row)
     const float *rln_g, *rln_b; float rln_eps; uint16_t *rln_out; long long rln_ld;

@@ -190,6 +190,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
                         ht = (ht * 16777619u) ^ (__float_as_uint(lg[d0 + e]) + 3u * __float_as_uint(lb[d0 + e]) + (unsigned)lane * 2654435761u);
                     }
                 pre_h[rb][0] = hx; pre_h[rb][1] = __float_as_uint(mean) * 31u + __float_as_uint(rstd) + (unsigned)lane * 2654435761u; pre_h[rb][2] = ht;
+                // (dbg & 512) the statistics AGAIN from the same registers, through the same instructions: does the wave reduction repeat?  Records
+                // {workgroup, row block, lane, sum as used, sum again, local part as used, local part again} behind the other records
+                if (g.dbg_out && (g.dbg & 512)) {
+                    float loc = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        float v8[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { v8[e] = xv[ks][e]; asm volatile("" : "+v"(v8[e])); }
+                        loc += ((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7]));
+                    }
+                    float s2 = loc;
+                    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+                    if (__float_as_uint(s2) != __float_as_uint(sum)) {
+                        const unsigned at = atomicAdd(g.dbg_out + 5, 1u);
+                        if (at < 40) {
+                            unsigned *r = g.dbg_out + 8 + 800 - 8 * 40 + at * 8;          // (the last 40 x 8 words of the verify-record area)
+                            r[0] = blockIdx.x; r[1] = (unsigned)((grp * WPB + wave) * RB + rb); r[2] = (unsigned)lane; r[3] = __float_as_uint(sum); r[4] = __float_as_uint(s2);
+                            r[5] = __float_as_uint(loc); r[6] = __float_as_uint(mean); r[7] = __float_as_uint(rstd);
+                        }
+                    }
+                }
             }
 #endif
 #pragma unroll

@@ -70,8 +70,25 @@ def stages(variant, dbg, iters=8):
                 print(f"      launch {it} row block {b} (workgroup slot {(b // (4 * 2)) % 512 if variant == 2 else -1}): output wrong {bool(bad_out[b])}; stages that differ: {[names[k] for k in st][:5]}")
     print(f"variant {variant} dbg {dbg}: wrong row blocks {n_bad_out} (+{n_hash_only} with a wrong hash but right output) in {iters} launches; FIRST wrong stage: {first}")
     sys.stdout.flush()
+def again(variant, iters=10):
+    """dbg & 512: the row sum recomputed from the same registers right after it was used."""
+    import struct
+    os.environ["OVO_MLP_RB"], os.environ["OVO_MLP_DBG"] = str(variant), "512"
+    out.zero_()
+    bad = 0
+    for it in range(iters):
+        xf = x0.clone(); call(xf); torch.cuda.synchronize()
+        bad += int(not torch.equal(xf, ref))
+    h = out.cpu().tolist()
+    f = lambda u: struct.unpack("f", struct.pack("I", u & 0xffffffff))[0]
+    print(f"variant {variant} dbg 512: {bad} of {iters} launches differ; lanes whose row sum does not repeat: {h[5]}")
+    for i in range(min(h[5], 40)):
+        r = h[8 + 800 - 320 + 8 * i: 8 + 800 - 320 + 8 * i + 8]
+        print(f"      workgroup {r[0]} row block {r[1]} lane {r[2]} (row {r[2] & 15}, quarter {r[2] >> 4}): sum as used {f(r[3])!r} again {f(r[4])!r} local part again {f(r[5])!r} mean {f(r[6])!r} rstd {f(r[7])!r}")
+    sys.stdout.flush()
 if os.environ.get("STAGES", "1") != "0":
-    stages(2, 0); stages(2, 2); stages(2, 128); stages(3, 0)
+    again(2); again(2); again(1)
+    stages(2, 0); stages(2, 128); stages(3, 0)
 if os.environ.get("STAGES") == "only":
     sys.exit(0)
 run(1, 0, "production: ONE 512-thread workgroup per CU")
