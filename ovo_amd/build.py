@@ -66,6 +66,10 @@ def build(force: bool = False, verbose: bool = True, gemm_debug: bool = False, e
     if experimental:                                   # kernels that were measured and lost (persistent 256 x 128 GEMM, one-launch round chain)
         for f in ("gemm8q.hip", "geometry.hip"):
             EXTRA[f] = EXTRA.get(f, []) + ["-DOVO_EXPERIMENTAL"]
+    # experiments only (tools/): OVO_HIPCC_EXTRA="mlp_stream.hip=-fno-slp-vectorize;gemm8p.hip=-mllvm,-amdgpu-..." adds flags to single translation units
+    for item in filter(None, os.environ.get("OVO_HIPCC_EXTRA", "").split(";")):
+        f, _, flags = item.partition("=")
+        EXTRA[f] = EXTRA.get(f, []) + [x for x in flags.split(",") if x]
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = sources()
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:

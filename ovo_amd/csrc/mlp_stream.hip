@@ -176,6 +176,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
                     }
                 }
             }
+#ifdef OVO_GEMM_DEBUG
+            const float q_loc_used = q;
+            const unsigned long long exec_used = __builtin_amdgcn_read_exec();
+#endif
             q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
             const float rstd = rsqrtf(q / (float)D + g.eps);
 #ifdef OVO_GEMM_DEBUG
@@ -192,7 +196,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
                 pre_h[rb][0] = hx; pre_h[rb][1] = __float_as_uint(mean) * 31u + __float_as_uint(rstd) + (unsigned)lane * 2654435761u; pre_h[rb][2] = ht;
                 // (dbg & 512) the statistics AGAIN from the same registers, through the same instructions: does the wave reduction repeat?  Records
                 // {workgroup, row block, lane, sum as used, sum again, local part as used, local part again} behind the other records
+                if (g.dbg_out && (g.dbg & 1024) && lane < 16) {              // the statistics themselves, per row: [blocks][16][4] floats behind the hashes
+                    const long long b = (grp * WPB + wave) * RB + rb;
+                    if (b < blocks) {
+                        float *so = (float *)(g.dbg_out + 8 + 800) + (long long)(5 + NCH) * blocks + (b * 16 + lane) * 4;
+                        so[0] = sum; so[1] = q; so[2] = mean; so[3] = rstd;
+                    }
+                }
                 if (g.dbg_out && (g.dbg & 512)) {
+                    const int c_dummy = 0;
                     float loc = 0.f;
 #pragma unroll
                     for (int ks = 0; ks < KS1; ++ks) {
@@ -203,12 +215,33 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_stream(MlpArgs g, int n_slo
                     }
                     float s2 = loc;
                     s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-                    if (__float_as_uint(s2) != __float_as_uint(sum)) {
+                    float mean2 = s2 / (float)D;
+                    asm volatile("" : "+v"(mean2));
+                    float q2 = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        if ((ks * 4 + fq) * 8 < D) {
+#pragma unroll
+                            for (int e = 0; e < 8; e += 2) {
+                                float x0 = xv[ks][e], x1 = xv[ks][e + 1];
+                                asm volatile("" : "+v"(x0), "+v"(x1));
+                                const float a0 = x0 - mean2, a1 = x1 - mean2;
+                                q2 += a0 * a0 + a1 * a1;
+                            }
+                        }
+                    }
+                    const float q2loc = q2;
+                    q2 += __shfl_xor(q2, 16, 64); q2 += __shfl_xor(q2, 32, 64);
+                    const float rstd2 = rsqrtf(q2 / (float)D + g.eps);
+                    if (__float_as_uint(s2) != __float_as_uint(sum) || __float_as_uint(q2) != __float_as_uint(q) || __float_as_uint(rstd2) != __float_as_uint(rstd)) {
                         const unsigned at = atomicAdd(g.dbg_out + 5, 1u);
                         if (at < 40) {
                             unsigned *r = g.dbg_out + 8 + 800 - 8 * 40 + at * 8;          // (the last 40 x 8 words of the verify-record area)
                             r[0] = blockIdx.x; r[1] = (unsigned)((grp * WPB + wave) * RB + rb); r[2] = (unsigned)lane; r[3] = __float_as_uint(sum); r[4] = __float_as_uint(s2);
-                            r[5] = __float_as_uint(loc); r[6] = __float_as_uint(mean); r[7] = __float_as_uint(rstd);
+                            r[5] = __float_as_uint(q); r[6] = __float_as_uint(q2); r[7] = __float_as_uint(q2loc);
+                            unsigned *r2 = g.dbg_out + 8 + 800 - 8 * 40 - 8 * 40 + at * 8;   // (a second record block below the first)
+                            r2[0] = __float_as_uint(q_loc_used); r2[1] = __float_as_uint(mean); r2[2] = __float_as_uint(mean2); r2[3] = (unsigned)exec_used; r2[4] = (unsigned)(exec_used >> 32);
+                            r2[5] = (unsigned)__builtin_amdgcn_read_exec(); r2[6] = (unsigned)(__builtin_amdgcn_read_exec() >> 32); r2[7] = (unsigned)c_dummy;
                         }
                     }
                 }

@@ -21,7 +21,7 @@ w2 = (torch.randn(d, hid, generator=g) * hid ** -0.5).to(DEV, torch.bfloat16)
 b1, b2 = torch.randn(hid, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
 NB = (rows + 15) // 16
 HW = 5 + hid // 64
-out = torch.zeros(8 + 4 * 200 + HW * NB, dtype=torch.int32, device=DEV)
+out = torch.zeros(8 + 4 * 200 + HW * NB + 64 * NB, dtype=torch.int32, device=DEV)
 os.environ["OVO_MLP_DBG_OUT"] = str(out.data_ptr())
 def call(xf):
     rc = lib.ovo_mlp_f32(xf.data_ptr(), rows, d, gamma.data_ptr(), beta.data_ptr(), 1e-6, w1.data_ptr(), k1, b1.data_ptr(), hid, w2.data_ptr(), hid, b2.data_ptr(), L.stream())
@@ -50,7 +50,7 @@ def stages(variant, dbg, iters=8):
     """Per row block: hashes of the LayerNorm-ed fragments, every chunk's hidden fragments and the FC2 accumulators (dbg & 256), against variant 1's."""
     os.environ["OVO_MLP_RB"], os.environ["OVO_MLP_DBG"] = "1", "256"
     out.zero_(); xf = x0.clone(); call(xf); torch.cuda.synchronize()
-    want = out[808:].view(NB, HW).clone()
+    want = out[808:808 + HW * NB].view(NB, HW).clone()
     assert torch.equal(xf, ref)
     os.environ["OVO_MLP_RB"], os.environ["OVO_MLP_DBG"] = str(variant), str(dbg | 256)
     names = ["x as loaded", "mean / rstd", "gamma / beta as read from LDS", "LN fragments"] + [f"hidden chunk {c}" for c in range(HW - 5)] + ["FC2 accumulators"]
@@ -58,7 +58,7 @@ def stages(variant, dbg, iters=8):
     n_bad_out, n_hash_only = 0, 0
     for it in range(iters):
         out.zero_(); xf = x0.clone(); call(xf); torch.cuda.synchronize()
-        got = out[808:].view(NB, HW)
+        got = out[808:808 + HW * NB].view(NB, HW)
         bad_out = ((xf - ref).abs().amax(1) > 0).view(-1, 16).any(1)
         bad_hash = (got != want)
         for b in torch.nonzero(bad_out | bad_hash.any(1)).flatten().tolist():
@@ -81,13 +81,40 @@ def again(variant, iters=10):
         bad += int(not torch.equal(xf, ref))
     h = out.cpu().tolist()
     f = lambda u: struct.unpack("f", struct.pack("I", u & 0xffffffff))[0]
-    print(f"variant {variant} dbg 512: {bad} of {iters} launches differ; lanes whose row sum does not repeat: {h[5]}")
+    print(f"variant {variant} dbg 512: {bad} of {iters} launches differ; lanes whose row sum / squared deviations / rstd do not repeat: {h[5]}")
     for i in range(min(h[5], 40)):
         r = h[8 + 800 - 320 + 8 * i: 8 + 800 - 320 + 8 * i + 8]
-        print(f"      workgroup {r[0]} row block {r[1]} lane {r[2]} (row {r[2] & 15}, quarter {r[2] >> 4}): sum as used {f(r[3])!r} again {f(r[4])!r} local part again {f(r[5])!r} mean {f(r[6])!r} rstd {f(r[7])!r}")
+        r2 = h[8 + 800 - 640 + 8 * i: 8 + 800 - 640 + 8 * i + 8]
+        if i < 12 or (r[2] & 15) == 0:
+            print(f"      workgroup {r[0]} row block {r[1]} lane {r[2]} (row {r[2] & 15}, quarter {r[2] >> 4}): sum as used {f(r[3])!r} again {f(r[4])!r}; squared deviations as used {f(r[5])!r} again "
+                  f"{f(r[6])!r}; this lane's part as used {f(r2[0])!r} again {f(r[7])!r}; mean {f(r2[1])!r} again {f(r2[2])!r}; exec at use {(r2[4] & 0xffffffff) << 32 | (r2[3] & 0xffffffff):016x} now {(r2[6] & 0xffffffff) << 32 | (r2[5] & 0xffffffff):016x}")
     sys.stdout.flush()
+def values(variant, iters=10):
+    """dbg & 1024: (sum, squared deviations, mean, rstd) of every row, against variant 1's and against torch's on the same x."""
+    os.environ["OVO_MLP_RB"], os.environ["OVO_MLP_DBG"] = "1", "1024"
+    out.zero_(); xf = x0.clone(); call(xf); torch.cuda.synchronize()
+    base = 808 + HW * NB
+    want = out[base:base + 64 * NB].view(torch.float32).view(NB * 16, 4).clone()
+    os.environ["OVO_MLP_RB"] = str(variant)
+    shown = 0
+    for it in range(iters):
+        out.zero_(); xf = x0.clone(); call(xf); torch.cuda.synchronize()
+        got = out[base:base + 64 * NB].view(torch.float32).view(NB * 16, 4)
+        bad_rows = torch.nonzero((got.view(torch.int32) != want.view(torch.int32)).any(1)).flatten()[:rows]
+        wrong_out = torch.nonzero(((xf - ref).abs().amax(1) > 0)).flatten()
+        print(f"variant {variant} launch {it}: rows with different statistics {bad_rows.numel()}, rows with a wrong result {wrong_out.numel()}")
+        for r in bad_rows.tolist()[:6]:
+            if shown < 24:
+                shown += 1
+                xs = x0[r].double()
+                print(f"      row {r} (block {r // 16}): sum, sq.dev, mean, rstd = {got[r].tolist()}  variant 1: {want[r].tolist()}  torch: sum {float(xs.sum()):.6f} "
+                      f"sq.dev {float(((xs - xs.mean()) ** 2).sum()):.6f}")
+    sys.stdout.flush()
+if os.environ.get("STAGES") == "again":
+    again(2, 20); again(2, 20); again(1)
+    sys.exit(0)
 if os.environ.get("STAGES", "1") != "0":
-    again(2); again(2); again(1)
+    values(2); again(2); again(1)
     stages(2, 0); stages(2, 128); stages(3, 0)
 if os.environ.get("STAGES") == "only":
     sys.exit(0)
