@@ -19,8 +19,11 @@ ARCH = "gfx950"
 
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result", "-I" + os.path.join(os.path.dirname(HERE), "include")]
-# per-file extra flags: geometry must not contract a*b+c into fma on its own (bit-exact parity)
-EXTRA = {"geometry.hip": ["-ffp-contract=off"]}
+# per-file extra flags: geometry must not contract a*b+c into fma on its own (bit-exact parity); the three translation units with a LayerNorm in
+# their operand load are built WITHOUT SLP vectorisation -- its packed-f32 (v_pk_*_f32) statistics chain gave wrong variances one time in ~10^5
+# whenever a wave of another workgroup shared the SIMD (round 6, csrc/mlp_stream.hip: mlp_stream_launch)
+EXTRA = {"geometry.hip": ["-ffp-contract=off"], "mlp_stream.hip": ["-fno-slp-vectorize"], "gemm_stream.hip": ["-fno-slp-vectorize"],
+         "winattn.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc() -> str:

@@ -330,6 +330,8 @@ __device__ __forceinline__ void wq_push(WaveQueue &q, int &tail, bool keep, floa
 // points of this rank's block-cyclic shard are listed, as LOCAL row numbers (the map of ovo_scatter_accum_touched).
 struct HitSink { int32_t *hits; int32_t *n_hits; int shard_rank, shard_count, block_log2; };
 
+constexpr int CNT_SLOTS = 32, CNT_STRIDE = 16;                     // counter slots of a tracking step; u64 words between two slots (128 bytes)
+
 // The chain of one batch of survivors (lane < count active): project, depth-test, colour-frame remap, seg lookup, vote.
 __device__ __forceinline__ void track_batch(const WaveQueue &q, int head, int count, const ovo_camera_t &cam, const float *__restrict__ depth,
                                             const int32_t *__restrict__ point_ins, const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
@@ -386,7 +388,7 @@ __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const in
                                   const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
                                   ovo_ratio_t ratio, int16_t *__restrict__ point_seg,
                                   int32_t *__restrict__ hist, int n_masks, int hist_cols,
-                                  unsigned long long *__restrict__ counters, const HitSink &sink) {
+                                  unsigned long long *__restrict__ counters, int cnt_slots, const HitSink &sink) {
     __shared__ WaveQueue s_q[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     WaveQueue &q = s_q[wave];
@@ -430,24 +432,33 @@ __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const in
     __syncthreads();
     if (threadIdx.x < 2) {
         const long long t = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
-        if (t) atomicAdd(counters + threadIdx.x, (unsigned long long)t);
+        if (t) atomicAdd(counters + (size_t)(b.bid % cnt_slots) * CNT_STRIDE + threadIdx.x, (unsigned long long)t);
     }
     __syncthreads();
 }
 
+// Round 6: the counter pair is SPREAD over CNT_SLOTS slots a cache line apart (workgroup b adds to slot b % CNT_SLOTS; the publisher sums them): 1024-4096
+// workgroups ending on the same two addresses serialised in one L2 atomic unit (~3 ns each).  cnt_slots = 1: the caller's own i64[2] (ovo_track_project).
 // Grid of the tracking pass: 1024 workgroups, not the usual 2048.  Every workgroup ends with one atomic pair on the same two counters and a
 // ragged last batch of its waves' rings; with twice the workgroups those fixed costs outweigh the extra waves in flight (tools/geom_bench.py,
 // 1 M / 5 M / 10 M points: 33.4 / 47.0 / 62.3 us at 2048, 23.0 / 38.4 / 54.1 at 1024, 22.1 / 49.9 / 81.3 at 512; without the counter atomics 4096
 // workgroups would take 48.7 us at 10 M -- the same-address atomics cost ~3 ns each).
-constexpr int TRACK_GRID_CAP = 1024;
+constexpr int TRACK_GRID_CAP_DEFAULT = 1024;
+static int track_grid_cap() {
+    static int cap = getenv("OVO_TRACK_GRID_CAP") ? atoi(getenv("OVO_TRACK_GRID_CAP")) : TRACK_GRID_CAP_DEFAULT;
+    if (ovo_knobs_dynamic()) cap = getenv("OVO_TRACK_GRID_CAP") ? atoi(getenv("OVO_TRACK_GRID_CAP")) : TRACK_GRID_CAP_DEFAULT;
+    return cap > 0 ? cap : TRACK_GRID_CAP_DEFAULT;
+}
+#define TRACK_GRID_CAP track_grid_cap()
 __global__ void __launch_bounds__(256) k_track_project(const float *__restrict__ pts, const int32_t *__restrict__ point_ins,
                                                        int64_t n, ovo_camera_t cam, const float *__restrict__ depth,
                                                        const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
                                                        ovo_ratio_t ratio, int16_t *__restrict__ point_seg,
                                                        int32_t *__restrict__ hist, int n_masks, int hist_cols,
-                                                       unsigned long long *__restrict__ counters, const long long *__restrict__ n_dev, HitSink sink) {
+                                                       unsigned long long *__restrict__ counters, int cnt_slots, const long long *__restrict__ n_dev,
+                                                       HitSink sink) {
     if (n_dev) n = *n_dev;                                         // device-resident map size (ovo_track_step): no host round trip
-    dev_track_project(this_block(), pts, point_ins, n, cam, depth, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, counters, sink);
+    dev_track_project(this_block(), pts, point_ins, n, cam, depth, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, counters, cnt_slots, sink);
 }
 
 // ---- a6: per-mask statistics ----
@@ -795,7 +806,8 @@ __global__ void __launch_bounds__(256) k_vote_decide(const int32_t *__restrict__
 struct Publish {
     const int32_t *res;          // device result block
     volatile int32_t *host;      // pinned host copy (same layout), host[0] = seq is written last
-    const unsigned long long *counters;   // {in frustum, matched}
+    const unsigned long long *counters;   // {in frustum, matched} x cnt_slots slots, CNT_STRIDE words apart
+    int cnt_slots;
     const long long *n_dev; long long n_host;
     unsigned int *ticket;
     int32_t seq, n_ints;
@@ -857,10 +869,14 @@ __device__ void dev_fuse_row(int d, int part, int parts, uint4 *masks, long long
 
 // the keyframe's result block -> pinned host memory, sequence word last (one workgroup)
 __device__ void dev_publish(int32_t *res, const Publish &pb, long long n_points) {
-    if (threadIdx.x == 0) {
-        res[1] = (int32_t)n_points;
-        res[2] = (int32_t)__hip_atomic_load(pb.counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        res[3] = (int32_t)__hip_atomic_load(pb.counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 64) {                                         // the counter slots, summed by the first wave
+        long long c0 = 0, c1 = 0;
+        if ((int)threadIdx.x < pb.cnt_slots) {
+            c0 = (long long)__hip_atomic_load(pb.counters + (size_t)threadIdx.x * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c1 = (long long)__hip_atomic_load(pb.counters + (size_t)threadIdx.x * CNT_STRIDE + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o, 64); c1 += __shfl_xor(c1, o, 64); }
+        if (threadIdx.x == 0) { res[1] = (int32_t)n_points; res[2] = (int32_t)c0; res[3] = (int32_t)c1; }
     }
     __syncthreads();
     if (!pb.host) return;
@@ -1121,7 +1137,7 @@ __global__ void __launch_bounds__(256) k_round_chain(const ChainKf *__restrict__
         // ---- pass F: cull / project / depth-test / seg lookup / votes over the whole map (ovo.py:208-222)
         if (kf.do_track && n_now > 0)
             dev_track_project(b, kf.xyz, kf.ins, n_now, kf.cam, kf.filter ? kf.depth_f : kf.depth_t, kf.seg_map, kf.seg_h, kf.seg_w, kf.ratio,
-                              kf.point_seg, kf.hist, kf.n_masks, kf.hist_cols, kf.counters, HitSink{nullptr, nullptr, 0, 1, 0});
+                              kf.point_seg, kf.hist, kf.n_masks, kf.hist_cols, kf.counters, CNT_SLOTS, HitSink{nullptr, nullptr, 0, 1, 0});
         grid_sync(gb, gen);                                                                                       // 6
         // ---- pass G: per-mask vote statistics, then the decisions in mask order (ovo.py:255-282)
         if (kf.do_track)
@@ -1154,7 +1170,7 @@ __global__ void __launch_bounds__(256) k_round_chain(const ChainKf *__restrict__
             }
             if (kf.do_track) {
                 Publish pb;
-                pb.res = kf.res; pb.host = kf.result; pb.counters = kf.counters; pb.n_dev = nullptr; pb.n_host = n_now; pb.ticket = nullptr;
+                pb.res = kf.res; pb.host = kf.result; pb.counters = kf.counters; pb.cnt_slots = CNT_SLOTS; pb.n_dev = nullptr; pb.n_host = n_now; pb.ticket = nullptr;
                 pb.seq = kf.seq; pb.n_ints = 8 + 6 * kf.n_masks;
                 if (threadIdx.x == 0) kf.res[6] = (int32_t)__hip_atomic_load(gb.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dev_publish(kf.res, pb, n_now);
@@ -1231,7 +1247,7 @@ int ovo_track_project(const float *pts, const int32_t *point_ins, int64_t n, con
     if (prof) ovo_prof_begin(2, 14.0 * (double)n, s);          // 12 B xyz read + 2 B mask id written per map point
     k_track_project<<<ovo_grid(n, 256, TRACK_GRID_CAP), 256, 0, s>>>(pts, point_ins, n, *cam, depth, seg_map, seg_h, seg_w, ratio,
                                                       point_seg, hist, n_masks, hist_cols,
-                                                      (unsigned long long *)counters, nullptr, HitSink{nullptr, nullptr, 0, 1, 0});
+                                                      (unsigned long long *)counters, 1, nullptr, HitSink{nullptr, nullptr, 0, 1, 0});
     if (prof) ovo_prof_end(s);
     OVO_CHECK_LAUNCH();
     return OVO_OK;
@@ -1301,8 +1317,8 @@ int ovo_map_backproject(const float *depth, const uint8_t *rgb, const uint8_t *e
 
 // ---- the keyframe chain without host round trips (ovo_map_step, ovo_track_step) ------------------------------------------------
 size_t ovo_track_workspace_bytes(int n_masks, int hist_cols) {
-    // hist | stats[4 n] | counters (2 x u64) | tickets (2 + n x u32) | dst[n] | result block [8 + 6 n]
-    return ((size_t)n_masks * hist_cols + 4 * (size_t)n_masks + 4 + 2 + n_masks + n_masks + 8 + 6 * (size_t)n_masks + 4) * sizeof(int32_t);
+    // hist | stats[4 n] | counters (CNT_SLOTS x 128 bytes) | tickets (2 + n x u32) | dst[n] | result block [8 + 6 n]
+    return ((size_t)n_masks * hist_cols + 4 * (size_t)n_masks + 2 * CNT_SLOTS * CNT_STRIDE + 2 + n_masks + n_masks + 8 + 6 * (size_t)n_masks + 4) * sizeof(int32_t);
 }
 
 int ovo_map_step(const ovo_map_step_t *a, ovo_stream_t stream) {
@@ -1372,7 +1388,7 @@ int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream) {
     int32_t *hist = (int32_t *)a->ws;
     int32_t *stats = hist + (size_t)nm * a->hist_cols;
     unsigned long long *counters = (unsigned long long *)(stats + 4 * (size_t)nm + ((((size_t)nm * a->hist_cols) & 1) ? 1 : 0));   // 8-byte aligned
-    unsigned int *tickets = (unsigned int *)(counters + 2);
+    unsigned int *tickets = (unsigned int *)(counters + CNT_SLOTS * CNT_STRIDE);
     int32_t *dst = (int32_t *)(tickets + 2 + nm);
     int32_t *res = dst + nm;
     const size_t zero_bytes = (size_t)((char *)dst - (char *)hist);
@@ -1394,7 +1410,7 @@ int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream) {
         const bool prof = ovo_prof_enabled();
         if (prof) ovo_prof_begin(2, 14.0 * (double)n_grid, s);
         k_track_project<<<ovo_grid(n_grid, 256, TRACK_GRID_CAP), 256, 0, s>>>(a->map.xyz, a->map.ins, known ? a->map.n : 0, a->cam, depth, a->seg_map, a->seg_h,
-                                                           a->seg_w, a->ratio, a->point_seg, hist, nm, a->hist_cols, counters, n_dev, sink);
+                                                           a->seg_w, a->ratio, a->point_seg, hist, nm, a->hist_cols, counters, CNT_SLOTS, n_dev, sink);
         if (prof) ovo_prof_end(s);
     }
     const int64_t seg_pixels = (int64_t)a->seg_h * a->seg_w;
@@ -1405,7 +1421,7 @@ int ovo_track_step(const ovo_track_step_t *a, ovo_stream_t stream) {
     if (n_grid > 0)
         k_assign_res<<<ovo_grid(n_grid, 256, 256), 256, 0, s>>>(a->map.ins, a->point_seg, known ? a->map.n : 0, res, nm, n_dev);
     Publish pb;
-    pb.res = res; pb.host = (volatile int32_t *)a->result_host; pb.counters = counters; pb.n_dev = (const long long *)a->map.state;
+    pb.res = res; pb.host = (volatile int32_t *)a->result_host; pb.counters = counters; pb.cnt_slots = CNT_SLOTS; pb.n_dev = (const long long *)a->map.state;
     pb.n_host = known ? a->map.n : -1; pb.ticket = tickets + 1; pb.seq = a->seq; pb.n_ints = 8 + 6 * nm;
     const long long px16 = a->masks ? a->pixels / 16 : 0;
     dim3 grid(a->masks ? ovo_grid(px16, 256, 8) : 1, nm);              // (few, fat workgroups: see k_kf_finish's launch)
@@ -1477,7 +1493,7 @@ int ovo_round_chain(ovo_round_chain_t *ctx, const ovo_map_step_t *maps, const ov
             c.hist = (int32_t *)t->ws;
             c.stats = c.hist + (size_t)nm * t->hist_cols;
             c.counters = (unsigned long long *)(c.stats + 4 * (size_t)nm + ((((size_t)nm * t->hist_cols) & 1) ? 1 : 0));
-            unsigned int *tickets = (unsigned int *)(c.counters + 2);
+            unsigned int *tickets = (unsigned int *)(c.counters + CNT_SLOTS * CNT_STRIDE);
             c.dst = (int32_t *)(tickets + 2 + nm);
             c.res = c.dst + nm;
             c.zero_bytes = (long long)((char *)c.dst - (char *)c.hist);
@@ -1520,7 +1536,7 @@ int ovo_keyframe_step(const ovo_map_step_t *a, const ovo_track_step_t *t, ovo_st
     int32_t *hist = (int32_t *)t->ws;
     int32_t *stats = hist + (size_t)nm * t->hist_cols;
     unsigned long long *counters = (unsigned long long *)(stats + 4 * (size_t)nm + ((((size_t)nm * t->hist_cols) & 1) ? 1 : 0));
-    unsigned int *tickets = (unsigned int *)(counters + 2);
+    unsigned int *tickets = (unsigned int *)(counters + CNT_SLOTS * CNT_STRIDE);
     int32_t *dst = (int32_t *)(tickets + 2 + nm);
     int32_t *res = dst + nm;
     const size_t zero_bytes = ((size_t)((char *)dst - (char *)hist) + 15) & ~(size_t)15;        // (dst / res are rewritten by the decisions anyway)
@@ -1564,7 +1580,7 @@ int ovo_keyframe_step(const ovo_map_step_t *a, const ovo_track_step_t *t, ovo_st
     const bool prof = ovo_prof_enabled();
     if (prof) ovo_prof_begin(2, 14.0 * (double)n_grid, s);
     k_track_project<<<ovo_grid(n_grid, 256, TRACK_GRID_CAP), 256, 0, s>>>(t->map.xyz, t->map.ins, 0, t->cam, depth, t->seg_map, t->seg_h, t->seg_w, t->ratio, t->point_seg, hist, nm,
-                                                       t->hist_cols, counters, (const long long *)t->map.state, sink);
+                                                       t->hist_cols, counters, CNT_SLOTS, (const long long *)t->map.state, sink);
     if (prof) ovo_prof_end(s);
     // ---- 6: vote statistics + decisions
     Decide d;
@@ -1579,7 +1595,7 @@ int ovo_keyframe_step(const ovo_map_step_t *a, const ovo_track_step_t *t, ovo_st
     f.ins = t->map.ins; f.point_seg = t->point_seg; f.n_host = -1; f.n_dev = (const long long *)t->map.state;
     f.masks = (uint4 *)t->masks; f.px16 = t->masks ? t->pixels / 16 : 0; f.n_masks = nm; f.dst = dst; f.res = res;
     Publish pb;
-    pb.res = res; pb.host = (volatile int32_t *)t->result_host; pb.counters = counters; pb.n_dev = (const long long *)t->map.state; pb.n_host = -1;
+    pb.res = res; pb.host = (volatile int32_t *)t->result_host; pb.counters = counters; pb.cnt_slots = CNT_SLOTS; pb.n_dev = (const long long *)t->map.state; pb.n_host = -1;
     pb.ticket = tickets + 1; pb.seq = t->seq; pb.n_ints = 8 + 6 * nm;
     k_kf_finish<<<f.g_assign + (t->masks ? f.gx * nm : 0), 256, 0, s>>>(f, pb);
     OVO_CHECK_LAUNCH();

@@ -14,6 +14,7 @@
 //     of the FC2 partial product -- no LDS round trip, no cross-lane move: the W1 rows of a chunk are laid out in LDS in the ORDER the FC2
 //     fragment wants them (LDS row 16 j + 4 fq + r holds hidden unit 32 (j / 2) + 8 fq + 4 (j % 2) + r, so that the two accumulator tiles 2 ks,
 //     2 ks + 1 of lane (fr, fq) are exactly hidden units 32 ks + 8 fq + 0..7 of row fr = its B fragment of k-step ks);
+//   * (launch shapes: mlp_stream_launch -- stage 1 as two 256-thread workgroups per CU, stage 2 as one of 512)
 //   * a wave carries RB row blocks through every chunk (their FC2 accumulators live across the chunks): what a chunk costs beside its products -- one
 //     barrier, the wait for its DMA -- is paid once per RB x 16 x 8 rows;
 //   * FC2's accumulators (D / 16 tiles per row block) live across the chunks; the epilogue adds b2 and the residual (x re-read: L2 / Infinity Cache)
@@ -499,16 +500,29 @@ int mlp_stream_launch(float *x, long long rows, int d, const float *ln_g, const 
     if (d == DD && k1 == KK && (rb_env == 0 || rb_env == CODE))                                                                        \
         return lut_env ? launch_mlp<KK, DD, 4 * DD, RB, RI, NTH, false, HCC>(g, s) : launch_mlp<KK, DD, 4 * DD, RB, RI, NTH, true, HCC>(g, s);
     // CODE (OVO_MLP_RB) = variant number of the measurement runs
-    // ONE 512-thread workgroup per CU is the production form (variant 1).  Measured (tools/mlp_bench.py, profiles/r05a_mlp_stream_variants.txt; 12
-    // frames of hiera_b+; the two launches: 600 / 397 us): 343-346 / 260 us per block once the next chunk's DMA really flies under this chunk's
-    // products (static buffer parity + tables in their own LDS objects, see the kernel), 353-404 / 284-303 before.
-    // Variants 2 / 3 -- TWO 256-thread workgroups per CU (32-unit chunks at width 224 so that the LDS fits twice; 2 or 4 / 2 row blocks per wave) --
-    // were 5-10 % faster in some sessions (320-391 / 267-288 us) but variant 2 is NOT DETERMINISTIC: under tools/mlp_stress.py (random allocations and
-    // GEMMs between launches) 1 of 400 launches at 65 536 rows and every launch at 786 432 rows differed from the first in whole 16-row blocks
-    // (errors up to 0.23), variant 1 in none of 460; a wait for every DMA right after its issue (OVO_MLP_DBG=2) removes it, an extra barrier per
-    // chunk does not.  The cause was not found (two workgroups' LDS-DMA on one CU is the only difference): they stay reachable through
-    // OVO_MLP_RB=2 / 3 for diagnosis only and `test_fused_mlp_stream_is_deterministic` holds the production form to bit-identical repeats.
-    GO(128, 112, 2, 2, 512, 64, 1) GO(128, 112, 2, 2, 256, 64, 2) GO(128, 112, 4, 2, 256, 64, 3)
+    // Variant 1 = ONE 512-thread workgroup per CU, variants 2 / 3 = TWO 256-thread workgroups per CU (32-unit chunks at width 224 so that the LDS fits
+    // twice; 2 or 4 / 2 row blocks per wave).  Measured (tools/mlp_bench.py, profiles/r06_mlp_variants.txt; 12 frames of hiera_b+; the two launches:
+    // 600 / 410 us): stage 1 (112 -> 448) 402-405 us as variant 1, 332-343 as variant 2, 353-376 as variant 3; stage 2 (224 -> 896) 270-279 / 280-289 /
+    // 282-301.  Stage 1 therefore runs as variant 2, stage 2 as variant 1.
+    //
+    // Round 5 kept variant 2 out of production: under tools/mlp_stress.py whole 16-row blocks came out wrong in 1 of 400 launches at 65 536 rows and in
+    // every launch at 786 432 rows, "cause not found", with the suspicion on two workgroups' LDS-DMA rings sharing a CU.  Round 6 found it
+    // (tools/mlp_race.py in a --gemm-debug build, tools/lds_dma_race.hip):
+    //   * NOT the LDS-DMA protocol: every chunk's weights IN LDS, compared with their global source right after the wait + barrier and again after the
+    //     chunk's products, were right in every failing launch (pieces another wave brought in; 0 wrong of ~10^9); the bare protocol with two
+    //     workgroups really co-resident (LDS base != 0 read back from HW_REG_LDS_ALLOC) never read a stale or early piece; nor ds_bpermute beside it.
+    //   * The first wrong intermediate of a wrong row block is always the LayerNorm's variance: the row SUM repeats bit for bit when recomputed from
+    //     the same registers, the sum of squared deviations does not -- and only the partial of lanes 48 .. 63 differs (one (x - mean)^2 pair
+    //     missing), in either the value used or the recomputed one.  That code is a chain of v_pk_add / v_pk_mul / v_pk_fma_f32 (the -O3 SLP
+    //     vectoriser pairs the scalar f32 operations) around an EXEC-masked block (the last, partial 8-column chunk of a 112-wide row).
+    //   * Built with -fno-slp-vectorize (no packed f32 in the loader) variants 1, 2, 3 are bit-stable: 0 of 2 260 stress launches, 0 of 60 at the
+    //     size where every launch failed.  A bare `v_pk_add_f32 ; s_and_saveexec_b64` chain beside MFMA partner waves (tools/pk_exec_hazard.hip)
+    //     does not reproduce it, so the exact trigger inside the packed sequence is not isolated; it needs a wave of ANOTHER workgroup on the SIMD
+    //     (in its MFMA phase while this one normalises), which is why one-workgroup-per-CU launches never showed it.
+    // ovo_amd/build.py therefore compiles the three files with an in-load LayerNorm (this one, gemm_stream.hip, winattn.hip) without SLP
+    // vectorisation, `test_fused_mlp_two_workgroup_form_under_stress` repeats the launch that failed every time, and the one-workgroup forms stay
+    // pinned to one workgroup per CU by their LDS request (launch_mlp).
+    GO(128, 112, 2, 2, 256, 64, 2) GO(128, 112, 2, 2, 512, 64, 1) GO(128, 112, 4, 2, 256, 64, 3)
     GO(256, 224, 1, 1, 512, 64, 1) GO(256, 224, 1, 1, 256, 32, 2) GO(256, 224, 2, 1, 256, 32, 3)
     if (rb_env) return OVO_E_UNSUPPORTED;
     GO(128, 96, 2, 2, 512, 64, 1) GO(192, 192, 1, 1, 512, 64, 1)          // hiera_t / hiera_s

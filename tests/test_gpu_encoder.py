@@ -611,14 +611,24 @@ def test_fused_mlp_stream_vs_two_products_and_torch(rows, d, k1):
                            w2.data_ptr(), hid, b2.data_ptr(), L.stream()) == L.E_UNSUPPORTED       # short streams: the two products
 
 
+_MLP_VARIANT_RESULTS = {}
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("rows,d,k1", [(786432, 112, 128), (196608, 224, 256)])
-def test_fused_mlp_stream_is_deterministic(rows, d, k1):
+def test_fused_mlp_stream_is_deterministic(rows, d, k1, variant, monkeypatch):
     """Repeated launches of ovo_mlp_f32 on the same input give the same bits, with other work (allocations at shifting addresses, a GEMM) between
-    them: the kernel's only cross-wave state is the double-buffered weight chunks in LDS (DMA under the previous chunk's products).  A variant
-    with two workgroups per CU failed exactly this at full size (mlp_stream.hip, mlp_stream_launch) -- 12-frame Hiera stage-1 / stage-2 sizes."""
+    them: the kernel's only cross-wave state is the double-buffered weight chunks in LDS (DMA under the previous chunk's products).  Variant 0 = the
+    default launch shape, 1 = one 512-thread workgroup per CU, 2 / 3 = two 256-thread workgroups per CU.  In round 5 variant 2 failed exactly this in
+    EVERY launch at 786 432 rows -- a packed-f32 LayerNorm-statistics chain from the SLP vectoriser, not the LDS-DMA ring (mlp_stream.hip:
+    mlp_stream_launch; the three files with an in-load LayerNorm are built with -fno-slp-vectorize) -- and is now the default shape of stage 1.  All
+    variants compute a row with the same instructions: their results are identical to each other too."""
     from ovo_amd import _lib as L
     import random
     lib = L.load()
+    monkeypatch.setenv("OVO_KNOBS_DYNAMIC", "1")
+    if variant:
+        monkeypatch.setenv("OVO_MLP_RB", str(variant))
     hid = 4 * d
     g = torch.Generator().manual_seed(rows + d)
     x0 = (torch.randn(rows, d, generator=g) * 2 + 0.5).to(DEV)
@@ -643,6 +653,8 @@ def test_fused_mlp_stream_is_deterministic(rows, d, k1):
         x = torch.cat([x0, torch.full((rnd.randrange(1, 64), d), 7.0, device=DEV)])
         call(x)
         assert torch.equal(x[:rows], ref), f"launch {it} differs from the first in {(x[:rows] != ref).any(1).sum().item()} rows"
+    first = _MLP_VARIANT_RESULTS.setdefault((rows, d), ref.cpu())
+    assert torch.equal(ref.cpu(), first), "launch shapes disagree"
 
 
 def test_layernorm_embed_im2col_rope():
