@@ -41,6 +41,7 @@ __device__ __forceinline__ void static_for(F &&f) {             // f(integral_co
 }
 
 #define OVO_8P_MFMA32_DEFAULT 0
+#define OVO_8P_MERGED_DEFAULT 0
 #define OVO_FENCE() asm volatile("" ::: "memory")
 #define OVO_BARRIER()                      \
     do {                                   \
@@ -57,7 +58,8 @@ __device__ __forceinline__ void static_for(F &&f) {             // f(integral_co
 //   MF 16: RT 16, CS 16, lrow = lane & 15, lcol = 4 (lane >> 4), value acc[i][j]
 //   MF 32: RT 32, CS  8, lrow = lane & 31, lcol = 4 (lane >> 5), value acc32[i][j / 4][4 (j % 4) .. + 3]   (D[n][m] of W-fragment x activation-fragment:
 //          lane holds m = lane % 32 and n = 8 (r / 4) + 4 (lane / 32) + r % 4 of the 32 x 32 tile)
-template <int BM, int BN, int WARPS_M, typename VT, bool STAGED, int MF = 16>
+// MERGED (round 6): a K-tile in TWO barrier intervals of two quadrants each (32 MFMAs per wave between barriers) instead of four of one -- see `body2`.
+template <int BM, int BN, int WARPS_M, typename VT, bool STAGED, int MF = 16, bool MERGED = false>
 __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (its parse of lambdas that call LDS-DMA builtins drops the stub silently)
     constexpr int WARPS_N = 8 / WARPS_M;
@@ -219,19 +221,27 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     stage_a(1, 0, 1, nt > 1);
     stage_b(1, 0, 1, nt > 1);
     if (lut) gelu_lut_fill((float2 *)(smem + LUT_OFF), tid, 512);     // ds_write only (lgkmcnt): the counted vmcnt below still sees the six stages alone
-    OVO_VMCNT(2 * NA + 2 * NB);                           // Ah0(0), Bh0(0) landed (this wave's pieces)
+    if constexpr (MERGED) OVO_VMCNT(2 * NA + NB);         // Ah0(0), Bh0(0), Bh1(0) landed (this wave's pieces): the first interval reads all three
+    else OVO_VMCNT(2 * NA + 2 * NB);                      // Ah0(0), Bh0(0) landed (this wave's pieces)
     OVO_BARRIER();
     stamp(1);
 #ifdef OVO_GEMM_DEBUG
     if (g.dbg & 2) { OVO_VMCNT(0); return; }
 #endif
     if (group == 1) OVO_BARRIER();                        // group 1 runs one barrier behind group 0 from here on
+#ifdef OVO_GEMM_DEBUG
+    if (g.dbg & 32) { load_b(smem, 1, wb1); }            // (ablation 32: wb1 holds something)
+#endif
 
     // One K-tile = four phases.  The counted wait of a phase leaves exactly the stages of the last four phases in flight
     // (2 NA + 2 NB pieces), i.e. the stage issued four phases ago -- first read in the NEXT phase -- has landed.
     auto body = [&](auto PAR, int t) {
         constexpr int b = decltype(PAR)::value;
+#ifdef OVO_GEMM_DEBUG        // ablations (tools/ builds; results are wrong): 16 = q2 multiplies the fragments q0 read, 32 = q1 too, 64 = no DMA traffic after the prologue
+        const bool v1 = t + 1 < nt && !(g.dbg & 64), v2 = t + 2 < nt && !(g.dbg & 64);
+#else
         const bool v1 = t + 1 < nt, v2 = t + 2 < nt;
+#endif
         const char *cur = smem + b * BUF;
         // q0: A.sub0 x B.sub0
         load_a(cur, 0);
@@ -242,6 +252,9 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
         quadrant(0, 0, wb0);
         OVO_BARRIER();
         // q1: A.sub0 x B.sub1
+#ifdef OVO_GEMM_DEBUG
+        if (!(g.dbg & 32))
+#endif
         load_b(cur, 1, wb1);
         stage_a(b ^ 1, 1, t + 1, v1);
         OVO_VMCNT(2 * NA + 2 * NB);
@@ -249,6 +262,9 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
         quadrant(0, 1, wb1);
         OVO_BARRIER();
         // q2: A.sub1 x B.sub1
+#ifdef OVO_GEMM_DEBUG
+        if (!(g.dbg & 16))
+#endif
         load_a(cur, 1);
         stage_a(b, 0, t + 2, v2);
         OVO_VMCNT(2 * NA + 2 * NB);
@@ -262,14 +278,46 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
         quadrant(1, 0, wb0);
         if (v1 || group == 0) OVO_BARRIER();              // group 1 skips its very last barrier: both groups execute 8 nt + 1
     };
+    // MERGED: two intervals per K-tile.  What the ablations of the four-phase loop showed (profiles/r06_gemm_ablation.txt, 8192^3: 732 us): without the
+    // fragment reads of q1 / q2 695, without any DMA after the prologue 673, without both 646 us = 1702 TFLOP/s -- the loop with NOTHING but q0's reads,
+    // its MFMAs and its barriers still runs 29 % under the MFMA rate: ~17 cycles per MFMA issued and ~75 cycles per barrier interval of 16.  Here an
+    // interval carries 32 MFMAs:
+    //     A: read A.sub0, B.sub0, B.sub1 | stage Bh1(t+1), Ah1(t+1) | wait | barrier | q0, q1 | barrier
+    //     B: read A.sub1                 | stage Ah0(t+2), Bh0(t+2) | wait | barrier | q2, q3 | barrier
+    // A half-tile is restaged in the interval after the other group's last read of it; the load segment ends with lgkmcnt(0) so that those reads
+    // HAVE returned before the barrier that lets the other group issue the DMA.  The wait of interval B leaves {Ah1(t+1), Ah0(t+2), Bh0(t+2)} in
+    // flight (A.sub0 / B.sub0 / B.sub1 of K-tile t+1 landed: read two intervals later), that of interval A the four newest stages (Ah1(t) landed).
+    auto body2 = [&](auto PAR, int t) {
+        constexpr int b = decltype(PAR)::value;
+        const bool v1 = t + 1 < nt, v2 = t + 2 < nt;
+        const char *cur = smem + b * BUF;
+        load_a(cur, 0);
+        load_b(cur, 0, wb0);
+        load_b(cur, 1, wb1);
+        stage_b(b ^ 1, 1, t + 1, v1);
+        stage_a(b ^ 1, 1, t + 1, v1);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NA + 2 * NB) : "memory");
+        OVO_BARRIER();
+        quadrant(0, 0, wb0);
+        quadrant(0, 1, wb1);
+        OVO_BARRIER();
+        load_a(cur, 1);
+        stage_a(b, 0, t + 2, v2);
+        stage_b(b, 0, t + 2, v2);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NA + NB) : "memory");
+        OVO_BARRIER();
+        quadrant(1, 1, wb1);
+        quadrant(1, 0, wb0);
+        if (v1 || group == 0) OVO_BARRIER();              // group 1 skips its very last barrier: both groups execute 4 nt + 1
+    };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     int t = 0;
     for (; t + 1 < nt; t += 2) {                          // two K-tiles per trip (static buffer parity)
-        body(I0{}, t);
-        body(I1{}, t + 1);
+        if constexpr (MERGED) { body2(I0{}, t); body2(I1{}, t + 1); }
+        else { body(I0{}, t); body(I1{}, t + 1); }
     }
-    if (t < nt) body(I0{}, t);
+    if (t < nt) { if constexpr (MERGED) body2(I0{}, t); else body(I0{}, t); }
     OVO_VMCNT(0);
     stamp(2);
 #ifdef OVO_GEMM_DEBUG
@@ -613,7 +661,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
 #endif
 }
 
-template <int BM, int BN, int WARPS_M, typename VT, bool STAGED, int MF = 16>
+template <int BM, int BN, int WARPS_M, typename VT, bool STAGED, int MF = 16, bool MERGED = false>
 int launch8p_(const GemmArgs &g0, hipStream_t s) {
     GemmArgs g = g0;
     g.dbg = 0; g.stamps = nullptr;
@@ -650,7 +698,7 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     static_assert(lds_all <= 160 * 1024, "LDS");
     static bool attr_done = false;              // per instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_gemm8p<BM, BN, WARPS_M, VT, STAGED, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
+        hipError_t e = hipFuncSetAttribute((const void *)k_gemm8p<BM, BN, WARPS_M, VT, STAGED, MF, MERGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
         if (e != hipSuccess) { ovo_set_error("ovo_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
         attr_done = true;
     }
@@ -663,7 +711,7 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     g.strip = strip_env >= 0 ? strip_env : (g.nbn >= 16 ? 8 : 0);
     if (g.strip > 0) g.chunk = (g.tiles + 7) / 8;
     const int grid = g.chunk > 0 ? g.chunk * 8 : g.tiles;
-    k_gemm8p<BM, BN, WARPS_M, VT, STAGED, MF><<<grid, 512, (STAGED && g.rope_cos) ? lds_all : lds, s>>>(g);
+    k_gemm8p<BM, BN, WARPS_M, VT, STAGED, MF, MERGED><<<grid, 512, (STAGED && g.rope_cos) ? lds_all : lds, s>>>(g);
     if (prof) ovo_prof_end(s);
     return OVO_OK;
 }
@@ -681,6 +729,12 @@ int launch8p(const GemmArgs &g, hipStream_t s) {
     if (g.best) return launch8p_<BM, BN, WARPS_M, VT, true>(g, s);
     if constexpr (std::is_same<VT, bf16x8>::value) {
         if (mf32) return launch8p_<BM, BN, WARPS_M, VT, true, 32>(g, s);
+    }
+    // OVO_8P_MERGED: two barrier intervals per K-tile (the 256 x 256 tile's staged forms)
+    static int merged = getenv("OVO_8P_MERGED") ? atoi(getenv("OVO_8P_MERGED")) : OVO_8P_MERGED_DEFAULT;
+    if (ovo_knobs_dynamic()) merged = getenv("OVO_8P_MERGED") ? atoi(getenv("OVO_8P_MERGED")) : OVO_8P_MERGED_DEFAULT;
+    if constexpr (BN == 256) {
+        if (merged) return launch8p_<BM, BN, WARPS_M, VT, true, 16, true>(g, s);
     }
     return launch8p_<BM, BN, WARPS_M, VT, true>(g, s);
 }

@@ -151,6 +151,40 @@ def test_gemm_pingpong_mfma32_loop_vs_mfma16_loop_and_torch(monkeypatch, tile, m
         assert (a16 != a32).float().mean() < 0.02, name                      # ... and only rarely
 
 
+@pytest.mark.parametrize("m,n,k", [(4616, 3072, 1024), (1154, 1024, 448), (300, 260, 64), (700, 516, 1792), (257, 516, 128), (513, 260, 320), (2308, 1024, 4096)])
+def test_gemm_pingpong_merged_intervals_bit_identical(monkeypatch, m, n, k):
+    """The 256 x 256 ping-pong kernel with TWO barrier intervals per K-tile (OVO_8P_MERGED=1, gemm8p.hip `body2`: 32 MFMAs per wave between barriers,
+    half-tiles restaged one interval after their last read) against the four-phase loop: same fragments, same k order -- every epilogue form
+    bit-identical, one to 64 K-tiles (odd and even counts: both buffer parities end a tile), ragged M / N edges."""
+    from ovo_amd import _lib as L
+    dtype = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(m + 3 * n + 7 * k + 2)
+    a = torch.randn(m, k + 64, generator=g).to(DEV, dtype)[:, :k]
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(DEV, dtype)
+    bias, add = torch.randn(n, generator=g).to(DEV), torch.randn(m, n, generator=g).to(DEV)
+    monkeypatch.setenv("OVO_GEMM_TILE", "256x256")
+
+    def forms():
+        out = {"f32_gelu_add": _gemm(a, w, bias, add=add, act=1), "bf16": _gemm(a, w, bias, out_dtype=dtype),
+               "bf16_gelu": _gemm(a, w, bias, act=1, out_dtype=dtype), "f32": _gemm(a, w, bias)}
+        x = add.clone()
+        gg = L.Gemm()
+        gg.A, gg.lda, gg.W, gg.ldw, gg.bias = a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr()
+        gg.C, gg.ldc, gg.add, gg.ld_add = x.data_ptr(), n, x.data_ptr(), n
+        gg.M, gg.N, gg.K, gg.in_dtype, gg.out_dtype, gg.act, gg.alpha = m, n, k, 2, 0, 0, 1.0
+        L.check(L.load().ovo_gemm(C.byref(gg), L.stream()))
+        out["f32_inplace"] = x
+        return out
+    monkeypatch.setenv("OVO_8P_MERGED", "0")
+    ref = forms()
+    monkeypatch.setenv("OVO_8P_MERGED", "1")
+    for rep in range(3):                                                     # (a synchronisation slip would not show every time)
+        got = forms()
+        for name in got:
+            assert torch.equal(got[name], ref[name]), (name, rep, float((got[name].float() - ref[name].float()).abs().max()))
+    torch.testing.assert_close(got["f32"], a.float() @ w.float().T + bias, atol=3e-4, rtol=3e-4)
+
+
 @pytest.mark.parametrize("b,t,heads,hd", [(8, 577, 16, 64), (5, 50, 4, 72)])
 def test_gemm_rope_epilogue_mfma32_loop(monkeypatch, b, t, heads, hd):
     """ovo_gemm_rope through the 32 x 32 x 16 loop (head_dim 64: the LDS table-slice form; 72: the per-wave form) against the 16 x 16 x 32 loop."""
