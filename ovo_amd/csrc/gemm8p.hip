@@ -41,7 +41,7 @@ __device__ __forceinline__ void static_for(F &&f) {             // f(integral_co
 }
 
 #define OVO_8P_MFMA32_DEFAULT 0
-#define OVO_8P_MERGED_DEFAULT 0
+#define OVO_8P_MERGED_DEFAULT 1
 #define OVO_FENCE() asm volatile("" ::: "memory")
 #define OVO_BARRIER()                      \
     do {                                   \
@@ -284,6 +284,9 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     // interval carries 32 MFMAs:
     //     A: read A.sub0, B.sub0, B.sub1 | stage Bh1(t+1), Ah1(t+1) | wait | barrier | q0, q1 | barrier
     //     B: read A.sub1                 | stage Ah0(t+2), Bh0(t+2) | wait | barrier | q2, q3 | barrier
+    // Measured (profiles/r06_gemm_merged.txt, tools/gemm_bench.py, one session): 8192^3 740.7 -> 727.7 us, FC1 (16156, 4096, 1024) 132.8 -> 130.1, FC2 + f32
+    // residual 114.8 -> 112.2, QKV + rotary 118.5 -> 115.5, K = 448 unchanged: +2 % where the K-loop dominates, bit-identical
+    // (test_gemm_pingpong_merged_intervals_bit_identical); the default for the 256 x 256 tile (OVO_8P_MERGED=0: the four-phase loop).
     // A half-tile is restaged in the interval after the other group's last read of it; the load segment ends with lgkmcnt(0) so that those reads
     // HAVE returned before the barrier that lets the other group issue the DMA.  The wait of interval B leaves {Ah1(t+1), Ah0(t+2), Bh0(t+2)} in
     // flight (A.sub0 / B.sub0 / B.sub1 of K-tile t+1 landed: read two intervals later), that of interval A the four newest stages (Ah1(t) landed).
