@@ -472,7 +472,7 @@ int launch_mlp(const MlpArgs &g, hipStream_t s) {
 namespace ovo_gemm_detail {
 
 // x f32 [rows, d] += fc2(GELU(fc1(LayerNorm(x)))) in one launch.  OVO_E_UNSUPPORTED (nothing launched) for shapes without an instantiation:
-// the caller runs the two products.  Instantiations: Hiera hiera_b+ / hiera_s / hiera_t stage 1-2 widths (112, 224 | 96, 192) and hiera_l's 144.
+// the caller runs the two products.  Instantiations: Hiera hiera_b+ / hiera_s / hiera_t stage 1-2 widths (112, 224 | 96, 192) and hiera_l's 144, 288.
 int mlp_stream_launch(float *x, long long rows, int d, const float *ln_g, const float *ln_b, float eps, const void *w1, long long ldw1, const float *b1,
                       int hid, const void *w2, long long ldw2, const float *b2, hipStream_t s) {
     auto read_off = [] { return getenv("OVO_NO_MLP_FUSE") != nullptr || getenv("OVO_GEMM_NO_STREAM") != nullptr || getenv("OVO_GEMM_TILE") != nullptr; };
@@ -526,7 +526,8 @@ int mlp_stream_launch(float *x, long long rows, int d, const float *ln_g, const 
     GO(256, 224, 1, 1, 512, 64, 1) GO(256, 224, 1, 1, 256, 32, 2) GO(256, 224, 2, 1, 256, 32, 3)
     if (rb_env) return OVO_E_UNSUPPORTED;
     GO(128, 96, 2, 2, 512, 64, 1) GO(192, 192, 1, 1, 512, 64, 1)          // hiera_t / hiera_s
-    GO(192, 144, 1, 1, 512, 64, 1)                                         // hiera_l stage 1 (its stage 2, 288 -> K 320, takes the two launches)
+    GO(192, 144, 1, 1, 512, 64, 1) GO(320, 288, 1, 1, 512, 32, 1)          // hiera_l stages 1 and 2 (the reference's default trunk, ovo.yaml:35; 288 -> K 320: chunks of 32
+                                                                           // hidden units so that two W1 / W2 chunk pairs fit the LDS beside the tables)
 #undef GO
     return OVO_E_UNSUPPORTED;
 }
