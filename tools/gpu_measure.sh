@@ -1,5 +1,6 @@
 #!/bin/bash
-# One GPU-box session: parity tests, smoke, bench, kernel-trace stats and the PMC traffic passes (summaries go to profiles/ by hand).
+# One GPU-box session: parity tests, smoke, bench, kernel-trace stats and the PMC traffic passes (summaries go to profiles/ by hand).  The PMC passes run the bench's own
+# encoder groups (14 + 14 + 10 frames: the roofline pass profiles 14 + 10), so that `roofline.traffic` and `algorithmic_bytes_per_launch` describe the same launches.
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
@@ -9,6 +10,7 @@ R=$GRAFT_REPO_ROOT
 timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
 timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2> $OUT/bench_driver_flags.err
 timeout 600 python bench.py --sam hiera_l --no-cpu-baseline --sustain-seconds 0 --projection-world 0 --no-online > $OUT/bench_hiera_l.json 2> $OUT/bench_hiera_l.err
 timeout 600 python bench.py --sam-full --no-cpu-baseline --sustain-seconds 0 --projection-world 0 --no-online > $OUT/bench_sam_full.json 2> $OUT/bench_sam_full.err
 (timeout 300 python tools/query_bench.py; timeout 300 python tools/query_bench.py 1250000) > $OUT/query_bench.log 2>&1
@@ -25,17 +27,21 @@ timeout 300 python tools/replicated_cost.py 64 8 > $OUT/replicated_cost.txt 2>&1
 timeout 600 python tools/vit_bench.py > $OUT/vit_bench.txt 2>&1
 timeout 300 python tools/attn_bench.py > $OUT/attn_bench.txt 2>&1
 timeout 300 python tools/scatter_bench.py > $OUT/scatter_bench.txt 2>&1; timeout 300 python tools/scatter_bench.py 5000000 768 60000 >> $OUT/scatter_bench.txt 2>&1
-RBS=0 timeout 300 python tools/mlp_bench.py > $OUT/mlp_bench.txt 2>&1
+RBS=0,1,2,3 timeout 300 python tools/mlp_bench.py > $OUT/mlp_bench.txt 2>&1
+timeout 900 python tools/mlp_stress.py > $OUT/mlp_stress.txt 2>&1
+(cd /tmp && hipcc --offload-arch=gfx950 -O3 -o /tmp/lds_dma_race $R/tools/lds_dma_race.hip && timeout 300 /tmp/lds_dma_race 4096 20) > $OUT/lds_dma_race.txt 2>&1
 timeout 300 python tools/winattn_bench.py 12 > $OUT/winattn_bench.txt 2>&1
 (timeout 300 python tools/patch_embed_bench.py 12; timeout 300 python tools/patch_embed_bench.py 1) > $OUT/patch_embed_bench.txt 2>&1
 timeout 300 python tools/round_host.py 8 > $OUT/round_host.txt 2>&1
 timeout 300 python tools/resize_batch_bench.py > $OUT/resize_batch_bench_now.txt 2>&1
 # BASELINE configs[3]'s process layout on ONE GPU over gloo (8 ranks, 5 M-point map): executes rings, staging and shards at world 8; not a scaling number
 (export OVO_FORCE_DEVICE=0 OVO_DIST_BACKEND=gloo; timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 8 --steps 8 --warmup 2 --map-points 5000000 --no-cpu-baseline --no-roofline --dense-merge none 2>&1 | tail -1) > $OUT/bench_world8_one_gpu_5m.json
+# the same layout with north_star's literal collective (`dense_merge reduce`: every rank a WHOLE accumulator, one bucketed sum-reduce) at a size eight whole accumulators fit one GPU
+(export OVO_FORCE_DEVICE=0 OVO_DIST_BACKEND=gloo; timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 8 --steps 8 --warmup 2 --map-points 400000 --no-cpu-baseline --no-roofline --dense-merge reduce 2>&1 | tail -1) > $OUT/bench_world8_one_gpu_dense_merge.json
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $R/bench.py --no-cpu-baseline --steps 24 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/prof_bench.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 4 --warmup 4 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --no-shared-crops --steps 24 --warmup 14 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu-baseline --no-roofline --no-shared-crops --steps 24 --warmup 14 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- python $R/tools/pmc_calib.py > $OUT/calib_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- python $R/tools/pmc_calib.py > $OUT/calib_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/wa_fetch -- python $R/tools/winattn_bench.py 12 > $OUT/wa_fetch.log 2>&1
