@@ -40,7 +40,7 @@ timeout 300 python tools/resize_batch_bench.py > $OUT/resize_batch_bench_now.txt
 (export OVO_FORCE_DEVICE=0 OVO_DIST_BACKEND=gloo; timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 8 --steps 8 --warmup 2 --map-points 400000 --no-cpu-baseline --no-roofline --dense-merge reduce 2>&1 | tail -1) > $OUT/bench_world8_one_gpu_dense_merge.json
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python $R/bench.py --no-cpu-baseline --steps 24 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/prof_bench.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --no-shared-crops --steps 24 --warmup 14 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/bench.py --no-cpu-baseline --census $OUT/pmc_census.json --no-shared-crops --steps 24 --warmup 14 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/bench.py --no-cpu-baseline --no-roofline --no-shared-crops --steps 24 --warmup 14 --sustain-seconds 0 --projection-world 0 --no-online > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- python $R/tools/pmc_calib.py > $OUT/calib_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/calib_write -- python $R/tools/pmc_calib.py > $OUT/calib_write.log 2>&1
@@ -52,7 +52,7 @@ ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format cs
 ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/geom_write -- python $R/tools/geom_bench.py 10000000 > $OUT/geom_write.log 2>&1
 ITERS=3 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU --output-format csv -d $OUT/geom_sq -- python $R/tools/geom_bench.py 10000000 > $OUT/geom_sq.log 2>&1
 cd $R
-python tools/pmc_traffic.py --fetch-dir $OUT/pmc_fetch --write-dir $OUT/pmc_write --calib-fetch-dir $OUT/calib_fetch --calib-write-dir $OUT/calib_write --out $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
+python tools/pmc_traffic.py --fetch-dir $OUT/pmc_fetch --write-dir $OUT/pmc_write --calib-fetch-dir $OUT/calib_fetch --calib-write-dir $OUT/calib_write --census $OUT/pmc_census.json --out $OUT/pmc_traffic.json > $OUT/pmc_traffic.log 2>&1
 python tools/pmc_traffic.py --fetch-dir $OUT/geom_fetch --write-dir $OUT/geom_write --out $OUT/geom_10m_pmc_traffic.json > $OUT/geom_pmc.log 2>&1
 python tools/pmc_traffic.py --fetch-dir $OUT/wa_fetch --write-dir $OUT/wa_write --out $OUT/winattn_pmc_traffic.json > $OUT/wa_pmc.log 2>&1
 python tools/sq_counters.py $OUT/geom_sq > $OUT/geom_10m_sq_counters.txt 2>&1

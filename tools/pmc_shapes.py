@@ -1,7 +1,7 @@
 """HBM traffic per launch, shape by shape, against the algorithmic bytes of the same launch (the bench's PMC pass mixes 4- and
 12-frame groups, so its per-kernel average has no single algorithmic denominator).
 
-For every product / attention shape of the 12-frame encoder groups this runs the one-shape tools under rocprofv3 twice -- `--pmc FETCH_SIZE`, then
+For every product / attention shape of the encoder groups (ViT: the bench's 14 frames = 16 156 rows; Hiera: 12 frames) this runs the one-shape tools under rocprofv3 twice -- `--pmc FETCH_SIZE`, then
 `--pmc WRITE_SIZE`, each with `--kernel-trace` only (MI355X_MICROARCH.md: separate passes; KiB units; FETCH_SIZE x 2 on gfx950) -- and prints
     shape | kernel | algorithmic MB | fetched MB | written MB | (fetched + written) / algorithmic
 `ROTATE=4` cycles the weights through four buffers so that a repeated launch does not find them in the last-level cache.
@@ -21,10 +21,10 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # (label, kind, dims, env)
 CASES = [
-    ("ViT QKV + rotary", "gemm", (13848, 3072, 1024), {"BIAS": "1", "ROPE": "1"}),
-    ("ViT out proj (+= f32 stream)", "gemm", (13848, 1024, 1024), {"BIAS": "1", "ADD": "1", "INPLACE": "1", "OUT": "f32"}),
-    ("ViT FC1 + GELU", "gemm", (13848, 4096, 1024), {"BIAS": "1", "ACT": "1"}),
-    ("ViT FC2 (+= f32 stream)", "gemm", (13848, 1024, 4096), {"BIAS": "1", "ADD": "1", "INPLACE": "1", "OUT": "f32"}),
+    ("ViT QKV + rotary", "gemm", (16156, 3072, 1024), {"BIAS": "1", "ROPE": "1"}),
+    ("ViT out proj (+= f32 stream)", "gemm", (16156, 1024, 1024), {"BIAS": "1", "ADD": "1", "INPLACE": "1", "OUT": "f32"}),
+    ("ViT FC1 + GELU", "gemm", (16156, 4096, 1024), {"BIAS": "1", "ACT": "1"}),
+    ("ViT FC2 (+= f32 stream)", "gemm", (16156, 1024, 4096), {"BIAS": "1", "ADD": "1", "INPLACE": "1", "OUT": "f32"}),
     ("Hiera s3 QKV", "gemm", (58800, 1344, 448), {"BIAS": "1"}),
     ("Hiera s3 proj (+= f32)", "gemm", (58800, 448, 448), {"BIAS": "1", "ADD": "1", "INPLACE": "1", "OUT": "f32"}),
     ("Hiera s3 FC1 + GELU", "gemm", (49152, 1792, 448), {"BIAS": "1", "ACT": "1"}),
@@ -32,7 +32,7 @@ CASES = [
     ("Hiera s1 FC1 + GELU (bf16 A)", "gemm", (786432, 448, 128), {"BIAS": "1", "ACT": "1"}),
     ("Hiera s2 FC1 + GELU (bf16 A)", "gemm", (196608, 896, 256), {"BIAS": "1", "ACT": "1"}),
     ("Hiera s1 FC2 (+= f32)", "gemm", (786432, 112, 448), {"BIAS": "1", "ADD": "1", "INPLACE": "1", "OUT": "f32"}),
-    ("ViT attention", "attn", (24, 16, 577, 577, 64), {}),
+    ("ViT attention", "attn", (28, 16, 577, 577, 64), {}),
     ("Hiera global attention", "attn", (12, 8, 4096, 4096, 56), {}),
     ("Hiera 14x14 windows", "attn", (300, 8, 196, 196, 56), {}),
     ("Hiera 8x8 windows", "attn", (12288, 2, 64, 64, 56), {}),

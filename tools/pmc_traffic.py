@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--write-dir", required=True)
     ap.add_argument("--calib-fetch-dir")
     ap.add_argument("--calib-write-dir")
+    ap.add_argument("--census", help="bench.py --census output of the SAME command: algorithmic bytes per launch of exactly the launches counted here")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     fetch_fix, write_fix, notes = 2.0, 1.0, {}
@@ -83,11 +84,23 @@ def main():
         kernels[short(k)] = {"launches": max(fn, wn), "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                              "hbm_bytes_per_launch": (fb or 0.0) + (wb or 0.0)}
     with open(a.out, "w") as fh:
-        json.dump({"unit": "bytes per launch (KiB counters x 1024; FETCH_SIZE x 2 on gfx950)", "notes": notes, "csrc_sha16": csrc_sha16(), "kernels": kernels}, fh, indent=1)
+        census = None
+        if a.census and os.path.exists(a.census):
+            with open(a.census) as cf:
+                census = json.load(cf)
+        json.dump({"unit": "bytes per launch (KiB counters x 1024; FETCH_SIZE x 2 on gfx950)", "notes": notes, "csrc_sha16": csrc_sha16(), "census": census,
+                   "kernels": kernels}, fh, indent=1)
     top = sorted(kernels.items(), key=lambda kv: -(kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]))[:12]
     for k, v in top:
         print(f"{v['launches']:6d} x {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB  {k}")
     print(json.dumps(notes))
+    if a.census and os.path.exists(a.census):
+        with open(a.census) as cf:
+            for tile, c in json.load(cf)["tiles"].items():
+                hit = [v for k, v in kernels.items() if f"k_gemm8p<{tile.replace(',', ', ')}" in k]
+                if hit and c["launches"]:
+                    print(f"tile {tile}: PMC {hit[0]['hbm_bytes_per_launch'] / 1e6:.1f} MB over {hit[0]['launches']} launches, algorithmic {c['algorithmic_bytes_per_launch'] / 1e6:.1f} MB over "
+                          f"{c['launches']} launches: ratio {hit[0]['hbm_bytes_per_launch'] / c['algorithmic_bytes_per_launch']:.3f}")
 
 
 if __name__ == "__main__":
