@@ -329,6 +329,21 @@ __device__ __forceinline__ void wq_push(WaveQueue &q, int &tail, bool keep, floa
 // find them again with a scan over point_seg (k_scatter_scan: 33 us for 2.6 MB, launch + latency).  hits == NULL: no list.  shard_count > 1: only the
 // points of this rank's block-cyclic shard are listed, as LOCAL row numbers (the map of ovo_scatter_accum_touched).
 struct HitSink { int32_t *hits; int32_t *n_hits; int shard_rank, shard_count, block_log2; };
+// A wave collects its hits in 256 LDS slots and reserves list space with ONE returning atomic per flush (when the slots fill, and at the end of its
+// pass): the first form reserved per batch of 64 survivors, and the wave waited ~1.5 us for every one of those round trips -- k_track_project 20.6 ->
+// 46 us in the bench's isolated pass.
+constexpr int HIT_SLOTS = 256;
+__device__ __forceinline__ void hits_flush(const HitSink &sink, const int32_t *hbuf, int &hcount) {
+    const int lane = threadIdx.x & 63;
+    if (hcount > 0) {
+        int at = 0;
+        if (lane == 0) at = atomicAdd(sink.n_hits, hcount);
+        at = __shfl(at, 0, 64);
+        for (int k = lane; k < hcount; k += 64) sink.hits[at + k] = hbuf[k];
+        __builtin_amdgcn_wave_barrier();
+    }
+    hcount = 0;
+}
 
 constexpr int CNT_SLOTS = 32, CNT_STRIDE = 16;                     // counter slots of a tracking step; u64 words between two slots (128 bytes)
 
@@ -336,7 +351,7 @@ constexpr int CNT_SLOTS = 32, CNT_STRIDE = 16;                     // counter sl
 __device__ __forceinline__ void track_batch(const WaveQueue &q, int head, int count, const ovo_camera_t &cam, const float *__restrict__ depth,
                                             const int32_t *__restrict__ point_ins, const int32_t *__restrict__ seg_map, int seg_h, int seg_w,
                                             const ovo_ratio_t &ratio, int16_t *__restrict__ point_seg, int32_t *__restrict__ hist, int n_masks,
-                                            int hist_cols, long long &n_match, const HitSink &sink) {
+                                            int hist_cols, long long &n_match, const HitSink &sink, int32_t *hbuf, int &hcount) {
     const int lane = threadIdx.x & 63;
     int cell = 0;
     bool vote = false;
@@ -372,13 +387,14 @@ __device__ __forceinline__ void track_batch(const WaveQueue &q, int head, int co
         point_seg[i] = (int16_t)seg;
     }
     wave_hist_add(hist, cell, vote);
-    if (sink.hits) {                                                // one atomic per batch of 64 survivors
+    if (sink.hits) {                                                // into the wave's LDS slots (hits_flush reserves the list space)
         const unsigned long long m = __ballot(hit_row >= 0);
         if (m) {
-            int at = 0;
-            if (lane == 0) at = atomicAdd(sink.n_hits, (int)__popcll(m));
-            at = __shfl(at, 0, 64);
-            if (hit_row >= 0) sink.hits[at + (int)__popcll(m & ((1ull << lane) - 1ull))] = hit_row;
+            const int c = (int)__popcll(m);
+            if (hcount + c > HIT_SLOTS) hits_flush(sink, hbuf, hcount);
+            if (hit_row >= 0) hbuf[hcount + (int)__popcll(m & ((1ull << lane) - 1ull))] = hit_row;
+            __builtin_amdgcn_wave_barrier();
+            hcount += c;
         }
     }
 }
@@ -390,8 +406,11 @@ __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const in
                                   int32_t *__restrict__ hist, int n_masks, int hist_cols,
                                   unsigned long long *__restrict__ counters, int cnt_slots, const HitSink &sink) {
     __shared__ WaveQueue s_q[4];
+    __shared__ int32_t s_hits[4][HIT_SLOTS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     WaveQueue &q = s_q[wave];
+    int32_t *hbuf = s_hits[wave];
+    int hcount = 0;
     long long n_in = 0, n_match = 0;
     int head = 0, tail = 0;                                         // wave-uniform ring positions (mod 256 at use)
     const int64_t step = (int64_t)b.nblk * blockDim.x;
@@ -411,7 +430,7 @@ __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const in
             wq_push(q, tail, in, px[k], py[k], pz[k], (int)i);
             __builtin_amdgcn_wave_barrier();                        // the ring is private to the wave: LDS operations of one wave stay in order
             if (tail - head >= 64) {                                // at most 63 + 64 queued: the 256-slot ring never wraps onto live entries
-                track_batch(q, head, 64, cam, depth, point_ins, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, n_match, sink);
+                track_batch(q, head, 64, cam, depth, point_ins, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, n_match, sink, hbuf, hcount);
                 head += 64; n_in += 1;
                 __builtin_amdgcn_wave_barrier();
             }
@@ -419,8 +438,9 @@ __device__ void dev_track_project(Blk b, const float *__restrict__ pts, const in
     }
     if (tail - head > 0) {
         n_in += lane < tail - head;
-        track_batch(q, head, tail - head, cam, depth, point_ins, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, n_match, sink);
+        track_batch(q, head, tail - head, cam, depth, point_ins, seg_map, seg_h, seg_w, ratio, point_seg, hist, n_masks, hist_cols, n_match, sink, hbuf, hcount);
     }
+    if (sink.hits) hits_flush(sink, hbuf, hcount);
     // the two counters: wave reduction, then across the workgroup's waves through LDS -> one atomic pair per workgroup
     // (every wave of the grid adding to the same two addresses serialises in the L2 atomic unit: 16k same-address atomics)
     for (int o = 32; o > 0; o >>= 1) {
