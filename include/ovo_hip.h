@@ -276,6 +276,21 @@ int ovo_gemm_unwindow(const ovo_gemm_t *g, const ovo_window_t *win, ovo_stream_t
  * ovo_gemm_f32a, which ovo_hiera_forward chains itself). */
 int ovo_gemm_rowln(const ovo_gemm_t *g, const ovo_window_t *win, const float *ln_g, const float *ln_b, float eps, void *ln_out, int64_t ld_ln,
                    ovo_stream_t stream);
+/* The LayerNorm FOLD of the ViT's batched forwards (ABI v12; no reference counterpart -- open_clip / PE run LayerNorm and Linear as two modules, transformer
+ * blocks of `model.encode_image`, clip_generator.py:122 / textregion.py:142):  LN(x) . W^T + b = rstd (bf16(x) . W'^T - mean rowsum(W')) + b' with
+ * W' = W . gamma and b' = b + W . beta (ovo_vit_layer_t.qkv_wf ...).  Three pieces, all OVO_E_UNSUPPORTED (nothing launched) outside the 256-row ping-pong
+ * kernel's range (M >= 2048, N >= 256, N % 64 == 0, K % 64 == 0, bf16 operands, alpha = 1):
+ *   ovo_gemm_fold_out:   ovo_gemm with f32 C += f32 add (the epilogue that writes the residual stream x) that ALSO writes xb bf16 [C rows, ld_xb] = bf16(C row)
+ *                        and stats f32 [N / 64][ld_stats][2] = (sum, sum of squares) of each 64-column group (part) of each row, PART-major (ld_stats >= M rows
+ *                        apart: both sides move a part's consecutive rows as whole cache lines);
+ *   ovo_gemm_fold_stats: the same two outputs from an existing f32 matrix x [M, D] (the first LayerNorm of a forward): ONE part, stats [1][M][2];
+ *   ovo_gemm_fold_in:    ovo_gemm (rope == NULL) / ovo_gemm_rope with 2-byte output whose A is xb, W = W', bias = b': the row's partials (`parts` per row,
+ *                        <= 16, covering D columns) are summed in order, mean / rstd = rsqrt(var + eps) formed once per tile, and the epilogue applies the
+ *                        line above before the activation (act 0 or 1) / rotary embedding (head_dim 64). */
+int ovo_gemm_fold_out(const ovo_gemm_t *g, void *xb, int64_t ld_xb, float *stats, int64_t ld_stats, ovo_stream_t stream);
+int ovo_gemm_fold_stats(const float *x, int64_t ldx, int M, int D, void *xb, int64_t ld_xb, float *stats, ovo_stream_t stream);
+int ovo_gemm_fold_in(const ovo_gemm_t *g, const ovo_rope_t *rope, const float *stats, int64_t ld_stats, int parts, int D, const float *rowsum, float eps,
+                     ovo_stream_t stream);
 /* ovo_gemm whose A operand is the f32 residual stream itself (Hiera stages 1-2 inside SAM2AutomaticMaskGenerator.generate,
  * mask_generator.py:113; no reference counterpart -- there LayerNorm and the linear layer are two modules): g->A is ignored,
  * product row m reads x[src(m), 0..d) -- src(m) = m, or with `win` the SPATIAL token of window-major row m (a padding row
@@ -446,6 +461,12 @@ typedef struct {
     const float *ln2_g, *ln2_b;
     const void *fc1_w; const float *fc1_b;   /* [mlp_dim, width]                            */
     const void *fc2_w; const float *fc2_b;   /* [width, mlp_dim]                            */
+    /* ABI v12, optional (all six or none; NULL = the LayerNorm kernels run): the two LayerNorms folded into the products that follow them,         */
+    /* LN(x) . W^T + b = rstd (bf16(x) . W'^T - mean colsum(W')) + b'.  *_wf = bf16(W . gamma) (column k times gamma[k], in f32, ONE rounding),     */
+    /* *_cs = f32 row sums of the ROUNDED W' (what the product really multiplies), *_bf = b + W . beta (f32).  Used for batched forwards only       */
+    /* (>= 2048 token rows, width and mlp_dim multiples of 64, width <= 1024, act 0 / 1); otherwise the plain weights above are used.              */
+    const void *qkv_wf; const float *qkv_bf, *qkv_cs;
+    const void *fc1_wf; const float *fc1_bf, *fc1_cs;
 } ovo_vit_layer_t;
 
 typedef struct {

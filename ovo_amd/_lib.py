@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libovo_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 E_UNSUPPORTED = -3          # OVO_E_UNSUPPORTED: the entry point does not cover this shape; the caller takes its general path
 
 
@@ -69,7 +69,8 @@ class VitConfig(C.Structure):
 class VitLayer(C.Structure):
     """ovo_vit_layer_t"""
     _fields_ = [(n, _P) for n in ("ln1_g", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_g", "ln2_b",
-                                   "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+                                   "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                                   "qkv_wf", "qkv_bf", "qkv_cs", "fc1_wf", "fc1_bf", "fc1_cs")]      # ABI 12: the LayerNorm fold's weights (or NULL)
 
 
 class VitWeights(C.Structure):
@@ -175,6 +176,9 @@ _SIGNATURES = {
     "ovo_gemm_rope": (_I32, [C.POINTER(Gemm), C.POINTER(Rope), _P]),
     "ovo_gemm_periodic": (_I32, [C.POINTER(Gemm), _I64, _P]),
     "ovo_gemm_unwindow": (_I32, [C.POINTER(Gemm), C.POINTER(Window), _P]),
+    "ovo_gemm_fold_out": (_I32, [C.POINTER(Gemm), _P, _I64, _P, _I64, _P]),
+    "ovo_gemm_fold_stats": (_I32, [_P, _I64, _I32, _I32, _P, _I64, _P, _P]),
+    "ovo_gemm_fold_in": (_I32, [C.POINTER(Gemm), C.POINTER(Rope), _P, _I64, _I32, _I32, _P, _F32, _P]),
     "ovo_gemm_rowln": (_I32, [C.POINTER(Gemm), C.POINTER(Window), _P, _P, _F32, _P, _I64, _P]),
     "ovo_gemm_f32a": (_I32, [C.POINTER(Gemm), C.POINTER(Window), _P, C.c_int, _P, _P, C.c_float, C.c_int, C.c_int, _P]),
     "ovo_decode_best": (_I32, [_P, _I64, _F32, _P, _P, _P]),
@@ -351,6 +355,17 @@ def q_prescale_enabled() -> bool:
     """The encoders fold log2(e) / sqrt(head_dim) into the q rows of their QKV projections at load time (OVO_Q_PRESCALE=0: the
     attention kernel multiplies the bf16 queries itself -- a second rounding of every query; kept for A/B measurements)."""
     return os.environ.get("OVO_Q_PRESCALE", "1") != "0"
+
+
+def fold_layernorm(weight: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """LN(x) . W^T + b = rstd (x . W'^T - mean colsum(W')) + b' (ovo_vit_layer_t.qkv_wf ..., ABI 12): returns W' = W . gamma (f32; the caller rounds it to bf16
+    ONCE), b' = b + W . beta (f32, taken in f64) and the row sums of the ROUNDED W' (f32, taken in f64) -- the product multiplies the rounded matrix, so the
+    mean's coefficient has to be its sum, not the sum of the unrounded one."""
+    w = weight.detach().double()
+    wf = (w * gamma.detach().double()[None, :]).float()
+    bf = (bias.detach().double() + w @ beta.detach().double()).float()
+    cs = wf.to(torch.bfloat16).double().sum(dim=1).float()
+    return wf, bf, cs
 
 
 def fold_q_scale(weight: torch.Tensor, bias: Optional[torch.Tensor], q_rows: int, head_dim: int):

@@ -98,7 +98,7 @@ int ovo_marker(int id, ovo_stream_t stream) {
     return OVO_OK;
 }
 const char *ovo_hip_last_error(void) { return g_err; }
-int ovo_hip_abi_version(void) { return 11; }
+int ovo_hip_abi_version(void) { return 12; }
 
 int ovo_profile_start(void) {
     g_prof.recs.clear();

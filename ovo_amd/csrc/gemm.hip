@@ -335,6 +335,30 @@ int launch(const GemmArgs &g0, hipStream_t s) {
     return OVO_OK;
 }
 
+// The 256-row ping-pong kernels' tile width for a shape (256 or 128) and whether they beat the ring kernels there: the cost model of `dispatch` below
+// (its comment block explains the constants); also the LayerNorm fold's choice, which runs on these kernels regardless of `wins`.
+static int choose8p(int M, int N, int K, bool out_f32, bool add, bool *wins) {
+    auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    const double flop = 2.0 * M * (double)N * K, kt = K / 64;
+    const double bytes = 2.0 * ((double)M * K + (double)N * K) + (double)M * N * (out_f32 ? 4.0 : 2.0) * (add ? 2.0 : 1.0);
+    const double t_mem = bytes / 4.0e6;                                            // us at 4 TB/s
+    // (the ring kernels' rate falls with K: 650 TFLOP/s from 16 K-tiles, ~560 at 7 (K = 448), ~400 at 4 (K = 256): profiles/r03c_gemm_variants.txt)
+    const double t_ring = flop / (kt <= 4 ? 400.0e6 : (kt <= 8 ? 560.0e6 : 650.0e6)) + 4.0;
+    const double r256 = (double)((blocks(256, 256) + 255) / 256), r128 = (double)((blocks(256, 128) + 255) / 256);
+    // per-K-tile cost of the 256x128 form rises once every CU holds a tile and stays in its K-loop (measured: 0.62 us with <= 192 tiles
+    // in flight, ~0.70 on a full chip with short K-loops whose phases interleave, 0.86 at K >= 3072: every CU in its K-loop at once)
+    const double s128 = blocks(256, 128) <= 192 ? 0.62 : (kt >= 48 ? 0.86 : 0.70);
+    // short K-loops over many rounds (Hiera stage 3: K = 448, 6-10 rounds): the rounds of different CUs drift apart and the 256 x 128 form's
+    // shorter tiles overlap each other's prologues and epilogues (11 us per round measured instead of 14), the 256 x 256 form's do not (20.5):
+    // (58800, 1344, 448) 126 us on the ring kernel -> 112; (196608, 1344, 256) 352 -> 300
+    const double fix256 = (kt <= 8 && r256 >= 4) ? 10.0 : 8.0, fix128 = (kt <= 8 && r128 >= 4) ? 6.5 : 9.0;
+    double t256 = r256 * (fix256 + 1.5 * kt), t128 = r128 * (fix128 + s128 * kt);
+    t256 = t256 > t_mem ? t256 : t_mem; t128 = t128 > t_mem ? t128 : t_mem;
+    const double t8 = t256 < t128 ? t256 : t128;
+    if (wins) *wins = t8 < 0.93 * (t_ring > t_mem ? t_ring : t_mem);
+    return t256 < t128 ? 256 : 128;
+}
+
 template <typename VT>
 int dispatch(const GemmArgs &g, hipStream_t s) {
     const GemmKnobs &kn = gemm_knobs();
@@ -390,24 +414,10 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
         if (rc != OVO_E_UNSUPPORTED) return rc;
     }
     if (k64 && g.M >= 2048 && g.N >= 256 && !force_tile && !kn.no_8p) {
-        const double flop = 2.0 * g.M * (double)g.N * g.K, kt = g.K / 64;
-        const double bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K) + (double)g.M * g.N * (g.out_dtype == 0 ? 4.0 : 2.0) * (g.add ? 2.0 : 1.0);
-        const double t_mem = bytes / 4.0e6;                                            // us at 4 TB/s
-        // (the ring kernels' rate falls with K: 650 TFLOP/s from 16 K-tiles, ~560 at 7 (K = 448), ~400 at 4 (K = 256): profiles/r03c_gemm_variants.txt)
-        const double t_ring = flop / (kt <= 4 ? 400.0e6 : (kt <= 8 ? 560.0e6 : 650.0e6)) + 4.0;
-        const double r256 = (double)((blocks(256, 256) + 255) / 256), r128 = (double)((blocks(256, 128) + 255) / 256);
-        // per-K-tile cost of the 256x128 form rises once every CU holds a tile and stays in its K-loop (measured: 0.62 us with <= 192 tiles
-        // in flight, ~0.70 on a full chip with short K-loops whose phases interleave, 0.86 at K >= 3072: every CU in its K-loop at once)
-        const double s128 = blocks(256, 128) <= 192 ? 0.62 : (kt >= 48 ? 0.86 : 0.70);
-        // short K-loops over many rounds (Hiera stage 3: K = 448, 6-10 rounds): the rounds of different CUs drift apart and the 256 x 128 form's
-        // shorter tiles overlap each other's prologues and epilogues (11 us per round measured instead of 14), the 256 x 256 form's do not (20.5):
-        // (58800, 1344, 448) 126 us on the ring kernel -> 112; (196608, 1344, 256) 352 -> 300
-        const double fix256 = (kt <= 8 && r256 >= 4) ? 10.0 : 8.0, fix128 = (kt <= 8 && r128 >= 4) ? 6.5 : 9.0;
-        double t256 = r256 * (fix256 + 1.5 * kt), t128 = r128 * (fix128 + s128 * kt);
-        t256 = t256 > t_mem ? t256 : t_mem; t128 = t128 > t_mem ? t128 : t_mem;
-        const double t8 = t256 < t128 ? t256 : t128;
-        if (t8 < 0.93 * (t_ring > t_mem ? t_ring : t_mem)) {
-            const int rc = gemm8p_launch(g, t256 < t128 ? 256 : 128, std::is_same<VT, bf16x8>::value ? 2 : 1, s);
+        bool wins = false;
+        const int bn8 = choose8p(g.M, g.N, g.K, g.out_dtype == 0, g.add != nullptr, &wins);
+        if (wins) {
+            const int rc = gemm8p_launch(g, bn8, std::is_same<VT, bf16x8>::value ? 2 : 1, s);
             if (rc != OVO_E_UNSUPPORTED) return rc;
         }
     }
@@ -444,7 +454,8 @@ int dispatch(const GemmArgs &g, hipStream_t s) {
 
 struct RowLn { const float *g, *b; float eps; void *out; long long ld; };
 static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, int n_valid, ovo_stream_t stream, const ovo_rope_t *rope = nullptr,
-                      const ovo_window_t *win = nullptr, long long add_rows = 0, const RowLn *rln = nullptr) {
+                      const ovo_window_t *win = nullptr, long long add_rows = 0, const RowLn *rln = nullptr, const ovo_gemm_detail::FoldOut *fold_out = nullptr,
+                      const ovo_gemm_detail::FoldIn *fold_in = nullptr) {
     OVO_REQUIRE(p, "null descriptor");
     OVO_REQUIRE(p->M >= 0 && p->N > 0 && p->K > 0, "bad shape");
     if (p->M == 0) return OVO_OK;
@@ -465,6 +476,7 @@ static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, 
     g.rope_cos = g.rope_sin = nullptr; g.rope_T = 1; g.rope_hd = 4; g.rope_cols = 0; g.rope_t0 = 0;
     g.ln_x = g.ln_g = g.ln_b = nullptr; g.ln_eps = 0.f; g.ln_d = 0; g.ln_mode = 0; g.pool_ww = 0; g.qpool_out = nullptr; g.qpool_cols = 0;
     g.rln_g = g.rln_b = nullptr; g.rln_eps = 0.f; g.rln_out = nullptr; g.rln_ld = 0;
+    g.xb_out = nullptr; g.ld_xb = 0; g.stat_out = nullptr; g.stat_ld = 0; g.fold_stats = nullptr; g.fold_parts = 0; g.fold_D = 0; g.fold_cs = nullptr; g.fold_eps = 0.f;
     g.dbg = 0; g.slab16 = 0; g.rope_lds = 0; g.stamps = nullptr; g.win_per = 0; g.win_ww = g.win_wh = g.win_nww = g.win_nwin = 1; g.win_H = g.win_W = 0;
     if (win) {
         OVO_REQUIRE(win->B > 0 && win->H > 0 && win->W > 0 && win->wh > 0 && win->ww > 0, "bad window descriptor");
@@ -487,10 +499,76 @@ static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, 
         OVO_CHECK_LAUNCH();
         return OVO_OK;
     }
+    if (fold_out || fold_in) {                                    // the LayerNorm fold: ping-pong kernel or nothing
+        const int bn = ovo_gemm_detail::gemm_fold_ok(p->M, p->N, p->K) ? choose8p(p->M, p->N, p->K, p->out_dtype == 0, p->add != nullptr, nullptr) : 0;
+        if (!bn || p->in_dtype != 2 || p->alpha != 1.0f || win || add_rows || best) return OVO_E_UNSUPPORTED;
+        if (fold_out) {
+            if (p->out_dtype != 0 || !p->add || p->act != 0 || rope) return OVO_E_UNSUPPORTED;
+            OVO_REQUIRE(fold_out->xb && fold_out->stats && fold_out->ld_xb % 8 == 0 && ((uintptr_t)fold_out->xb & 15) == 0 && fold_out->ld_stats >= p->M &&
+                        ((uintptr_t)fold_out->stats & 7) == 0, "bad fold outputs");
+            g.xb_out = (uint16_t *)fold_out->xb; g.ld_xb = fold_out->ld_xb; g.stat_out = fold_out->stats; g.stat_ld = fold_out->ld_stats;
+        } else {
+            if (p->out_dtype == 0 || p->add || !(p->act == 0 || p->act == 1) || !p->bias) return OVO_E_UNSUPPORTED;
+            OVO_REQUIRE(fold_in->stats && fold_in->colsum && fold_in->parts >= 1 && fold_in->parts <= 16 && fold_in->D > 0 && ((uintptr_t)fold_in->colsum & 15) == 0 &&
+                        fold_in->ld_stats >= p->M && ((uintptr_t)fold_in->stats & 7) == 0, "bad fold inputs");
+            g.fold_stats = fold_in->stats; g.stat_ld = fold_in->ld_stats; g.fold_parts = fold_in->parts; g.fold_D = fold_in->D; g.fold_cs = fold_in->colsum; g.fold_eps = fold_in->eps;
+        }
+        const int rc = gemm8p_launch(g, bn, 2, (hipStream_t)stream);
+        if (rc != OVO_OK) return rc;
+        OVO_CHECK_LAUNCH();
+        return OVO_OK;
+    }
     const int rc = p->in_dtype == 2 ? dispatch<bf16x8>(g, (hipStream_t)stream) : dispatch<f16x8>(g, (hipStream_t)stream);
     if (rc != OVO_OK) return rc;
     OVO_CHECK_LAUNCH();
     return OVO_OK;
+}
+
+// ---- the LayerNorm fold's entry points (gemm_common.h) ----
+// The first LayerNorm of a forward has no producer product in front of it: one wave per row writes the bf16 copy and the row's (sum, sum of squares) as ONE
+// partial (parts = 1) -- the same quantities, in the same layout, that the producer epilogue leaves for every later LayerNorm.
+__global__ void __launch_bounds__(256) k_fold_rowstats(const float *__restrict__ x, long long ldx, int M, int D, uint16_t *__restrict__ xb, long long ld_xb, float2 *__restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 v = *(const float4 *)(x + row * ldx + c);
+        *(uint2 *)(xb + row * ld_xb + c) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+        s1 += (v.x + v.y) + (v.z + v.w);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) stats[row] = make_float2(s1, s2);
+}
+int ovo_gemm_detail::gemm_fold_rowstats(const float *x, long long ldx, int M, int D, void *xb, long long ld_xb, float *stats, ovo_stream_t stream) {
+    OVO_REQUIRE(x && xb && stats && M > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ld_xb % 4 == 0, "bad argument");
+    k_fold_rowstats<<<(M + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, ldx, M, D, (uint16_t *)xb, ld_xb, (float2 *)stats);
+    OVO_CHECK_LAUNCH();
+    return OVO_OK;
+}
+int ovo_gemm_detail::gemm_fold_parts(int N) { return N / 64; }      // one partial per 64-column wave tile of the producer (either tile width)
+bool ovo_gemm_detail::gemm_fold_ok(int M, int N, int K) {
+    // both halves run on the ping-pong kernel: batched forwards only (M >= 2048 rows, the dispatcher's own bound), whole 64-deep K-tiles, whole 64-column wave tiles
+    return M >= 2048 && K % 64 == 0 && K >= 64 && N % 64 == 0 && N >= 256;
+}
+int ovo_gemm_detail::gemm_fold_producer(const ovo_gemm_t *p, const FoldOut &o, ovo_stream_t stream) { return gemm_entry(p, nullptr, 1, 0, stream, nullptr, nullptr, 0, nullptr, &o); }
+int ovo_gemm_detail::gemm_fold_consumer(const ovo_gemm_t *p, const ovo_rope_t *rope, const FoldIn &f, ovo_stream_t stream) {
+    return gemm_entry(p, nullptr, 1, 0, stream, rope, nullptr, 0, nullptr, nullptr, &f);
+}
+
+extern "C" int ovo_gemm_fold_out(const ovo_gemm_t *p, void *xb, int64_t ld_xb, float *stats, int64_t ld_stats, ovo_stream_t stream) {
+    const ovo_gemm_detail::FoldOut o = {xb, (long long)ld_xb, stats, (long long)ld_stats};
+    return ovo_gemm_detail::gemm_fold_producer(p, o, stream);
+}
+extern "C" int ovo_gemm_fold_stats(const float *x, int64_t ldx, int M, int D, void *xb, int64_t ld_xb, float *stats, ovo_stream_t stream) {
+    return ovo_gemm_detail::gemm_fold_rowstats(x, ldx, M, D, xb, ld_xb, stats, stream);
+}
+extern "C" int ovo_gemm_fold_in(const ovo_gemm_t *p, const ovo_rope_t *rope, const float *stats, int64_t ld_stats, int parts, int D, const float *rowsum, float eps,
+                                ovo_stream_t stream) {
+    const ovo_gemm_detail::FoldIn f = {stats, (long long)ld_stats, parts, D, rowsum, eps};
+    return ovo_gemm_detail::gemm_fold_consumer(p, rope, f, stream);
 }
 
 extern "C" int ovo_gemm(const ovo_gemm_t *p, ovo_stream_t stream) { return gemm_entry(p, nullptr, 1, 0, stream); }

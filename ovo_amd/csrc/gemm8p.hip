@@ -96,6 +96,11 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     constexpr int SLAB32 = 8 * (BM / WARPS_M / 2) * ((BN / (8 / WARPS_M)) * 4 + 16), SLAB16 = 8 * (BM / WARPS_M) * ((BN / (8 / WARPS_M)) * 2 + 16), RING = 2 * (BM + BN) * 128;
     constexpr int LUT_OFF = STAGED ? (SLAB32 > RING ? (SLAB32 > SLAB16 ? SLAB32 : SLAB16) : (SLAB16 > RING ? SLAB16 : RING)) : RING;
     const float2 *lut = (STAGED && g.act == 1 && g.gelu_lut) ? (const float2 *)(smem + LUT_OFF) : nullptr;
+    // LayerNorm fold, consumer side (gemm_common.h): (mean, rstd) of the tile's 256 rows, behind the table; filled in the prologue, read by the epilogue
+    constexpr int ROPE_END = 8 * 32 * ((BN / (8 / WARPS_M)) * 4 + 16) + 2 * WARPS_M * 32 * (64 * 4 + 16);      // (rope_out's slabs + table slice: may reach past the table)
+    constexpr int RS_OFF = LUT_OFF + GELU_LUT_BYTES > ROPE_END ? LUT_OFF + GELU_LUT_BYTES : ROPE_END;
+    float2 *row_ms = (float2 *)(smem + RS_OFF);
+    const bool fold = STAGED && g.fold_stats != nullptr;
     // (the table is FILLED after the prologue's six DMA stages are in flight -- two erff per thread under the first tiles' load latency, round 5)
 #ifdef OVO_GEMM_DEBUG        // tools/ builds only (python -m ovo_amd.build --gemm-debug): early exits, per-phase time stamps, de-phased starts
     if (g.dbg & 1) return;
@@ -213,6 +218,15 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
 
     const int nt = g.K / 64;
 
+    // fold: this thread's row's partial statistics, requested BEFORE the ring's first stages (older in the in-order vmcnt queue: the counted waits below
+    // keep their meaning) and summed after the prologue's wait.  Unconditional loads (a load inside a select becomes guarded dword loads and full drains).
+    float2 fpart[16];
+    if (fold && tid < BM) {
+        const int row = m0 + tid < g.M ? m0 + tid : g.M - 1;
+        const float2 *sp = (const float2 *)g.fold_stats + row;                 // [part][row]: a wave instruction reads 64 consecutive rows of one part
+#pragma unroll
+        for (int q = 0; q < 16; ++q) fpart[q] = sp[(long long)(q < g.fold_parts ? q : g.fold_parts - 1) * g.stat_ld];
+    }
     // ---- prologue: the six stages of "phases -6 .. -1": Ah0(0) Bh0(0) Bh1(0) Ah1(0) Ah0(1) Bh0(1)
     stage_a(0, 0, 0);
     stage_b(0, 0, 0);
@@ -220,11 +234,19 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
     stage_a(0, 1, 0);
     stage_a(1, 0, 1, nt > 1);
     stage_b(1, 0, 1, nt > 1);
-    if (lut) gelu_lut_fill((float2 *)(smem + LUT_OFF), tid, 512);     // ds_write only (lgkmcnt): the counted vmcnt below still sees the six stages alone
+    // the table's stores behind the six stages: untracked (gemm_common.h), or the compiler drains the stages in front of each of them
+    if (lut) gelu_lut_fill<true>((float2 *)(smem + LUT_OFF), tid, 512);
     if constexpr (MERGED) OVO_VMCNT(2 * NA + NB);         // Ah0(0), Bh0(0), Bh1(0) landed (this wave's pieces): the first interval reads all three
     else OVO_VMCNT(2 * NA + 2 * NB);                      // Ah0(0), Bh0(0) landed (this wave's pieces)
     OVO_BARRIER();
     stamp(1);
+    if (fold && tid < BM) {                               // partials in their fixed order -> mean, rstd (one-pass variance: the partials are sums and sums of squares)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const float w = q < g.fold_parts ? 1.f : 0.f; s1 += w * fpart[q].x; s2 += w * fpart[q].y; }
+        const float inv = 1.0f / (float)g.fold_D, mean = s1 * inv, var = fmaxf(s2 * inv - mean * mean, 0.f);
+        lds_store_b64_untracked(row_ms + tid, mean, rsqrtf(var + g.fold_eps));      // (first read in the epilogue, behind the K-loop's waits and barriers)
+    }
 #ifdef OVO_GEMM_DEBUG
     if (g.dbg & 2) { OVO_VMCNT(0); return; }
 #endif
@@ -357,24 +379,33 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
             static_assert(WTN == 64, "read mapping below: 8 lanes x 16 bytes per row");
             char *slab = smem + wave * (WROWS * RB2);
             const int nw = n0 + wc * WTN;
-            float4 bias_r[NJ];
+            float4 bias_r[NJ], cs_r[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int n = nw + j * CS + lcol;
                 bias_r[j] = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                cs_r[j] = (fold && n < g.N) ? *(const float4 *)(g.fold_cs + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            auto write_all = [&](auto KIND_) {
+            auto write_all = [&](auto KIND_, auto FOLD_) {
                 constexpr int KIND = decltype(KIND_)::value;
+                constexpr bool FOLD = decltype(FOLD_)::value;
                 static_for<0, NI>([&](auto I_) {
                     constexpr int i = decltype(I_)::value;
                     float row_mx = -3.0e38f;
                     int row_arg = 0x7fffffff;
+                    float2 ms = make_float2(0.f, 1.f);
+                    if constexpr (FOLD) ms = row_ms[wr * WTM + i * RT + lrow];                 // (mean, rstd) of this lane's row
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         const f32x4 pc = piece(i, j);
                         float v[4] = {pc[0], pc[1], pc[2], pc[3]};
+                        if constexpr (FOLD) {                                             // LN(x) . W^T + b from bf16(x) . W'^T: rstd (acc - mean colsum) + b'
+                            v[0] = ms.y * (v[0] - ms.x * cs_r[j].x); v[1] = ms.y * (v[1] - ms.x * cs_r[j].y);
+                            v[2] = ms.y * (v[2] - ms.x * cs_r[j].z); v[3] = ms.y * (v[3] - ms.x * cs_r[j].w);
+                        } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] *= g.alpha;                    // (the operations of math4, in its order)
+                            for (int r = 0; r < 4; ++r) v[r] *= g.alpha;                // (the operations of math4, in its order)
+                        }
                         v[0] += bias_r[j].x; v[1] += bias_r[j].y; v[2] += bias_r[j].z; v[3] += bias_r[j].w;
                         if (KIND == 1) {
 #pragma unroll
@@ -397,9 +428,11 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     }
                 });
             };
-            if (kind16 == 0) write_all(std::integral_constant<int, 0>{});
-            else if (kind16 == 2) write_all(std::integral_constant<int, 2>{});
-            else write_all(std::integral_constant<int, 1>{});
+            using NoFold = std::integral_constant<bool, false>;
+            using Fold = std::integral_constant<bool, true>;
+            if (kind16 == 0) { if (fold) write_all(std::integral_constant<int, 0>{}, Fold{}); else write_all(std::integral_constant<int, 0>{}, NoFold{}); }
+            else if (kind16 == 2) write_all(std::integral_constant<int, 2>{}, NoFold{});
+            else { if (fold) write_all(std::integral_constant<int, 1>{}, Fold{}); else write_all(std::integral_constant<int, 1>{}, NoFold{}); }
             OVO_FENCE();
             const int q = lane >> 3, c = (lane & 7) * 8, n = nw + c;
             const bool in0 = n < g.N, in1 = n + 4 < g.N;
@@ -445,7 +478,7 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                         v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
                     }
                 }
-                if constexpr (KIND == 3) { v[0] += addv.x; v[1] += addv.y; v[2] += addv.z; v[3] += addv.w; }
+                if constexpr (KIND == 3 || KIND == 4) { v[0] += addv.x; v[1] += addv.y; v[2] += addv.z; v[3] += addv.w; }
             }
         };
         // (measured and dropped, round 6: KIND 3's residual rows FETCHED AHEAD of the slab round trip -- two groups of 8 row instructions in flight, pass 1's
@@ -460,12 +493,13 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     *(f32x4 *)(slab + (i * RT + lrow) * ROWB + (j * CS + lcol) * 4) = piece(pass * (NI / 2) + i, j);
             OVO_FENCE();
             const int mw = m0 + wr * WTM + pass * HM, nw = n0 + wc * WTN;
-            if (KIND == 3 || (KIND < 0 && g.out_dtype == 0)) {                       // f32 rows: 16 lanes x 16 bytes per row, 4 rows per instruction
+            if (KIND == 3 || KIND == 4 || (KIND < 0 && g.out_dtype == 0)) {          // f32 rows: 16 lanes x 16 bytes per row, 4 rows per instruction
                 constexpr int LPR = WTN / 4, RPI = 64 / LPR;
                 const int c = (lane % LPR) * 4, n = nw + c;
                 const float4 bias = (g.bias && n < g.N) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 int tok = 0, nh = 0, tstep = 0;           // rotary position of the lane's row, advanced RPI rows per trip
                 if (KIND < 0 && g.rope_cos) { tok = (mw + lane / LPR) % g.rope_T; nh = n % g.rope_hd; tstep = RPI % g.rope_T; }
+                float keep1 = 0.f, keep2 = 0.f;           // KIND 4: (sum, sum of squares) of row mw + lane over this wave's 64 columns
 #pragma unroll 4
                 for (int it = 0; it < HM / RPI; ++it) {
                     const int r = it * RPI + lane / LPR, m = mw + r, tk = tok;
@@ -473,13 +507,41 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     if (tok >= g.rope_T) tok -= g.rope_T;
                     const f32x4 a = *(const f32x4 *)(slab + r * ROWB + c * 4);
                     const long long md = (m < g.M && n < g.N) ? row_dest(g, m) : -1;
-                    if (md < 0) continue;
-                    const float4 addv = (KIND == 3 || g.add) ? *(const float4 *)(g.add + add_row(g, m, md) * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float s1 = 0.f, s2 = 0.f;
+                    if (KIND != 4 && md < 0) continue;
+                    if (KIND != 4 || md >= 0) {
+                    const float4 addv = (KIND == 3 || KIND == 4 || g.add) ? *(const float4 *)(g.add + add_row(g, m, md) * g.ld_add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                     float v[4] = {a[0], a[1], a[2], a[3]};
                     mathk(tk, nh, n, v, bias, addv);
                     { const f32x4 vv = {v[0], v[1], v[2], v[3]};
                       if (g.res_plain) *(f32x4 *)((float *)g.C + md * g.ldc + n) = vv;        // (OVO_8P_RES_PLAIN=1, measurement: the f32 stream kept in the caches for the LayerNorm that follows)
                       else __builtin_nontemporal_store(vv, (f32x4 *)((float *)g.C + md * g.ldc + n)); }
+                    if constexpr (KIND == 4) {
+                        // LayerNorm fold, producer side: the row's bf16 copy (the next product's A operand) and this wave's share of its (sum, sum of
+                        // squares) -- the row's 64 columns sit in the 16 lanes of one DPP row: four row_shr adds, lane 15 of the row holds the total
+                        static_assert(LPR == 16 && WTN == 64 && HM <= 64, "one DPP row per output row, one partial per 64-column wave tile, at most one row per lane and pass");
+                        *(uint2 *)(g.xb_out + md * g.ld_xb + n) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+                        s1 = (v[0] + v[1]) + (v[2] + v[3]); s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                        s1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x111, 0xf, 0xf, true));
+                        s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0x111, 0xf, 0xf, true));
+                        s1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x112, 0xf, 0xf, true));
+                        s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0x112, 0xf, 0xf, true));
+                        s1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x114, 0xf, 0xf, true));
+                        s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0x114, 0xf, 0xf, true));
+                        s1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x118, 0xf, 0xf, true));
+                        s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0x118, 0xf, 0xf, true));
+                    }
+                    }
+                    if constexpr (KIND == 4) {
+                        // every lane active again: rows 4 it .. 4 it + 3 have their totals in lanes 15, 31, 47, 63 -- lanes 4 it .. 4 it + 3 fetch them (crossbar,
+                        // no memory), so that after the HM / 4 trips lane L < HM holds row L of the pass and the statistics leave as ONE 256-512-byte store per wave and pass
+                        const int src = ((lane & 3) * 16 + 15) * 4;
+                        const float t1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(s1))), t2 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(s2)));
+                        if ((lane >> 2) == it) { keep1 = t1; keep2 = t2; }
+                    }
+                }
+                if constexpr (KIND == 4) {
+                    if (lane < HM && mw + lane < g.M && nw < g.N) *((float2 *)g.stat_out + (long long)(nw >> 6) * g.stat_ld + (mw + lane)) = make_float2(keep1, keep2);
                 }
             } else {                                      // 2-byte rows: 8 lanes x 16 bytes per row, 8 rows per instruction
                 constexpr int LPR = WTN / 8, RPI = 64 / LPR;
@@ -529,7 +591,8 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
         // row group need the SAME [32 rows][64] slice of cos and sin): 32-row passes, per pass one cooperative load of the slice (4-8 float4 per thread)
         // instead of 4 table loads per lane and 8 rows from every wave: the ViT's QKV (13848, 3072, 1024) 99.2 -> 91.3 us, at 4 keyframes 37.6 -> 31.8
         // (plain: 81-83); same values, same arithmetic as math4: bit-identical.
-        auto rope_out = [&]() {
+        auto rope_out = [&](auto FOLD_) {
+            constexpr bool FOLD = decltype(FOLD_)::value;
             constexpr int PR = 32, NPASS = WTM / PR, TRB = 64 * 4 + 16;
             constexpr int SLABS = 8 * PR * ROWB, TBL = WARPS_M * PR * TRB;      // table: cos block, then sin block
             char *sl = smem + wave * (PR * ROWB);
@@ -540,6 +603,11 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
             const bool in0 = n < g.N, in1 = n + 4 < g.N, rot = n < g.rope_cols;
             const float4 bias0 = (g.bias && in0) ? *(const float4 *)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 bias1 = (g.bias && in1) ? *(const float4 *)(g.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float cs0[4] = {0.f, 0.f, 0.f, 0.f}, cs1[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (FOLD) {
+                const float4 q0 = in0 ? *(const float4 *)(g.fold_cs + n) : make_float4(0.f, 0.f, 0.f, 0.f), q1 = in1 ? *(const float4 *)(g.fold_cs + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                cs0[0] = q0.x; cs0[1] = q0.y; cs0[2] = q0.z; cs0[3] = q0.w; cs1[0] = q1.x; cs1[1] = q1.y; cs1[2] = q1.z; cs1[3] = q1.w;
+            }
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 if (pass) OVO_BARRIER();                            // every wave is done with the previous slice
@@ -566,8 +634,14 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                     const long long md = (m < g.M && in0) ? row_dest(g, m) : -1;
                     if (md < 0) continue;
                     float v0[4] = {a0[0], a0[1], a0[2], a0[3]}, v1[4] = {a1[0], a1[1], a1[2], a1[3]};
+                    if constexpr (FOLD) {
+                        const float2 ms = row_ms[wr * WTM + pass * PR + r];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v0[e] *= g.alpha; v1[e] *= g.alpha; }
+                        for (int e = 0; e < 4; ++e) { v0[e] = ms.y * (v0[e] - ms.x * cs0[e]); v1[e] = ms.y * (v1[e] - ms.x * cs1[e]); }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] *= g.alpha; v1[e] *= g.alpha; }
+                    }
                     v0[0] += bias0.x; v0[1] += bias0.y; v0[2] += bias0.z; v0[3] += bias0.w;
                     v1[0] += bias1.x; v1[1] += bias1.y; v1[2] += bias1.z; v1[3] += bias1.w;
                     if (rot && m % g.rope_T >= g.rope_t0) {
@@ -590,8 +664,10 @@ __global__ void __launch_bounds__(512) k_gemm8p(GemmArgs g) {
                 OVO_FENCE();
             }
         };
-        if (g.out_dtype == 0 && g.add && g.act == 0 && !g.rope_cos) rows_out(std::integral_constant<int, 3>{});
-        else if (g.out_dtype != 0 && !g.add && g.act == 0 && g.rope_cos && g.rope_hd == 64 && n0 % 64 == 0 && g.rope_lds) rope_out();
+        if (g.out_dtype == 0 && g.add && g.act == 0 && !g.rope_cos) { if (g.xb_out) rows_out(std::integral_constant<int, 4>{}); else rows_out(std::integral_constant<int, 3>{}); }
+        else if (g.out_dtype != 0 && !g.add && g.act == 0 && g.rope_cos && g.rope_hd == 64 && n0 % 64 == 0 && g.rope_lds) {
+            if (fold) rope_out(std::integral_constant<bool, true>{}); else rope_out(std::integral_constant<bool, false>{});
+        }
         else if (g.out_dtype != 0 && !g.add && g.act == 0 && g.rope_cos) rows_out(std::integral_constant<int, 2>{});
         else rows_out(std::integral_constant<int, -1>{});
     } else if constexpr (MF == 16) {
@@ -690,6 +766,12 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     static int res_plain = getenv("OVO_8P_RES_PLAIN") ? atoi(getenv("OVO_8P_RES_PLAIN")) : 0;
     if (ovo_knobs_dynamic()) res_plain = getenv("OVO_8P_RES_PLAIN") ? atoi(getenv("OVO_8P_RES_PLAIN")) : 0;
     g.res_plain = res_plain;
+    if (g.fold_stats || g.xb_out) {            // the LayerNorm fold lives in the staged epilogues the ViT's products take; anything else is refused, not approximated
+        const bool cons_ok = !g.fold_stats || (STAGED && g.out_dtype != 0 && !g.add && !g.best && g.fold_cs && g.fold_parts >= 1 && g.fold_parts <= 16 && g.N % 64 == 0 && g.slab16 &&
+                                               ((!g.rope_cos && (g.act == 0 || (g.act == 1 && g.gelu_lut))) || (g.rope_cos && g.act == 0 && g.rope_hd == 64 && g.rope_lds)));
+        const bool prod_ok = !g.xb_out || (STAGED && g.out_dtype == 0 && g.add && g.act == 0 && !g.rope_cos && g.stat_out && g.N % 64 == 0 && BN / (8 / WARPS_M) == 64 && g.win_per <= 0);
+        if (!cons_ok || !prod_ok || (g.fold_stats && g.xb_out)) { ovo_set_error("ovo_gemm: this product cannot take the folded LayerNorm"); return OVO_E_UNSUPPORTED; }
+    }
     g.nbn = (g.N + BN - 1) / BN;
     const int nbm = (g.M + BM - 1) / BM;
     constexpr size_t ring = 2 * (size_t)(BM + BN) * 128;                                  // two K-tile buffers
@@ -698,10 +780,11 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     constexpr size_t lds = (STAGED ? (slabs > ring ? (slabs > slabs16 ? slabs : slabs16) : (slabs16 > ring ? slabs16 : ring)) : ring) + (STAGED ? GELU_LUT_BYTES : 0);
     constexpr size_t rope_lds = 8 * 32 * (size_t)((BN / (8 / WARPS_M)) * 4 + 16) + 2 * (size_t)WARPS_M * 32 * (64 * 4 + 16);      // rope_out: 32-row slabs + the table slice
     constexpr size_t lds_all = lds > rope_lds ? lds : rope_lds;
-    static_assert(lds_all <= 160 * 1024, "LDS");
+    constexpr size_t fold_lds = lds_all + 256 * 8;                                        // + (mean, rstd) of the tile's rows (the LayerNorm fold's consumer)
+    static_assert(fold_lds <= 160 * 1024, "LDS");
     static bool attr_done = false;              // per instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_gemm8p<BM, BN, WARPS_M, VT, STAGED, MF, MERGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
+        hipError_t e = hipFuncSetAttribute((const void *)k_gemm8p<BM, BN, WARPS_M, VT, STAGED, MF, MERGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds);
         if (e != hipSuccess) { ovo_set_error("ovo_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return OVO_E_LAUNCH; }
         attr_done = true;
     }
@@ -714,7 +797,7 @@ int launch8p_(const GemmArgs &g0, hipStream_t s) {
     g.strip = strip_env >= 0 ? strip_env : (g.nbn >= 16 ? 8 : 0);
     if (g.strip > 0) g.chunk = (g.tiles + 7) / 8;
     const int grid = g.chunk > 0 ? g.chunk * 8 : g.tiles;
-    k_gemm8p<BM, BN, WARPS_M, VT, STAGED, MF, MERGED><<<grid, 512, (STAGED && g.rope_cos) ? lds_all : lds, s>>>(g);
+    k_gemm8p<BM, BN, WARPS_M, VT, STAGED, MF, MERGED><<<grid, 512, (STAGED && g.fold_stats) ? fold_lds : ((STAGED && g.rope_cos) ? lds_all : lds), s>>>(g);
     if (prof) ovo_prof_end(s);
     return OVO_OK;
 }

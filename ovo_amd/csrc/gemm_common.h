@@ -47,6 +47,16 @@ struct GemmArgs {
     // k_gemm<128, 448> (gemm.hip, round 5): a workgroup owns whole rows (N = 448 = BN), so after the f32 result (+ residual) is stored the LayerNorm of the
     // rows that FOLLOWS the product in Hiera stage 3 (norm2 before the MLP) is taken from the accumulators: rln_out bf16 [C rows, rln_ld] = LN(C row)
     const float *rln_g, *rln_b; float rln_eps; uint16_t *rln_out; long long rln_ld;
+    // LayerNorm FOLD (round 6, vit.hip; gemm8p only).  LN(x) . W^T + b = rstd (bf16(x) . W'^T - mean colsum(W')) + b' with W' = gamma . W and b' = b + W . beta:
+    //   PRODUCER (the f32 += residual epilogue that writes x): xb_out = bf16(x row) beside the f32 row, and stat_out[part][row][2] = (sum, sum of squares) of
+    //     the row's columns inside the 64-column wave tile `part` (N / 64 parts for either tile width; PART-major, stat_ld rows apart: a wave stores the 64 rows
+    //     of a pass as one 512-byte run and the consumer's 256 threads read a part's 256 rows as four -- row-major [row][part] made every lane of both touch its
+    //     own cache line: + 8 us per consumer launch at 16 K rows);
+    //   CONSUMER (a 2-byte-output product whose A operand is xb): fold_stats / fold_parts = the producer's partials, fold_D = the row length they cover,
+    //     fold_cs = column sums of W' (f32 [N]); `bias` = b'.  The epilogue forms mean / rstd per row once per tile (LDS) and applies the line above.
+    uint16_t *xb_out; long long ld_xb;
+    float *stat_out; long long stat_ld;
+    const float *fold_stats; int fold_parts, fold_D; const float *fold_cs; float fold_eps;
     int dbg;                   // tools/ only (OVO_8P_DEBUG): 1 = leave before anything, 2 = leave after the prologue, 4 = no epilogue, 8 = epilogue without the 2-byte stores
     unsigned long long *stamps;   // tools/ only (OVO_8P_STAMPS = address of u64[tiles][4]): s_memrealtime at start / K-loop / epilogue / end
 };
@@ -118,11 +128,22 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
 // Linear interpolation error <= h^2 / 8 max|Phi''| = 7e-6; |GELU error| <= 9.1e-6 absolute over all x (the polynomial: 8.6e-6).
 constexpr int GELU_LUT_N = 768;
 constexpr int GELU_LUT_BYTES = GELU_LUT_N * 8;
+// An 8-byte LDS store that the compiler's wait-count pass does not see.  A plain ds_write issued while LDS-DMA loads (buffer_load ... lds) are in flight gets
+// `s_waitcnt vmcnt(0)` in front of it -- the pass cannot prove that it does not alias the DMA's destination -- which drains every stage a prologue has just
+// prefetched (seen in k_gemm8p's ISA: the GELU table fill and the fold's (mean, rstd) rows, both behind the six prologue stages).  The caller orders the store
+// itself: an `s_waitcnt lgkmcnt(0)` + barrier before the first read (the K-loop's own, for both users).
+__device__ __forceinline__ void lds_store_b64_untracked(void *p, float a, float b) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f v = {a, b};
+    asm volatile("ds_write_b64 %0, %1" ::"v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)p), "v"(v) : "memory");
+}
+template <bool UNTRACKED = false>
 __device__ __forceinline__ void gelu_lut_fill(float2 *t, int tid, int nthreads) {
     for (int i = tid; i < GELU_LUT_N; i += nthreads) {
         const float x0 = (float)(i - GELU_LUT_N / 2) * (1.0f / 64.0f), x1 = (float)(i + 1 - GELU_LUT_N / 2) * (1.0f / 64.0f);
         const float p0 = 0.5f * (1.0f + erff(x0 * 0.70710678118654752f)), p1 = 0.5f * (1.0f + erff(x1 * 0.70710678118654752f));
-        t[i] = make_float2(p0, p1 - p0);
+        if constexpr (UNTRACKED) lds_store_b64_untracked(t + i, p0, p1 - p0);
+        else t[i] = make_float2(p0, p1 - p0);
     }
 }
 __device__ __forceinline__ float gelu_lut(float x, const float2 *t) {
@@ -248,6 +269,16 @@ inline double gemm_algorithmic_bytes(const GemmArgs &g) {
 
 // launch of the 256-row ping-pong kernels (gemm8p.hip); bn in {128, 256}; returns OVO_E_UNSUPPORTED when the shape does not fit
 int gemm8p_launch(const GemmArgs &g, int bn, int in_dtype, hipStream_t s);
+
+// The two halves of the LayerNorm fold (GemmArgs: xb_out ... fold_eps), as vit.hip calls them; both run on the ping-pong kernel or return OVO_E_UNSUPPORTED
+// (nothing launched: the caller takes the LayerNorm + plain product path).
+struct FoldOut { void *xb; long long ld_xb; float *stats; long long ld_stats; };        // producer: bf16 copy of the result rows, partial statistics [N / 64][ld_stats][2]
+struct FoldIn { const float *stats; long long ld_stats; int parts; int D; const float *colsum; float eps; };
+int gemm_fold_parts(int N);                                        // partial statistics per row a producer of width N writes: one per 64-column wave tile
+bool gemm_fold_ok(int M, int N, int K);                            // the shape can run on the ping-pong kernel (either half of the fold)
+int gemm_fold_producer(const ovo_gemm_t *p, const FoldOut &o, ovo_stream_t stream);
+int gemm_fold_consumer(const ovo_gemm_t *p, const ovo_rope_t *rope, const FoldIn &f, ovo_stream_t stream);
+int gemm_fold_rowstats(const float *x, long long ldx, int M, int D, void *xb, long long ld_xb, float *stats, ovo_stream_t stream);   // f32 rows -> bf16 copy + one partial per row
 // the persistent 256 x 128 form (gemm8q.hip: one DMA ring across a workgroup's tiles, epilogue of tile j behind the K-loop of tile j + 1)
 int gemm8q_launch(const GemmArgs &g, int in_dtype, hipStream_t s);
 // the weights-resident streaming form for tall short-K products (gemm_stream.hip); OVO_E_UNSUPPORTED when the shape has no instantiation

@@ -197,6 +197,9 @@ class HipViT:
             return L.ptr(x)
 
         self.q_prescaled = L.q_prescale_enabled()
+        # LayerNorm fold (ovo_vit_layer_t.qkv_wf ...): a second, gamma-scaled copy of the QKV / FC1 matrices (+ 340 MB for ViT-L); used by the library for
+        # batched forwards only.  OVO_VIT_LNFOLD=0: not prepared (and the library keeps its LayerNorm kernels)
+        self.ln_fold = os.environ.get("OVO_VIT_LNFOLD", "1") != "0" and spec.act in ("gelu",) and spec.width % 64 == 0 and spec.width <= 1024
         extra = spec.mlp_pad - spec.mlp_dim               # zero hidden units: act(0) = 0 and their fc2 columns are 0
 
         def pad_rows(t):
@@ -228,6 +231,11 @@ class HipViT:
             ly.out_w, ly.out_b = mat(ow), vec(ob)
             ly.ln2_g, ly.ln2_b = vec(sd[p + "ln_2.weight"]), vec(sd[p + "ln_2.bias"])
             ly.fc1_w, ly.fc1_b = mat(pad_rows(sd[p + "mlp.c_fc.weight"])), vec(pad_rows(sd[p + "mlp.c_fc.bias"]))
+            if self.ln_fold:                               # batched forwards: LayerNorm 1 / 2 live in the QKV / FC1 products (vit.hip)
+                wf, bf, cs = L.fold_layernorm(qw, qb, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"])
+                ly.qkv_wf, ly.qkv_bf, ly.qkv_cs = mat(wf), vec(bf), vec(cs)
+                wf, bf, cs = L.fold_layernorm(pad_rows(sd[p + "mlp.c_fc.weight"]), pad_rows(sd[p + "mlp.c_fc.bias"]), sd[p + "ln_2.weight"], sd[p + "ln_2.bias"])
+                ly.fc1_wf, ly.fc1_bf, ly.fc1_cs = mat(wf), vec(bf), vec(cs)
             ly.fc2_w, ly.fc2_b = mat(pad_cols(fw)), vec(fb)
         w = L.VitWeights()
         w.patch_w = mat(pw)

@@ -830,6 +830,44 @@ def test_vit_forward_vs_oracle_full_size(card, batch):
     assert err < _bound(spec.out_dim) and cos > 0.9999
 
 
+@pytest.mark.parametrize("name,base,over,batch", [
+    ("pe-l-336 x 4 layers (rope, 256 x 256 tiles, 16 partials)", "PE-Core-L14-336", dict(layers=4), 4),
+    ("width 512, no rope (256 x 256 tiles, 8 partials)", "PE-Core-L14-336", dict(layers=3, width=512, heads=8, mlp_dim=2048, out_dim=512, image_size=224, patch=16, use_rope=False), 12),
+    ("width 256 (256 x 128 tiles, 4 partials)", "PE-Core-L14-336", dict(layers=3, width=256, heads=4, mlp_dim=1024, out_dim=256, image_size=224, patch=16), 12),
+])
+def test_vit_layernorm_fold_vs_layernorm_kernels_and_oracle(monkeypatch, name, base, over, batch):
+    """The LayerNorm fold of batched forwards (ovo_vit_layer_t.qkv_wf ..., vit.hip): rstd (bf16(x) . W'^T - mean colsum(W')) + b' in the QKV / FC1 epilogues with
+    the statistics taken in the epilogue that wrote x -- against the LayerNorm kernels (OVO_VIT_LNFOLD=0, the same weights object) and the fp32 oracle."""
+    import dataclasses
+    from oracle import vit as OV
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state
+    spec = dataclasses.replace(SPECS[base], name="fold-test", **over)
+    sd = random_state(spec, seed=5)
+    gen = torch.Generator().manual_seed(3)
+    for k in list(sd):                                   # LayerNorm weights away from (1, 0): the fold moves them into the matrices
+        if ".ln_" in k and k.endswith("weight"):
+            sd[k] = 1.0 + 0.3 * torch.randn(sd[k].shape, generator=gen)
+        elif ".ln_" in k and k.endswith("bias"):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=gen)
+    vit = HipViT(spec, sd, device=DEV)
+    assert vit.ln_fold and batch * spec.tokens >= 2048
+    x = torch.randn(batch, 3, spec.image_size, spec.image_size, generator=gen)
+    x = x + 0.5                                          # a non-zero mean through the residual stream
+    ref = OV.vit_forward(sd, x, patch=spec.patch, heads=spec.heads, act=spec.act, rope=OV.rope_for(spec))
+    monkeypatch.setenv("OVO_VIT_LNFOLD", "1")
+    out_f = vit.forward(x.to(DEV)).cpu()
+    out_f2 = vit.forward(x.to(DEV)).cpu()
+    monkeypatch.setenv("OVO_VIT_LNFOLD", "0")
+    out_p = vit.forward(x.to(DEV)).cpu()
+    assert torch.equal(out_f, out_f2)                    # partial statistics are summed in a fixed order
+    assert not torch.equal(out_f, out_p)                 # (the fold really ran)
+    nr = torch.nn.functional.normalize(ref, dim=-1)
+    ef = (nr - torch.nn.functional.normalize(out_f, dim=-1)).abs().max().item()
+    ep = (nr - torch.nn.functional.normalize(out_p, dim=-1)).abs().max().item()
+    print(f"{name}: max |unit feature error| folded {ef:.2e}, LayerNorm kernels {ep:.2e}")
+    assert ef < _bound(spec.out_dim) and ef < 1.5 * ep + 1e-4
+
+
 def test_siglip_forward_vs_hf_golden():
     """SigLIP tower (no class token, tanh-GELU, attention-pool head) vs HuggingFace SiglipVisionModel (fp32) on the golden
     weights / input: width 64, hidden 176 (zero padded to 192 on the device), 2 layers, 16 tokens."""

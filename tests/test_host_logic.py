@@ -81,3 +81,19 @@ def test_instance3d_indexed_heap_vs_literal_restatement(n_top):
             assert c.fusion_views() == (a.fusion_views() if n_top > 0 else []) and c.is_top_kf(a.top_kf[0][1]) if a.top_kf else True
     finally:
         Instance3D.n_top_kf = 0
+
+
+def test_fold_layernorm_weights_identity():
+    """_lib.fold_layernorm (the ViT's LayerNorm fold, ovo_vit_layer_t.qkv_wf ...): LN(x) . W^T + b == rstd (x . W'^T - mean rowsum(W')) + b' in f64, before
+    any rounding; the returned row sums are those of the bf16-ROUNDED W' (what the product on the device multiplies)."""
+    import torch
+    from ovo_amd import _lib as L
+    g = torch.Generator().manual_seed(0)
+    x, w, b = torch.randn(7, 64, generator=g) + 0.3, torch.randn(48, 64, generator=g), torch.randn(48, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    wf, bf, cs = L.fold_layernorm(w, b, gamma, beta)
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.double(), (64,), gamma.double(), beta.double(), 1e-5), w.double(), b.double())
+    mean, var = x.double().mean(1, keepdim=True), x.double().var(1, unbiased=False, keepdim=True)
+    got = (x.double() @ wf.double().t() - mean * wf.double().sum(1)[None]) / torch.sqrt(var + 1e-5) + bf.double()[None]
+    assert (ref - got).abs().max() < 1e-5
+    assert (cs.double() - wf.to(torch.bfloat16).double().sum(1)).abs().max() < 1e-5
