@@ -171,6 +171,13 @@ def parity_block(pipe, frame, map_xyz, oracle_out):
     desc = tr.predict(img, torch.from_numpy(np.ascontiguousarray(used_masks)).to(dev), scale=1.0 / 255.0).cpu().numpy()
     ok = ~np.isnan(desc_ref).any(1)
     err = float(np.abs(desc[ok] - desc_ref[ok]).max()) if ok.any() else None
+    # the same descriptors through the BATCHED forward the timed region runs (one frame alone is 1154 token rows: the small-batch kernels, LayerNorm launches; the
+    # look-ahead groups of the bench are 16 156 rows: 256-row ping-pong kernels with the LayerNorms folded into the products): this frame's crops 14 times over
+    masks_dev = torch.from_numpy(np.ascontiguousarray(used_masks)).to(dev)
+    one = tr.vlm.preprocess(img, tr.forward_crops(img.shape[1], img.shape[2]), scale=1.0 / 255.0)
+    feats = tr.vlm.forward(one.repeat(14, 1, 1, 1), tokens=True)[:one.shape[0]]
+    desc_b = tr.pe_value_with_sam2_attn(tr.get_features_mask(masks_dev), feats).cpu().numpy()
+    err_b = float(np.abs(desc_b[ok] - desc_ref[ok]).max()) if ok.any() else None
     K = torch.from_numpy(syn.scannet_intrinsics(1.0)).to(dev)
     vm = VanillaMapper({"device": str(dev), "mapping": {"k_pooling": 3}}, K)
     n0 = map_xyz.shape[0]
@@ -188,9 +195,11 @@ def parity_block(pipe, frame, map_xyz, oracle_out):
     upd = upd.cpu().numpy().reshape(-1)
     same_points = bool(vm.pcd.shape[0] == pm_ref.xyz.shape[0] and np.array_equal(vm.pcd.cpu().numpy(), pm_ref.xyz))
     mism = int((upd != upd_ref.reshape(-1)).sum()) if upd.shape == upd_ref.reshape(-1).shape else -1
-    return {"max_abs_desc_err": None if err is None else round(err, 6), "descriptors": int(ok.sum()), "index_mismatches": mism,
+    return {"max_abs_desc_err": None if err is None else round(err, 6), "max_abs_desc_err_batched_forward": None if err_b is None else round(err_b, 6),
+            "descriptors": int(ok.sum()), "index_mismatches": mism,
             "points": int(upd.shape[0]), "map_points_identical": same_points,
-            "note": "one frame of this workload: GPU TextRegion descriptors vs the fp32 oracle on the same masks; per-point instance ids after "
+            "note": "one frame of this workload: GPU TextRegion descriptors vs the fp32 oracle on the same masks (alone = 1154 token rows, and as the first of 14 "
+                    "copies = the 16 156-row batched forward of the timed region: 256-row kernels, LayerNorms folded into the products); per-point instance ids after "
                     "back-projection + tracking on the initial map vs the oracle (bit-exact expected)"}
 
 

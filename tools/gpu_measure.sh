@@ -11,6 +11,7 @@ timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; ech
 timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2> $OUT/bench_driver_flags.err
+OVO_VIT_LNFOLD=0 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_flags_nofold.json 2> $OUT/bench_driver_flags_nofold.err
 timeout 600 python bench.py --sam hiera_l --no-cpu-baseline --sustain-seconds 0 --projection-world 0 --no-online > $OUT/bench_hiera_l.json 2> $OUT/bench_hiera_l.err
 timeout 600 python bench.py --sam-full --no-cpu-baseline --sustain-seconds 0 --projection-world 0 --no-online > $OUT/bench_sam_full.json 2> $OUT/bench_sam_full.err
 (timeout 300 python tools/query_bench.py; timeout 300 python tools/query_bench.py 1250000) > $OUT/query_bench.log 2>&1
@@ -26,6 +27,7 @@ timeout 300 python tools/replicated_cost.py 64 8 > $OUT/replicated_cost.txt 2>&1
 (for w in 1 2 4 8; do echo "world $w"; timeout 300 python tools/round_emulation.py $w; done) > $OUT/round_emulation.txt 2>&1
 timeout 600 python tools/vit_bench.py > $OUT/vit_bench.txt 2>&1
 timeout 300 python tools/attn_bench.py > $OUT/attn_bench.txt 2>&1
+(timeout 300 python tools/fold_bench.py; timeout 300 python tools/fold_bench.py 11540) > $OUT/fold_bench.txt 2>&1
 timeout 300 python tools/scatter_bench.py > $OUT/scatter_bench.txt 2>&1; timeout 300 python tools/scatter_bench.py 5000000 768 60000 >> $OUT/scatter_bench.txt 2>&1
 RBS=0,1,2,3 timeout 300 python tools/mlp_bench.py > $OUT/mlp_bench.txt 2>&1
 timeout 900 python tools/mlp_stress.py > $OUT/mlp_stress.txt 2>&1

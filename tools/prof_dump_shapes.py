@@ -1,3 +1,5 @@
+"""Per-shape averages of the 256-row GEMM launches in OVO_PROF_DUMP files (one line per profiled launch: kind M N K work ms flags), for A/B runs of the bench:
+    OVO_PROF_DUMP=a.txt python bench.py ...; OVO_VIT_LNFOLD=0 OVO_PROF_DUMP=b.txt python bench.py ...; python tools/prof_dump_shapes.py a.txt b.txt"""
 import sys, collections
 for f in sys.argv[1:]:
     agg = collections.defaultdict(lambda: [0, 0.0])
