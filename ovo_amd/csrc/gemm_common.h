@@ -257,14 +257,16 @@ __device__ __forceinline__ void finish_best(const GemmArgs &g, int m, int fq, fl
 // 5 window remap of the output / residual rows, 6 f32 A with LayerNorm / cast in the load, 7 fused argmax, 8 periodic residual
 inline int gemm_flags(const GemmArgs &g) {
     return (g.out_dtype == 0 ? 1 : 0) | (g.add ? 2 : 0) | ((g.act & 3) << 2) | (g.rope_cos ? 16 : 0) | (g.win_per > 0 ? 32 : 0) | (g.ln_mode ? 64 : 0) |
-           (g.best ? 128 : 0) | (g.add_rows > 0 ? 256 : 0);
+           (g.best ? 128 : 0) | (g.add_rows > 0 ? 256 : 0) | (g.xb_out ? 512 : 0) | (g.fold_stats ? 1024 : 0);
 }
 
 // algorithmic HBM bytes of a product: every operand read once, the result written once (what PMC traffic is compared with, bench.py roofline)
 inline double gemm_algorithmic_bytes(const GemmArgs &g) {
     const double mn = (double)g.M * g.N, a_bytes = g.ln_mode ? (double)g.M * g.ln_d * 4.0 : (double)g.M * g.K * 2.0;
     return a_bytes + (double)g.N * g.K * 2.0 + mn * (g.out_dtype == 0 ? 4.0 : 2.0) + (g.add ? (g.add_rows > 0 ? (double)g.add_rows * g.N * 4.0 : mn * 4.0) : 0.0) +
-           (g.bias ? g.N * 4.0 : 0.0);
+           (g.bias ? g.N * 4.0 : 0.0) +
+           (g.xb_out ? mn * 2.0 + (double)g.M * (g.N / 64) * 8.0 : 0.0) +                 // LayerNorm fold, producer: the bf16 copy + the partial statistics
+           (g.fold_stats ? (double)g.M * g.fold_parts * 8.0 + g.N * 4.0 : 0.0);           // consumer: the partials of its rows (once per row block of tiles at least) + row sums
 }
 
 // launch of the 256-row ping-pong kernels (gemm8p.hip); bn in {128, 256}; returns OVO_E_UNSUPPORTED when the shape does not fit
