@@ -830,6 +830,65 @@ def test_vit_forward_vs_oracle_full_size(card, batch):
     assert err < _bound(spec.out_dim) and cos > 0.9999
 
 
+@pytest.mark.parametrize("m,d,n,act", [(2308, 1024, 3072, 0), (4100, 512, 2048, 1), (2100, 256, 768, 0), (2049, 448, 1344, 1)])
+def test_gemm_fold_pieces_vs_torch(m, d, n, act):
+    """ovo_gemm_fold_out / ovo_gemm_fold_stats / ovo_gemm_fold_in on their own: the producer's f32 result is bit-identical to ovo_gemm's, its bf16 copy is the
+    rounding of that result, its partial statistics are the sums of each 64-column group; the consumer equals Linear(LayerNorm(x)) (+ GELU) in fp32 within bf16
+    operand rounding, from the producer's partials and from the single partial of ovo_gemm_fold_stats alike; ragged last row block (m % 256 != 0)."""
+    from ovo_amd import _lib as L
+    lib = L.load()
+    g0 = torch.Generator().manual_seed(m + n)
+    a = (torch.randn(m, d, generator=g0)).to(DEV, torch.bfloat16)
+    wo = (torch.randn(d, d, generator=g0) * d ** -0.5).to(DEV, torch.bfloat16)
+    bo = (torch.randn(d, generator=g0) * 0.1).to(DEV)
+    res = (torch.randn(m, d, generator=g0) + 0.4).to(DEV)
+    ref_x = _gemm(a, wo, bias=bo, add=res)
+    x = torch.empty_like(ref_x)
+    xb = torch.empty(m, d, dtype=torch.bfloat16, device=DEV)
+    parts = d // 64
+    stats = torch.full((parts, m, 2), float("nan"), device=DEV)
+    g = L.Gemm()
+    g.A, g.lda, g.W, g.ldw, g.bias = a.data_ptr(), d, wo.data_ptr(), d, bo.data_ptr()
+    g.C, g.ldc, g.add, g.ld_add = x.data_ptr(), d, res.data_ptr(), d
+    g.M, g.N, g.K, g.in_dtype, g.out_dtype, g.act, g.alpha = m, d, d, 2, 0, 0, 1.0
+    L.check(lib.ovo_gemm_fold_out(C.byref(g), L.ptr(xb), d, L.ptr(stats), m, L.stream()))
+    assert torch.equal(x, ref_x)
+    assert torch.equal(xb, ref_x.to(torch.bfloat16))
+    grp = ref_x.double().view(m, parts, 64)
+    want = torch.stack([grp.sum(-1), (grp * grp).sum(-1)], -1).permute(1, 0, 2)
+    torch.testing.assert_close(stats.double(), want, rtol=2e-6, atol=2e-4)
+    # consumer
+    gamma, beta = (1 + 0.3 * torch.randn(d, generator=g0)), 0.2 * torch.randn(d, generator=g0)
+    w, b = torch.randn(n, d, generator=g0) * d ** -0.5, 0.1 * torch.randn(n, generator=g0)
+    wf, bf, cs = L.fold_layernorm(w, b, gamma, beta)
+    wf_d, bf_d, cs_d = wf.to(DEV, torch.bfloat16), bf.to(DEV), cs.to(DEV)
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(ref_x.cpu().float(), (d,), gamma, beta, 1e-5), w, b)
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    out = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    g.A, g.lda, g.W, g.ldw, g.bias = xb.data_ptr(), d, wf_d.data_ptr(), d, bf_d.data_ptr()
+    g.C, g.ldc, g.add, g.ld_add = out.data_ptr(), n, None, 0
+    g.M, g.N, g.K, g.out_dtype, g.act = m, n, d, 2, act
+    L.check(lib.ovo_gemm_fold_in(C.byref(g), None, L.ptr(stats), m, parts, d, L.ptr(cs_d), 1e-5, L.stream()))
+    got = out.float().cpu()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 2.5e-2 * scale                    # bf16 operands + bf16 output
+    assert ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item() < 6e-3
+    one = torch.full((1, m, 2), float("nan"), device=DEV)
+    xb2 = torch.empty_like(xb)
+    L.check(lib.ovo_gemm_fold_stats(L.ptr(x), d, m, d, L.ptr(xb2), d, L.ptr(one), L.stream()))
+    assert torch.equal(xb2, xb)
+    out1 = torch.empty_like(out)
+    g.C = out1.data_ptr()
+    L.check(lib.ovo_gemm_fold_in(C.byref(g), None, L.ptr(one), m, 1, d, L.ptr(cs_d), 1e-5, L.stream()))
+    assert (out1.float() - out.float()).abs().max().item() < 2e-2 * scale     # same rows, statistics summed in another order
+    # outside the 256-row kernel's range nothing is launched
+    g.M = 1024
+    assert lib.ovo_gemm_fold_in(C.byref(g), None, L.ptr(stats), m, parts, d, L.ptr(cs_d), 1e-5, L.stream()) == L.E_UNSUPPORTED
+    g.M, g.act = m, 2
+    assert lib.ovo_gemm_fold_in(C.byref(g), None, L.ptr(stats), m, parts, d, L.ptr(cs_d), 1e-5, L.stream()) == L.E_UNSUPPORTED
+
+
 @pytest.mark.parametrize("name,base,over,batch", [
     ("pe-l-336 x 4 layers (rope, 256 x 256 tiles, 16 partials)", "PE-Core-L14-336", dict(layers=4), 4),
     ("width 512, no rope (256 x 256 tiles, 8 partials)", "PE-Core-L14-336", dict(layers=3, width=512, heads=8, mlp_dim=2048, out_dim=512, image_size=224, patch=16, use_rope=False), 12),
