@@ -927,6 +927,30 @@ def test_vit_layernorm_fold_vs_layernorm_kernels_and_oracle(monkeypatch, name, b
     assert ef < _bound(spec.out_dim) and ef < 1.5 * ep + 1e-4
 
 
+def test_vit_layernorm_fold_full_size_is_deterministic():
+    """The headline shape (PE-L/14-336, 28 crops = 16 156 token rows, 24 layers) through the folded forward, 8 times: bit-identical outputs (partial statistics are
+    summed in a fixed order; one workgroup per CU), finite, and within the descriptor bound of the LayerNorm-kernel forward of the same weights."""
+    import os
+    from ovo_amd.encoders.vit import SPECS, HipViT, random_state
+    spec = SPECS["PE-Core-L14-336"]
+    vit = HipViT(spec, random_state(spec, seed=3), device=DEV)
+    assert vit.ln_fold
+    x = torch.randn(28, 3, spec.image_size, spec.image_size, generator=torch.Generator().manual_seed(9)).to(DEV)
+    os.environ["OVO_VIT_LNFOLD"] = "1"
+    try:
+        first = vit.forward(x).clone()
+        for _ in range(7):
+            assert torch.equal(vit.forward(x), first)
+        os.environ["OVO_VIT_LNFOLD"] = "0"
+        plain = vit.forward(x)
+    finally:
+        os.environ.pop("OVO_VIT_LNFOLD", None)
+    assert torch.isfinite(first).all() and not torch.equal(first, plain)
+    err = (torch.nn.functional.normalize(first, dim=-1) - torch.nn.functional.normalize(plain, dim=-1)).abs().max().item()
+    print(f"folded vs LayerNorm-kernel forward, 24 layers at 16 156 rows: max |unit feature difference| = {err:.2e}")
+    assert err < 1.5e-3                                   # two bf16 forwards, each within 1e-3 of the fp32 oracle (test_vit_forward_vs_oracle_full_size)
+
+
 def test_siglip_forward_vs_hf_golden():
     """SigLIP tower (no class token, tanh-GELU, attention-pool head) vs HuggingFace SiglipVisionModel (fp32) on the golden
     weights / input: width 64, hidden 176 (zero padded to 192 on the device), 2 layers, 16 tokens."""
