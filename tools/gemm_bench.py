@@ -15,7 +15,7 @@ def run(m, n, k, iters=int(os.environ.get('ITERS', '100'))):
     g = L.Gemm(); g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, g.add, g.ld_add = a.data_ptr(), k + PAD, w.data_ptr(), k + PAD, None, out.data_ptr(), n, None, 0
     g.M, g.N, g.K, g.in_dtype, g.out_dtype, g.act, g.alpha = m, n, k, 2, odt[1], int(os.environ.get('ACT', '0')), 1.0
     if os.environ.get('BIAS'):
-        bias = torch.randn(n, device=dev); g.bias = bias.data_ptr()
+        bias = torch.randn(n, device=dev) + float(os.environ.get('BIAS_SHIFT', '0')); g.bias = bias.data_ptr()      # BIAS_SHIFT=100: every GELU table lookup hits the last entry (no LDS bank conflicts)
     if os.environ.get('ADD'):
         add = out if os.environ.get('INPLACE') else torch.randn(m, n, device=dev); g.add, g.ld_add = add.data_ptr(), n
     call = lambda: lib.ovo_gemm(C.byref(g), L.stream())

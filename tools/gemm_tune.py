@@ -1,6 +1,6 @@
 """Measure every candidate tile on every product the encoder forwards launch and (re)write ovo_amd/csrc/gemm_tuned.h.
 
-    python tools/gemm_tune.py [--write] [--batches 1,4,10,12,14] [--margin 0.02] [--report gpurun_out/gemm_tune.txt]
+    python tools/gemm_tune.py [--write] [--batches 1,4,5,6,10,12,14] [--margin 0.02] [--report gpurun_out/gemm_tune.txt]
 
 1. the ViT-L/14-336 and hiera_b+ forwards run once per batch size under the library's profiler (OVO_PROF_DUMP lines carry M, N, K and the launch's
    variant flags, gemm_common.h: gemm_flags) -> the set of products;
@@ -90,7 +90,7 @@ def time_tile(call, tile, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batches", default="1,4,10,12,14")      # 14 / 10: the encoder look-ahead groups of bench.py
+    ap.add_argument("--batches", default="1,4,5,6,10,12,14")      # the encoder look-ahead groups of bench.py: 14 + 10 (default flags), 5 | 14 + 6 (--steps 20 --warmup 5)
     ap.add_argument("--margin", type=float, default=0.02)
     ap.add_argument("--write", action="store_true")
     ap.add_argument("--report", default=os.path.join(R, "gpurun_out", "gemm_tune.txt"))
