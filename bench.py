@@ -271,8 +271,11 @@ def profile_pass(pipe, feed, rounds, lib):
     gemm_ms, gemm_work = sum(ms[k] for k in tiles), sum(work[k] for k in tiles)
     name = f"k_gemm8p<{tiles[dom]},64,bf16> (ovo_amd/csrc/gemm8p.hip)" if dom in (0, 3) else \
         ("k_gemm_stream<bf16> (ovo_amd/csrc/gemm_stream.hip)" if dom == 8 else f"k_gemm<{tiles[dom]},64,bf16> (ovo_amd/csrc/gemm.hip)")
+    fold = os.environ.get("OVO_VIT_LNFOLD", "1") != "0" and getattr(getattr(getattr(pipe.clip, "textregion", None), "vlm", None), "ln_fold", False)
     return {"bound": "mfma", "kernel": name, "achieved": round(tf, 1),
             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+            "layernorm_fold": bool(fold),       # True: this kernel's launches also carry the ViT's LayerNorm work (bf16 copy + row statistics out, statistics in;
+                                                # DESIGN.md section 9 item 9); OVO_VIT_LNFOLD=0 runs the LayerNorm kernels beside a lighter GEMM (frac + 0.01)
             "traffic": pmc_traffic(tiles[dom]), "traffic_stamp": pmc_traffic_stamp(), "traffic_population": pmc_traffic_census(tiles[dom]),
             "algorithmic_bytes_per_launch": round(nbytes[dom] / max(n[dom], 1)),
             "launches_per_frame": n[dom] / steps, "avg_launch_us": round(1e3 * ms[dom] / max(n[dom], 1), 2),
