@@ -337,7 +337,7 @@ int launch(const GemmArgs &g0, hipStream_t s) {
 
 // The 256-row ping-pong kernels' tile width for a shape (256 or 128) and whether they beat the ring kernels there: the cost model of `dispatch` below
 // (its comment block explains the constants); also the LayerNorm fold's choice, which runs on these kernels regardless of `wins`.
-static int choose8p(int M, int N, int K, bool out_f32, bool add, bool *wins) {
+static int choose8p(int M, int N, int K, bool out_f32, bool add, bool *wins, bool tie256 = false) {
     auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     const double flop = 2.0 * M * (double)N * K, kt = K / 64;
     const double bytes = 2.0 * ((double)M * K + (double)N * K) + (double)M * N * (out_f32 ? 4.0 : 2.0) * (add ? 2.0 : 1.0);
@@ -356,7 +356,9 @@ static int choose8p(int M, int N, int K, bool out_f32, bool add, bool *wins) {
     t256 = t256 > t_mem ? t256 : t_mem; t128 = t128 > t_mem ? t128 : t_mem;
     const double t8 = t256 < t128 ? t256 : t128;
     if (wins) *wins = t8 < 0.93 * (t_ring > t_mem ? t_ring : t_mem);
-    return t256 < t128 ? 256 : 128;
+    // (both under the memory floor: the model cannot tell them apart.  The fold's launches take the wide tile then -- its out-projection at 16 156 rows measured
+    //  47.4 us on 256 x 256 against 53.6 on 256 x 128, tools/fold_bench.py with OVO_FOLD_TILE; the plain products keep the rule the tile table was measured against)
+    return t256 < t128 || (tie256 && t256 == t128) ? 256 : 128;
 }
 
 template <typename VT>
@@ -500,7 +502,8 @@ static int gemm_entry(const ovo_gemm_t *p, unsigned long long *best, int store, 
         return OVO_OK;
     }
     if (fold_out || fold_in) {                                    // the LayerNorm fold: ping-pong kernel or nothing
-        const int bn = ovo_gemm_detail::gemm_fold_ok(p->M, p->N, p->K) ? choose8p(p->M, p->N, p->K, p->out_dtype == 0, p->add != nullptr, nullptr) : 0;
+        int bn = ovo_gemm_detail::gemm_fold_ok(p->M, p->N, p->K) ? choose8p(p->M, p->N, p->K, p->out_dtype == 0, p->add != nullptr, nullptr, true) : 0;
+        if (bn && ovo_knobs_dynamic() && getenv("OVO_FOLD_TILE")) bn = atoi(getenv("OVO_FOLD_TILE")) == 128 ? 128 : 256;      // tools/fold_bench.py: either tile width on the fold's launches
         if (!bn || p->in_dtype != 2 || p->alpha != 1.0f || win || add_rows || best) return OVO_E_UNSUPPORTED;
         if (fold_out) {
             if (p->out_dtype != 0 || !p->add || p->act != 0 || rope) return OVO_E_UNSUPPORTED;
