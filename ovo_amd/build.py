@@ -22,8 +22,11 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 # per-file extra flags: geometry must not contract a*b+c into fma on its own (bit-exact parity); the three translation units with a LayerNorm in
 # their operand load are built WITHOUT SLP vectorisation -- its packed-f32 (v_pk_*_f32) statistics chain gave wrong variances one time in ~10^5
 # whenever a wave of another workgroup shared the SIMD (round 6, csrc/mlp_stream.hip: mlp_stream_launch)
+# gemm8p.hip: no SLP vectorisation either, for speed -- its epilogues hold a value's table entry / bias / accumulator in registers that do not pair up, and the
+# packed form pays two v_mov per v_pk_fma to line them up: FC1 + GELU (57344, 1792, 448) 135.1 -> 131.1 us, (16156, 4096, 1024) 133.6 -> 131.0, the other
+# epilogues unchanged (two alternating rounds of both builds in one session, tools/gemm_bench.py); results are bit-identical (the same IEEE operations)
 EXTRA = {"geometry.hip": ["-ffp-contract=off"], "mlp_stream.hip": ["-fno-slp-vectorize"], "gemm_stream.hip": ["-fno-slp-vectorize"],
-         "winattn.hip": ["-fno-slp-vectorize"]}
+         "winattn.hip": ["-fno-slp-vectorize"], "gemm8p.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc() -> str:
@@ -48,6 +51,7 @@ def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "ovo_hip.h"))
+    deps.append(os.path.abspath(__file__))                       # the flags live here
     if force or _stale(obj, deps):
         cmd = [hipcc(), "-c", os.path.join(CSRC, src), "-o", obj] + COMMON + EXTRA.get(src, [])
         r = subprocess.run(cmd, capture_output=True, text=True)
